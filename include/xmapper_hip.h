@@ -1,0 +1,132 @@
+/* xmapper_hip.h — C ABI of libxmapper_hip.so: the MI355X-native drop-in for X-Mapper's per-read seed-and-extend path.
+ *
+ * The reference (mathjeff/Mapper, 100 % Java) has no FFI seam; the narrowest stable boundary on this path is
+ *     AlignerWorker.align(Query) -> QueryAlignments          src/main/java/mapper/AlignerWorker.java:256-261
+ *     (batch form: the loop of AlignerWorker.process()        src/main/java/mapper/AlignerWorker.java:177-231)
+ * which is also the public Api.align(Query, ReferenceDatabase, AlignmentParameters, Logger)   Api.java:79-92.
+ * Every entry point below cites the reference code it replaces.  INTEGRATION.md shows the JNI binding a maintainer
+ * would add on the Java side.  Plain pointers and sizes only; no Java, torch or C++ types cross this boundary.
+ *
+ * Bases are 4-bit IUPAC masks, one per byte: A=1 C=2 G=4 T=8, ambiguity = OR (QuickVariants Basepairs encoding, see
+ * HashBlock_Matcher.java:184-196).  Contigs are passed forward-only in the order Mapper.sortAndComplementReference
+ * produces (Mapper.java:1151-1172: length-descending); the reverse complements are implied.
+ *
+ * Errors: like the reference (any worker exception aborts the run, AlignerWorker.java:195-197, Mapper.java:1070-1077)
+ * a failing call returns non-zero, produces no partial result, and xm_last_error() describes it.
+ * Threading: an xm_index is immutable after build (xm_index_ensure_length excepted) and may be shared; calls that use
+ * the GPU serialise per index.
+ */
+#ifndef XMAPPER_HIP_H
+#define XMAPPER_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* AlignmentParameters (AlignmentParameters.java:8-35).  StartingInsertionStartFree is always false at entry. */
+typedef struct xm_params {
+  double MutationPenalty, InsertionStart_Penalty, InsertionExtension_Penalty, DeletionStart_Penalty, DeletionExtension_Penalty,
+      MaxErrorRate, UnalignedPenalty, AmbiguityPenalty, Max_PenaltySpan;
+  int32_t MaxNumMatches;
+  int32_t reserved;
+} xm_params;
+
+typedef struct xm_ref {
+  int32_t num_contigs;
+  const char* const* names;      /* may be NULL */
+  const uint8_t* const* codes;   /* [num_contigs] forward strand */
+  const int64_t* lengths;        /* [num_contigs] */
+} xm_ref;
+
+/* How the reference database is assembled (Mapper.java:657-692 vs Api.java:41-69). */
+typedef struct xm_build_opts {
+  int32_t enable_gapmers;        /* 1 (default); 0 = --no-gapmers (Mapper.java:245) */
+  int32_t min_interesting_size;  /* <=0: (int)max(log4(N+1)-2, 1)  (HashBlock_Database.java:52) */
+  int32_t max_hashed_length;     /* <=0: chooseMaxDuplicationLength = 2*ceil(log2 N) (DuplicationDetector.java:17-36); grows on demand */
+  int32_t dup_window;            /* 1000 for Mapper.run (Mapper.java:691), 1 for Api.newDatabase (Api.java:66) */
+  int32_t dup_min_copies;        /* 2 */
+  int32_t dup_min_length;        /* <=0: chooseMinDuplicationLength */
+  int32_t dup_max_length;        /* <=0: chooseMaxDuplicationLength */
+  int32_t device;                /* HIP device ordinal; <0: current device */
+  int32_t host_only;             /* 1: build the host-side tables only (no GPU touched): index inspection on CPU-only machines */
+  int32_t reserved;
+} xm_build_opts;
+
+typedef struct xm_index xm_index;
+
+/* A batch of queries = the List<QueryBuilder> one AlignerWorker.process() call consumes (AlignerWorker.java:177). */
+typedef struct xm_query_batch {
+  int64_t num_queries;
+  const int32_t* mate_count;     /* [nq] 1 or 2 (Query.getNumSequences()) */
+  const int64_t* mate_offset;    /* [2*nq] offset of each mate in `codes` */
+  const int32_t* mate_length;    /* [2*nq] */
+  const uint8_t* codes;          /* mates as given in the FASTQ (mate 2 NOT reverse-complemented) */
+  int64_t codes_length;
+  const double* expected_inner;  /* [nq] Query.getExpectedInnerDistance() (paired only; --spacing, Mapper.java:34) */
+  const double* deviation;       /* [nq] Query.getSpacingDeviationPerUnitPenalty() (Mapper.java:35) */
+} xm_query_batch;
+
+/* Results = List<QueryAlignments> (AlignerWorker.java:231,652-656) flattened into two streams.
+ * For query q, ints[int_off[q] .. int_off[q+1]) and dbls[dbl_off[q] .. dbl_off[q+1]) hold, in this order:
+ *   ints: numComponents (1; 2 when a pair fell back to unpaired alignments, AlignerWorker.java:643)
+ *         per component: numAlignments
+ *           per alignment (= QueryAlignment ctor args, QueryMatch_Aligner.java:267): innerDistance, numSequences
+ *             per sequence (= SequenceAlignment): contigIndex, referenceReversed, numBlocks,
+ *               per block (= AlignedBlock): startA, startB, lengthA, lengthB
+ *   dbls:   per alignment: spacingPenalty, overlapMultiplier, duplicationBonus, totalPenalty
+ *             per sequence: totalPenalty, alignedPenalty
+ * An unaligned query is one component with zero alignments (QueryAlignments.unaligned, AlignerWorker.java:480). */
+typedef struct xm_result {
+  int64_t num_queries, num_ints, num_dbls;
+  int32_t* ints;
+  double* dbls;
+  int64_t* int_off;  /* [nq+1] */
+  int64_t* dbl_off;  /* [nq+1] */
+  /* counters of this call: 0 reads, 1 bucket-header probes (PackedMap.getNumMatchesLowerBound), 2 bucket fetches (PackedMap.get),
+   * 3 positions fetched, 4 candidates extended (QueryMatch_Aligner.doAlign), 5 PathAligner calls, 6 PathAligner nodes, 7 quick accepts,
+   * 8 alignments written, 9 reference-window bytes (4-bit), 10 read bytes (4-bit), 11 reads rerun with a larger scratch scale */
+  int64_t counters[16];
+  double kernel_ms;   /* sum of the align kernel's launch durations (HIP events on the launch stream) */
+  double h2d_ms, d2h_ms;
+  int32_t kernel_launches;
+  int32_t reserved;
+} xm_result;
+
+typedef struct xm_index_info_t {
+  int32_t num_contigs, min_interesting_size, max_hashed_length, enable_gapmers, dup_window, position_bytes;
+  int64_t total_forward_size, index_bytes, num_positions;
+  double dup_granularity;
+} xm_index_info_t;
+
+const char* xm_last_error(void);
+int xm_device_count(void);
+
+/* Replaces new SequenceDatabase + new HashBlock_Database(...).prepare() + new DuplicationDetector(...).helpSetup()
+ * (Mapper.java:657-692, Api.java:41-69, HashBlock_Database.java:490-665, PackedMap.java:54-153, DuplicationDetector.java:97-436)
+ * and uploads the result to HBM. */
+int xm_index_build(const xm_ref* ref, const xm_build_opts* opts, xm_index** out);
+/* Readable_HashBlock_Database.getContainingMap's lazy growth (Readable_HashBlock_Database.java:108-113): hash tables
+ * through gapmers that use `length` bases.  xm_align_batch calls this itself for the longest mate of the batch. */
+int xm_index_ensure_length(xm_index* index, int32_t length);
+void xm_index_free(xm_index* index);
+int xm_index_get_info(const xm_index* index, xm_index_info_t* info);
+/* inspection (parity tests): one PackedMap as (counts per bucket or -1 if overfull, concatenated encoded positions) */
+int xm_index_table_info(const xm_index* index, int32_t used_length, int32_t* capacity, int32_t* max_count_per_key, int64_t* num_stored, int64_t* num_overfull);
+int xm_index_table_dump(const xm_index* index, int32_t used_length, int32_t* counts, int64_t* positions);
+int64_t xm_index_dup_keys(const xm_index* index, int32_t contig, int32_t* out, int64_t cap);
+
+/* Replaces the per-read loop of AlignerWorker.process() / Api.align (AlignerWorker.java:177-231,306-644): every query is
+ * aligned on the GPU; *out is allocated by the library and released with xm_result_free. */
+int xm_align_batch(xm_index* index, const xm_params* params, const xm_query_batch* batch, xm_result** out);
+void xm_result_free(xm_result* result);
+
+/* Bulk form of Readable_HashBlock_Database.getNumMatchesLowerBound + matchBlock / PackedMap.get (PackedMap.java:160-172,
+ * 228-236) for n (used_length, lookup key) pairs: counts[i] = number of stored positions, -1 when the bucket is overfull or
+ * holds more than the table's limit; positions are written to out_positions[i*max_per_probe ...] (at most max_per_probe each,
+ * not reverse-complemented).  Device-resident micro-kernel used for the seed-lookup roofline measurement. */
+int xm_seed_probe(xm_index* index, int64_t n, const int32_t* used_length, const int32_t* keys, int32_t max_per_probe, int32_t* counts, int64_t* out_positions, double* kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

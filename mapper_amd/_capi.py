@@ -1,0 +1,117 @@
+"""ctypes binding of libxmapper_hip.so (include/xmapper_hip.h).  No CPU fallback: if the HIP library cannot be loaded
+the import of this module fails loudly."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "_lib", "libxmapper_hip.so")
+
+
+class XmParams(C.Structure):
+    """xm_params = AlignmentParameters (M/AlignmentParameters.java:8-35)."""
+    _fields_ = [("MutationPenalty", C.c_double), ("InsertionStart_Penalty", C.c_double), ("InsertionExtension_Penalty", C.c_double),
+                ("DeletionStart_Penalty", C.c_double), ("DeletionExtension_Penalty", C.c_double), ("MaxErrorRate", C.c_double),
+                ("UnalignedPenalty", C.c_double), ("AmbiguityPenalty", C.c_double), ("Max_PenaltySpan", C.c_double),
+                ("MaxNumMatches", C.c_int32), ("reserved", C.c_int32)]
+
+
+class XmRef(C.Structure):
+    _fields_ = [("num_contigs", C.c_int32), ("names", C.POINTER(C.c_char_p)), ("codes", C.POINTER(C.c_void_p)), ("lengths", C.POINTER(C.c_int64))]
+
+
+class XmBuildOpts(C.Structure):
+    _fields_ = [("enable_gapmers", C.c_int32), ("min_interesting_size", C.c_int32), ("max_hashed_length", C.c_int32), ("dup_window", C.c_int32),
+                ("dup_min_copies", C.c_int32), ("dup_min_length", C.c_int32), ("dup_max_length", C.c_int32), ("device", C.c_int32),
+                ("host_only", C.c_int32), ("reserved", C.c_int32)]
+
+
+class XmQueryBatch(C.Structure):
+    _fields_ = [("num_queries", C.c_int64), ("mate_count", C.c_void_p), ("mate_offset", C.c_void_p), ("mate_length", C.c_void_p),
+                ("codes", C.c_void_p), ("codes_length", C.c_int64), ("expected_inner", C.c_void_p), ("deviation", C.c_void_p)]
+
+
+class XmResult(C.Structure):
+    _fields_ = [("num_queries", C.c_int64), ("num_ints", C.c_int64), ("num_dbls", C.c_int64), ("ints", C.POINTER(C.c_int32)),
+                ("dbls", C.POINTER(C.c_double)), ("int_off", C.POINTER(C.c_int64)), ("dbl_off", C.POINTER(C.c_int64)),
+                ("counters", C.c_int64 * 16), ("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
+                ("kernel_launches", C.c_int32), ("reserved", C.c_int32)]
+
+
+class XmIndexInfo(C.Structure):
+    _fields_ = [("num_contigs", C.c_int32), ("min_interesting_size", C.c_int32), ("max_hashed_length", C.c_int32), ("enable_gapmers", C.c_int32),
+                ("dup_window", C.c_int32), ("position_bytes", C.c_int32), ("total_forward_size", C.c_int64), ("index_bytes", C.c_int64),
+                ("num_positions", C.c_int64), ("dup_granularity", C.c_double)]
+
+
+EXPORTS = ["xm_last_error", "xm_device_count", "xm_index_build", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
+           "xm_index_table_info", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_seed_probe"]
+
+
+def build_library(force=False):
+    """Compile libxmapper_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "xmapper_hip.h")]
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", CSRC], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            try:
+                build_library()
+            except Exception as e:  # noqa: BLE001
+                raise ImportError("libxmapper_hip.so is missing and could not be built with hipcc; mapper_amd has no CPU fallback: %s" % e)
+        L = C.CDLL(LIB_PATH)
+        L.xm_last_error.restype = C.c_char_p
+        L.xm_index_build.argtypes = [C.POINTER(XmRef), C.POINTER(XmBuildOpts), C.POINTER(C.c_void_p)]
+        L.xm_index_ensure_length.argtypes = [C.c_void_p, C.c_int32]
+        L.xm_index_free.argtypes = [C.c_void_p]
+        L.xm_index_get_info.argtypes = [C.c_void_p, C.POINTER(XmIndexInfo)]
+        L.xm_index_table_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.xm_index_table_dump.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.xm_index_dup_keys.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        L.xm_index_dup_keys.restype = C.c_int64
+        L.xm_align_batch.argtypes = [C.c_void_p, C.POINTER(XmParams), C.POINTER(XmQueryBatch), C.POINTER(C.POINTER(XmResult))]
+        L.xm_result_free.argtypes = [C.POINTER(XmResult)]
+        L.xm_seed_probe.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+def make_ref(contigs):
+    """contigs: list of (name, uint8 code array).  Returns (XmRef, keepalive)."""
+    n = len(contigs)
+    names = (C.c_char_p * n)(*[nm.encode() for nm, _ in contigs])
+    arrays = [np.ascontiguousarray(c, dtype=np.uint8) for _, c in contigs]
+    codes = (C.c_void_p * n)(*[a.ctypes.data for a in arrays])
+    lengths = (C.c_int64 * n)(*[len(a) for a in arrays])
+    ref = XmRef(n, names, codes, lengths)
+    return ref, (names, arrays, codes, lengths)
+
+
+def make_batch(mate_count, mate_offset, mate_length, codes, expected_inner, deviation):
+    arrs = (np.ascontiguousarray(mate_count, dtype=np.int32), np.ascontiguousarray(mate_offset, dtype=np.int64),
+            np.ascontiguousarray(mate_length, dtype=np.int32), np.ascontiguousarray(codes, dtype=np.uint8),
+            np.ascontiguousarray(expected_inner, dtype=np.float64), np.ascontiguousarray(deviation, dtype=np.float64))
+    b = XmQueryBatch(len(arrs[0]), arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, len(arrs[3]),
+                     arrs[4].ctypes.data, arrs[5].ctypes.data)
+    return b, arrs
+
+
+def copy_result(r):
+    """XmResult -> dict of numpy arrays (copies; the C result can be freed afterwards)."""
+    ints = np.ctypeslib.as_array(r.ints, shape=(max(r.num_ints, 1),))[:r.num_ints].copy()
+    dbls = np.ctypeslib.as_array(r.dbls, shape=(max(r.num_dbls, 1),))[:r.num_dbls].copy()
+    io = np.ctypeslib.as_array(r.int_off, shape=(r.num_queries + 1,)).copy()
+    do = np.ctypeslib.as_array(r.dbl_off, shape=(r.num_queries + 1,)).copy()
+    return dict(ints=ints, dbls=dbls, int_off=io, dbl_off=do, counters=list(r.counters), kernel_ms=r.kernel_ms, h2d_ms=r.h2d_ms,
+                d2h_ms=r.d2h_ms, kernel_launches=r.kernel_launches)

@@ -1,0 +1,539 @@
+// libxmapper_hip.so: kernels, HBM residency and the C ABI of include/xmapper_hip.h.
+//
+// Kernel design (round 1): one read per lane, persistent lanes.  The per-read algorithm is a long, data-dependent
+// state machine (adaptive pyramid walk -> bucket probes -> votes -> ungapped check -> best-first gapped search), so a
+// lane pulls reads from a global counter until the batch is drained; each lane owns a scratch arena in HBM (sized by
+// `scale`), the index is read-only in HBM (bucket header = 2 adjacent u32, positions contiguous per bucket, reference
+// one 4-bit code per byte).  Results go to a bump-allocated result arena and are put into query order on the host.
+// Reads whose fixed-capacity scratch overflowed are rerun by a second launch with a 4x larger scale (never on the CPU).
+#include "../../include/xmapper_hip.h"
+#include "xm_worker.h"
+#include "xm_index_host.h"
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <mutex>
+#include <cstring>
+#include <cstdlib>
+
+using namespace xm;
+
+namespace {
+
+thread_local std::string g_error;
+int fail(const std::string& msg) { g_error = msg; return 1; }
+
+#define HIP_CHECK(expr)                                                                                     \
+  do {                                                                                                      \
+    hipError_t _e = (expr);                                                                                 \
+    if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e));      \
+  } while (0)
+
+struct BatchView {
+  int64_t nq;
+  const int32_t* mateCount;
+  const int64_t* mateOffset;
+  const int32_t* mateLength;
+  const uint8_t* codes;
+  const double* expectedInner;
+  const double* deviation;
+};
+
+struct OutView {
+  int32_t* ints; double* dbls;          // result arenas
+  unsigned long long intCap, dblCap;
+  unsigned long long* cursor;           // [0] ints used, [1] dbls used
+  int32_t* status;                      // [nq]
+  int64_t* intOff; int64_t* dblOff;     // [nq] offsets into the arenas
+  int32_t* intLen; int32_t* dblLen;     // [nq]
+};
+
+__device__ __forceinline__ void addCounters(DevCounters* g, const DevCounters& l) {
+  atomicAdd(&g->reads, l.reads); atomicAdd(&g->headerProbes, l.headerProbes); atomicAdd(&g->bucketFetches, l.bucketFetches);
+  atomicAdd(&g->hitsFetched, l.hitsFetched); atomicAdd(&g->candidatesExtended, l.candidatesExtended); atomicAdd(&g->pathAlignerCalls, l.pathAlignerCalls);
+  atomicAdd(&g->pathAlignerNodes, l.pathAlignerNodes); atomicAdd(&g->quickAccepts, l.quickAccepts); atomicAdd(&g->alignmentsOut, l.alignmentsOut);
+  atomicAdd(&g->refWindowBytes, l.refWindowBytes); atomicAdd(&g->readBytes, l.readBytes);
+}
+
+// One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
+__global__ void __launch_bounds__(256) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale,
+                                                       uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters) {
+  unsigned long long lane = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  uint8_t* arena = arenas + lane * arenaBytes;
+  DevCounters local;
+  memset(&local, 0, sizeof(local));
+  ReadCtx cx;
+  while (true) {
+    unsigned long long item = atomicAdd(nextItem, 1ull);
+    if ((long long)item >= nTodo) break;
+    int64_t q = todo ? todo[item] : (int64_t)item;
+    ReadIn in;
+    in.nMates = batch.mateCount[q];
+    for (int m = 0; m < 2; m++) {
+      in.mate[m] = batch.codes + batch.mateOffset[q * 2 + m];
+      in.mateLen[m] = m < in.nMates ? batch.mateLength[q * 2 + m] : 0;
+    }
+    // single-end Query: expectedInnerDistance 0, deviation 1 (spacing penalty is always 0, T/SamWriter_Test.java:26)
+    in.expectedInner = in.nMates > 1 ? batch.expectedInner[q] : 0.0;
+    in.deviation = in.nMates > 1 ? batch.deviation[q] : 1.0;
+    ReadResult rr;
+    runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr);
+    int32_t st = cx.status;
+    if (st == XM_OK) {
+      int64_t ni, nd;
+      resultSize(rr, ni, nd);
+      unsigned long long io = atomicAdd(&out.cursor[0], (unsigned long long)ni);
+      unsigned long long dofs = atomicAdd(&out.cursor[1], (unsigned long long)nd);
+      if (io + (unsigned long long)ni > out.intCap || dofs + (unsigned long long)nd > out.dblCap) {
+        st = XM_ST_OUT_OVERFLOW;
+      } else {
+        OutWriter w;
+        w.ints = out.ints + io; w.dbls = out.dbls + dofs; w.ni = 0; w.nd = 0;
+        resultWrite(rr, w, &local);
+        out.intOff[q] = (int64_t)io; out.dblOff[q] = (int64_t)dofs; out.intLen[q] = (int32_t)ni; out.dblLen[q] = (int32_t)nd;
+      }
+    }
+    out.status[q] = st;
+  }
+  addCounters(counters, local);
+}
+
+// PackedMap.getNumMatchesLowerBound + PackedMap.get for a batch of (used length, key): one lane per probe.
+__global__ void __launch_bounds__(256) xm_seed_probe_kernel(IndexView ix, long long n, const int32_t* usedLength, const int32_t* keys, int maxPerProbe,
+                                                            int32_t* counts, int64_t* outPositions) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int used = usedLength[i];
+  if (used < 0 || used > ix.maxHashedLength) { counts[i] = -2; return; }
+  const Table* t = &ix.tables[used];
+  uint32_t k = packedKey(t, keys[i]);
+  const uint32_t* off = ix.bucketOff + t->offBase + k;
+  uint32_t o0 = off[0], o1 = off[1];
+  if (o0 & XM_OVERFULL) { counts[i] = -1; return; }
+  int count = (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
+  if (count > t->maxCount) { counts[i] = -1; return; }
+  counts[i] = count;
+  int64_t first = t->posBase + (int64_t)(o0 & ~XM_OVERFULL);
+  int m = count < maxPerProbe ? count : maxPerProbe;
+  for (int j = 0; j < m; j++) outPositions[i * maxPerProbe + j] = ix.posIs64 ? (int64_t)ix.positions64[first + j] : (int64_t)ix.positions32[first + j];
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  void ensure(size_t count) {
+    if (count <= n && p) return;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = count ? count : 1;
+    HIP_CHECK(hipMalloc((void**)&p, n * sizeof(T)));
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct xm_index {
+  HostIndex host;
+  bool hostOnly = false;
+  int device = 0;
+  std::mutex mu;
+  // device residency
+  DevBuf<int64_t> dContigStart, dSeqCumStart, dDupKeyStart;
+  DevBuf<int32_t> dContigLen, dDupKeys;
+  DevBuf<uint8_t> dRefCodes;
+  DevBuf<Table> dTables;
+  DevBuf<uint32_t> dBucketOff, dPositions32;
+  DevBuf<uint64_t> dPositions64;
+  bool posIs64 = false;
+  IndexView view;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // per-call scratch kept across calls
+  DevBuf<uint8_t> dArenas, dCodes;
+  DevBuf<int32_t> dMateCount, dMateLength, dStatus, dIntLen, dDblLen, dOutInts;
+  DevBuf<int64_t> dMateOffset, dIntOff, dDblOff, dTodo;
+  DevBuf<double> dExpected, dDeviation, dOutDbls;
+  DevBuf<unsigned long long> dCursors;  // [0],[1] result cursors, [2] next item
+  DevBuf<DevCounters> dCounters;
+  int numCUs = 0;
+
+  void upload() {
+    HIP_CHECK(hipSetDevice(device));
+    if (!stream) { HIP_CHECK(hipStreamCreate(&stream)); HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); }
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    numCUs = prop.multiProcessorCount;
+    auto up = [&](auto& buf, const auto& vec) {
+      buf.ensure(vec.size());
+      if (!vec.empty()) HIP_CHECK(hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice));
+    };
+    up(dContigStart, host.contigStart); up(dContigLen, host.contigLen); up(dSeqCumStart, host.seqCumStart); up(dRefCodes, host.refCodes);
+    up(dTables, host.tables); up(dBucketOff, host.bucketOff); up(dDupKeyStart, host.dupKeyStart);
+    dDupKeys.ensure(host.dupKeys.size());
+    if (!host.dupKeys.empty()) HIP_CHECK(hipMemcpy(dDupKeys.p, host.dupKeys.data(), host.dupKeys.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    posIs64 = host.seqCumStart.back() > 0xFFFFFFFFll;
+    if (posIs64) {
+      up(dPositions64, host.positions);
+    } else {
+      std::vector<uint32_t> p32(host.positions.size());
+      for (size_t i = 0; i < p32.size(); i++) p32[i] = (uint32_t)host.positions[i];
+      up(dPositions32, p32);
+    }
+    view.numContigs = host.numContigs(); view.minInterestingSize = host.minInterestingSize; view.maxHashedLength = host.maxHashedLength;
+    view.enableGapmers = host.enableGapmers; view.posIs64 = posIs64 ? 1 : 0; view.dupWindow = host.dupWindow; view.dupGranularity = host.dupGranularity();
+    view.totalForwardAndReverseSize = host.totalForwardSize * 2;
+    view.contigStart = dContigStart.p; view.contigLen = dContigLen.p; view.seqCumStart = dSeqCumStart.p; view.refCodes = dRefCodes.p;
+    view.tables = dTables.p; view.bucketOff = dBucketOff.p; view.positions32 = dPositions32.p; view.positions64 = dPositions64.p;
+    view.dupKeyStart = dDupKeyStart.p; view.dupKeys = dDupKeys.p;
+  }
+  ~xm_index() {
+    if (hostOnly) return;
+    dContigStart.release(); dSeqCumStart.release(); dDupKeyStart.release(); dContigLen.release(); dDupKeys.release(); dRefCodes.release();
+    dTables.release(); dBucketOff.release(); dPositions32.release(); dPositions64.release(); dArenas.release(); dCodes.release();
+    dMateCount.release(); dMateLength.release(); dStatus.release(); dIntLen.release(); dDblLen.release(); dOutInts.release();
+    dMateOffset.release(); dIntOff.release(); dDblOff.release(); dTodo.release(); dExpected.release(); dDeviation.release(); dOutDbls.release();
+    dCursors.release(); dCounters.release();
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+extern "C" {
+
+const char* xm_last_error(void) { return g_error.c_str(); }
+
+int xm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int xm_index_build(const xm_ref* ref, const xm_build_opts* optsIn, xm_index** out) {
+  if (!ref || !out) return fail("xm_index_build: null argument");
+  xm_build_opts o;
+  memset(&o, 0, sizeof(o));
+  o.enable_gapmers = 1; o.dup_window = 1000; o.dup_min_copies = 2; o.device = -1;
+  if (optsIn) o = *optsIn;
+  xm_index* idx = nullptr;
+  try {
+    idx = new xm_index();
+    idx->host.setReference(ref->num_contigs, ref->names, ref->codes, ref->lengths);
+    idx->host.build(o.enable_gapmers, o.min_interesting_size, o.max_hashed_length, o.dup_window, o.dup_min_copies, o.dup_min_length, o.dup_max_length);
+    idx->hostOnly = o.host_only != 0;
+    if (!idx->hostOnly) {
+      int n = 0;
+      if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+        throw std::runtime_error("no HIP device available: libxmapper_hip.so has no CPU path (pass host_only=1 only to inspect the index)");
+      int dev = o.device;
+      if (dev < 0) HIP_CHECK(hipGetDevice(&dev));
+      idx->device = dev;
+      idx->upload();
+    }
+    *out = idx;
+    return 0;
+  } catch (std::exception& e) {
+    delete idx;
+    return fail(std::string("xm_index_build: ") + e.what());
+  }
+}
+
+int xm_index_ensure_length(xm_index* idx, int32_t length) {
+  if (!idx) return fail("null index");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (length <= idx->host.maxHashedLength) return 0;
+    idx->host.ensureLength(length);
+    if (!idx->hostOnly) idx->upload();
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_index_ensure_length: ") + e.what()); }
+}
+
+void xm_index_free(xm_index* idx) { delete idx; }
+
+int xm_index_get_info(const xm_index* idx, xm_index_info_t* info) {
+  if (!idx || !info) return fail("null argument");
+  const HostIndex& h = idx->host;
+  info->num_contigs = h.numContigs(); info->min_interesting_size = h.minInterestingSize; info->max_hashed_length = h.maxHashedLength;
+  info->enable_gapmers = h.enableGapmers; info->dup_window = h.dupWindow; info->position_bytes = h.seqCumStart.back() > 0xFFFFFFFFll ? 8 : 4;
+  info->total_forward_size = h.totalForwardSize;
+  info->num_positions = (int64_t)h.positions.size();
+  info->index_bytes = (int64_t)(h.bucketOff.size() * 4 + h.positions.size() * (size_t)info->position_bytes + h.refCodes.size() + h.dupKeys.size() * 4);
+  info->dup_granularity = h.dupGranularity();
+  return 0;
+}
+
+int xm_index_table_info(const xm_index* idx, int32_t L, int32_t* capacity, int32_t* maxCount, int64_t* numStored, int64_t* numOverfull) {
+  if (!idx) return fail("null index");
+  const HostIndex& h = idx->host;
+  if (L < 0 || L > h.maxHashedLength) return fail("length not hashed");
+  const Table& t = h.tables[(size_t)L];
+  *capacity = t.capacity; *maxCount = t.maxCount;
+  int64_t o = 0;
+  for (int k = 0; k < t.capacity; k++) if (h.bucketOff[(size_t)(t.offBase + k)] & XM_OVERFULL) o++;
+  *numOverfull = o;
+  *numStored = (int64_t)(h.bucketOff[(size_t)(t.offBase + t.capacity)] & ~XM_OVERFULL);
+  return 0;
+}
+
+int xm_index_table_dump(const xm_index* idx, int32_t L, int32_t* counts, int64_t* positionsOut) {
+  if (!idx) return fail("null index");
+  const HostIndex& h = idx->host;
+  if (L < 0 || L > h.maxHashedLength) return fail("length not hashed");
+  const Table& t = h.tables[(size_t)L];
+  int64_t w = 0;
+  for (int k = 0; k < t.capacity; k++) {
+    uint32_t o0 = h.bucketOff[(size_t)(t.offBase + k)], o1 = h.bucketOff[(size_t)(t.offBase + k + 1)];
+    if (o0 & XM_OVERFULL) { counts[k] = -1; continue; }
+    int c = (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
+    counts[k] = c;
+    for (int j = 0; j < c; j++) positionsOut[w++] = (int64_t)h.positions[(size_t)(t.posBase + (o0 & ~XM_OVERFULL) + j)];
+  }
+  return 0;
+}
+
+int64_t xm_index_dup_keys(const xm_index* idx, int32_t contig, int32_t* out, int64_t cap) {
+  if (!idx || contig < 0 || contig >= idx->host.numContigs()) return -1;
+  const HostIndex& h = idx->host;
+  int64_t a = h.dupKeyStart[(size_t)contig], b = h.dupKeyStart[(size_t)contig + 1];
+  for (int64_t i = a; i < b && i - a < cap; i++) out[i - a] = h.dupKeys[(size_t)i];
+  return b - a;
+}
+
+void xm_result_free(xm_result* r) {
+  if (!r) return;
+  free(r->ints); free(r->dbls); free(r->int_off); free(r->dbl_off);
+  free(r);
+}
+
+int xm_align_batch(xm_index* idx, const xm_params* p, const xm_query_batch* b, xm_result** out) {
+  if (!idx || !p || !b || !out) return fail("xm_align_batch: null argument");
+  if (idx->hostOnly) return fail("xm_align_batch: index was built with host_only=1; this library aligns on the GPU only");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    const int64_t nq = b->num_queries;
+    int maxLen = 1;
+    for (int64_t q = 0; q < nq; q++) {
+      if (b->mate_count[q] < 1 || b->mate_count[q] > 2) throw std::runtime_error("mate_count must be 1 or 2");
+      for (int m = 0; m < b->mate_count[q]; m++) {
+        int32_t len = b->mate_length[q * 2 + m];
+        if (len < 1 || len > 60000) throw std::runtime_error("mate length out of range (1..60000)");
+        if (b->mate_offset[q * 2 + m] < 0 || b->mate_offset[q * 2 + m] + len > b->codes_length) throw std::runtime_error("mate outside of codes");
+        if (len > maxLen) maxLen = len;
+      }
+    }
+    if (maxLen > idx->host.maxHashedLength) {  // Readable_HashBlock_Database.getContainingMap growth, done before the launch
+      idx->host.ensureLength(maxLen);
+      idx->upload();
+    }
+    HIP_CHECK(hipSetDevice(idx->device));
+    hipStream_t s = idx->stream;
+    xm_result* res = (xm_result*)calloc(1, sizeof(xm_result));
+    res->num_queries = nq;
+    res->int_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq + 1));
+    res->dbl_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq + 1));
+    if (nq == 0) {
+      res->ints = (int32_t*)malloc(4); res->dbls = (double*)malloc(8); res->int_off[0] = res->dbl_off[0] = 0;
+      *out = res;
+      return 0;
+    }
+    // ---- H2D
+    hipEvent_t e0 = idx->ev0, e1 = idx->ev1;
+    HIP_CHECK(hipEventRecord(e0, s));
+    idx->dMateCount.ensure((size_t)nq); idx->dMateOffset.ensure((size_t)nq * 2); idx->dMateLength.ensure((size_t)nq * 2);
+    idx->dCodes.ensure((size_t)b->codes_length); idx->dExpected.ensure((size_t)nq); idx->dDeviation.ensure((size_t)nq);
+    HIP_CHECK(hipMemcpyAsync(idx->dMateCount.p, b->mate_count, sizeof(int32_t) * (size_t)nq, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(idx->dMateOffset.p, b->mate_offset, sizeof(int64_t) * (size_t)nq * 2, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(idx->dMateLength.p, b->mate_length, sizeof(int32_t) * (size_t)nq * 2, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(idx->dCodes.p, b->codes, (size_t)b->codes_length, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(idx->dExpected.p, b->expected_inner, sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(idx->dDeviation.p, b->deviation, sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipEventRecord(e1, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    res->h2d_ms = ms;
+
+    BatchView bv{nq, idx->dMateCount.p, idx->dMateOffset.p, idx->dMateLength.p, idx->dCodes.p, idx->dExpected.p, idx->dDeviation.p};
+    Params params;
+    params.MutationPenalty = p->MutationPenalty; params.InsertionStart_Penalty = p->InsertionStart_Penalty; params.InsertionExtension_Penalty = p->InsertionExtension_Penalty;
+    params.DeletionStart_Penalty = p->DeletionStart_Penalty; params.DeletionExtension_Penalty = p->DeletionExtension_Penalty; params.MaxErrorRate = p->MaxErrorRate;
+    params.UnalignedPenalty = p->UnalignedPenalty; params.AmbiguityPenalty = p->AmbiguityPenalty; params.Max_PenaltySpan = p->Max_PenaltySpan;
+    params.MaxNumMatches = p->MaxNumMatches; params.StartingInsertionStartFree = 0;
+
+    idx->dStatus.ensure((size_t)nq); idx->dIntOff.ensure((size_t)nq); idx->dDblOff.ensure((size_t)nq); idx->dIntLen.ensure((size_t)nq); idx->dDblLen.ensure((size_t)nq);
+    idx->dCursors.ensure(4); idx->dCounters.ensure(1);
+    HIP_CHECK(hipMemsetAsync(idx->dCounters.p, 0, sizeof(DevCounters), s));
+
+    std::vector<int32_t> status((size_t)nq, -1), intLen((size_t)nq, 0), dblLen((size_t)nq, 0);
+    std::vector<int64_t> intOffA((size_t)nq, 0), dblOffA((size_t)nq, 0);
+    // per-query result slices gathered across launches
+    std::vector<std::vector<int32_t>> lateInts;
+    std::vector<std::vector<double>> lateDbls;
+    std::vector<int64_t> lateIndex((size_t)nq, -1);
+    std::vector<int32_t> arenaInts;
+    std::vector<double> arenaDbls;
+
+    std::vector<int64_t> todo;  // empty = all
+    int scale = 1;
+    bool first = true;
+    unsigned long long intCap = (unsigned long long)nq * 40 + 4096, dblCap = (unsigned long long)nq * 12 + 4096;
+    double kernelMs = 0;
+    int launches = 0;
+    int64_t rerun = 0;
+    const size_t arenaUnit = 288 * 1024;
+    while (true) {
+      long long nTodo = first ? (long long)nq : (long long)todo.size();
+      if (nTodo == 0) break;
+      // lanes: enough waves to cover memory latency, bounded by the scratch budget
+      size_t arenaBytes = arenaUnit * (size_t)scale;
+      long long maxLanesByMem = (long long)((48ull << 30) / arenaBytes);
+      long long lanes = (long long)idx->numCUs * 256 * (scale == 1 ? 2 : 1);
+      if (lanes > maxLanesByMem) lanes = maxLanesByMem;
+      if (lanes > nTodo) lanes = nTodo;
+      lanes = ((lanes + 63) / 64) * 64;
+      if (lanes < 64) lanes = 64;
+      int block = 256;
+      if (lanes < block) block = (int)lanes;
+      int grid = (int)((lanes + block - 1) / block);
+      lanes = (long long)grid * block;
+      idx->dArenas.ensure((size_t)lanes * arenaBytes);
+      idx->dOutInts.ensure((size_t)intCap); idx->dOutDbls.ensure((size_t)dblCap);
+      if (!first) {
+        idx->dTodo.ensure(todo.size());
+        HIP_CHECK(hipMemcpyAsync(idx->dTodo.p, todo.data(), sizeof(int64_t) * todo.size(), hipMemcpyHostToDevice, s));
+      }
+      HIP_CHECK(hipMemsetAsync(idx->dCursors.p, 0, sizeof(unsigned long long) * 4, s));
+      OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
+      HIP_CHECK(hipEventRecord(e0, s));
+      hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, first ? (const int64_t*)nullptr : idx->dTodo.p, nTodo, scale,
+                         idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipEventRecord(e1, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      kernelMs += ms;
+      launches++;
+      // ---- D2H
+      HIP_CHECK(hipEventRecord(e0, s));
+      unsigned long long cursors[4];
+      HIP_CHECK(hipMemcpy(cursors, idx->dCursors.p, sizeof(cursors), hipMemcpyDeviceToHost));
+      std::vector<int32_t> st((size_t)nq), il((size_t)nq), dl((size_t)nq);
+      std::vector<int64_t> io((size_t)nq), dofs((size_t)nq);
+      HIP_CHECK(hipMemcpy(st.data(), idx->dStatus.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(il.data(), idx->dIntLen.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(dl.data(), idx->dDblLen.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(io.data(), idx->dIntOff.p, sizeof(int64_t) * (size_t)nq, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(dofs.data(), idx->dDblOff.p, sizeof(int64_t) * (size_t)nq, hipMemcpyDeviceToHost));
+      size_t usedI = (size_t)std::min<unsigned long long>(cursors[0], intCap), usedD = (size_t)std::min<unsigned long long>(cursors[1], dblCap);
+      std::vector<int32_t> hi(usedI ? usedI : 1);
+      std::vector<double> hd(usedD ? usedD : 1);
+      if (usedI) HIP_CHECK(hipMemcpy(hi.data(), idx->dOutInts.p, sizeof(int32_t) * usedI, hipMemcpyDeviceToHost));
+      if (usedD) HIP_CHECK(hipMemcpy(hd.data(), idx->dOutDbls.p, sizeof(double) * usedD, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipEventRecord(e1, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      res->d2h_ms += ms;
+      std::vector<int64_t> nextScale, nextOut;
+      auto consider = [&](int64_t q) {
+        int32_t code = st[(size_t)q];
+        if (code == XM_OK) {
+          status[(size_t)q] = 0;
+          if (first) { intOffA[(size_t)q] = io[(size_t)q]; dblOffA[(size_t)q] = dofs[(size_t)q]; intLen[(size_t)q] = il[(size_t)q]; dblLen[(size_t)q] = dl[(size_t)q]; }
+          else {
+            lateIndex[(size_t)q] = (int64_t)lateInts.size();
+            lateInts.emplace_back(hi.begin() + io[(size_t)q], hi.begin() + io[(size_t)q] + il[(size_t)q]);
+            lateDbls.emplace_back(hd.begin() + dofs[(size_t)q], hd.begin() + dofs[(size_t)q] + dl[(size_t)q]);
+          }
+        } else if (code == XM_ST_OVERFLOW) nextScale.push_back(q);
+        else if (code == XM_ST_OUT_OVERFLOW) nextOut.push_back(q);
+        else if (code == XM_ST_AMBIGUOUS) throw std::runtime_error("Failed to align query " + std::to_string(q) + ": it contains a non-ACGT base (MultiHashBlock path is not supported by this build)");
+        else if (code == XM_ST_NEED_GROW) throw std::runtime_error("Failed to align query " + std::to_string(q) + ": gapmer longer than the hashed lengths");
+        else throw std::runtime_error("Failed to align query " + std::to_string(q) + ": the reference implementation would have thrown here (status " + std::to_string(code) + ")");
+      };
+      if (first) { for (int64_t q = 0; q < nq; q++) consider(q); arenaInts.swap(hi); arenaDbls.swap(hd); }
+      else for (int64_t q : todo) consider(q);
+      first = false;
+      if (!nextOut.empty()) {  // result arena too small: rerun those reads at the same scale with room to spare
+        todo.swap(nextOut);
+        todo.insert(todo.end(), nextScale.begin(), nextScale.end());
+        intCap = intCap * 4 + 65536; dblCap = dblCap * 4 + 65536;
+        if (!nextScale.empty()) scale *= 4;
+        rerun += (int64_t)todo.size();
+        if (scale > 4096) throw std::runtime_error("scratch scale limit reached");
+        continue;
+      }
+      if (nextScale.empty()) break;
+      todo.swap(nextScale);
+      rerun += (int64_t)todo.size();
+      scale *= 4;
+      if (scale > 4096) throw std::runtime_error("Failed to align: scratch scale limit reached (query needs more than 4096x the default scratch)");
+    }
+    // ---- canonical streams in query order
+    int64_t ti = 0, td = 0;
+    for (int64_t q = 0; q < nq; q++) {
+      res->int_off[q] = ti; res->dbl_off[q] = td;
+      if (lateIndex[(size_t)q] >= 0) { ti += (int64_t)lateInts[(size_t)lateIndex[(size_t)q]].size(); td += (int64_t)lateDbls[(size_t)lateIndex[(size_t)q]].size(); }
+      else { ti += intLen[(size_t)q]; td += dblLen[(size_t)q]; }
+    }
+    res->int_off[nq] = ti; res->dbl_off[nq] = td;
+    res->num_ints = ti; res->num_dbls = td;
+    res->ints = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ti ? ti : 1));
+    res->dbls = (double*)malloc(sizeof(double) * (size_t)(td ? td : 1));
+    for (int64_t q = 0; q < nq; q++) {
+      if (lateIndex[(size_t)q] >= 0) {
+        const auto& vi = lateInts[(size_t)lateIndex[(size_t)q]];
+        const auto& vd = lateDbls[(size_t)lateIndex[(size_t)q]];
+        if (!vi.empty()) memcpy(res->ints + res->int_off[q], vi.data(), vi.size() * sizeof(int32_t));
+        if (!vd.empty()) memcpy(res->dbls + res->dbl_off[q], vd.data(), vd.size() * sizeof(double));
+      } else {
+        if (intLen[(size_t)q]) memcpy(res->ints + res->int_off[q], arenaInts.data() + intOffA[(size_t)q], (size_t)intLen[(size_t)q] * sizeof(int32_t));
+        if (dblLen[(size_t)q]) memcpy(res->dbls + res->dbl_off[q], arenaDbls.data() + dblOffA[(size_t)q], (size_t)dblLen[(size_t)q] * sizeof(double));
+      }
+    }
+    DevCounters dc;
+    HIP_CHECK(hipMemcpy(&dc, idx->dCounters.p, sizeof(dc), hipMemcpyDeviceToHost));
+    res->counters[0] = (int64_t)dc.reads; res->counters[1] = (int64_t)dc.headerProbes; res->counters[2] = (int64_t)dc.bucketFetches; res->counters[3] = (int64_t)dc.hitsFetched;
+    res->counters[4] = (int64_t)dc.candidatesExtended; res->counters[5] = (int64_t)dc.pathAlignerCalls; res->counters[6] = (int64_t)dc.pathAlignerNodes;
+    res->counters[7] = (int64_t)dc.quickAccepts; res->counters[8] = (int64_t)dc.alignmentsOut; res->counters[9] = (int64_t)dc.refWindowBytes; res->counters[10] = (int64_t)dc.readBytes;
+    res->counters[11] = rerun;
+    res->kernel_ms = kernelMs;
+    res->kernel_launches = launches;
+    *out = res;
+    return 0;
+  } catch (std::exception& e) {
+    return fail(std::string("xm_align_batch: ") + e.what());
+  }
+}
+
+int xm_seed_probe(xm_index* idx, int64_t n, const int32_t* usedLength, const int32_t* keys, int32_t maxPerProbe, int32_t* counts, int64_t* outPositions, double* kernelMs) {
+  if (!idx || idx->hostOnly) return fail("xm_seed_probe: needs a device-resident index");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    HIP_CHECK(hipSetDevice(idx->device));
+    hipStream_t s = idx->stream;
+    DevBuf<int32_t> dUsed, dKeys, dCounts;
+    DevBuf<int64_t> dPos;
+    dUsed.ensure((size_t)n); dKeys.ensure((size_t)n); dCounts.ensure((size_t)n); dPos.ensure((size_t)n * (size_t)(maxPerProbe > 0 ? maxPerProbe : 1));
+    HIP_CHECK(hipMemcpyAsync(dUsed.p, usedLength, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(dKeys.p, keys, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+    int block = 256;
+    int grid = (int)((n + block - 1) / block);
+    HIP_CHECK(hipEventRecord(idx->ev0, s));
+    if (n > 0) hipLaunchKernelGGL(xm_seed_probe_kernel, dim3(grid), dim3(block), 0, s, idx->view, (long long)n, dUsed.p, dKeys.p, (int)maxPerProbe, dCounts.p, dPos.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(idx->ev1, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
+    if (kernelMs) *kernelMs = ms;
+    HIP_CHECK(hipMemcpy(counts, dCounts.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    if (outPositions && maxPerProbe > 0) HIP_CHECK(hipMemcpy(outPositions, dPos.p, sizeof(int64_t) * (size_t)n * (size_t)maxPerProbe, hipMemcpyDeviceToHost));
+    dUsed.release(); dKeys.release(); dCounts.release(); dPos.release();
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_seed_probe: ") + e.what()); }
+}
+
+}  // extern "C"

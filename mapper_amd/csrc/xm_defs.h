@@ -1,0 +1,189 @@
+// xmapper-hip device core: shared definitions.
+//
+// The per-read seed-and-extend path of X-Mapper (reference: /root/reference/src/main/java/mapper/, cited as M/)
+// written for gfx950.  All code in csrc/xm_*.h is plain C-style C++ with fixed-capacity arrays carved out of a
+// per-read scratch arena in HBM, no recursion, no host library calls; fp64 in the reference's evaluation order
+// (build with -ffp-contract=off).  The same sources compile for the host (XM_HD empty) ONLY for the CPU-side
+// simulation harness under tests/hostsim, which exists so the kernel logic can be checked where there is no GPU;
+// libxmapper_hip.so never contains or calls a host build of this code.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define XM_HD __host__ __device__
+#define XM_INL __host__ __device__ __forceinline__
+#define XM_NOINL __host__ __device__ __noinline__
+#else
+#define XM_HD
+#define XM_INL inline
+#define XM_NOINL
+#endif
+
+namespace xm {
+
+// ---------------------------------------------------------------- status codes (per read)
+enum : int32_t {
+  XM_OK = 0,
+  XM_ST_OVERFLOW = 1,      // a fixed-capacity scratch structure overflowed: rerun this read with a larger scale
+  XM_ST_OUT_OVERFLOW = 2,  // the result arena overflowed: rerun with a larger result arena
+  XM_ST_AMBIGUOUS = 3,     // read contains non-ACGT bases (MultiHashBlock path): not supported by this build
+  XM_ST_NEED_GROW = 4,     // a gapmer uses more bases than the largest hashed length (host must grow the index)
+  XM_ST_INTERNAL = 5,      // the reference would have thrown (e.g. TreeMap.subMap fromKey > toKey): whole batch fails
+};
+
+// ---------------------------------------------------------------- Java arithmetic
+XM_INL int32_t jadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+XM_INL int32_t jmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+XM_INL int32_t jabs(int32_t v) { return v == INT32_MIN ? v : (v < 0 ? -v : v); }
+XM_INL int32_t j2i(double d) {  // (int)double: truncation, saturation, NaN -> 0
+  if (d != d) return 0;
+  if (d >= 2147483647.0) return INT32_MAX;
+  if (d <= -2147483648.0) return INT32_MIN;
+  return (int32_t)d;
+}
+XM_INL double dmin(double a, double b) { return a < b ? a : b; }  // Math.min on non-NaN operands
+XM_INL double dmax(double a, double b) { return a > b ? a : b; }
+XM_INL double jmaxd(double a, double b) {  // Math.max incl. NaN propagation
+  if (a != a || b != b) return NAN;
+  return a > b ? a : b;
+}
+XM_INL int imin(int a, int b) { return a < b ? a : b; }
+XM_INL int imax(int a, int b) { return a > b ? a : b; }
+XM_INL int iabs(int a) { return a < 0 ? -a : a; }
+XM_INL double jnextUp(double d) {  // Math.nextUp
+  if (d != d || d == INFINITY) return d;
+  if (d == 0.0) { uint64_t b = 1; double r; __builtin_memcpy(&r, &b, 8); return r; }
+  uint64_t b;
+  __builtin_memcpy(&b, &d, 8);
+  if (d > 0) b += 1; else b -= 1;
+  double r;
+  __builtin_memcpy(&r, &b, 8);
+  return r;
+}
+
+// ---------------------------------------------------------------- Basepairs (4-bit IUPAC mask A=1 C=2 G=4 T=8)
+XM_INL uint8_t bpComplement(uint8_t b) { return (uint8_t)(((b & 1) << 3) | ((b & 2) << 1) | ((b & 4) >> 1) | ((b & 8) >> 3)); }
+XM_INL bool bpCanMatch(uint8_t a, uint8_t b) { return (a & b) != 0; }
+XM_INL int bpPop(uint8_t b) { return __builtin_popcount(b & 15); }
+XM_INL bool bpIsAmbiguous(uint8_t b) { return bpPop(b) != 1; }
+XM_INL bool bpIsFullyAmbiguous(uint8_t b) { return (b & 15) == 15; }
+XM_INL double bpFalseNegativeRate(uint8_t b) { int n = bpPop(b); return n <= 1 ? 0.0 : (double)(n - 1) / 3.0; }
+
+// A sequence view: forward bytes in memory, optionally read as its reverse complement.
+// `rc` doubles as Sequence.getComplementedFrom() != null.
+struct SeqView {
+  const uint8_t* base;
+  int32_t len;
+  uint8_t rc;
+  uint8_t id;  // identity (Java object identity): queries: mate*2+rc, 4 = joined; references: unused
+  XM_INL uint8_t at(int i) const { return rc ? bpComplement(base[len - 1 - i]) : base[i]; }
+};
+
+// ---------------------------------------------------------------- AlignmentParameters (M/AlignmentParameters.java:8-35)
+struct Params {
+  double MutationPenalty, InsertionStart_Penalty, InsertionExtension_Penalty, DeletionStart_Penalty, DeletionExtension_Penalty,
+      MaxErrorRate, UnalignedPenalty, AmbiguityPenalty, Max_PenaltySpan;
+  int32_t MaxNumMatches;
+  int32_t StartingInsertionStartFree;
+  XM_INL double getStartingInsertionStartPenalty() const { return StartingInsertionStartFree ? 0.0 : InsertionStart_Penalty; }  // :36-40
+  XM_INL double getMinPossibleNonzeroPenalty() const {                                                                            // :42-47
+    double r = MutationPenalty;
+    r = dmin(r, getStartingInsertionStartPenalty() + InsertionStart_Penalty);
+    r = dmin(r, DeletionStart_Penalty + DeletionExtension_Penalty);
+    return r;
+  }
+  XM_INL double getPenalty(uint8_t q, uint8_t r) const {  // :156-180
+    if (!bpCanMatch(r, q)) return MutationPenalty;
+    return AmbiguityPenalty * bpFalseNegativeRate((uint8_t)(q | r));
+  }
+};
+
+// ---------------------------------------------------------------- index in HBM
+struct Table {          // one PackedMap (M/PackedMap.java) as CSR
+  int32_t capacity;     // number of buckets (key mod capacity)
+  int32_t maxCount;     // maxInterestingCountPerKey
+  int64_t offBase;      // first entry of this table in bucketOff (capacity+1 entries)
+  int64_t posBase;      // first entry of this table in positions
+};
+static const uint32_t XM_OVERFULL = 0x80000000u;  // bit 31 of bucketOff[k]: bucket k is overfull
+
+struct IndexView {
+  int32_t numContigs, minInterestingSize, maxHashedLength, enableGapmers, posIs64;
+  int32_t dupWindow;
+  double dupGranularity;
+  int64_t totalForwardAndReverseSize;
+  const int64_t* contigStart;   // [numContigs] first base of the forward contig in refCodes
+  const int32_t* contigLen;     // [numContigs]
+  const int64_t* seqCumStart;   // [2*numContigs+1] encoded-position base of fwd0,rev0,fwd1,rev1,...
+  const uint8_t* refCodes;      // forward contigs, one 4-bit code per byte
+  const Table* tables;          // [maxHashedLength+1]
+  const uint32_t* bucketOff;
+  const uint32_t* positions32;
+  const uint64_t* positions64;
+  const int64_t* dupKeyStart;   // [numContigs+1]
+  const int32_t* dupKeys;       // sorted duplication starts per forward contig (M/Readable_DuplicationDetector.java)
+};
+
+XM_INL SeqView refView(const IndexView& ix, int contig, bool rc) {
+  SeqView v;
+  v.base = ix.refCodes + ix.contigStart[contig];
+  v.len = ix.contigLen[contig];
+  v.rc = rc ? 1 : 0;
+  v.id = 0;
+  return v;
+}
+
+// ---------------------------------------------------------------- capacities (scale s = 1, 4, 16, ...)
+struct Caps {
+  int32_t scale;
+  int32_t maxLevels, maxPyramidBlocks, maxHistory, maxCounters, maxPending, maxQM, maxGoodAlignments, maxBlocks,
+      maxNodes, nodeHash, maxBuckets, matcherEntries, maxSections, maxPieces, maxCountMap, maxJoined;
+};
+XM_INL Caps makeCaps(int scale) {
+  Caps c;
+  c.scale = scale;
+  c.maxLevels = 48 * scale;
+  c.maxPyramidBlocks = 1536 * scale;
+  c.maxHistory = 192 * scale;
+  c.maxCounters = 96 * scale;
+  c.maxPending = 64 * scale;
+  c.maxQM = 64 * scale;
+  c.maxGoodAlignments = 16 * scale;
+  c.maxBlocks = 16 * scale;
+  c.maxNodes = 1536 * scale;
+  c.nodeHash = 4096 * scale;  // power of two >= 2 * maxNodes
+  c.maxBuckets = 96 * scale;
+  c.matcherEntries = 6144 * scale;
+  c.maxSections = 40 * scale;
+  c.maxPieces = 16 * scale;
+  c.maxCountMap = 32 * scale;
+  c.maxJoined = 512 * scale;
+  return c;
+}
+
+// ---------------------------------------------------------------- bump arena
+struct Arena {
+  uint8_t* base;
+  size_t size, used;
+  bool overflow;
+  XM_INL void init(void* p, size_t n) { base = (uint8_t*)p; size = n; used = 0; overflow = false; }
+  XM_INL void* alloc(size_t bytes) {
+    size_t a = (used + 15) & ~(size_t)15;
+    if (a + bytes > size) { overflow = true; return (void*)base; }  // caller checks `overflow` before use
+    used = a + bytes;
+    return base + a;
+  }
+};
+template <typename T>
+XM_INL T* arenaArray(Arena& a, size_t n) { return (T*)a.alloc(sizeof(T) * (n ? n : 1)); }
+
+// ---------------------------------------------------------------- counters for the roofline accounting
+struct DevCounters {
+  unsigned long long reads, headerProbes, bucketFetches, hitsFetched, candidatesExtended, pathAlignerCalls, pathAlignerNodes,
+      quickAccepts, blocksOut, alignmentsOut, refWindowBytes, readBytes;
+};
+
+}  // namespace xm

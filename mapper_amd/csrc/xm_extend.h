@@ -1,0 +1,987 @@
+// xmapper-hip device core: the extension chain.
+// Replaces (per candidate, on the GPU): M/StraightAligner.java, M/SkipHighAmbiguity_Aligner.java, M/HashBlock_Aligner.java,
+// M/HashBlock_Matcher.java, M/CountMap.java, M/BlockAligner.java, M/PathAligner.java (+ _Runner, AlignmentNode,
+// AlignmentAnalysis, PenaltyAnalysis), M/AlignmentParameters.java:73-180.
+// The decorator chain of M/QueryMatch_Aligner.java:18-29 is unrolled into straight1 -> skipHighAmbiguity -> hashBlock<1> ->
+// blockAligner -> straight2 -> hashBlock<2> -> straight3 -> pathAligner; HashBlock_Aligner's tail self-call is a loop.
+// All penalties are IEEE doubles evaluated in the reference's order; PathAligner is an exact emulation of the reference's
+// best-first search (bucket-by-exact-double, insertion order inside a bucket, stale re-exploration, == tie-breaks).
+#pragma once
+#include "xm_seed.h"
+
+namespace xm {
+
+struct ABlock { int32_t startA, startB, lenA, lenB; };  // AlignedBlock
+XM_INL int abEndA(const ABlock& b) { return b.startA + b.lenA; }
+XM_INL int abEndB(const ABlock& b) { return b.startB + b.lenB; }
+XM_INL int abIndelType(const ABlock& b) { return b.lenA == b.lenB ? 0 : (b.lenA > b.lenB ? 1 : 2); }
+
+struct SeqAl {  // SequenceAlignment; `blocks` has room for caps.maxBlocks entries
+  ABlock* blocks;
+  int32_t nb;
+  int32_t contig;
+  uint8_t referenceReversed;
+  uint8_t seqAId;
+  double totalPenalty, alignedPenalty;
+};
+XM_INL int saStartA(const SeqAl& a) { return a.blocks[0].startA; }
+XM_INL int saEndA(const SeqAl& a) { return abEndA(a.blocks[a.nb - 1]); }
+XM_INL int saStartB(const SeqAl& a) { return a.blocks[0].startB; }
+XM_INL int saEndB(const SeqAl& a) { return abEndB(a.blocks[a.nb - 1]); }
+XM_INL void saCopy(SeqAl& dst, const SeqAl& src) {
+  dst.nb = src.nb; dst.contig = src.contig; dst.referenceReversed = src.referenceReversed; dst.seqAId = src.seqAId;
+  dst.totalPenalty = src.totalPenalty; dst.alignedPenalty = src.alignedPenalty;
+  for (int i = 0; i < src.nb; i++) dst.blocks[i] = src.blocks[i];
+}
+
+struct Section { int32_t start, end; };  // SequenceSection over a known sequence
+XM_INL int secLen(const Section& s) { return s.end - s.start; }
+
+struct Matcher {  // HashBlock_Matcher
+  int32_t referenceStart, referenceLength, blockLength, sectionLength, maxSectionIndex, numPossibilities, maxPossibility;
+  int32_t nSections;   // locations.size()
+  uint8_t* present;    // [maxSections] 0 = "null" entry
+  int16_t* tables;     // [nSections][numPossibilities], value = position - referenceStart, or -1 / -2
+  int32_t tableCap, maxSections;
+};
+enum : int { M_NO_MATCHES = -1, M_MULTIPLE = -2, M_UNKNOWN = -3 };
+
+struct Analysis {  // AlignmentAnalysis
+  Matcher* matcher;
+  int32_t predictedBestOffset, lastCheckedOffset;
+  bool confidentAboutBestOffset;
+  double maxInsertionExtensionPenalty, maxDeletionExtensionPenalty;
+};
+
+struct ExtEnv {  // everything the chain needs
+  const Caps* caps;
+  DevCounters* dc;
+  int32_t* status;
+  Arena* tmp;        // stack-discipline scratch (mark = tmp->used, release = restore)
+  SeqView query;     // sequenceA
+  SeqView reference; // sequenceB (forward contig)
+  int32_t contig;
+  Matcher* slotA; Matcher* slotB; Matcher* slotT;
+};
+
+// ---------------------------------------------------------------- penalties (M/AlignmentParameters.java)
+XM_INL double blockPenalty(const ExtEnv& e, const Params& p, const ABlock& b) {  // :106-126
+  double penalty = 0;
+  if (b.lenA == b.lenB) {
+    for (int i = 0; i < b.lenA; i++) penalty += p.getPenalty(e.query.at(b.startA + i), e.reference.at(b.startB + i));
+  } else if (b.lenA > 0) {
+    penalty += p.InsertionStart_Penalty;
+    penalty += p.InsertionExtension_Penalty * b.lenA;
+  } else {
+    penalty += p.DeletionStart_Penalty;
+    penalty += p.DeletionExtension_Penalty * b.lenB;
+  }
+  return penalty;
+}
+// newSequenceAlignment :73-95 over out.blocks[0..nb)
+XM_INL void finishSeqAl(const ExtEnv& e, const Params& p, SeqAl& out, bool referenceReversed) {
+  int alignedQueryLength = 0;
+  double totalPenalty = 0;
+  for (int i = 0; i < out.nb; i++) {
+    totalPenalty += blockPenalty(e, p, out.blocks[i]);
+    alignedQueryLength += out.blocks[i].lenA;
+  }
+  if (out.nb > 0 && p.StartingInsertionStartFree && out.blocks[0].lenB == 0) totalPenalty -= p.InsertionStart_Penalty;
+  double alignedPenalty = totalPenalty;
+  if (out.nb > 0) {
+    int unalignedQueryLength = e.query.len - alignedQueryLength;
+    totalPenalty += (double)unalignedQueryLength * p.UnalignedPenalty;
+  }
+  out.referenceReversed = referenceReversed ? 1 : 0;
+  out.seqAId = e.query.id;
+  out.contig = e.contig;
+  out.totalPenalty = totalPenalty;
+  out.alignedPenalty = alignedPenalty;
+}
+
+// ---------------------------------------------------------------- HashBlock_Matcher (M/HashBlock_Matcher.java)
+XM_INL int encodedCharToInt(uint8_t b) { return b == 1 ? 0 : b == 2 ? 1 : b == 4 ? 2 : 3; }  // callers guarantee unambiguous
+XM_INL int matcherSectionIndex(const Matcher& m, int referenceIndex) { return (referenceIndex - m.referenceStart) / m.sectionLength; }
+XM_INL void matcherInit(Matcher& m, const ExtEnv& e, const Section& referenceSection, int sectionLength) {  // :14-29
+  if (sectionLength < 1) sectionLength = 1;
+  // (int)(log(5*sectionLength)/log(4) + 1): 5*sectionLength is never a power of 4, so this is floor(log4(v)) + 1
+  int v = sectionLength * 5, k = 0;
+  long long pw = 1;
+  while (pw * 4 <= v) { pw *= 4; k++; }
+  m.blockLength = k + 1;
+  if (m.blockLength < 3) m.blockLength = 3;
+  m.referenceStart = referenceSection.start;
+  m.referenceLength = secLen(referenceSection);
+  m.sectionLength = sectionLength;
+  m.maxSectionIndex = matcherSectionIndex(m, e.reference.len - 1);
+  m.numPossibilities = 1 << (2 * m.blockLength);
+  m.maxPossibility = m.numPossibilities - 1;
+  m.nSections = 0;
+}
+XM_INL int matcherEncodeBlock(const Matcher& m, const SeqView& s, int index) {  // :79-91
+  if (index + m.blockLength > s.len) return M_UNKNOWN;
+  int sum = 0;
+  for (int i = 0; i < m.blockLength; i++) {
+    uint8_t here = s.at(index + i);
+    if (bpIsAmbiguous(here)) return M_UNKNOWN;
+    sum = sum * 4 + encodedCharToInt(here);
+  }
+  return sum;
+}
+XM_NOINL void matcherIndexSection(Matcher& m, const ExtEnv& e, int sectionIndex, int16_t* section) {  // :40-77
+  for (int i = 0; i < m.numPossibilities; i++) section[i] = M_NO_MATCHES;
+  int previousEncoded = M_UNKNOWN;
+  int startIndex = m.referenceStart + sectionIndex * m.sectionLength;
+  int endIndex = imin(startIndex + m.sectionLength, m.referenceStart + m.referenceLength - m.blockLength);
+  for (int i = startIndex; i < endIndex; i++) {
+    int encoded;
+    if (previousEncoded == M_UNKNOWN) {
+      encoded = matcherEncodeBlock(m, e.reference, i);
+    } else {
+      uint8_t nextChar = e.reference.at(i + m.blockLength - 1);
+      if (bpIsAmbiguous(nextChar)) encoded = M_UNKNOWN;
+      else encoded = ((previousEncoded * 4) & m.maxPossibility) + encodedCharToInt(nextChar);
+    }
+    if (encoded == M_UNKNOWN) continue;  // (sic) previousEncoded keeps its stale value
+    int16_t existing = section[encoded];
+    section[encoded] = (existing == M_NO_MATCHES) ? (int16_t)(i - m.referenceStart) : (int16_t)M_MULTIPLE;
+    previousEncoded = encoded;
+  }
+}
+// getSection :203-215; returns -1 for a "null" entry (a section skipped by an earlier jump), else the section slot
+XM_INL int matcherGetSection(Matcher& m, const ExtEnv& e, int index) {
+  if (m.nSections > index) return m.present[index] ? index : -1;
+  if (index >= m.maxSections || (long long)(index + 1) * m.numPossibilities > m.tableCap) { *e.status = XM_ST_OVERFLOW; return -1; }
+  while (m.nSections <= index) m.present[m.nSections++] = 0;
+  m.present[index] = 1;
+  matcherIndexSection(m, e, index, m.tables + (size_t)index * m.numPossibilities);
+  return index;
+}
+XM_INL bool matcherCanPositionsMatch(const Matcher& m, const ExtEnv& e, int queryIndex, int referenceIndex) {  // :159-171
+  if (referenceIndex + m.blockLength > m.referenceStart + m.referenceLength) return false;
+  for (int i = 0; i < m.blockLength; i++) if (!bpCanMatch(e.query.at(queryIndex + i), e.reference.at(referenceIndex + i))) return false;
+  return true;
+}
+XM_NOINL int matcherLookup(Matcher& m, const ExtEnv& e, int queryIndex, int minReferenceIndex, int maxReferenceIndex) {  // :98-141
+  if (minReferenceIndex < 0) return M_UNKNOWN;
+  if (maxReferenceIndex > e.reference.len) return M_UNKNOWN;
+  int encoded = matcherEncodeBlock(m, e.query, queryIndex);
+  if (encoded < 0) return M_UNKNOWN;
+  int matched = M_NO_MATCHES;
+  int minSectionIndex = imax(0, matcherSectionIndex(m, minReferenceIndex));
+  int maxSection = imin(m.maxSectionIndex, matcherSectionIndex(m, maxReferenceIndex));
+  for (int sectionIndex = minSectionIndex; sectionIndex <= maxSection; sectionIndex++) {
+    int slot = matcherGetSection(m, e, sectionIndex);
+    if (*e.status) return M_UNKNOWN;
+    int lookedUp;
+    if (m.sectionLength < 3) {  // scanSection :143-157
+      lookedUp = M_NO_MATCHES;
+      int startIndex = m.referenceStart + sectionIndex * m.sectionLength;
+      int endIndex = startIndex + m.sectionLength;
+      for (int i = startIndex; i < endIndex; i++) {
+        if (matcherCanPositionsMatch(m, e, queryIndex, i)) {
+          if (lookedUp == M_NO_MATCHES) lookedUp = i; else { lookedUp = M_MULTIPLE; break; }
+        }
+      }
+    } else if (slot >= 0) {
+      int16_t v = m.tables[(size_t)slot * m.numPossibilities + encoded];
+      lookedUp = v >= 0 ? (int)v + m.referenceStart : (int)v;
+    } else {
+      return M_UNKNOWN;
+    }
+    if (lookedUp == M_UNKNOWN) return M_UNKNOWN;
+    if (lookedUp == M_MULTIPLE) return M_MULTIPLE;
+    if (lookedUp == M_NO_MATCHES) continue;
+    if (lookedUp < minReferenceIndex || lookedUp > maxReferenceIndex) continue;
+    if (matched != M_NO_MATCHES) return M_MULTIPLE;
+    matched = lookedUp;
+  }
+  return matched;
+}
+
+// ---------------------------------------------------------------- CountMap (M/CountMap.java)
+struct CountMap {
+  int32_t mostPopularKey, mostPopularCount, n, cap;
+  bool haveCounts;
+  int32_t* keys; int32_t* vals;
+  int32_t* status;
+  XM_INL void put(int key, int value) {
+    for (int i = 0; i < n; i++) if (keys[i] == key) { vals[i] = value; return; }
+    if (n >= cap) { *status = XM_ST_OVERFLOW; return; }
+    keys[n] = key; vals[n] = value; n++;
+  }
+  XM_INL void add(int key, int value) {
+    if (key == mostPopularKey || mostPopularCount == 0) {
+      mostPopularCount += value;
+      mostPopularKey = key;
+      if (haveCounts) put(mostPopularKey, mostPopularCount);
+    } else {
+      if (!haveCounts) { haveCounts = true; put(mostPopularKey, mostPopularCount); }
+      int count = value;
+      for (int i = 0; i < n; i++) if (keys[i] == key) { count = vals[i] + value; break; }
+      put(key, count);
+      if (count > mostPopularCount) { mostPopularKey = key; mostPopularCount = count; }
+    }
+  }
+};
+
+// ---------------------------------------------------------------- PathAligner (M/PathAligner.java)
+struct PathAligner {
+  static constexpr double disallowed = 1000000.0;
+  // node pool (SoA)
+  int16_t* nx; int16_t* ny; double* npen; double* nix; double* niy; uint8_t* nfl;  // fl: 1 reachedMain, 2 reachedOther
+  int32_t nNodes, maxNodes;
+  int32_t* hash; int32_t hashMask;  // (x,y) -> latest node index + 1
+  // prioritizedNodes: bucket per exact double key; list entries in insertion order
+  double* bkey; int32_t* bhead; int32_t* btail; int32_t nBuckets, maxBuckets;
+  int16_t* lx; int16_t* ly; int32_t* lnext; int32_t nList;
+  // problem
+  Params parameters;
+  const ExtEnv* e;
+  Analysis* analysis;
+  int32_t startIndexA, endIndexA, startIndexB, endIndexB, textALength, textBLength;
+  int32_t startX, startY, goalX, goalY, diagonal, stepDelta;
+  double maxInterestingPenalty, activePenalty;
+  bool mayQueryExtendPastEndOfReference, searchReverse;
+
+  XM_INL uint8_t charA(int i) const { return e->query.at(startIndexA + i); }
+  XM_INL uint8_t charB(int i) const { return e->reference.at(startIndexB + i); }
+  XM_INL int signedDist(int x, int y) const { return x - y - diagonal; }
+
+  XM_INL int findNode(int x, int y) const {  // getNode :541-553
+    if (x < 0 || y < 0) return -1;
+    uint32_t key = ((uint32_t)x << 16) | (uint32_t)(y & 0xFFFF);
+    uint32_t h = (key * 2654435761u) & (uint32_t)hashMask;
+    while (true) {
+      int32_t v = hash[h];
+      if (v == 0) return -1;
+      int idx = v - 1;
+      if (nx[idx] == x && ny[idx] == y) return idx;
+      h = (h + 1) & (uint32_t)hashMask;
+    }
+  }
+  XM_INL void saveNode(int idx) {  // :523-539 (overwrites the node at (x,y))
+    int x = nx[idx], y = ny[idx];
+    if (x < 0 || y < 0) return;
+    uint32_t key = ((uint32_t)x << 16) | (uint32_t)(y & 0xFFFF);
+    uint32_t h = (key * 2654435761u) & (uint32_t)hashMask;
+    while (true) {
+      int32_t v = hash[h];
+      if (v == 0) { hash[h] = idx + 1; return; }
+      int o = v - 1;
+      if (nx[o] == x && ny[o] == y) { hash[h] = idx + 1; return; }
+      h = (h + 1) & (uint32_t)hashMask;
+    }
+  }
+  XM_INL double estimateOverallPenalty(int x, int y, double pen, double insX, double insY, uint8_t fl) const {  // :475-521
+    if (!analysis->confidentAboutBestOffset) return pen;
+    int sd = signedDist(x, y);
+    if (fl & 1) {
+      if (sd * stepDelta > 0) {
+        double ext = fabs(sd * parameters.InsertionExtension_Penalty);
+        if (ext > analysis->maxInsertionExtensionPenalty) return disallowed;
+      } else {
+        double ext = fabs(sd * parameters.DeletionExtension_Penalty);
+        if (ext > analysis->maxDeletionExtensionPenalty) return disallowed;
+      }
+      if (fl & 2) return pen;
+      double indelPenalty = dmin(parameters.InsertionStart_Penalty + parameters.InsertionExtension_Penalty, parameters.DeletionStart_Penalty + parameters.DeletionExtension_Penalty);
+      return pen + indelPenalty;
+    }
+    if (sd * stepDelta < 0) {
+      double ext = fabs(sd * parameters.InsertionExtension_Penalty);
+      if (ext > analysis->maxInsertionExtensionPenalty) return disallowed;
+      double startP = dmin(parameters.InsertionStart_Penalty, insX - pen);
+      return pen + startP + ext;
+    } else {
+      double ext = fabs(sd * parameters.DeletionExtension_Penalty);
+      if (ext > analysis->maxDeletionExtensionPenalty) return disallowed;
+      double startP = dmin(parameters.DeletionStart_Penalty, insY - pen);
+      return pen + startP + ext;
+    }
+  }
+  XM_NOINL void putNode(int x, int y, double pen, double insX, double insY, uint8_t fl) {  // :446-473
+    double est = estimateOverallPenalty(x, y, pen, insX, insY, fl);
+    if (est < activePenalty) est = activePenalty;
+    if (nNodes >= maxNodes) { *e->status = XM_ST_OVERFLOW; return; }
+    int b = -1;
+    for (int i = 0; i < nBuckets; i++) if (bkey[i] == est) { b = i; break; }
+    if (b < 0) {
+      if (nBuckets >= maxBuckets) { *e->status = XM_ST_OVERFLOW; return; }
+      b = nBuckets++;
+      bkey[b] = est; bhead[b] = -1; btail[b] = -1;
+    }
+    int li = nList++;
+    lx[li] = (int16_t)x; ly[li] = (int16_t)y; lnext[li] = -1;
+    if (btail[b] >= 0) lnext[btail[b]] = li; else bhead[b] = li;
+    btail[b] = li;
+    int idx = nNodes++;
+    nx[idx] = (int16_t)x; ny[idx] = (int16_t)y; npen[idx] = pen; nix[idx] = insX; niy[idx] = insY; nfl[idx] = fl;
+    saveNode(idx);
+    if (e->dc) e->dc->pathAlignerNodes++;
+  }
+  XM_NOINL void update(int x, int y) {  // :555-571 + computeUpdated :573-719
+    if (x <= 0 || x > textALength) return;
+    if (y <= 0 || y > textBLength) return;
+    int existing = findNode(x, y);
+    int left = findNode(x - stepDelta, y);
+    int up = findNode(x, y - stepDelta);
+    int diag = findNode(x - stepDelta, y - stepDelta);
+    double insertXPenalty = disallowed, insertYPenalty = disallowed, overlayPenalty = disallowed;
+    if (diag >= 0) overlayPenalty = npen[diag] + parameters.getPenalty(charA(x - 1), charB(y - 1));
+    if (left >= 0) {
+      if (y == goalY && mayQueryExtendPastEndOfReference) {
+        insertXPenalty = npen[left] + parameters.UnalignedPenalty;
+      } else {
+        bool allowed = true;
+        int prevA = x - 1 - stepDelta, prevB = y - 1;
+        if (prevA >= 0 && prevA < textALength && prevB >= 0 && prevB < textBLength) {
+          if (!bpCanMatch(charA(prevA), charB(prevB))) allowed = false;
+        }
+        if (allowed) {
+          int nextA = x - 1, nextB = y - 1 + stepDelta;
+          if (nextA >= 0 && nextA < textALength && nextB >= 0 && nextB < textBLength) {
+            uint8_t a = charA(nextA), b = charB(nextB);
+            if (parameters.getPenalty(a, b) == 0) allowed = false;
+            else if (bpIsFullyAmbiguous(a) || bpIsFullyAmbiguous(b)) allowed = false;
+          }
+        }
+        double newInsertX = allowed ? npen[left] + parameters.InsertionStart_Penalty + parameters.InsertionExtension_Penalty : disallowed;
+        double extendInsertX = nix[left] + parameters.InsertionExtension_Penalty;
+        insertXPenalty = dmin(extendInsertX, newInsertX);
+      }
+    }
+    if (up >= 0) {
+      bool allowed = true;
+      int prevA = x - 1, prevB = y - 1 - stepDelta;
+      if (prevA >= 0 && prevA < textALength && prevB >= 0 && prevB < textBLength) {
+        if (!bpCanMatch(charA(prevA), charB(prevB))) allowed = false;
+      }
+      if (allowed) {
+        int nextA = x - 1 + stepDelta, nextB = y - 1;
+        if (nextA >= 0 && nextA < textALength && nextB >= 0 && nextB < textBLength) {
+          uint8_t a = charA(nextA), b = charB(nextB);
+          if (parameters.getPenalty(a, b) == 0) allowed = false;
+          else if (bpIsFullyAmbiguous(a) || bpIsFullyAmbiguous(b)) allowed = false;
+        }
+      }
+      double newInsertY = allowed ? npen[up] + parameters.DeletionStart_Penalty + parameters.DeletionExtension_Penalty : disallowed;
+      double extendInsertY = niy[up] + parameters.DeletionExtension_Penalty;
+      insertYPenalty = dmin(extendInsertY, newInsertY);
+    }
+    double bestPenalty = dmin(dmin(overlayPenalty, insertXPenalty), insertYPenalty);
+    if (existing < 0 || bestPenalty < npen[existing] || insertXPenalty < nix[existing] || insertYPenalty < niy[existing]) {
+      uint8_t fl = 0;
+      if (bestPenalty != disallowed) {
+        if (bestPenalty == overlayPenalty) fl = nfl[diag];
+        else if (bestPenalty == insertXPenalty) fl = nfl[left];
+        else fl = nfl[up];
+        if (iabs(signedDist(x, y)) == 0) fl |= 1; else fl |= 2;
+      }
+      putNode(x, y, bestPenalty, insertXPenalty, insertYPenalty, fl);
+    }
+  }
+  XM_INL bool chooseSearchReverse() const {  // :17-53
+    int sumMis = 0, numMis = 0, sumMatch = 0, numMatch = 0;
+    int offset = analysis->predictedBestOffset;
+    int s = imax(startIndexA, startIndexB - offset);
+    int t = imin(endIndexA, endIndexB - offset);
+    int length = t - s;
+    for (int i = 0; i < length; i++) {
+      int j = i - diagonal;
+      if (j >= 0 && j < textBLength) {
+        if (!bpCanMatch(charA(i), charB(j))) { sumMis += i; numMis++; } else { sumMatch += i; numMatch++; }
+      }
+    }
+    if (numMis > 1 && numMatch > 1) return (sumMis / numMis) > (sumMatch / numMatch);
+    return true;
+  }
+};
+
+XM_INL bool paCanRemoveSection(const ABlock& b) {  // :358-366
+  if (b.lenA <= 0 && b.lenB <= 0) return true;
+  if ((b.startA <= 0 && b.lenA <= 0) || (b.startB <= 0 && b.lenB <= 0)) return true;
+  return false;
+}
+
+// PathAligner.align :55-293.  false = null
+XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, const Params& params, Analysis& analysis, SeqAl& out) {
+  Arena& tmp = *e.tmp;
+  size_t mark = tmp.used;
+  const Caps& caps = *e.caps;
+  PathAligner pa;
+  pa.e = &e;
+  pa.analysis = &analysis;
+  pa.parameters = params;
+  pa.maxNodes = caps.maxNodes;
+  pa.nx = arenaArray<int16_t>(tmp, caps.maxNodes); pa.ny = arenaArray<int16_t>(tmp, caps.maxNodes);
+  pa.npen = arenaArray<double>(tmp, caps.maxNodes); pa.nix = arenaArray<double>(tmp, caps.maxNodes); pa.niy = arenaArray<double>(tmp, caps.maxNodes);
+  pa.nfl = arenaArray<uint8_t>(tmp, caps.maxNodes);
+  pa.hash = arenaArray<int32_t>(tmp, caps.nodeHash);
+  pa.hashMask = caps.nodeHash - 1;
+  pa.maxBuckets = caps.maxBuckets;
+  pa.bkey = arenaArray<double>(tmp, caps.maxBuckets); pa.bhead = arenaArray<int32_t>(tmp, caps.maxBuckets); pa.btail = arenaArray<int32_t>(tmp, caps.maxBuckets);
+  pa.lx = arenaArray<int16_t>(tmp, caps.maxNodes); pa.ly = arenaArray<int16_t>(tmp, caps.maxNodes); pa.lnext = arenaArray<int32_t>(tmp, caps.maxNodes);
+  if (tmp.overflow) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+  for (int i = 0; i < caps.nodeHash; i++) pa.hash[i] = 0;
+  pa.nNodes = 0; pa.nBuckets = 0; pa.nList = 0;
+  pa.activePenalty = 0;
+  if (e.dc) e.dc->pathAlignerCalls++;
+
+  pa.maxInterestingPenalty = secLen(qs) * params.MaxErrorRate;
+  pa.startIndexA = qs.start; pa.endIndexA = qs.end; pa.startIndexB = rs.start; pa.endIndexB = rs.end;
+  pa.textALength = secLen(qs); pa.textBLength = secLen(rs);
+  if (pa.textALength + 2 > 32000 || pa.textBLength + 2 > 32000) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+  pa.diagonal = pa.startIndexB - (pa.startIndexA + analysis.predictedBestOffset);
+  pa.stepDelta = 1;
+  pa.searchReverse = pa.chooseSearchReverse();
+  if (pa.searchReverse) { pa.stepDelta = -1; pa.mayQueryExtendPastEndOfReference = pa.startIndexB == 0; }
+  else { pa.stepDelta = 1; pa.mayQueryExtendPastEndOfReference = pa.endIndexB == e.reference.len; }
+  int width = pa.textALength + 2, height = pa.endIndexB - pa.startIndexB + 2;
+  if (pa.searchReverse) { pa.startX = width - 1; pa.startY = height - 1; pa.goalX = 1; pa.goalY = 1; }
+  else { pa.startX = 0; pa.startY = 0; pa.goalX = width - 2; pa.goalY = height - 2; }
+  const double disallowed = PathAligner::disallowed;
+  if (pa.textBLength >= pa.textALength) {
+    double startingInsertionStartPenalty = params.getStartingInsertionStartPenalty();
+    if (!pa.mayQueryExtendPastEndOfReference) startingInsertionStartPenalty = disallowed;
+    int initialDeletionCount = imax(0, pa.textBLength - pa.textALength) + 1;
+    for (int i = 0; i < initialDeletionCount && !*e.status; i++) pa.putNode(pa.startX, pa.startY + i * pa.stepDelta, 0, startingInsertionStartPenalty, disallowed, 0);
+  } else {
+    int initialInsertionCount = imax(0, pa.textALength - pa.textBLength) + 1;
+    for (int i = 0; i < initialInsertionCount && !*e.status; i++) pa.putNode(pa.startX + i * pa.stepDelta, pa.startY, 0, disallowed, disallowed, 0);
+  }
+  if (pa.mayQueryExtendPastEndOfReference) {
+    int initialInsertionCount = j2i(analysis.maxInsertionExtensionPenalty / params.DeletionExtension_Penalty);
+    for (int i = 1; i < initialInsertionCount && !*e.status; i++) pa.putNode(pa.startX + i * pa.stepDelta, pa.startY, i * params.UnalignedPenalty, disallowed, disallowed, 0);
+  }
+  bool haveLast = false;
+  int lastX = 0, lastY = 0;
+  while (!haveLast) {
+    if (*e.status) { tmp.used = mark; return false; }
+    // priorities.poll(): smallest live key
+    int b = -1;
+    for (int i = 0; i < pa.nBuckets; i++) if (b < 0 || pa.bkey[i] < pa.bkey[b]) b = i;
+    if (b < 0) { *e.status = XM_ST_INTERNAL; tmp.used = mark; return false; }  // Java: NullPointerException
+    pa.activePenalty = pa.bkey[b];
+    int li = pa.bhead[b];
+    while (li >= 0) {
+      int x = pa.lx[li], y = pa.ly[li];
+      if (pa.activePenalty > pa.maxInterestingPenalty + 0.000001) { tmp.used = mark; return false; }
+      if (x == pa.goalX) { haveLast = true; lastX = x; lastY = y; break; }
+      pa.update(x + pa.stepDelta, y);  // explore :722-729
+      pa.update(x, y + pa.stepDelta);
+      pa.update(x + pa.stepDelta, y + pa.stepDelta);
+      if (*e.status) { tmp.used = mark; return false; }
+      li = pa.lnext[li];
+    }
+    // prioritizedNodes.remove(activePenalty): swap-remove the bucket
+    pa.nBuckets--;
+    pa.bkey[b] = pa.bkey[pa.nBuckets]; pa.bhead[b] = pa.bhead[pa.nBuckets]; pa.btail[b] = pa.btail[pa.nBuckets];
+  }
+  // traceback :195-264
+  int i = lastX, j = lastY;
+  int nb = 0;
+  const int sd = pa.stepDelta;
+  const int sA = pa.startIndexA, sB = pa.startIndexB;
+  while (i != pa.startX && j != pa.startY) {
+    if (nb >= caps.maxBlocks) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+    int node = pa.findNode(i, j);
+    double bestPenalty = pa.npen[node], insertXPenalty = pa.nix[node], insertYPenalty = pa.niy[node];
+    ABlock blk;
+    if (bestPenalty == insertXPenalty) {
+      int oldI = i;
+      i -= sd;
+      while (i != pa.startX) {
+        int other = pa.findNode(i, j);
+        double otherNew = pa.npen[other] + params.InsertionStart_Penalty + params.InsertionExtension_Penalty;
+        double otherExtend = pa.nix[other] + params.InsertionExtension_Penalty;
+        if (otherNew < otherExtend) break;
+        i -= sd;
+      }
+      if (pa.searchReverse) blk = ABlock{sA + oldI - 1, sB + j - 1, i - oldI, 0};
+      else blk = ABlock{sA + i, sB + j, oldI - i, 0};
+    } else if (bestPenalty == insertYPenalty) {
+      int oldJ = j;
+      j -= sd;
+      while (j != pa.startY) {
+        int other = pa.findNode(i, j);
+        double otherNew = pa.npen[other] + params.DeletionStart_Penalty + params.DeletionExtension_Penalty;
+        double otherExtend = pa.niy[other] + params.DeletionExtension_Penalty;
+        if (otherNew < otherExtend) break;
+        j -= sd;
+      }
+      if (pa.searchReverse) blk = ABlock{sA + i - 1, sB + oldJ - 1, 0, j - oldJ};
+      else blk = ABlock{sA + i, sB + j, 0, oldJ - j};
+    } else {
+      int oldI = i, oldJ = j;
+      i -= sd;
+      j -= sd;
+      while (i != pa.startX && j != pa.startY) {
+        int other = pa.findNode(i, j);
+        if (pa.npen[other] == pa.nix[other] || pa.npen[other] == pa.niy[other]) break;
+        i -= sd;
+        j -= sd;
+      }
+      if (pa.searchReverse) blk = ABlock{sA + oldI - 1, sB + oldJ - 1, i - oldI, j - oldJ};
+      else blk = ABlock{sA + i, sB + j, oldI - i, oldJ - j};
+    }
+    out.blocks[nb++] = blk;
+  }
+  tmp.used = mark;  // the search structures are dead from here on
+  if (!pa.searchReverse) for (int a = 0, b2 = nb - 1; a < b2; a++, b2--) { ABlock t = out.blocks[a]; out.blocks[a] = out.blocks[b2]; out.blocks[b2] = t; }
+  if (nb < 1) return false;
+  // justify :307-352
+  ABlock* s = out.blocks;
+  for (int k = 1; k < nb - 1; k++) {
+    while (true) {
+      ABlock left = s[k - 1], middle = s[k], right = s[k + 1];
+      if ((middle.lenA > 0) == (middle.lenB > 0)) break;
+      if (left.lenA == 0 || left.lenB == 0) break;
+      if (right.lenA == 0 || right.lenB == 0) break;
+      if (middle.lenA > 0) { if (e.query.at(abEndA(left) - 1) != e.query.at(abEndA(middle) - 1)) break; }
+      else { if (e.reference.at(abEndB(left) - 1) != e.reference.at(abEndB(middle) - 1)) break; }
+      s[k - 1] = ABlock{left.startA, left.startB, left.lenA - 1, left.lenB - 1};
+      s[k] = ABlock{middle.startA - 1, middle.startB - 1, middle.lenA, middle.lenB};
+      s[k + 1] = ABlock{right.startA - 1, right.startB - 1, right.lenA + 1, right.lenB + 1};
+    }
+  }
+  int drop = 0;
+  while (drop < nb && paCanRemoveSection(s[drop])) drop++;
+  if (drop >= nb) { *e.status = XM_ST_INTERNAL; return false; }  // Java: IndexOutOfBoundsException
+  if (drop > 0) { for (int k = drop; k < nb; k++) s[k - drop] = s[k]; nb -= drop; }
+  out.nb = nb;
+  finishSeqAl(e, params, out, e.query.rc != 0);
+  if (out.alignedPenalty > pa.maxInterestingPenalty) return false;
+  return true;
+}
+
+// ---------------------------------------------------------------- StraightAligner (M/StraightAligner.java)
+XM_INL void straightAlignment(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, const Analysis& an, SeqAl& out) {  // :73-94
+  int queryStartIndex = qs.start, queryEndIndex = qs.end, referenceStartIndex = rs.start, referenceEndIndex = rs.end;
+  int off = an.predictedBestOffset;
+  if (queryStartIndex + off > referenceStartIndex) referenceStartIndex = queryStartIndex + off; else queryStartIndex = referenceStartIndex - off;
+  if (queryEndIndex + off < referenceEndIndex) referenceEndIndex = queryEndIndex + off; else queryEndIndex = referenceEndIndex - off;
+  out.nb = 1;
+  out.blocks[0] = ABlock{queryStartIndex, referenceStartIndex, queryEndIndex - queryStartIndex, referenceEndIndex - referenceStartIndex};
+  finishSeqAl(e, p, out, e.query.rc != 0);
+}
+
+typedef bool (*NextAligner)(const ExtEnv&, const Section&, const Section&, const Params&, Analysis&, SeqAl&);
+
+// :13-71; `next` is the rest of the chain
+template <typename Next>
+XM_INL bool straightAlign(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out, Next next) {
+  an.lastCheckedOffset = an.predictedBestOffset;
+  ABlock simpleBlock[1];
+  SeqAl simple;
+  simple.blocks = simpleBlock;
+  straightAlignment(e, qs, rs, p, an, simple);
+  double simpleTotal = simple.alignedPenalty;
+  double maxInterestingPenalty = secLen(qs) * p.MaxErrorRate;
+  double indelPenalty = dmin(p.getStartingInsertionStartPenalty() + p.InsertionExtension_Penalty, p.DeletionStart_Penalty + p.DeletionExtension_Penalty);
+  if (simpleTotal <= 0) { saCopy(out, simple); return true; }
+  if (an.confidentAboutBestOffset) {
+    if (simpleTotal <= indelPenalty || (an.maxInsertionExtensionPenalty <= 0 && an.maxDeletionExtensionPenalty <= 0)) {
+      if (simpleTotal <= maxInterestingPenalty) { saCopy(out, simple); return true; }
+      return false;
+    }
+    if (indelPenalty > maxInterestingPenalty) return false;
+  }
+  double rate = simple.alignedPenalty / secLen(qs);
+  Params sub = p;
+  sub.MaxErrorRate = dmin(rate, p.MaxErrorRate);
+  bool have = next(e, qs, rs, sub, an, out);
+  if (*e.status) return false;
+  if (!have || out.alignedPenalty >= simpleTotal) {
+    if (simpleTotal <= maxInterestingPenalty) { saCopy(out, simple); return true; }
+  }
+  return have;
+}
+
+// ---------------------------------------------------------------- HashBlock_Aligner (M/HashBlock_Aligner.java)
+struct PenaltyAnalysis { double minPossiblePenalty, maxInsertionExtensionPenalty, maxDeletionExtensionPenalty; int32_t offsetWithMostHashblockMatches, numHashBlockMatchesWithBestOffset; };
+
+XM_INL double hbaMinIndelPenaltyForBlockMismatches(int numMismatches, const Params& p) {  // :286-310
+  numMismatches = imax(1, numMismatches);
+  double minPenaltyPerInitialIndel = dmin(p.getStartingInsertionStartPenalty() + p.InsertionExtension_Penalty, p.DeletionStart_Penalty + p.DeletionExtension_Penalty);
+  double minPenaltyPerExtension = dmin(p.InsertionExtension_Penalty, p.DeletionExtension_Penalty);
+  double minPenaltyPerSubsequentIndel = dmin(p.InsertionStart_Penalty + p.InsertionExtension_Penalty, p.DeletionStart_Penalty + p.DeletionExtension_Penalty);
+  double minPenaltyPerSubsequentChange = dmin(p.MutationPenalty, minPenaltyPerSubsequentIndel);
+  if (numMismatches <= 1) return minPenaltyPerInitialIndel;
+  if (numMismatches <= 2) return minPenaltyPerInitialIndel + minPenaltyPerExtension;
+  return minPenaltyPerInitialIndel + minPenaltyPerExtension + (numMismatches - 2) * minPenaltyPerSubsequentChange;
+}
+XM_INL double hbaLongInsertion(int numMismatches, double totalPenalty, const Params& p, int blockLength) {  // :322-354
+  double availablePenalty = totalPenalty - p.getStartingInsertionStartPenalty();
+  double penaltyOfOnlySNPs = numMismatches * p.MutationPenalty;
+  double penaltyPerBlockExtension = blockLength * p.InsertionExtension_Penalty;
+  double extraPenaltyPerBlockExtension = penaltyPerBlockExtension - p.MutationPenalty;
+  if (extraPenaltyPerBlockExtension <= 0) return availablePenalty;
+  if (numMismatches < 2) return availablePenalty;
+  double penaltyOfShortExtension = 2 * p.InsertionExtension_Penalty;
+  if (penaltyOfShortExtension > availablePenalty) return availablePenalty;
+  double penaltyOfShortSNPs = 2 * p.MutationPenalty;
+  double maxAllowedPenaltyIncreasePastAllSNPs = availablePenalty - penaltyOfOnlySNPs;
+  double maxAllowedPenaltyForBlockExtensions = maxAllowedPenaltyIncreasePastAllSNPs + penaltyOfShortSNPs - penaltyOfShortExtension;
+  double maxNumBlockExtensions = maxAllowedPenaltyForBlockExtensions / extraPenaltyPerBlockExtension;
+  double r = (maxNumBlockExtensions * blockLength + 2) * p.InsertionExtension_Penalty;
+  r = dmin(r, availablePenalty);
+  if (r < penaltyOfShortExtension) r = 0;
+  return r;
+}
+XM_INL double hbaManyInsertions(int numMismatches, double totalPenalty, const Params& p) {  // :356-376
+  double availablePenalty = totalPenalty + (p.InsertionStart_Penalty - p.getStartingInsertionStartPenalty());
+  double penaltyOfOnlySNPs = numMismatches * p.MutationPenalty;
+  double penaltyPerShortIndel = p.InsertionStart_Penalty + 2 * p.InsertionExtension_Penalty;
+  double extra = penaltyPerShortIndel - 2 * p.MutationPenalty;
+  if (extra <= 0) return availablePenalty;
+  double maxNumShortIndels = (availablePenalty - penaltyOfOnlySNPs) / extra;
+  if (maxNumShortIndels < 1) maxNumShortIndels = 0;
+  double r = maxNumShortIndels * 2 * p.InsertionExtension_Penalty;
+  return dmin(r, availablePenalty);
+}
+XM_INL double hbaManyDeletions(int numMismatches, double totalPenalty, const Params& p) {  // :378-400
+  double availablePenalty = totalPenalty;
+  double penaltyOfOnlySNPs = numMismatches * p.MutationPenalty;
+  double penaltyPerShortIndel = p.DeletionStart_Penalty + 2 * p.DeletionExtension_Penalty;
+  double extra = penaltyPerShortIndel - 2 * p.MutationPenalty;
+  if (extra <= 0) return availablePenalty;
+  double maxNumShortIndels = (availablePenalty - penaltyOfOnlySNPs) / extra;
+  if (maxNumShortIndels < 1) maxNumShortIndels = 0;
+  double r = maxNumShortIndels * 2 * p.DeletionExtension_Penalty;
+  r = dmin(r, availablePenalty);
+  if (r < 0) r = 0;
+  return r;
+}
+
+// analyzePenalty :94-283.  storeSlot: where a matcher created for a matcher-less analysis lives (A for the outer
+// HashBlock_Aligner, B for the inner one); temporaries go to slot T.
+XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, Matcher* storeSlot) {
+  Arena& tmp = *e.tmp;
+  size_t mark = tmp.used;
+  PenaltyAnalysis result;
+  result.minPossiblePenalty = 0; result.maxInsertionExtensionPenalty = 0; result.maxDeletionExtensionPenalty = 0;
+  result.offsetWithMostHashblockMatches = 0; result.numHashBlockMatchesWithBestOffset = 0;
+  Matcher* matcher = an.matcher;
+  double maxInterestingPenalty = p.MaxErrorRate * secLen(qs);
+  int numMismatches = 0;
+  int maxNonmatchingBlockEnd = qs.start;
+  CountMap counts;
+  counts.mostPopularKey = 0; counts.mostPopularCount = 0; counts.n = 0; counts.cap = e.caps->maxCountMap; counts.haveCounts = false;
+  counts.keys = arenaArray<int32_t>(tmp, counts.cap); counts.vals = arenaArray<int32_t>(tmp, counts.cap); counts.status = e.status;
+  if (tmp.overflow) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return result; }
+  int numLateBlocksSupportingInsertion = 0, numLateBlocksSupportingDeletion = 0;
+  int minPossibleOffset = rs.start - qs.start;
+  int maxPossibleOffset = rs.end - qs.end;
+  int lookupUncertainty = maxPossibleOffset - minPossibleOffset;
+  if (!matcher || iabs(matcher->sectionLength - lookupUncertainty) > lookupUncertainty / 2) {
+    Matcher* slot = an.matcher ? e.slotT : storeSlot;
+    matcherInit(*slot, e, rs, lookupUncertainty);
+    if (slot->referenceLength > 32000) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return result; }
+    matcher = slot;
+    if (!an.matcher) an.matcher = matcher;
+  }
+  int blockLength = matcher->blockLength;
+  int maxBlockStart = qs.end - blockLength;
+  for (int blockStartIndex = qs.start; blockStartIndex <= maxBlockStart; blockStartIndex++) {
+    if (blockStartIndex >= maxNonmatchingBlockEnd) {
+      int position = matcherLookup(*matcher, e, blockStartIndex, blockStartIndex + minPossibleOffset, blockStartIndex + maxPossibleOffset + 1);
+      if (*e.status) { tmp.used = mark; return result; }
+      int offset = position - blockStartIndex;
+      if (position == M_UNKNOWN || position == M_MULTIPLE) continue;
+      if (position == M_NO_MATCHES) {
+        numMismatches++;
+        maxNonmatchingBlockEnd = blockStartIndex + blockLength;
+        if (hbaMinIndelPenaltyForBlockMismatches(numMismatches, p) > maxInterestingPenalty) break;
+        continue;
+      }
+      int otherStartIndex = position;
+      int reverseCount = imin(blockStartIndex - maxNonmatchingBlockEnd, otherStartIndex);
+      bool foundMismatch = false;
+      for (int i = 1; i <= reverseCount; i++) {
+        if (!bpCanMatch(e.query.at(blockStartIndex - i), e.reference.at(otherStartIndex - i))) {
+          numMismatches++;
+          foundMismatch = true;
+          maxNonmatchingBlockEnd = blockStartIndex + blockLength;
+          break;
+        }
+      }
+      if (!foundMismatch) {
+        int forwardShift = qs.end - blockStartIndex;
+        for (int i = blockLength; i < forwardShift; i++) {
+          int indexA = blockStartIndex + i, indexB = otherStartIndex + i;
+          uint8_t ca = e.query.at(indexA);
+          uint8_t cb = (indexB < rs.end) ? e.reference.at(indexB) : (uint8_t)0;
+          if (!bpCanMatch(ca, cb)) {
+            numMismatches++;
+            foundMismatch = true;
+            maxNonmatchingBlockEnd = indexA + 1;
+            break;
+          }
+        }
+        if (!foundMismatch) maxNonmatchingBlockEnd = qs.end;
+        int numOther = 0;
+        int forwardShift2 = maxNonmatchingBlockEnd - blockStartIndex - blockLength;
+        for (int i = blockLength; i < forwardShift2; i++) {
+          int indexA = blockStartIndex + i;
+          int lookupResult = matcherLookup(*matcher, e, indexA, indexA + minPossibleOffset, indexA + maxPossibleOffset + 1);
+          if (*e.status) { tmp.used = mark; return result; }
+          int offset2 = lookupResult - indexA;
+          if (lookupResult >= 0 && offset2 == offset) {
+            numOther++;
+            i = i - 1 + blockLength;
+          }
+        }
+        if (offset != counts.mostPopularKey && counts.mostPopularCount > 0) {
+          if (offset > counts.mostPopularKey) numLateBlocksSupportingDeletion += numOther;
+          else numLateBlocksSupportingInsertion += numOther;
+        }
+        counts.add(offset, numOther);
+      }
+      if (foundMismatch) {
+        if (hbaMinIndelPenaltyForBlockMismatches(numMismatches, p) > maxInterestingPenalty) break;
+      } else {
+        counts.add(offset, 1);
+      }
+      if (*e.status) { tmp.used = mark; return result; }
+    }
+  }
+  int mostPopularOffset = counts.mostPopularKey;
+  int mostPopularOffset_count = counts.mostPopularCount;
+  tmp.used = mark;
+  double indelPenalty = hbaMinIndelPenaltyForBlockMismatches(numMismatches, p);
+  result.minPossiblePenalty = indelPenalty;
+  bool couldDiffer = mostPopularOffset_count < 1 || an.lastCheckedOffset != mostPopularOffset;
+  if (couldDiffer) {
+    double mismatchPenalty = numMismatches * p.MutationPenalty;
+    if (result.minPossiblePenalty > mismatchPenalty) result.minPossiblePenalty = mismatchPenalty;
+  }
+  // setMaxExtensionPenalty :313-319
+  double longInsertion = hbaLongInsertion(numMismatches + numLateBlocksSupportingDeletion, maxInterestingPenalty, p, blockLength);
+  double manyInsertions = hbaManyInsertions(numMismatches + numLateBlocksSupportingInsertion, maxInterestingPenalty, p);
+  result.maxInsertionExtensionPenalty = dmax(longInsertion, manyInsertions);
+  result.maxDeletionExtensionPenalty = hbaManyDeletions(numMismatches + numLateBlocksSupportingInsertion, maxInterestingPenalty, p);
+  if (result.maxInsertionExtensionPenalty > an.maxInsertionExtensionPenalty) result.maxInsertionExtensionPenalty = an.maxInsertionExtensionPenalty;
+  if (result.maxDeletionExtensionPenalty > an.maxDeletionExtensionPenalty) result.maxDeletionExtensionPenalty = an.maxDeletionExtensionPenalty;
+  if (mostPopularOffset_count < 1) mostPopularOffset = an.predictedBestOffset;
+  result.offsetWithMostHashblockMatches = mostPopularOffset;
+  result.numHashBlockMatchesWithBestOffset = mostPopularOffset_count;
+  return result;
+}
+
+// HashBlock_Aligner.align :21-81 with the tail self-call as a loop
+template <typename Next>
+XM_INL bool hashBlockAlign(const ExtEnv& e, const Section& qs, Section rs, const Params& p, Analysis an, SeqAl& out, Matcher* storeSlot, Next next) {
+  while (true) {
+    double maxInterestingPenalty = p.MaxErrorRate * secLen(qs);
+    if (secLen(qs) > secLen(rs)) return next(e, qs, rs, p, an, out);
+    PenaltyAnalysis pa = hbaAnalyzePenalty(e, qs, rs, p, an, storeSlot);
+    if (*e.status) return false;
+    if (pa.minPossiblePenalty > maxInterestingPenalty) return false;
+    Analysis sub = an;  // child()
+    sub.maxInsertionExtensionPenalty = pa.maxInsertionExtensionPenalty;
+    sub.maxDeletionExtensionPenalty = pa.maxDeletionExtensionPenalty;
+    double extra = pa.numHashBlockMatchesWithBestOffset * p.MutationPenalty + pa.minPossiblePenalty;
+    if (extra > maxInterestingPenalty) {
+      sub.predictedBestOffset = pa.offsetWithMostHashblockMatches;
+      sub.confidentAboutBestOffset = true;
+    } else if (!an.confidentAboutBestOffset) {
+      sub.predictedBestOffset = pa.offsetWithMostHashblockMatches;
+    }
+    if (an.confidentAboutBestOffset && sub.predictedBestOffset == an.predictedBestOffset) sub.confidentAboutBestOffset = true;
+    Section sec = rs;
+    if (sub.confidentAboutBestOffset) {
+      int maxDeletionLength = j2i((double)pa.maxDeletionExtensionPenalty / (double)p.DeletionExtension_Penalty);
+      int maxInsertionLength = j2i((double)pa.maxInsertionExtensionPenalty / (double)p.InsertionExtension_Penalty);
+      int maxIndelLength = imax(maxDeletionLength, maxInsertionLength);
+      sec.start = imax(rs.start, qs.start + sub.predictedBestOffset - maxIndelLength);
+      sec.end = imin(rs.end, qs.end + sub.predictedBestOffset + maxIndelLength);
+    }
+    if (secLen(sec) < secLen(rs)) { rs = sec; an = sub; continue; }
+    return next(e, qs, sec, p, sub, out);
+  }
+}
+
+// ---------------------------------------------------------------- the inner chain: straight3 -> pathAligner, hashBlock<2>, straight2
+struct NextPath {
+  XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const { return pathAlign(e, qs, rs, p, an, out); }
+};
+struct NextStraight3 {
+  XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const { return straightAlign(e, qs, rs, p, an, out, NextPath()); }
+};
+struct NextHashBlock2 {
+  XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const { return hashBlockAlign(e, qs, rs, p, an, out, e.slotB, NextStraight3()); }
+};
+XM_NOINL bool innerChain(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) {  // StraightAligner #2 of :18-29
+  return straightAlign(e, qs, rs, p, an, out, NextHashBlock2());
+}
+
+// ---------------------------------------------------------------- BlockAligner (M/BlockAligner.java)
+XM_NOINL bool baAlignPiece(const ExtEnv& e, const Section& qs, const Section& rs, double maxPenalty, const Params& p, bool firstPiece, const Analysis& parent, SeqAl& out) {  // :215-249
+  if (maxPenalty < 0) return false;
+  Section sub = rs;
+  if (parent.confidentAboutBestOffset) {
+    int maxInsertionLength = j2i((double)parent.maxInsertionExtensionPenalty / (double)p.InsertionExtension_Penalty);
+    int maxDeletionLength = j2i((double)parent.maxDeletionExtensionPenalty / (double)p.DeletionExtension_Penalty);
+    int maxIndelLength = imax(maxInsertionLength, maxDeletionLength);
+    int referenceStart = imax(rs.start, qs.start + parent.predictedBestOffset - maxIndelLength);
+    int referenceEnd = imin(rs.end, qs.end + parent.predictedBestOffset + maxIndelLength);
+    if (referenceEnd > referenceStart) { sub.start = referenceStart; sub.end = referenceEnd; }
+  }
+  Params sp = p;
+  if (!firstPiece) sp.StartingInsertionStartFree = 1;
+  sp.MaxErrorRate = maxPenalty / secLen(qs);
+  Analysis child = parent;
+  child.confidentAboutBestOffset = false;
+  return innerChain(e, qs, sub, sp, child, out);
+}
+
+XM_INL bool baTryMerge(const ExtEnv& e, const SeqAl& left, const SeqAl& right, const Params& p, SeqAl& out) {  // :158-212
+  if (saEndB(left) != saStartB(right)) return false;
+  const ABlock& l = left.blocks[left.nb - 1];
+  const ABlock& r = right.blocks[0];
+  if (abIndelType(l) != abIndelType(r)) return false;
+  if (abEndA(l) != r.startA) return false;
+  if (abEndB(l) != r.startB) return false;
+  if (left.nb - 1 + 1 + right.nb - 1 > e.caps->maxBlocks) { *e.status = XM_ST_OVERFLOW; return false; }
+  int n = 0;
+  for (int i = 0; i < left.nb - 1; i++) out.blocks[n++] = left.blocks[i];
+  out.blocks[n++] = ABlock{l.startA, l.startB, l.lenA + r.lenA, l.lenB + r.lenB};
+  for (int i = 1; i < right.nb; i++) out.blocks[n++] = right.blocks[i];
+  out.nb = n;
+  finishSeqAl(e, p, out, left.referenceReversed != 0);
+  return true;
+}
+
+XM_NOINL bool blockAlign(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) {  // :17-36
+  Arena& tmp = *e.tmp;
+  size_t mark = tmp.used;
+  const Caps& caps = *e.caps;
+  double maxInterestingPenalty = p.MaxErrorRate * secLen(qs);
+  // initialAlignments :39-96
+  double maxInterestingPenaltyWholeQuery = p.MaxErrorRate * e.query.len;  // (sic) uses query.getLength()
+  int numBasesToEncodeReferencePosition = j2i(log((double)secLen(rs) / log(4.0))) + 1;  // (sic) :48
+  int numHashblocks = secLen(qs) / numBasesToEncodeReferencePosition + 1;
+  int targetNumHashblocksPerBlock = j2i(sqrt((double)numHashblocks)) + 1;
+  int targetBlockSize = targetNumHashblocksPerBlock * numBasesToEncodeReferencePosition;
+  int numBlocks = secLen(qs) / targetBlockSize;
+  if (numBlocks > caps.maxPieces) { *e.status = XM_ST_OVERFLOW; return false; }
+  if (numBlocks < 1) return false;  // "no initial alignments"
+  // two piece lists (ping-pong across joinAlignments rounds); blocks are packed into one pool per list
+  const int poolCap = 4 * caps.maxBlocks + 4 * caps.maxPieces;
+  SeqAl* listA = arenaArray<SeqAl>(tmp, caps.maxPieces);
+  SeqAl* listB = arenaArray<SeqAl>(tmp, caps.maxPieces);
+  ABlock* poolA = arenaArray<ABlock>(tmp, (size_t)poolCap);
+  ABlock* poolB = arenaArray<ABlock>(tmp, (size_t)poolCap);
+  ABlock* scratchBlocks = arenaArray<ABlock>(tmp, (size_t)caps.maxBlocks);
+  uint8_t* have = arenaArray<uint8_t>(tmp, caps.maxPieces);
+  if (tmp.overflow) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+  for (int i = 0; i < caps.maxPieces; i++) have[i] = 0;
+  SeqAl scratch;
+  scratch.blocks = scratchBlocks;
+  int usedA = 0, usedB = 0;
+  // commit `src` into list entry `dst`, taking its blocks from `pool`
+  auto commit = [&](SeqAl& dst, const SeqAl& src, ABlock* pool, int& used) -> bool {
+    if (used + src.nb > poolCap) { *e.status = XM_ST_OVERFLOW; return false; }
+    dst.blocks = pool + used;
+    used += src.nb;
+    saCopy(dst, src);
+    return true;
+  };
+  double usedPenalty = 0;
+  int numRemainingAlignments = numBlocks;
+  while (true) {
+    bool failedSubalignment = false, failedThenFound = false;
+    int startPosition = qs.start;
+    for (int i = 0; i < numBlocks; i++) {
+      int endPosition = qs.start + (secLen(qs) * (i + 1) / numBlocks);
+      if (!have[i]) {
+        Section sub{startPosition, endPosition};
+        double averagePenalty = (maxInterestingPenaltyWholeQuery - usedPenalty) / numRemainingAlignments;
+        bool ok = baAlignPiece(e, sub, rs, averagePenalty, p, i == 0, an, scratch);
+        if (*e.status) { tmp.used = mark; return false; }
+        if (ok) {
+          if (!commit(listA[i], scratch, poolA, usedA)) { tmp.used = mark; return false; }
+          if (failedSubalignment) failedThenFound = true;
+          numRemainingAlignments--;
+          have[i] = 1;
+          usedPenalty += listA[i].alignedPenalty;
+        } else {
+          failedSubalignment = true;
+        }
+      }
+      startPosition = endPosition;
+    }
+    if (numRemainingAlignments < 1) break;
+    if (!failedThenFound) { tmp.used = mark; return false; }
+  }
+  // joinAlignments rounds :99-144
+  SeqAl* cur = listA;
+  SeqAl* nxt = listB;
+  ABlock* nxtPool = poolB;
+  ABlock* curPool = poolA;
+  int n = numBlocks;
+  bool even = false;
+  while (n > 1) {
+    int rn = 0;
+    int nxtUsed = 0;
+    double used = 0;
+    for (int i = 0; i < n; i++) used += cur[i].alignedPenalty;
+    for (int i = 0; i < n; i += 2) {
+      if (i + 1 < n) {
+        bool merged = baTryMerge(e, cur[i], cur[i + 1], p, scratch);
+        if (*e.status) { tmp.used = mark; return false; }
+        if (!merged) {
+          used -= cur[i].alignedPenalty;
+          used -= cur[i + 1].alignedPenalty;
+          Section sub{saStartA(cur[i]), saEndA(cur[i + 1])};
+          bool ok = baAlignPiece(e, sub, rs, maxInterestingPenalty - used, p, i == 0, an, scratch);
+          if (*e.status) { tmp.used = mark; return false; }
+          if (!ok) { tmp.used = mark; return false; }
+          if (!commit(nxt[rn], scratch, nxtPool, nxtUsed)) { tmp.used = mark; return false; }
+          used += nxt[rn].alignedPenalty;
+          rn++;
+        } else {
+          if (!even) {  // !allowSimpleMerges: keep `left`, retry from its right neighbour
+            if (!commit(nxt[rn], cur[i], nxtPool, nxtUsed)) { tmp.used = mark; return false; }
+            rn++;
+            i--;
+            continue;
+          }
+          if (!commit(nxt[rn], scratch, nxtPool, nxtUsed)) { tmp.used = mark; return false; }
+          rn++;
+        }
+      } else {
+        if (!commit(nxt[rn], cur[i], nxtPool, nxtUsed)) { tmp.used = mark; return false; }
+        rn++;
+      }
+    }
+    SeqAl* t = cur; cur = nxt; nxt = t;
+    ABlock* tp = curPool; curPool = nxtPool; nxtPool = tp;
+    n = rn;
+    even = !even;
+  }
+  (void)usedB; (void)curPool;
+  saCopy(out, cur[0]);
+  tmp.used = mark;
+  return true;
+}
+
+// ---------------------------------------------------------------- the outer chain (M/QueryMatch_Aligner.java:18-29)
+struct NextBlock {
+  XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const { return blockAlign(e, qs, rs, p, an, out); }
+};
+struct NextHashBlock1 {
+  XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const {
+    // SkipHighAmbiguity_Aligner :13-28
+    int numAmbiguities = 0;
+    for (int i = rs.start; i < rs.end; i++) if (bpIsAmbiguous(e.reference.at(i))) numAmbiguities++;
+    if (numAmbiguities >= secLen(rs) / 4) return false;
+    return hashBlockAlign(e, qs, rs, p, an, out, e.slotA, NextBlock());
+  }
+};
+XM_NOINL bool outerChain(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) {
+  return straightAlign(e, qs, rs, p, an, out, NextHashBlock1());
+}
+
+}  // namespace xm

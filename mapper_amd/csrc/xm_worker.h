@@ -1,0 +1,702 @@
+// xmapper-hip device core: candidate -> QueryAlignment and the per-read driver.
+// Replaces (per read, on the GPU): M/QueryMatch_Aligner.java and M/AlignerWorker.java:306-644
+// (alignToAncestralReference, getPenaltyLowerBound, quicklyConfidentInBestAlignment, getUnpairedAlignments) plus
+// M/Readable_DuplicationDetector.java:28-47.  One read is processed start to finish by one lane; all state lives in that
+// lane's scratch arena (persistent part bump-allocated from the bottom, stack-discipline temporaries above it).
+#pragma once
+#include "xm_extend.h"
+
+namespace xm {
+
+struct QAl {  // QueryAlignment
+  int32_t nSeq, innerDistance;
+  SeqAl seq[2];
+  double spacingPenalty, overlapMultiplier, duplicationBonus, totalPenalty;
+};
+
+struct ReadIn {  // one query
+  int32_t nMates;
+  const uint8_t* mate[2];
+  int32_t mateLen[2];
+  double expectedInner, deviation;
+};
+
+struct QMAligner {  // QueryMatch_Aligner
+  Params parameters;
+  int32_t nMates;        // 1 or 2 (query.getNumSequences())
+  int32_t queryLength;   // query.getLength()
+  double expectedInner, deviation;
+  QAl* good; int32_t nGood;     // blocks of accepted alignments live compactly in blockPool
+  QAl cand;                      // the candidate doAlign is building (blocks: candBlocks[k], capacity caps.maxBlocks)
+  ABlock* blockPool; int32_t poolUsed, poolCap;
+  double bestPenalty;
+  int16_t* bestIdx; int32_t nBest;  // result of getBestAlignments()
+};
+
+struct ReadCtx {
+  const IndexView* ix;
+  Caps caps;
+  DevCounters* dc;
+  int32_t status;
+  int32_t listIdCounter;
+  ReadIn in;
+  Params params;
+  Arena persist;  // bottom part of the lane's arena
+  Arena tmp;      // top part
+  SeedEnv seed;
+  Comp comps[2];
+  PathsCounter pc;
+};
+
+XM_INL SeqView queryView(const ReadCtx& cx, uint8_t seqAId) {
+  SeqView v;
+  int m = seqAId >> 1;
+  v.base = cx.in.mate[m]; v.len = cx.in.mateLen[m]; v.rc = seqAId & 1; v.id = seqAId;
+  return v;
+}
+
+XM_INL double divideRoundUp(double a, double b) {  // M/QueryMatch_Aligner.java:56-61
+  double r = a / b;
+  if (r * b < a) r = jnextUp(r);
+  return r;
+}
+
+XM_INL void qmaInit(ReadCtx& cx, QMAligner& a, int nMates, int queryLength) {
+  a.parameters = cx.params;
+  a.nMates = nMates;
+  a.queryLength = queryLength;
+  a.expectedInner = cx.in.expectedInner;
+  a.deviation = cx.in.deviation;
+  a.nGood = 0;
+  a.nBest = 0;
+  a.bestPenalty = (double)INT32_MAX;
+  int n = cx.caps.maxGoodAlignments;
+  a.good = arenaArray<QAl>(cx.persist, n);
+  a.poolCap = 12 * n + 4 * cx.caps.maxBlocks;
+  a.poolUsed = 0;
+  a.blockPool = arenaArray<ABlock>(cx.persist, (size_t)a.poolCap);
+  ABlock* candBlocks = arenaArray<ABlock>(cx.persist, (size_t)2 * cx.caps.maxBlocks);
+  a.bestIdx = arenaArray<int16_t>(cx.persist, n);
+  if (cx.persist.overflow) { cx.status = XM_ST_OVERFLOW; return; }
+  for (int k = 0; k < 2; k++) a.cand.seq[k].blocks = candBlocks + (size_t)k * cx.caps.maxBlocks;
+}
+
+XM_INL void makeExtEnv(ReadCtx& cx, ExtEnv& e, const SeqView& query, int contig) {
+  e.caps = &cx.caps; e.dc = cx.dc; e.status = &cx.status; e.tmp = &cx.tmp;
+  e.query = query;
+  e.reference = refView(*cx.ix, contig, false);
+  e.contig = contig;
+  e.slotA = e.slotB = e.slotT = nullptr;
+}
+
+// alignMatch :412-462 (fromHashblockMatch is always true).  The matcher slots live in tmp for the duration of the call.
+XM_NOINL bool qmaAlignMatch(ReadCtx& cx, const SeqView& seqA, int contig, int offset, const Params& params, SeqAl& out) {
+  size_t mark = cx.tmp.used;
+  ExtEnv e;
+  makeExtEnv(cx, e, seqA, contig);
+  Matcher* slots = arenaArray<Matcher>(cx.tmp, 3);
+  if (cx.tmp.overflow) { cx.status = XM_ST_OVERFLOW; cx.tmp.used = mark; return false; }
+  for (int i = 0; i < 3; i++) {
+    slots[i].present = arenaArray<uint8_t>(cx.tmp, cx.caps.maxSections);
+    slots[i].tables = arenaArray<int16_t>(cx.tmp, cx.caps.matcherEntries);
+    slots[i].tableCap = cx.caps.matcherEntries;
+    slots[i].maxSections = cx.caps.maxSections;
+    slots[i].nSections = 0;
+    slots[i].sectionLength = 0;
+  }
+  if (cx.tmp.overflow) { cx.status = XM_ST_OVERFLOW; cx.tmp.used = mark; return false; }
+  e.slotA = &slots[0]; e.slotB = &slots[1]; e.slotT = &slots[2];
+  int refLen = e.reference.len;
+  int startB = imax(0, offset), endB = imin(offset + seqA.len, refLen);
+  Section qs{startB - offset, endB - offset};
+  double maxInterestingPenalty = secLen(qs) * params.MaxErrorRate;
+  int maxIndelLength = j2i(dmax(0.0, (maxInterestingPenalty - params.DeletionStart_Penalty) / params.DeletionExtension_Penalty));
+  int maxShift = maxIndelLength;
+  Section rs{imax(0, startB - maxShift), imin(endB + maxShift, refLen)};
+  Analysis an;
+  an.matcher = nullptr;
+  an.maxInsertionExtensionPenalty = maxInterestingPenalty - params.InsertionStart_Penalty;
+  an.maxDeletionExtensionPenalty = maxInterestingPenalty - params.DeletionStart_Penalty;
+  an.predictedBestOffset = offset;
+  an.lastCheckedOffset = 0;
+  an.confidentAboutBestOffset = true;
+  if (cx.dc) cx.dc->refWindowBytes += (unsigned long long)((secLen(rs) + 1) / 2);
+  bool ok = outerChain(e, qs, rs, params, an, out);
+  cx.tmp.used = mark;
+  return ok && cx.status == 0;
+}
+
+// ---- helpers over finished SequenceAlignments
+XM_INL double saPenaltyInRange(ReadCtx& cx, const Params& p, const SeqAl& a, int startIndexB, int endIndexB) {  // M/AlignmentParameters.java:97-154
+  SeqView q = queryView(cx, a.seqAId);
+  SeqView r = refView(*cx.ix, a.contig, false);
+  double total = 0;
+  for (int k = 0; k < a.nb; k++) {
+    const ABlock& b = a.blocks[k];
+    double penalty = 0;
+    if (b.lenA == b.lenB) {
+      for (int i = 0; i < b.lenA; i++) {
+        int bIndex = b.startB + i;
+        if (bIndex >= startIndexB && bIndex < endIndexB) penalty += p.getPenalty(q.at(b.startA + i), r.at(bIndex));
+      }
+    } else if (b.startB < endIndexB && abEndB(b) > startIndexB) {
+      if (b.lenA > 0) { penalty += p.InsertionStart_Penalty; penalty += p.InsertionExtension_Penalty * b.lenA; }
+      else { penalty += p.DeletionStart_Penalty; penalty += p.DeletionExtension_Penalty * b.lenB; }
+    }
+    total += penalty;
+  }
+  return total;
+}
+XM_INL int saLengthA(const SeqAl& a) { int t = 0; for (int i = 0; i < a.nb; i++) t += a.blocks[i].lenA; return t; }
+XM_INL int saInsertAOrBLength(const SeqAl& a) { int t = 0; for (int i = 0; i < a.nb; i++) if (a.blocks[i].lenA != a.blocks[i].lenB) t += a.blocks[i].lenA + a.blocks[i].lenB; return t; }
+XM_INL int saLengthABefore(const SeqAl& a, int refIndex) {  // [inferred, see oracle/xmo_types.h]
+  int t = 0;
+  for (int i = 0; i < a.nb; i++) {
+    const ABlock& b = a.blocks[i];
+    if (abEndB(b) <= refIndex) t += b.lenA;
+    else if (b.startB >= refIndex) t += 0;
+    else if (b.lenA == b.lenB) t += refIndex - b.startB;
+  }
+  return t;
+}
+XM_INL int saLengthAAfter(const SeqAl& a, int refIndex) {
+  int t = 0;
+  for (int i = 0; i < a.nb; i++) {
+    const ABlock& b = a.blocks[i];
+    if (b.startB >= refIndex) t += b.lenA;
+    else if (abEndB(b) <= refIndex) t += 0;
+    else if (b.lenA == b.lenB) t += abEndB(b) - refIndex;
+  }
+  return t;
+}
+XM_INL bool saHasIndel(const SeqAl& a) { for (int i = 0; i < a.nb; i++) if (a.blocks[i].lenA != a.blocks[i].lenB) return true; return false; }
+XM_INL bool saHasAmbiguous(ReadCtx& cx, const SeqAl& a) {
+  SeqView q = queryView(cx, a.seqAId);
+  SeqView r = refView(*cx.ix, a.contig, false);
+  for (int k = 0; k < a.nb; k++) {
+    const ABlock& b = a.blocks[k];
+    if (b.lenA != b.lenB) continue;
+    for (int i = 0; i < b.lenA; i++) if (bpIsAmbiguous(q.at(b.startA + i)) || bpIsAmbiguous(r.at(b.startB + i))) return true;
+  }
+  return false;
+}
+XM_INL bool saSame(const SeqAl& x, const SeqAl& y) {
+  if (x.referenceReversed != y.referenceReversed || x.nb != y.nb || x.contig != y.contig) return false;
+  for (int i = 0; i < x.nb; i++) {
+    const ABlock &a = x.blocks[i], &b = y.blocks[i];
+    if (a.startA != b.startA || a.startB != b.startB || a.lenA != b.lenA || a.lenB != b.lenB) return false;
+  }
+  return true;
+}
+
+// extract :362-405: cut [queryStart, queryEnd) of the joined alignment out for one mate
+XM_NOINL bool qmaExtract(ReadCtx& cx, const Params& p, const SeqAl& joined, int queryStart, int queryEnd, uint8_t mateSeqAId, SeqAl& out) {
+  bool reverse = (mateSeqAId & 1) != 0;
+  bool referenceReversed = (joined.referenceReversed != 0) != reverse;
+  int n = 0;
+  for (int k = 0; k < joined.nb; k++) {
+    const ABlock& b = joined.blocks[k];
+    if (b.startA >= queryEnd) break;
+    if (abEndA(b) <= queryStart) continue;
+    int selectionStart = imax(b.startA, queryStart);
+    int selectionEnd = imin(abEndA(b), queryEnd);
+    int querySelectionLength = selectionEnd - selectionStart;
+    int referenceSelectionLength, referenceStart;
+    int blockOffset = b.startB - b.startA;
+    if (b.lenA == b.lenB) { referenceSelectionLength = querySelectionLength; referenceStart = selectionStart + blockOffset; }
+    else if (b.lenA > b.lenB) { referenceSelectionLength = 0; referenceStart = b.startB; }
+    else { referenceSelectionLength = b.lenB; referenceStart = selectionStart + blockOffset; }
+    if (n >= cx.caps.maxBlocks) { cx.status = XM_ST_OVERFLOW; return false; }
+    out.blocks[n++] = ABlock{selectionStart - queryStart, referenceStart, querySelectionLength, referenceSelectionLength};
+  }
+  if (n < 1) return false;
+  out.nb = n;
+  ExtEnv e;
+  makeExtEnv(cx, e, queryView(cx, mateSeqAId), joined.contig);
+  finishSeqAl(e, p, out, referenceReversed);
+  return true;
+}
+
+// doAlign :94-272.  Builds the candidate in a.cand and returns true when it is a valid alignment.
+XM_NOINL bool qmaDoAlign(ReadCtx& cx, QMAligner& a, const QMatch& match, double extraSpacing) {
+  const SeedEnv& se = cx.seed;
+  if (cx.dc) cx.dc->candidatesExtended++;
+  if (a.nGood >= cx.caps.maxGoodAlignments) { cx.status = XM_ST_OVERFLOW; return false; }
+  QAl& res = a.cand;
+  size_t mark = cx.tmp.used;
+  double innerDistance = (match.n < 2 ? 0 : qmTotalDistanceBetweenComponents(se, match)) + extraSpacing;
+  // computeSpacingPenalty :530-546
+  double spacingPenalty;
+  if (innerDistance < 0 && innerDistance > -1 * a.queryLength) spacingPenalty = 0;
+  else spacingPenalty = (double)j2i(fabs(innerDistance - a.expectedInner) / a.deviation);
+  double overlapMultiplier = 1, duplicationBonus = 0;
+  int queryTotalLengthI = qmQueryTotalLength(se, match);
+  double maxAllowedPenalty = jnextUp(queryTotalLengthI * a.parameters.MaxErrorRate);
+  if (innerDistance > 0) {
+    double minPossiblePenalty = spacingPenalty + match.priority * a.parameters.MutationPenalty;
+    if (minPossiblePenalty > maxAllowedPenalty) return false;
+  }
+  bool haveComponents = false;
+  double componentsPenalty = 0;
+  if (match.n > 1 && innerDistance < 0) {
+    // tryJoinQuerySequences :274-319
+    const SeqMatch& m1 = match.c[0];
+    const SeqMatch& m2 = match.c[1];
+    int offset = m2.offset - m1.offset;
+    SeqView s1 = queryView(cx, offset >= 0 ? m1.seqAId : m2.seqAId);
+    SeqView s2 = queryView(cx, offset >= 0 ? m2.seqAId : m1.seqAId);
+    int off = offset >= 0 ? offset : -offset;
+    int suffixStartIndex = s1.len - off;
+    bool joinable = suffixStartIndex >= 0;
+    if (joinable) {
+      int match2IndexEnd = imin(s2.len, s1.len - off);
+      for (int i = 0; i < match2IndexEnd; i++) if (s1.at(i + off) != s2.at(i)) { joinable = false; break; }
+    }
+    if (joinable) {
+      int endIndex = s2.len;
+      if (endIndex - suffixStartIndex < 0) { cx.status = XM_ST_INTERNAL; return false; }  // getRange with a negative length throws
+      int jl = s1.len + (endIndex - suffixStartIndex);
+      if (jl > cx.caps.maxJoined) { cx.status = XM_ST_OVERFLOW; return false; }
+      uint8_t* jb = arenaArray<uint8_t>(cx.tmp, jl);
+      ABlock* jblocks = arenaArray<ABlock>(cx.tmp, cx.caps.maxBlocks);
+      if (cx.tmp.overflow) { cx.status = XM_ST_OVERFLOW; cx.tmp.used = mark; return false; }
+      for (int i = 0; i < s1.len; i++) jb[i] = s1.at(i);
+      for (int i = suffixStartIndex; i < endIndex; i++) jb[s1.len + i - suffixStartIndex] = s2.at(i);
+      SeqView joined;
+      joined.base = jb; joined.len = jl; joined.rc = 0; joined.id = 4;
+      // computeJoinedAlignment :321-330
+      int joinedOffset = imin(m1.offset, m2.offset);
+      Params subp = a.parameters;
+      subp.MaxErrorRate = jnextUp(subp.MaxErrorRate);
+      SeqAl jal;
+      jal.blocks = jblocks;
+      bool ok = qmaAlignMatch(cx, joined, m1.contig, joinedOffset, subp, jal);
+      if (cx.status) { cx.tmp.used = mark; return false; }
+      // splitAlignment :332-360
+      if (!ok) { cx.tmp.used = mark; return false; }
+      int l1 = seqALen(se, m1.seqAId), l2 = seqALen(se, m2.seqAId);
+      bool ok1, ok2;
+      if (offset >= 0) {
+        ok1 = qmaExtract(cx, a.parameters, jal, 0, l1, m1.seqAId, res.seq[0]);
+        ok2 = qmaExtract(cx, a.parameters, jal, offset, l2 + offset, m2.seqAId, res.seq[1]);
+      } else {
+        ok2 = qmaExtract(cx, a.parameters, jal, 0, l2, m2.seqAId, res.seq[1]);
+        ok1 = qmaExtract(cx, a.parameters, jal, -offset, l1 - offset, m1.seqAId, res.seq[0]);
+      }
+      cx.tmp.used = mark;
+      if (cx.status) return false;
+      if (!ok1 || !ok2) return false;
+      haveComponents = true;
+      componentsPenalty += res.seq[0].totalPenalty;
+      componentsPenalty += res.seq[1].totalPenalty;
+    }
+  }
+  if (!haveComponents) {
+    bool remaining[2] = {true, match.n > 1};
+    int numRemaining = match.n;
+    int first, step, last;
+    if (match.hint) { first = 0; step = 1; last = match.n; } else { first = match.n - 1; step = -1; last = -1; }
+    double maxTotalComponentPenalty;
+    if (innerDistance < 0 && match.n > 1) {
+      double queryTotalLength = queryTotalLengthI;
+      double estimatedOverlap = dmin(-1 * innerDistance, (double)imin(seqALen(se, match.c[0].seqAId), seqALen(se, match.c[1].seqAId)));
+      double estimatedUniqueLength = queryTotalLength - estimatedOverlap;
+      maxTotalComponentPenalty = divideRoundUp(maxAllowedPenalty - spacingPenalty, queryTotalLength) * estimatedUniqueLength * 2;
+    } else {
+      maxTotalComponentPenalty = maxAllowedPenalty - spacingPenalty;
+    }
+    while (true) {
+      int numBases = 0;
+      for (int i = 0; i < match.n; i++) if (remaining[i]) numBases += seqALen(se, match.c[i].seqAId);
+      if (numBases < 1) break;
+      Params prs = a.parameters;
+      prs.MaxErrorRate = divideRoundUp(maxTotalComponentPenalty - componentsPenalty, numBases);
+      bool foundAMatch = false;
+      for (int i = first; i != last; i += step) {
+        if (remaining[i]) {
+          bool ok = qmaAlignMatch(cx, queryView(cx, match.c[i].seqAId), match.c[i].contig, match.c[i].offset, prs, res.seq[i]);
+          if (cx.status) return false;
+          if (ok) {
+            foundAMatch = true;
+            remaining[i] = false;
+            componentsPenalty += res.seq[i].totalPenalty;
+            numRemaining--;
+            break;
+          }
+        }
+      }
+      if (numRemaining < 1) break;
+      if (!foundAMatch) return false;
+    }
+  }
+  res.nSeq = match.n;
+  double totalUsedPenalty = componentsPenalty;
+  if (innerDistance < 0) {
+    // computeDuplicationBonus :506-520
+    if (res.nSeq >= 2) {
+      const SeqAl& x = res.seq[0];
+      const SeqAl& y = res.seq[1];
+      double overlappingLength = imin(saEndB(x), saEndB(y)) - imax(saStartB(x), saStartB(y));
+      if (!(overlappingLength < 0))
+        duplicationBonus = (saPenaltyInRange(cx, a.parameters, x, saStartB(y), saEndB(y)) + saPenaltyInRange(cx, a.parameters, y, saStartB(x), saEndB(x))) / 2;
+    }
+    totalUsedPenalty -= duplicationBonus;
+    // multiplyPenaltyForOverlap :464-504
+    double multipliedPenalty = totalUsedPenalty;
+    if (res.nSeq >= 2) {
+      const SeqAl& f = res.seq[0];
+      const SeqAl& s = res.seq[1];
+      double overlappingLengthB = imin(saEndB(f), saEndB(s)) - imax(saStartB(f), saStartB(s));
+      if (overlappingLengthB > 0) {
+        int uniqueLengthA;
+        if (saStartB(f) <= saStartB(s)) uniqueLengthA = saLengthABefore(f, saStartB(s)) + saLengthA(s) + saLengthAAfter(f, saEndB(s));
+        else uniqueLengthA = saLengthABefore(s, saStartB(f)) + saLengthA(f) + saLengthAAfter(s, saEndB(f));
+        double deletion = imin(saInsertAOrBLength(f), saInsertAOrBLength(s));
+        uniqueLengthA = j2i((double)uniqueLengthA - deletion);
+        if (uniqueLengthA > 0) {
+          int totalLengthA = saLengthA(f) + saLengthA(s);
+          multipliedPenalty = divideRoundUp(totalUsedPenalty, uniqueLengthA) * totalLengthA;
+        }
+      }
+    }
+    if (totalUsedPenalty != 0) overlapMultiplier = multipliedPenalty / totalUsedPenalty; else overlapMultiplier = 1;
+    totalUsedPenalty = multipliedPenalty;
+  }
+  totalUsedPenalty += spacingPenalty;
+  if (totalUsedPenalty > maxAllowedPenalty) return false;
+  res.innerDistance = res.nSeq > 1 ? saStartB(res.seq[1]) - saEndB(res.seq[0]) : 0;
+  res.spacingPenalty = spacingPenalty;
+  res.overlapMultiplier = overlapMultiplier;
+  res.duplicationBonus = duplicationBonus;
+  res.totalPenalty = totalUsedPenalty;
+  return true;
+}
+
+// align :35-54.  returns the index of the alignment in a.good, or -1 for null
+XM_INL int qmaAlign(ReadCtx& cx, QMAligner& a, const QMatch& match, double extraSpacing) {
+  if (!qmaDoAlign(cx, a, match, extraSpacing) || cx.status) return -1;
+  int needBlocks = 0;
+  for (int k = 0; k < a.cand.nSeq; k++) needBlocks += a.cand.seq[k].nb;
+  if (a.poolUsed + needBlocks > a.poolCap) { cx.status = XM_ST_OVERFLOW; return -1; }
+  int idx = a.nGood++;
+  a.good[idx] = a.cand;
+  for (int k = 0; k < a.cand.nSeq; k++) {
+    a.good[idx].seq[k].blocks = a.blockPool + a.poolUsed;
+    for (int i = 0; i < a.cand.seq[k].nb; i++) a.blockPool[a.poolUsed++] = a.cand.seq[k].blocks[i];
+  }
+  double pen = a.good[idx].totalPenalty;
+  if (pen < a.bestPenalty) {
+    a.bestPenalty = pen;
+    double newTargetPenalty = pen + a.parameters.Max_PenaltySpan;
+    double newTargetErrorRate = divideRoundUp(newTargetPenalty, a.queryLength);
+    if (newTargetErrorRate < a.parameters.MaxErrorRate) a.parameters.MaxErrorRate = newTargetErrorRate;
+  }
+  return idx;
+}
+
+// getBestAlignments :71-92 (withoutDuplicates keeps first occurrences; HashSet order is unpinned in the reference)
+XM_NOINL void qmaGetBestAlignments(QMAligner& a) {
+  double maxInterestingPenaltyAnywhere = a.queryLength * a.parameters.MaxErrorRate;
+  double cutoffPenalty = a.bestPenalty + a.parameters.Max_PenaltySpan;
+  if (cutoffPenalty > maxInterestingPenaltyAnywhere) cutoffPenalty = maxInterestingPenaltyAnywhere;
+  a.nBest = 0;
+  for (int i = 0; i < a.nGood; i++) {
+    if (!(a.good[i].totalPenalty <= cutoffPenalty)) continue;
+    bool dup = false;
+    for (int j = 0; j < a.nBest && !dup; j++) {
+      const QAl& u = a.good[a.bestIdx[j]];
+      const QAl& v = a.good[i];
+      if (u.nSeq != v.nSeq) continue;
+      bool same = true;
+      for (int k = 0; k < u.nSeq; k++) if (!saSame(u.seq[k], v.seq[k])) { same = false; break; }
+      if (same) dup = true;
+    }
+    if (!dup) a.bestIdx[a.nBest++] = (int16_t)i;
+  }
+}
+
+// ---------------------------------------------------------------- duplication map (M/Readable_DuplicationDetector.java:28-47)
+XM_INL bool mayContainDuplicationInRange(const IndexView& ix, int contig, int startIndex, int endIndex) {
+  int w = ix.dupWindow;
+  int windowStart = startIndex / w, windowEnd = endIndex / w;
+  const int32_t* keys = ix.dupKeys + ix.dupKeyStart[contig];
+  int n = (int)(ix.dupKeyStart[contig + 1] - ix.dupKeyStart[contig]);
+  if (n == 0) return false;
+  int lo = 0, hi = n;  // floorEntry(endIndex): last key <= endIndex
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (keys[mid] <= endIndex) lo = mid + 1; else hi = mid; }
+  if (lo > 0) {
+    int pw = keys[lo - 1] / w;
+    if (pw >= windowStart && pw <= windowEnd) return true;
+  }
+  lo = 0; hi = n;  // ceilingEntry(startIndex): first key >= startIndex
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (keys[mid] >= startIndex) hi = mid; else lo = mid + 1; }
+  if (lo < n) {
+    int nw = keys[lo] / w;
+    if (nw >= windowStart && nw <= windowEnd) return true;
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------- result streams (layout: include/xmapper_hip.h)
+struct OutWriter { int32_t* ints; double* dbls; int64_t ni, nd; };
+XM_INL void countQAl(const QAl& q, int64_t& ni, int64_t& nd) {
+  ni += 2; nd += 4;
+  for (int k = 0; k < q.nSeq; k++) { ni += 3 + 4 * q.seq[k].nb; nd += 2; }
+}
+XM_INL void writeQAl(OutWriter& w, const QAl& q) {
+  w.ints[w.ni++] = q.innerDistance;
+  w.ints[w.ni++] = q.nSeq;
+  w.dbls[w.nd++] = q.spacingPenalty; w.dbls[w.nd++] = q.overlapMultiplier; w.dbls[w.nd++] = q.duplicationBonus; w.dbls[w.nd++] = q.totalPenalty;
+  for (int k = 0; k < q.nSeq; k++) {
+    const SeqAl& s = q.seq[k];
+    w.ints[w.ni++] = s.contig; w.ints[w.ni++] = s.referenceReversed; w.ints[w.ni++] = s.nb;
+    for (int b = 0; b < s.nb; b++) { w.ints[w.ni++] = s.blocks[b].startA; w.ints[w.ni++] = s.blocks[b].startB; w.ints[w.ni++] = s.blocks[b].lenA; w.ints[w.ni++] = s.blocks[b].lenB; }
+    w.dbls[w.nd++] = s.totalPenalty; w.dbls[w.nd++] = s.alignedPenalty;
+  }
+}
+
+// what alignToAncestralReference returns: up to 2 components, each a list of alignments of one aligner
+struct ReadResult {
+  int32_t nComponents;
+  QMAligner* aligner[2];
+  int32_t single[2];  // >= 0: the component is exactly this one alignment of aligner[c] (QueryAlignments.singleChoice)
+  int32_t empty[2];   // 1: the component is empty regardless of the aligner
+};
+
+XM_INL double penaltyLowerBound(const ReadCtx& cx, int numMismatchedHashblocks) {  // M/AlignerWorker.java:487-491
+  double mutationPenalty = numMismatchedHashblocks * cx.params.MutationPenalty;
+  double indelPenalty = cx.ix->minInterestingSize * numMismatchedHashblocks * cx.params.DeletionExtension_Penalty;
+  return dmin(mutationPenalty, indelPenalty);
+}
+
+XM_NOINL bool quicklyConfidentInBestAlignment(ReadCtx& cx, QMAligner& a, int alIdx, const QMatch& m) {  // :494-587
+  if (alIdx < 0) return false;
+  const QAl& al = a.good[alIdx];
+  for (int k = 0; k < al.nSeq; k++) if (saHasIndel(al.seq[k])) return false;
+  int contig = m.c[0].contig;
+  int matchStart = qmStartIndexB(m), matchEnd = qmEndIndexB(m);
+  double granularity = cx.ix->dupGranularity;
+  double penalty = al.totalPenalty;
+  double numberOfMutations = (penalty + cx.params.Max_PenaltySpan) / cx.params.MutationPenalty;
+  double existingMutationRate = numberOfMutations / qmQueryTotalLength(cx.seed, m);
+  if (penalty <= 0 && cx.params.Max_PenaltySpan < cx.params.getMinPossibleNonzeroPenalty()) return true;
+  double probabilityMutationInSection = 1 - pow(1 - existingMutationRate, granularity);
+  double acceptableProbability = 1.0 / (double)cx.ix->totalForwardAndReverseSize;
+  double numberOfUnmatchedBlocksForHighConfidence = log(acceptableProbability) / log(probabilityMutationInSection);
+  double totalLengthForHighConfidence = numberOfUnmatchedBlocksForHighConfidence * granularity;
+  double matchMiddle = (double)((matchStart + matchEnd) / 2);
+  double interestingWindow = jmaxd(totalLengthForHighConfidence, (double)((matchEnd - matchStart + 1) / 2));
+  int windowStart = j2i(matchMiddle - interestingWindow);
+  int windowEnd = j2i(matchMiddle + interestingWindow);
+  bool hasNearbyDuplication = false;
+  if (mayContainDuplicationInRange(*cx.ix, contig, windowStart, windowEnd)) hasNearbyDuplication = true;
+  else if (matchStart <= interestingWindow) hasNearbyDuplication = true;
+  else if (matchEnd >= cx.ix->contigLen[contig] - interestingWindow) hasNearbyDuplication = true;
+  if (hasNearbyDuplication) return false;
+  for (int k = 0; k < al.nSeq; k++) if (saHasAmbiguous(cx, al.seq[k])) return false;
+  return true;
+}
+
+XM_INL void compInit(ReadCtx& cx, Comp& c, const SeqView& query, const SeqView& rcQuery) {  // M/Counting_HashBlockPath.java:20-37
+  const Caps& k = cx.caps;
+  Arena& A = cx.persist;
+  PBlock* blocks = arenaArray<PBlock>(A, k.maxPyramidBlocks);
+  int32_t* ls = arenaArray<int32_t>(A, k.maxLevels + 2);
+  c.counters = arenaArray<Counter>(A, k.maxCounters);
+  c.good = arenaArray<int16_t>(A, k.maxCounters);
+  c.history = arenaArray<QBlock>(A, k.maxHistory);
+  c.pending = arenaArray<QBlock>(A, k.maxPending);
+  c.hp.items = arenaArray<int16_t>(A, k.maxCounters);
+  c.best.items = arenaArray<int16_t>(A, k.maxCounters);
+  c.all.items = arenaArray<int16_t>(A, k.maxCounters);
+  if (A.overflow) { cx.status = XM_ST_OVERFLOW; return; }
+  c.pyr.init(query, blocks, k.maxPyramidBlocks, ls, k.maxLevels, &cx.status);
+  pathInit(c.path);
+  c.query = query; c.rcQuery = rcQuery;
+  c.nCounters = 0; c.nGood = 0; c.foundGood = false; c.done = false; c.nHistory = 0; c.pendHead = c.pendTail = 0;
+  c.numBlocksMatchingAnywhere = 0; c.maxNonoverlappingBlockVisited = 0; c.numNonoverlappingBlocksVisited = 0; c.minNumDistinctMismatches = -1;
+  c.nextBlockId = 0;
+  c.hp.id = c.best.id = c.all.id = 0; c.hp.n = c.best.n = c.all.n = 0;
+  int maxPossibleIndel = j2i((query.len * cx.params.MaxErrorRate - cx.params.DeletionStart_Penalty) / cx.params.DeletionExtension_Penalty);
+  c.maxIndelLengthToConsider = maxPossibleIndel / 2;
+}
+
+// getUnpairedAlignments :602-644
+XM_NOINL void getUnpairedAlignments(ReadCtx& cx, ReadResult& rr) {
+  rr.nComponents = 2;
+  double expectedInnerDistance = cx.in.expectedInner;
+  for (int sequenceIndex = 0; sequenceIndex < 2; sequenceIndex++) {
+    rr.single[sequenceIndex] = -1;
+    rr.empty[sequenceIndex] = 0;
+    int len = cx.in.mateLen[sequenceIndex];
+    double maxInterestingSubqueryPenalty = len * cx.params.MaxErrorRate;
+    int maxNumMismatches = j2i(maxInterestingSubqueryPenalty / cx.params.MutationPenalty);
+    ListRef locs = compFindGoodPositionsHavingPriorityUpTo(cx.comps[sequenceIndex], cx.seed, maxNumMismatches);  // findGoodComponentMatches
+    if (cx.status) return;
+    QMAligner* sub = arenaArray<QMAligner>(cx.persist, 1);
+    if (cx.persist.overflow) { cx.status = XM_ST_OVERFLOW; return; }
+    qmaInit(cx, *sub, 1, len);
+    if (cx.status) return;
+    rr.aligner[sequenceIndex] = sub;
+    for (int i = 0; i < locs.n; i++) {
+      const Counter& k = cx.comps[sequenceIndex].counters[locs.items[i]];
+      SeqMatch sm = counterMatch(k);
+      int minInnerDistance;
+      if (sequenceIndex % 2 == 1) minInnerDistance = smStartB(sm);
+      else minInnerDistance = cx.ix->contigLen[sm.contig] - smEndB(cx.seed, sm);
+      double innerDistance = minInnerDistance;
+      if (innerDistance < expectedInnerDistance) innerDistance = expectedInnerDistance;
+      double spacingPenalty = innerDistance / cx.in.deviation;
+      if (spacingPenalty > maxInterestingSubqueryPenalty) continue;
+      QMatch qm;
+      qm.n = 1; qm.priority = -1; qm.c[0] = sm; qm.hint = 0;
+      qmaAlign(cx, *sub, qm, innerDistance);
+      if (cx.status) return;
+    }
+    qmaGetBestAlignments(*sub);
+  }
+}
+
+// alignToAncestralReference :306-484
+XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr) {
+  const ReadIn& in = cx.in;
+  if (cx.dc) { cx.dc->reads++; for (int m = 0; m < in.nMates; m++) cx.dc->readBytes += (unsigned long long)((in.mateLen[m] + 1) / 2); }
+  rr.nComponents = 1; rr.single[0] = -1; rr.empty[0] = 0; rr.aligner[0] = nullptr;
+  // reads with ambiguous bases need the MultiHashBlock path, which this build does not implement
+  for (int m = 0; m < in.nMates; m++) for (int i = 0; i < in.mateLen[m]; i++) if (bpIsAmbiguous(in.mate[m][i])) { cx.status = XM_ST_AMBIGUOUS; return; }
+  for (int m = 0; m < in.nMates; m++) if (in.mateLen[m] > cx.ix->maxHashedLength) { cx.status = XM_ST_NEED_GROW; return; }
+  int queryLength = 0;
+  for (int m = 0; m < in.nMates; m++) queryLength += in.mateLen[m];
+  double maxInterestingPenalty = queryLength * cx.params.MaxErrorRate;
+  int maxInnerDistance = j2i(maxInterestingPenalty * in.deviation + in.expectedInner);
+  cx.seed.ix = cx.ix; cx.seed.caps = &cx.caps; cx.seed.dc = cx.dc; cx.seed.status = &cx.status; cx.seed.listIdCounter = &cx.listIdCounter;
+  cx.seed.mateLen = cx.in.mateLen;
+  cx.listIdCounter = 0;
+  for (int i = 0; i < in.nMates; i++) {
+    SeqView fwd = queryView(cx, (uint8_t)(i * 2)), rc = queryView(cx, (uint8_t)(i * 2 + 1));
+    if (i > 0) compInit(cx, cx.comps[i], rc, fwd); else compInit(cx, cx.comps[i], fwd, rc);  // :317-318
+    if (cx.status) return;
+  }
+  PathsCounter& pc = cx.pc;
+  pc.comps = cx.comps; pc.nComps = in.nMates;
+  pc.maxOffsetBetweenComponents = jadd(maxInnerDistance, cx.comps[0].query.len);
+  pc.foundNonemptyResult = false; pc.havePrevious = false; pc.nAssembled = 0; pc.nFiltered = 0;
+  pc.assembled = arenaArray<QMatch>(cx.persist, cx.caps.maxQM);
+  pc.filtered = arenaArray<QMatch>(cx.persist, cx.caps.maxQM);
+  pc.nearby = arenaArray<int16_t>(cx.persist, cx.caps.maxCounters);
+  QMAligner* aligner = arenaArray<QMAligner>(cx.persist, 1);
+  if (cx.persist.overflow) { cx.status = XM_ST_OVERFLOW; return; }
+  const SeedEnv& se = cx.seed;
+
+  int optimisticBestAlignment = -1;
+  bool haveOptimisticMatch = false;
+  QMatch optimisticBestMatch;
+  int numMismatches = 0;
+  pcOptimisticGetBestMatches(pc, se);
+  if (cx.status) return;
+  qmaInit(cx, *aligner, in.nMates, queryLength);
+  if (cx.status) return;
+  rr.aligner[0] = aligner;
+  if (pc.nFiltered == 1) {
+    optimisticBestMatch = pc.filtered[0];
+    haveOptimisticMatch = true;
+    optimisticBestAlignment = qmaAlign(cx, *aligner, optimisticBestMatch, 0);
+    if (cx.status) return;
+    if (quicklyConfidentInBestAlignment(cx, *aligner, optimisticBestAlignment, optimisticBestMatch)) {
+      if (cx.dc) cx.dc->quickAccepts++;
+      rr.single[0] = optimisticBestAlignment;
+      return;
+    }
+  }
+  if (optimisticBestAlignment >= 0) {
+    while (true) {
+      double possiblePenalty = penaltyLowerBound(cx, numMismatches);
+      if (possiblePenalty > aligner->good[optimisticBestAlignment].totalPenalty + cx.params.Max_PenaltySpan) {
+        rr.single[0] = optimisticBestAlignment;
+        return;
+      }
+      pcFindGoodPositionsHavingPriority(pc, se, numMismatches);
+      if (cx.status) return;
+      numMismatches++;
+      bool done = false;
+      for (int i = 0; i < pc.nFiltered; i++) if (!qmSamePosition(optimisticBestMatch, pc.filtered[i])) { done = true; break; }
+      if (done) break;
+    }
+  }
+  double bestPenalty = (double)INT32_MAX;
+  int candidateNumMismatches = 0;
+  while (true) {
+    double estimatedPenalty = penaltyLowerBound(cx, candidateNumMismatches);
+    if (estimatedPenalty > bestPenalty + cx.params.Max_PenaltySpan) break;
+    if (candidateNumMismatches > pcGetNumBlocks(pc)) break;
+    pcFindGoodPositionsHavingPriority(pc, se, candidateNumMismatches);
+    if (cx.status) return;
+    for (int i = 0; i < pc.nFiltered; i++) {
+      int al;
+      if (haveOptimisticMatch && qmSamePosition(pc.filtered[i], optimisticBestMatch)) al = optimisticBestAlignment;
+      else al = qmaAlign(cx, *aligner, pc.filtered[i], 0);
+      if (cx.status) return;
+      if (al >= 0) {
+        double penalty = aligner->good[al].totalPenalty;
+        if (bestPenalty > penalty) bestPenalty = penalty;
+      }
+    }
+    if (estimatedPenalty >= maxInterestingPenalty) break;
+    candidateNumMismatches++;
+  }
+  qmaGetBestAlignments(*aligner);
+  if (aligner->nBest < 1 && in.nMates > 1) {
+    pcFindPartiallyGoodPositions(pc, se);
+    if (cx.status) return;
+    for (int i = 0; i < pc.nFiltered; i++) {
+      int al = qmaAlign(cx, *aligner, pc.filtered[i], 0);
+      if (cx.status) return;
+      if (al >= 0) {
+        double penalty = aligner->good[al].totalPenalty;
+        if (bestPenalty > penalty) bestPenalty = penalty;
+      }
+    }
+  }
+  qmaGetBestAlignments(*aligner);
+  int numBest = aligner->nBest;
+  if (numBest < 1 && in.nMates > 1) {
+    getUnpairedAlignments(cx, rr);
+    if (cx.status) return;
+  }
+  if ((int64_t)numBest > (int64_t)cx.params.MaxNumMatches) {  // :476-481
+    rr.nComponents = 1; rr.single[0] = -1; rr.empty[0] = 1;
+  }
+}
+
+// size / write the result of one read in stream format
+XM_INL void resultSize(const ReadResult& rr, int64_t& ni, int64_t& nd) {
+  ni = 1; nd = 0;
+  for (int c = 0; c < rr.nComponents; c++) {
+    ni += 1;
+    if (rr.empty[c] || !rr.aligner[c]) continue;
+    if (rr.single[c] >= 0) { countQAl(rr.aligner[c]->good[rr.single[c]], ni, nd); continue; }
+    for (int i = 0; i < rr.aligner[c]->nBest; i++) countQAl(rr.aligner[c]->good[rr.aligner[c]->bestIdx[i]], ni, nd);
+  }
+}
+XM_INL void resultWrite(const ReadResult& rr, OutWriter& w, DevCounters* dc) {
+  w.ints[w.ni++] = rr.nComponents;
+  for (int c = 0; c < rr.nComponents; c++) {
+    if (rr.empty[c] || !rr.aligner[c]) { w.ints[w.ni++] = 0; continue; }
+    if (rr.single[c] >= 0) { w.ints[w.ni++] = 1; writeQAl(w, rr.aligner[c]->good[rr.single[c]]); if (dc) dc->alignmentsOut++; continue; }
+    w.ints[w.ni++] = rr.aligner[c]->nBest;
+    for (int i = 0; i < rr.aligner[c]->nBest; i++) { writeQAl(w, rr.aligner[c]->good[rr.aligner[c]->bestIdx[i]]); if (dc) dc->alignmentsOut++; }
+  }
+}
+
+// Carve a lane's arena and align one read.  `arena` must be 16-byte aligned.
+XM_INL void runRead(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* arena, size_t arenaBytes, DevCounters* dc, ReadResult& rr) {
+  cx.ix = ix; cx.caps = makeCaps(scale); cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
+  cx.params.StartingInsertionStartFree = 0;
+  size_t persistBytes = arenaBytes * 5 / 12;
+  persistBytes &= ~(size_t)15;
+  cx.persist.init(arena, persistBytes);
+  cx.tmp.init((uint8_t*)arena + persistBytes, arenaBytes - persistBytes);
+  alignRead(cx, rr);
+}
+
+}  // namespace xm

@@ -1,0 +1,189 @@
+// HOST SIMULATION OF THE DEVICE KERNEL — TEST HARNESS ONLY.
+//
+// There is no GPU in the development container, so the kernel sources (mapper_amd/csrc/xm_*.h) are also compiled for the
+// host here and driven read by read, exactly as a lane of xm_align_kernel would, to let the CPU-only test tier compare the
+// kernel logic with the oracle.  This file is built by tests/ into tests/_build/libxm_hostsim.so; it is never linked into
+// or loaded by libxmapper_hip.so / the mapper_amd package, which has no CPU path.
+#include "../../include/xmapper_hip.h"
+#include "../../mapper_amd/csrc/xm_worker.h"
+#include "../../mapper_amd/csrc/xm_index_host.h"
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace xm;
+
+static thread_local std::string g_err;
+
+struct SimIndex {
+  HostIndex host;
+  IndexView view;
+  std::vector<uint32_t> p32;
+  void refresh() {
+    bool is64 = host.seqCumStart.back() > 0xFFFFFFFFll;
+    p32.clear();
+    if (!is64) { p32.resize(host.positions.size()); for (size_t i = 0; i < p32.size(); i++) p32[i] = (uint32_t)host.positions[i]; }
+    view.numContigs = host.numContigs(); view.minInterestingSize = host.minInterestingSize; view.maxHashedLength = host.maxHashedLength;
+    view.enableGapmers = host.enableGapmers; view.posIs64 = is64 ? 1 : 0; view.dupWindow = host.dupWindow; view.dupGranularity = host.dupGranularity();
+    view.totalForwardAndReverseSize = host.totalForwardSize * 2;
+    view.contigStart = host.contigStart.data(); view.contigLen = host.contigLen.data(); view.seqCumStart = host.seqCumStart.data(); view.refCodes = host.refCodes.data();
+    view.tables = host.tables.data(); view.bucketOff = host.bucketOff.data(); view.positions32 = p32.data(); view.positions64 = (const uint64_t*)host.positions.data();
+    view.dupKeyStart = host.dupKeyStart.data(); view.dupKeys = host.dupKeys.data();
+  }
+};
+
+extern "C" {
+
+const char* xmsim_last_error() { return g_err.c_str(); }
+
+void* xmsim_index_build(const xm_ref* ref, const xm_build_opts* o) {
+  try {
+    SimIndex* s = new SimIndex();
+    s->host.setReference(ref->num_contigs, ref->names, ref->codes, ref->lengths);
+    s->host.build(o->enable_gapmers, o->min_interesting_size, o->max_hashed_length, o->dup_window, o->dup_min_copies, o->dup_min_length, o->dup_max_length);
+    s->refresh();
+    return s;
+  } catch (std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void xmsim_index_free(void* p) { delete (SimIndex*)p; }
+
+// same result layout as xm_align_batch; counters[11] = reads rerun at a larger scale; returns non-zero on failure
+int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, xm_result** out) {
+  SimIndex* idx = (SimIndex*)idxp;
+  try {
+    int maxLen = 1;
+    for (int64_t q = 0; q < b->num_queries; q++) for (int m = 0; m < b->mate_count[q]; m++) if (b->mate_length[q * 2 + m] > maxLen) maxLen = b->mate_length[q * 2 + m];
+    if (maxLen > idx->host.maxHashedLength) { idx->host.ensureLength(maxLen); idx->refresh(); }
+    Params params;
+    params.MutationPenalty = p->MutationPenalty; params.InsertionStart_Penalty = p->InsertionStart_Penalty; params.InsertionExtension_Penalty = p->InsertionExtension_Penalty;
+    params.DeletionStart_Penalty = p->DeletionStart_Penalty; params.DeletionExtension_Penalty = p->DeletionExtension_Penalty; params.MaxErrorRate = p->MaxErrorRate;
+    params.UnalignedPenalty = p->UnalignedPenalty; params.AmbiguityPenalty = p->AmbiguityPenalty; params.Max_PenaltySpan = p->Max_PenaltySpan;
+    params.MaxNumMatches = p->MaxNumMatches; params.StartingInsertionStartFree = 0;
+    const int64_t nq = b->num_queries;
+    std::vector<int32_t> ints;
+    std::vector<double> dbls;
+    xm_result* res = (xm_result*)calloc(1, sizeof(xm_result));
+    res->num_queries = nq;
+    res->int_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq + 1));
+    res->dbl_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq + 1));
+    DevCounters dc;
+    memset(&dc, 0, sizeof(dc));
+    int64_t rerun = 0;
+    std::vector<uint8_t> arena;
+    static ReadCtx cx;  // large; keep it off the stack
+    for (int64_t q = 0; q < nq; q++) {
+      ReadIn in;
+      in.nMates = b->mate_count[q];
+      for (int m = 0; m < 2; m++) { in.mate[m] = b->codes + b->mate_offset[q * 2 + m]; in.mateLen[m] = m < in.nMates ? b->mate_length[q * 2 + m] : 0; }
+      in.expectedInner = in.nMates > 1 ? b->expected_inner[q] : 0.0;
+      in.deviation = in.nMates > 1 ? b->deviation[q] : 1.0;
+      int scale = 1;
+      while (true) {
+        size_t bytes = (size_t)288 * 1024 * (size_t)scale;
+        arena.resize(bytes + 64);
+        uint8_t* a = (uint8_t*)(((uintptr_t)arena.data() + 15) & ~(uintptr_t)15);
+        ReadResult rr;
+        DevCounters before = dc;
+        runRead(cx, &idx->view, params, in, scale, a, bytes, &dc, rr);
+        if (cx.status == XM_ST_OVERFLOW) { dc = before; scale *= 4; rerun++; if (scale > 4096) throw std::runtime_error("scratch scale limit"); continue; }
+        if (cx.status != XM_OK) throw std::runtime_error("Failed to align query " + std::to_string(q) + " (status " + std::to_string(cx.status) + ")");
+        int64_t ni, nd;
+        resultSize(rr, ni, nd);
+        res->int_off[q] = (int64_t)ints.size(); res->dbl_off[q] = (int64_t)dbls.size();
+        ints.resize(ints.size() + (size_t)ni); dbls.resize(dbls.size() + (size_t)nd);
+        OutWriter w;
+        w.ints = ints.data() + res->int_off[q]; w.dbls = dbls.data() + res->dbl_off[q]; w.ni = 0; w.nd = 0;
+        resultWrite(rr, w, &dc);
+        break;
+      }
+    }
+    res->int_off[nq] = (int64_t)ints.size(); res->dbl_off[nq] = (int64_t)dbls.size();
+    res->num_ints = (int64_t)ints.size(); res->num_dbls = (int64_t)dbls.size();
+    res->ints = (int32_t*)malloc(sizeof(int32_t) * (ints.size() + 1));
+    res->dbls = (double*)malloc(sizeof(double) * (dbls.size() + 1));
+    if (!ints.empty()) memcpy(res->ints, ints.data(), ints.size() * sizeof(int32_t));
+    if (!dbls.empty()) memcpy(res->dbls, dbls.data(), dbls.size() * sizeof(double));
+    res->counters[0] = (int64_t)dc.reads; res->counters[1] = (int64_t)dc.headerProbes; res->counters[2] = (int64_t)dc.bucketFetches; res->counters[3] = (int64_t)dc.hitsFetched;
+    res->counters[4] = (int64_t)dc.candidatesExtended; res->counters[5] = (int64_t)dc.pathAlignerCalls; res->counters[6] = (int64_t)dc.pathAlignerNodes;
+    res->counters[7] = (int64_t)dc.quickAccepts; res->counters[8] = (int64_t)dc.alignmentsOut; res->counters[9] = (int64_t)dc.refWindowBytes; res->counters[10] = (int64_t)dc.readBytes;
+    res->counters[11] = rerun;
+    *out = res;
+    return 0;
+  } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+void xmsim_result_free(xm_result* r) {
+  if (!r) return;
+  free(r->ints); free(r->dbls); free(r->int_off); free(r->dbl_off); free(r);
+}
+
+int xmsim_table_info(void* idxp, int L, int32_t* capacity, int32_t* maxCount, int64_t* numStored) {
+  SimIndex* idx = (SimIndex*)idxp;
+  if (L < 0 || L > idx->host.maxHashedLength) return 1;
+  const Table& t = idx->host.tables[(size_t)L];
+  *capacity = t.capacity; *maxCount = t.maxCount;
+  *numStored = (int64_t)(idx->host.bucketOff[(size_t)(t.offBase + t.capacity)] & ~XM_OVERFULL);
+  return 0;
+}
+int xmsim_table_dump(void* idxp, int L, int32_t* counts, int64_t* positionsOut) {
+  SimIndex* idx = (SimIndex*)idxp;
+  const HostIndex& h = idx->host;
+  const Table& t = h.tables[(size_t)L];
+  int64_t w = 0;
+  for (int k = 0; k < t.capacity; k++) {
+    uint32_t o0 = h.bucketOff[(size_t)(t.offBase + k)], o1 = h.bucketOff[(size_t)(t.offBase + k + 1)];
+    if (o0 & XM_OVERFULL) { counts[k] = -1; continue; }
+    int c = (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
+    counts[k] = c;
+    for (int j = 0; j < c; j++) positionsOut[w++] = (int64_t)h.positions[(size_t)(t.posBase + (o0 & ~XM_OVERFULL) + j)];
+  }
+  return 0;
+}
+int xmsim_index_info(void* idxp, int32_t* minInteresting, int32_t* maxHashed) {
+  SimIndex* idx = (SimIndex*)idxp;
+  *minInteresting = idx->host.minInterestingSize; *maxHashed = idx->host.maxHashedLength;
+  return 0;
+}
+int xmsim_ensure_length(void* idxp, int length) {
+  SimIndex* idx = (SimIndex*)idxp;
+  try { idx->host.ensureLength(length); idx->refresh(); return 0; } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+int64_t xmsim_dup_keys(void* idxp, int contig, int32_t* out, int64_t cap) {
+  SimIndex* idx = (SimIndex*)idxp;
+  const HostIndex& h = idx->host;
+  int64_t a = h.dupKeyStart[(size_t)contig], bb = h.dupKeyStart[(size_t)contig + 1];
+  for (int64_t i = a; i < bb && i - a < cap; i++) out[i - a] = h.dupKeys[(size_t)i];
+  return bb - a;
+}
+
+// read-side pyramid dump in the layout of oracle xmo_pyramid_dump (14 ints per block)
+int64_t xmsim_pyramid_dump(const uint8_t* codes, int len, int32_t* out, int64_t capRows) {
+  std::vector<PBlock> blocks((size_t)len * 64 + 64);
+  std::vector<int32_t> ls((size_t)len + 8);
+  int32_t status = 0;
+  SeqView s;
+  s.base = codes; s.len = len; s.rc = 0; s.id = 0;
+  Pyramid pyr;
+  pyr.init(s, blocks.data(), (int)blocks.size(), ls.data(), len + 4, &status);
+  int64_t n = 0;
+  for (int level = 0;; level++) {
+    if (level > 0) { pyr.ensure(level); if (status) return -1; }
+    int cnt = pyr.count(level);
+    if (cnt == 0) break;
+    for (int i = 0; i < cnt; i++) {
+      PBlock h = pyr.blockAt(level, i);
+      if (n < capRows) {
+        int32_t* o = out + n * 14;
+        o[0] = level; o[1] = h.start; o[2] = h.len; o[3] = h.fwd; o[4] = h.rev; o[5] = h.flags; o[6] = h.gapDir; o[7] = h.extraGap;
+        QBlock g;
+        int st = withGapAndExtension(h, s, g);
+        o[8] = st; o[9] = st ? g.start : 0; o[10] = st ? g.len : 0; o[11] = st ? g.used : 0; o[12] = st ? g.fwd : 0; o[13] = st ? g.rev : 0;
+      }
+      n++;
+    }
+  }
+  return n;
+}
+
+}  // extern "C"
