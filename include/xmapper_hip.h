@@ -90,6 +90,7 @@ typedef struct xm_result {
   double h2d_ms, d2h_ms;
   int32_t kernel_launches;
   int32_t reserved;
+  int64_t prof[16];   /* diagnostic builds (-DXM_PROFILE) only: shader-clock ticks per phase summed over lanes; otherwise 0 */
 } xm_result;
 
 typedef struct xm_index_info_t {
@@ -119,6 +120,10 @@ int64_t xm_index_dup_keys(const xm_index* index, int32_t contig, int32_t* out, i
  * aligned on the GPU; *out is allocated by the library and released with xm_result_free. */
 int xm_align_batch(xm_index* index, const xm_params* params, const xm_query_batch* batch, xm_result** out);
 void xm_result_free(xm_result* result);
+/* The same in two steps, for callers that keep a batch in HBM (and for measuring the path without the PCIe copy):
+ * xm_batch_upload validates and copies the batch to the device, xm_align_resident aligns the resident batch. */
+int xm_batch_upload(xm_index* index, const xm_query_batch* batch);
+int xm_align_resident(xm_index* index, const xm_params* params, xm_result** out);
 
 /* Bulk form of Readable_HashBlock_Database.getNumMatchesLowerBound + matchBlock / PackedMap.get (PackedMap.java:160-172,
  * 228-236) for n (used_length, lookup key) pairs: counts[i] = number of stored positions, -1 when the bucket is overfull or

@@ -37,7 +37,7 @@ class XmResult(C.Structure):
     _fields_ = [("num_queries", C.c_int64), ("num_ints", C.c_int64), ("num_dbls", C.c_int64), ("ints", C.POINTER(C.c_int32)),
                 ("dbls", C.POINTER(C.c_double)), ("int_off", C.POINTER(C.c_int64)), ("dbl_off", C.POINTER(C.c_int64)),
                 ("counters", C.c_int64 * 16), ("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
-                ("kernel_launches", C.c_int32), ("reserved", C.c_int32)]
+                ("kernel_launches", C.c_int32), ("reserved", C.c_int32), ("prof", C.c_int64 * 16)]
 
 
 class XmIndexInfo(C.Structure):
@@ -47,7 +47,7 @@ class XmIndexInfo(C.Structure):
 
 
 EXPORTS = ["xm_last_error", "xm_device_count", "xm_index_build", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
-           "xm_index_table_info", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_seed_probe"]
+           "xm_index_table_info", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_align_resident", "xm_seed_probe"]
 
 
 def build_library(force=False):
@@ -82,6 +82,8 @@ def lib():
         L.xm_index_dup_keys.restype = C.c_int64
         L.xm_align_batch.argtypes = [C.c_void_p, C.POINTER(XmParams), C.POINTER(XmQueryBatch), C.POINTER(C.POINTER(XmResult))]
         L.xm_result_free.argtypes = [C.POINTER(XmResult)]
+        L.xm_batch_upload.argtypes = [C.c_void_p, C.POINTER(XmQueryBatch)]
+        L.xm_align_resident.argtypes = [C.c_void_p, C.POINTER(XmParams), C.POINTER(C.POINTER(XmResult))]
         L.xm_seed_probe.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         _lib = L
     return _lib
@@ -114,4 +116,4 @@ def copy_result(r):
     io = np.ctypeslib.as_array(r.int_off, shape=(r.num_queries + 1,)).copy()
     do = np.ctypeslib.as_array(r.dbl_off, shape=(r.num_queries + 1,)).copy()
     return dict(ints=ints, dbls=dbls, int_off=io, dbl_off=do, counters=list(r.counters), kernel_ms=r.kernel_ms, h2d_ms=r.h2d_ms,
-                d2h_ms=r.d2h_ms, kernel_launches=r.kernel_launches)
+                d2h_ms=r.d2h_ms, kernel_launches=r.kernel_launches, prof=list(r.prof))

@@ -1,0 +1,292 @@
+"""Host-side mirror of the reference's programmatic API for the seed-and-extend path.
+
+Mirrors src/main/java/mapper/Api.java:18-107 (newDatabase / align / alignOnce), AlignmentParameters.java:8-35 and the
+Query / QueryAlignment / SequenceAlignment / AlignedBlock result types the Java host consumes, on top of the C ABI of
+include/xmapper_hip.h.  Everything is aligned on the GPU by libxmapper_hip.so; there is no CPU path.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _capi
+
+_CODE = np.full(256, 15, dtype=np.uint8)
+for _ch, _v in {"A": 1, "C": 2, "G": 4, "T": 8, "U": 8, "R": 5, "Y": 10, "S": 6, "W": 9, "K": 12, "M": 3, "B": 14, "D": 13, "H": 11, "V": 7, "N": 15}.items():
+    _CODE[ord(_ch)] = _v
+    _CODE[ord(_ch.lower())] = _v
+_DECODE = "?ACMGRSVTWYHKDBN"
+_COMP = np.array([((b & 1) << 3) | ((b & 2) << 1) | ((b & 4) >> 1) | ((b & 8) >> 3) for b in range(16)], dtype=np.uint8)
+
+
+def encode(text):
+    """IUPAC text -> 4-bit Basepairs codes, one per byte."""
+    return _CODE[np.frombuffer(text.encode("ascii"), dtype=np.uint8)].copy()
+
+
+def decode(codes):
+    return "".join(_DECODE[int(c) & 15] for c in codes)
+
+
+def reverse_complement(codes):
+    return _COMP[np.asarray(codes, dtype=np.uint8)[::-1]]
+
+
+class AlignmentParameters:
+    """AlignmentParameters.java:8-35; defaults are Mapper.main's (Mapper.java:66-73, 409-453)."""
+
+    def __init__(self, MutationPenalty=1.0, InsertionStart_Penalty=1.5, InsertionExtension_Penalty=0.5 + 0.1, DeletionStart_Penalty=1.5,
+                 DeletionExtension_Penalty=0.5, MaxErrorRate=0.1, UnalignedPenalty=0.1, AmbiguityPenalty=0.1, MaxNumMatches=2**31 - 1,
+                 Max_PenaltySpan=0.5):
+        self.MutationPenalty = MutationPenalty
+        self.InsertionStart_Penalty = InsertionStart_Penalty
+        self.InsertionExtension_Penalty = InsertionExtension_Penalty
+        self.DeletionStart_Penalty = DeletionStart_Penalty
+        self.DeletionExtension_Penalty = DeletionExtension_Penalty
+        self.MaxErrorRate = MaxErrorRate
+        self.UnalignedPenalty = UnalignedPenalty
+        self.AmbiguityPenalty = AmbiguityPenalty
+        self.MaxNumMatches = MaxNumMatches
+        self.Max_PenaltySpan = Max_PenaltySpan
+
+    def _c(self):
+        p = _capi.XmParams()
+        for f, _ in _capi.XmParams._fields_:
+            if f != "reserved":
+                setattr(p, f, getattr(self, f))
+        return p
+
+
+class Query:
+    """Query(seq) / Query(seq1, seq2, expectedInnerDistance, spacingDeviationPerUnitPenalty) [QuickVariants]."""
+
+    def __init__(self, *sequences, expected_inner_distance=0.0, spacing_deviation_per_unit_penalty=1.0, name=None, names=None):
+        self.sequences = [encode(s) if isinstance(s, str) else np.ascontiguousarray(s, dtype=np.uint8) for s in sequences]
+        if not 1 <= len(self.sequences) <= 2:
+            raise ValueError("a Query has 1 or 2 sequences")
+        self.expected_inner_distance = float(expected_inner_distance)
+        self.spacing_deviation_per_unit_penalty = float(spacing_deviation_per_unit_penalty)
+        self.names = names or ([name] * len(self.sequences) if name else ["query"] * len(self.sequences))
+
+
+class AlignedBlock:
+    __slots__ = ("startA", "startB", "lengthA", "lengthB")
+
+    def __init__(self, sa, sb, la, lb):
+        self.startA, self.startB, self.lengthA, self.lengthB = sa, sb, la, lb
+
+
+class SequenceAlignment:
+    """SequenceAlignment [QuickVariants]: ordered AlignedBlocks + referenceReversed + penalties."""
+
+    def __init__(self, contig, reference_reversed, blocks, total_penalty, aligned_penalty):
+        self.contig, self.reference_reversed, self.sections = contig, bool(reference_reversed), blocks
+        self.penalty, self.aligned_penalty = total_penalty, aligned_penalty
+
+    def start_index_b(self):
+        return self.sections[0].startB
+
+    def end_index_b(self):
+        return self.sections[-1].startB + self.sections[-1].lengthB
+
+    def aligned_text(self, query_codes, ref_codes):
+        """(getAlignedTextA, getAlignedTextB); query_codes must be the strand that was aligned."""
+        a, b = [], []
+        for s in self.sections:
+            a.append(decode(query_codes[s.startA:s.startA + s.lengthA]) if s.lengthA > 0 else "-" * s.lengthB)
+            b.append(decode(ref_codes[s.startB:s.startB + s.lengthB]) if s.lengthB > 0 else "-" * s.lengthA)
+        return "".join(a), "".join(b)
+
+
+class QueryAlignment:
+    """QueryAlignment(components, spacingPenalty, overlapMultiplier, duplicationBonus, totalPenalty, innerDistance)
+    (QueryMatch_Aligner.java:267)."""
+
+    def __init__(self, components, spacing_penalty, overlap_multiplier, duplication_bonus, penalty, inner_distance):
+        self.components = components
+        self.spacing_penalty, self.overlap_multiplier, self.duplication_bonus = spacing_penalty, overlap_multiplier, duplication_bonus
+        self.penalty, self.inner_distance = penalty, inner_distance
+
+
+def decode_streams(ints, dbls, int_off, dbl_off, q):
+    """-> QueryAlignments of query q as list (components) of lists of QueryAlignment."""
+    ii = ints[int_off[q]:int_off[q + 1]]
+    dd = dbls[dbl_off[q]:dbl_off[q + 1]]
+    i = d = 0
+    comps = []
+    ncomp = int(ii[i]); i += 1
+    for _ in range(ncomp):
+        nal = int(ii[i]); i += 1
+        als = []
+        for _ in range(nal):
+            inner, nseq = int(ii[i]), int(ii[i + 1]); i += 2
+            sp, om, db, tp = (float(x) for x in dd[d:d + 4]); d += 4
+            seqs = []
+            for _ in range(nseq):
+                contig, rev, nb = int(ii[i]), int(ii[i + 1]), int(ii[i + 2]); i += 3
+                blocks = [AlignedBlock(int(ii[i + 4 * k]), int(ii[i + 4 * k + 1]), int(ii[i + 4 * k + 2]), int(ii[i + 4 * k + 3])) for k in range(nb)]
+                i += 4 * nb
+                seqs.append(SequenceAlignment(contig, rev, blocks, float(dd[d]), float(dd[d + 1])))
+                d += 2
+            als.append(QueryAlignment(seqs, sp, om, db, tp, inner))
+        comps.append(als)
+    return comps
+
+
+class BatchResult:
+    def __init__(self, d):
+        self.__dict__.update(d)
+
+    def __len__(self):
+        return len(self.int_off) - 1
+
+    def query_alignments(self, q):
+        return decode_streams(self.ints, self.dbls, self.int_off, self.dbl_off, q)
+
+
+class ReferenceDatabase:
+    """ReferenceDatabase.java: HashBlock_Database + DuplicationDetector of a reference, resident in HBM."""
+
+    def __init__(self, contigs, mode="mapper", enable_gapmers=True, max_query_length=0, device=-1, host_only=False, dup=None):
+        """contigs: list of (name, IUPAC text or code array), already in Mapper.sortAndComplementReference order
+        (use sort_reference()).  mode 'mapper' = Mapper.run assembly (duplication window 1000), 'api' = Api.newDatabase (window 1)."""
+        self._L = _capi.lib()
+        self.contigs = [(n, encode(s) if isinstance(s, str) else np.ascontiguousarray(s, dtype=np.uint8)) for n, s in contigs]
+        ref, self._keep = _capi.make_ref(self.contigs)
+        o = _capi.XmBuildOpts()
+        o.enable_gapmers = 1 if enable_gapmers else 0
+        o.min_interesting_size = -1
+        o.max_hashed_length = int(max_query_length)
+        o.dup_window = 1 if mode == "api" else 1000
+        o.dup_min_copies = 2
+        o.dup_min_length = o.dup_max_length = -1
+        if dup:
+            o.dup_min_length, o.dup_max_length, o.dup_min_copies, o.dup_window = dup
+        o.device = device
+        o.host_only = 1 if host_only else 0
+        h = C.c_void_p()
+        if self._L.xm_index_build(C.byref(ref), C.byref(o), C.byref(h)):
+            raise RuntimeError(self._L.xm_last_error().decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.xm_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def info(self):
+        i = _capi.XmIndexInfo()
+        if self._L.xm_index_get_info(self._h, C.byref(i)):
+            raise RuntimeError(self._L.xm_last_error().decode())
+        return {f: getattr(i, f) for f, _ in _capi.XmIndexInfo._fields_}
+
+    def ensure_length(self, n):
+        if self._L.xm_index_ensure_length(self._h, int(n)):
+            raise RuntimeError(self._L.xm_last_error().decode())
+
+    def table(self, used_length):
+        cap, mx, n, o = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+        if self._L.xm_index_table_info(self._h, used_length, C.byref(cap), C.byref(mx), C.byref(n), C.byref(o)):
+            return None
+        counts = np.zeros(cap.value, dtype=np.int32)
+        pos = np.zeros(max(n.value, 1), dtype=np.int64)
+        self._L.xm_index_table_dump(self._h, used_length, counts.ctypes.data, pos.ctypes.data)
+        return dict(capacity=cap.value, maxCount=mx.value, counts=counts, positions=pos[:n.value])
+
+    def dup_keys(self, contig):
+        n = self._L.xm_index_dup_keys(self._h, contig, None, 0)
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        self._L.xm_index_dup_keys(self._h, contig, out.ctypes.data, n)
+        return out[:n]
+
+    def align_arrays(self, mate_count, mate_offset, mate_length, codes, expected_inner, deviation, parameters):
+        """One AlignerWorker.process() batch (AlignerWorker.java:177-231) from flat arrays -> BatchResult."""
+        b, keep = _capi.make_batch(mate_count, mate_offset, mate_length, codes, expected_inner, deviation)
+        p = parameters._c() if isinstance(parameters, AlignmentParameters) else parameters
+        res = C.POINTER(_capi.XmResult)()
+        if self._L.xm_align_batch(self._h, C.byref(p), C.byref(b), C.byref(res)):
+            raise RuntimeError("Failed to align: " + self._L.xm_last_error().decode())
+        d = _capi.copy_result(res.contents)
+        self._L.xm_result_free(res)
+        return BatchResult(d)
+
+    def upload_arrays(self, mate_count, mate_offset, mate_length, codes, expected_inner, deviation):
+        """xm_batch_upload: validate + copy one batch to HBM; it stays resident for align_resident()."""
+        b, keep = _capi.make_batch(mate_count, mate_offset, mate_length, codes, expected_inner, deviation)
+        if self._L.xm_batch_upload(self._h, C.byref(b)):
+            raise RuntimeError(self._L.xm_last_error().decode())
+
+    def align_resident(self, parameters):
+        p = parameters._c() if isinstance(parameters, AlignmentParameters) else parameters
+        res = C.POINTER(_capi.XmResult)()
+        if self._L.xm_align_resident(self._h, C.byref(p), C.byref(res)):
+            raise RuntimeError("Failed to align: " + self._L.xm_last_error().decode())
+        d = _capi.copy_result(res.contents)
+        self._L.xm_result_free(res)
+        return BatchResult(d)
+
+    def align_batch(self, queries, parameters):
+        nq = len(queries)
+        mc = np.zeros(nq, np.int32); mo = np.zeros(2 * nq, np.int64); ml = np.zeros(2 * nq, np.int32)
+        ei = np.zeros(nq); dv = np.ones(nq)
+        chunks, off = [], 0
+        for i, q in enumerate(queries):
+            mc[i] = len(q.sequences)
+            ei[i], dv[i] = q.expected_inner_distance, q.spacing_deviation_per_unit_penalty
+            for m, s in enumerate(q.sequences):
+                mo[2 * i + m], ml[2 * i + m] = off, len(s)
+                chunks.append(s)
+                off += len(s)
+        codes = np.concatenate(chunks) if chunks else np.zeros(1, np.uint8)
+        return self.align_arrays(mc, mo, ml, codes, ei, dv, parameters)
+
+    def seed_probe(self, used_length, keys, max_per_probe=8):
+        """Bulk PackedMap.get (PackedMap.java:160-172) on the device -> (counts, positions[n, max_per_probe], kernel_ms)."""
+        used = np.ascontiguousarray(used_length, dtype=np.int32)
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        n = len(used)
+        counts = np.zeros(n, np.int32)
+        pos = np.zeros((n, max(max_per_probe, 1)), np.int64)
+        ms = C.c_double()
+        if self._L.xm_seed_probe(self._h, n, used.ctypes.data, keys.ctypes.data, max_per_probe, counts.ctypes.data, pos.ctypes.data, C.byref(ms)):
+            raise RuntimeError(self._L.xm_last_error().decode())
+        return counts, pos, ms.value
+
+
+def sort_reference(contigs):
+    """Mapper.sortAndComplementReference (Mapper.java:1151-1172): length-descending, stable within equal lengths."""
+    return sorted(contigs, key=lambda c: -len(c[1]))
+
+
+# ---- Api.java:18-107
+def newDatabase(references, **kw):
+    """Api.newDatabase(List<String>) (Api.java:25-31): contigs are named reference-<i>."""
+    if isinstance(references, str):
+        references = [references]
+    if isinstance(references, dict):
+        items = list(references.items())
+    else:
+        items = [("reference-%d" % i, r) for i, r in enumerate(references)]
+    kw.setdefault("mode", "api")
+    return ReferenceDatabase(items, **kw)
+
+
+def align(query, reference_database, parameters):
+    """Api.align (Api.java:79-92) -> List<QueryAlignment> (QueryAlignments.getTopLevelAlignments())."""
+    if isinstance(query, str):
+        query = Query(query)
+    comps = reference_database.align_batch([query], parameters).query_alignments(0)
+    return comps[0] if len(comps) == 1 else []
+
+
+def alignOnce(query, reference_text, parameters):
+    """Api.alignOnce (Api.java:96-107)."""
+    db = newDatabase(reference_text)
+    try:
+        return align(query, db, parameters)
+    finally:
+        db.close()

@@ -53,10 +53,11 @@ __device__ __forceinline__ void addCounters(DevCounters* g, const DevCounters& l
   atomicAdd(&g->hitsFetched, l.hitsFetched); atomicAdd(&g->candidatesExtended, l.candidatesExtended); atomicAdd(&g->pathAlignerCalls, l.pathAlignerCalls);
   atomicAdd(&g->pathAlignerNodes, l.pathAlignerNodes); atomicAdd(&g->quickAccepts, l.quickAccepts); atomicAdd(&g->alignmentsOut, l.alignmentsOut);
   atomicAdd(&g->refWindowBytes, l.refWindowBytes); atomicAdd(&g->readBytes, l.readBytes);
+  for (int i = 0; i < 16; i++) if (l.t[i]) atomicAdd(&g->t[i], l.t[i]);
 }
 
 // One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
-__global__ void __launch_bounds__(256) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale,
+__global__ void __launch_bounds__(256) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed,
                                                        uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters) {
   unsigned long long lane = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   uint8_t* arena = arenas + lane * arenaBytes;
@@ -77,8 +78,10 @@ __global__ void __launch_bounds__(256) xm_align_kernel(IndexView ix, Params para
     in.expectedInner = in.nMates > 1 ? batch.expectedInner[q] : 0.0;
     in.deviation = in.nMates > 1 ? batch.deviation[q] : 1.0;
     ReadResult rr;
-    runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr);
+    DevCounters before = local;
+    runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed != 0);
     int32_t st = cx.status;
+    if (st != XM_OK) local = before;  // work of a read that is rerun by a later pass is counted there
     if (st == XM_OK) {
       int64_t ni, nd;
       resultSize(rr, ni, nd);
@@ -158,6 +161,8 @@ struct xm_index {
   DevBuf<unsigned long long> dCursors;  // [0],[1] result cursors, [2] next item
   DevBuf<DevCounters> dCounters;
   int numCUs = 0;
+  int64_t residentNq = -1;   // batch kept in HBM by xm_batch_upload
+  double residentH2dMs = 0;
 
   void upload() {
     HIP_CHECK(hipSetDevice(device));
@@ -308,38 +313,27 @@ void xm_result_free(xm_result* r) {
   free(r);
 }
 
-int xm_align_batch(xm_index* idx, const xm_params* p, const xm_query_batch* b, xm_result** out) {
-  if (!idx || !p || !b || !out) return fail("xm_align_batch: null argument");
-  if (idx->hostOnly) return fail("xm_align_batch: index was built with host_only=1; this library aligns on the GPU only");
-  try {
-    std::lock_guard<std::mutex> lock(idx->mu);
-    const int64_t nq = b->num_queries;
-    int maxLen = 1;
-    for (int64_t q = 0; q < nq; q++) {
-      if (b->mate_count[q] < 1 || b->mate_count[q] > 2) throw std::runtime_error("mate_count must be 1 or 2");
-      for (int m = 0; m < b->mate_count[q]; m++) {
-        int32_t len = b->mate_length[q * 2 + m];
-        if (len < 1 || len > 60000) throw std::runtime_error("mate length out of range (1..60000)");
-        if (b->mate_offset[q * 2 + m] < 0 || b->mate_offset[q * 2 + m] + len > b->codes_length) throw std::runtime_error("mate outside of codes");
-        if (len > maxLen) maxLen = len;
-      }
+// validation + Readable_HashBlock_Database growth + host-to-device copy of one batch; the batch stays resident in HBM
+static void uploadBatchLocked(xm_index* idx, const xm_query_batch* b) {
+  const int64_t nq = b->num_queries;
+  int maxLen = 1;
+  for (int64_t q = 0; q < nq; q++) {
+    if (b->mate_count[q] < 1 || b->mate_count[q] > 2) throw std::runtime_error("mate_count must be 1 or 2");
+    for (int m = 0; m < b->mate_count[q]; m++) {
+      int32_t len = b->mate_length[q * 2 + m];
+      if (len < 1 || len > 60000) throw std::runtime_error("mate length out of range (1..60000)");
+      if (b->mate_offset[q * 2 + m] < 0 || b->mate_offset[q * 2 + m] + len > b->codes_length) throw std::runtime_error("mate outside of codes");
+      if (len > maxLen) maxLen = len;
     }
-    if (maxLen > idx->host.maxHashedLength) {  // Readable_HashBlock_Database.getContainingMap growth, done before the launch
-      idx->host.ensureLength(maxLen);
-      idx->upload();
-    }
-    HIP_CHECK(hipSetDevice(idx->device));
-    hipStream_t s = idx->stream;
-    xm_result* res = (xm_result*)calloc(1, sizeof(xm_result));
-    res->num_queries = nq;
-    res->int_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq + 1));
-    res->dbl_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq + 1));
-    if (nq == 0) {
-      res->ints = (int32_t*)malloc(4); res->dbls = (double*)malloc(8); res->int_off[0] = res->dbl_off[0] = 0;
-      *out = res;
-      return 0;
-    }
-    // ---- H2D
+  }
+  if (maxLen > idx->host.maxHashedLength) {  // Readable_HashBlock_Database.getContainingMap growth, done before the launch
+    idx->host.ensureLength(maxLen);
+    idx->upload();
+  }
+  HIP_CHECK(hipSetDevice(idx->device));
+  hipStream_t s = idx->stream;
+  idx->residentNq = -1;
+  if (nq > 0) {
     hipEvent_t e0 = idx->ev0, e1 = idx->ev1;
     HIP_CHECK(hipEventRecord(e0, s));
     idx->dMateCount.ensure((size_t)nq); idx->dMateOffset.ensure((size_t)nq * 2); idx->dMateLength.ensure((size_t)nq * 2);
@@ -354,7 +348,62 @@ int xm_align_batch(xm_index* idx, const xm_params* p, const xm_query_batch* b, x
     HIP_CHECK(hipStreamSynchronize(s));
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    res->h2d_ms = ms;
+    idx->residentH2dMs = ms;
+  }
+  idx->residentNq = nq;
+}
+
+static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** out);
+
+int xm_batch_upload(xm_index* idx, const xm_query_batch* b) {
+  if (!idx || !b) return fail("xm_batch_upload: null argument");
+  if (idx->hostOnly) return fail("xm_batch_upload: index was built with host_only=1");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    uploadBatchLocked(idx, b);
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_batch_upload: ") + e.what()); }
+}
+
+int xm_align_resident(xm_index* idx, const xm_params* p, xm_result** out) {
+  if (!idx || !p || !out) return fail("xm_align_resident: null argument");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (idx->residentNq < 0) throw std::runtime_error("no batch is resident (call xm_batch_upload first)");
+    return alignResidentLocked(idx, p, out);
+  } catch (std::exception& e) { return fail(std::string("xm_align_resident: ") + e.what()); }
+}
+
+int xm_align_batch(xm_index* idx, const xm_params* p, const xm_query_batch* b, xm_result** out) {
+  if (!idx || !p || !b || !out) return fail("xm_align_batch: null argument");
+  if (idx->hostOnly) return fail("xm_align_batch: index was built with host_only=1; this library aligns on the GPU only");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    uploadBatchLocked(idx, b);
+    int rc = alignResidentLocked(idx, p, out);
+    if (rc == 0) (*out)->h2d_ms = idx->residentH2dMs;
+    return rc;
+  } catch (std::exception& e) {
+    return fail(std::string("xm_align_batch: ") + e.what());
+  }
+}
+
+static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** out) {
+  {
+    const int64_t nq = idx->residentNq;
+    HIP_CHECK(hipSetDevice(idx->device));
+    hipStream_t s = idx->stream;
+    xm_result* res = (xm_result*)calloc(1, sizeof(xm_result));
+    res->num_queries = nq;
+    res->int_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq + 1));
+    res->dbl_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq + 1));
+    if (nq == 0) {
+      res->ints = (int32_t*)malloc(4); res->dbls = (double*)malloc(8); res->int_off[0] = res->dbl_off[0] = 0;
+      *out = res;
+      return 0;
+    }
+    hipEvent_t e0 = idx->ev0, e1 = idx->ev1;
+    float ms = 0;
 
     BatchView bv{nq, idx->dMateCount.p, idx->dMateOffset.p, idx->dMateLength.p, idx->dCodes.p, idx->dExpected.p, idx->dDeviation.p};
     Params params;
@@ -376,9 +425,13 @@ int xm_align_batch(xm_index* idx, const xm_params* p, const xm_query_batch* b, x
     std::vector<int32_t> arenaInts;
     std::vector<double> arenaDbls;
 
-    std::vector<int64_t> todo;  // empty = all
-    int scale = 1;
-    bool first = true;
+    // Passes: (1) light pass over every read at scale 1: reads that reach the gapped extension chain stop with
+    // XM_ST_NEED_HEAVY instead of serialising their wave; (2) full pass over exactly those reads; (3..) reads whose scratch
+    // overflowed are rerun in full mode with 4x, 16x, ... the scratch.  All passes run on the GPU.
+    std::vector<int64_t> todo;  // empty on the first pass = all reads
+    std::vector<int64_t> pendingHeavy, pendingScale;
+    int scale = 1, overflowScale = 1;
+    bool first = true, heavy = false;
     unsigned long long intCap = (unsigned long long)nq * 40 + 4096, dblCap = (unsigned long long)nq * 12 + 4096;
     double kernelMs = 0;
     int launches = 0;
@@ -408,13 +461,14 @@ int xm_align_batch(xm_index* idx, const xm_params* p, const xm_query_batch* b, x
       HIP_CHECK(hipMemsetAsync(idx->dCursors.p, 0, sizeof(unsigned long long) * 4, s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
       HIP_CHECK(hipEventRecord(e0, s));
-      hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, first ? (const int64_t*)nullptr : idx->dTodo.p, nTodo, scale,
+      hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, first ? (const int64_t*)nullptr : idx->dTodo.p, nTodo, scale, heavy ? 1 : 0,
                          idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       HIP_CHECK(hipStreamSynchronize(s));
       HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       kernelMs += ms;
+      if (launches < 8) res->counters[12 + (launches < 4 ? launches : 3)] += (int64_t)(ms * 1000.0);  // per-pass kernel microseconds (passes 1,2,3,4+)
       launches++;
       // ---- D2H
       HIP_CHECK(hipEventRecord(e0, s));
@@ -436,7 +490,7 @@ int xm_align_batch(xm_index* idx, const xm_params* p, const xm_query_batch* b, x
       HIP_CHECK(hipStreamSynchronize(s));
       HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       res->d2h_ms += ms;
-      std::vector<int64_t> nextScale, nextOut;
+      std::vector<int64_t> nextScale, nextOut, nextHeavy;
       auto consider = [&](int64_t q) {
         int32_t code = st[(size_t)q];
         if (code == XM_OK) {
@@ -447,7 +501,8 @@ int xm_align_batch(xm_index* idx, const xm_params* p, const xm_query_batch* b, x
             lateInts.emplace_back(hi.begin() + io[(size_t)q], hi.begin() + io[(size_t)q] + il[(size_t)q]);
             lateDbls.emplace_back(hd.begin() + dofs[(size_t)q], hd.begin() + dofs[(size_t)q] + dl[(size_t)q]);
           }
-        } else if (code == XM_ST_OVERFLOW) nextScale.push_back(q);
+        } else if (code == XM_ST_NEED_HEAVY) nextHeavy.push_back(q);
+        else if (code == XM_ST_OVERFLOW) nextScale.push_back(q);
         else if (code == XM_ST_OUT_OVERFLOW) nextOut.push_back(q);
         else if (code == XM_ST_AMBIGUOUS) throw std::runtime_error("Failed to align query " + std::to_string(q) + ": it contains a non-ACGT base (MultiHashBlock path is not supported by this build)");
         else if (code == XM_ST_NEED_GROW) throw std::runtime_error("Failed to align query " + std::to_string(q) + ": gapmer longer than the hashed lengths");
@@ -456,19 +511,31 @@ int xm_align_batch(xm_index* idx, const xm_params* p, const xm_query_batch* b, x
       if (first) { for (int64_t q = 0; q < nq; q++) consider(q); arenaInts.swap(hi); arenaDbls.swap(hd); }
       else for (int64_t q : todo) consider(q);
       first = false;
-      if (!nextOut.empty()) {  // result arena too small: rerun those reads at the same scale with room to spare
+      pendingHeavy.insert(pendingHeavy.end(), nextHeavy.begin(), nextHeavy.end());
+      pendingScale.insert(pendingScale.end(), nextScale.begin(), nextScale.end());
+      if (!nextOut.empty()) {  // result arena too small: rerun those reads with the same settings and room to spare
         todo.swap(nextOut);
-        todo.insert(todo.end(), nextScale.begin(), nextScale.end());
         intCap = intCap * 4 + 65536; dblCap = dblCap * 4 + 65536;
-        if (!nextScale.empty()) scale *= 4;
         rerun += (int64_t)todo.size();
-        if (scale > 4096) throw std::runtime_error("scratch scale limit reached");
         continue;
       }
-      if (nextScale.empty()) break;
-      todo.swap(nextScale);
+      if (!pendingHeavy.empty()) {
+        todo.swap(pendingHeavy);
+        pendingHeavy.clear();
+        // the full pass runs at scale 4 straight away: far fewer lanes are needed than in the light pass, and most reads whose
+        // gapped search outgrows the scale-1 scratch then finish here instead of costing one more (latency-bound) pass
+        scale = 4;
+        if (overflowScale < 4) overflowScale = 4;
+        heavy = true;
+        continue;
+      }
+      if (pendingScale.empty()) break;
+      todo.swap(pendingScale);
+      pendingScale.clear();
       rerun += (int64_t)todo.size();
-      scale *= 4;
+      overflowScale *= 4;
+      scale = overflowScale;
+      heavy = true;
       if (scale > 4096) throw std::runtime_error("Failed to align: scratch scale limit reached (query needs more than 4096x the default scratch)");
     }
     // ---- canonical streams in query order
@@ -499,12 +566,11 @@ int xm_align_batch(xm_index* idx, const xm_params* p, const xm_query_batch* b, x
     res->counters[4] = (int64_t)dc.candidatesExtended; res->counters[5] = (int64_t)dc.pathAlignerCalls; res->counters[6] = (int64_t)dc.pathAlignerNodes;
     res->counters[7] = (int64_t)dc.quickAccepts; res->counters[8] = (int64_t)dc.alignmentsOut; res->counters[9] = (int64_t)dc.refWindowBytes; res->counters[10] = (int64_t)dc.readBytes;
     res->counters[11] = rerun;
+    for (int i = 0; i < 16; i++) res->prof[i] = (int64_t)dc.t[i];
     res->kernel_ms = kernelMs;
     res->kernel_launches = launches;
     *out = res;
     return 0;
-  } catch (std::exception& e) {
-    return fail(std::string("xm_align_batch: ") + e.what());
   }
 }
 

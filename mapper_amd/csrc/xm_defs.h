@@ -32,6 +32,7 @@ enum : int32_t {
   XM_ST_AMBIGUOUS = 3,     // read contains non-ACGT bases (MultiHashBlock path): not supported by this build
   XM_ST_NEED_GROW = 4,     // a gapmer uses more bases than the largest hashed length (host must grow the index)
   XM_ST_INTERNAL = 5,      // the reference would have thrown (e.g. TreeMap.subMap fromKey > toKey): whole batch fails
+  XM_ST_NEED_HEAVY = 6,    // light pass only: the read needs the gapped extension chain; the full pass reruns it
 };
 
 // ---------------------------------------------------------------- Java arithmetic
@@ -139,12 +140,14 @@ XM_INL SeqView refView(const IndexView& ix, int contig, bool rc) {
 // ---------------------------------------------------------------- capacities (scale s = 1, 4, 16, ...)
 struct Caps {
   int32_t scale;
+  int32_t heavyAllowed;  // 0: light pass (a read that reaches the gapped chain stops with XM_ST_NEED_HEAVY)
   int32_t maxLevels, maxPyramidBlocks, maxHistory, maxCounters, maxPending, maxQM, maxGoodAlignments, maxBlocks,
-      maxNodes, nodeHash, maxBuckets, matcherEntries, maxSections, maxPieces, maxCountMap, maxJoined;
+      maxNodes, nodeHash, maxBuckets, bucketHash, matcherEntries, maxSections, maxPieces, maxCountMap, maxJoined;
 };
 XM_INL Caps makeCaps(int scale) {
   Caps c;
   c.scale = scale;
+  c.heavyAllowed = 1;
   c.maxLevels = 48 * scale;
   c.maxPyramidBlocks = 1536 * scale;
   c.maxHistory = 192 * scale;
@@ -155,7 +158,8 @@ XM_INL Caps makeCaps(int scale) {
   c.maxBlocks = 16 * scale;
   c.maxNodes = 1536 * scale;
   c.nodeHash = 4096 * scale;  // power of two >= 2 * maxNodes
-  c.maxBuckets = 96 * scale;
+  c.maxBuckets = 512 * scale;
+  c.bucketHash = 2048 * scale;  // power of two >= 4 * maxBuckets
   c.matcherEntries = 6144 * scale;
   c.maxSections = 40 * scale;
   c.maxPieces = 16 * scale;
@@ -184,6 +188,16 @@ XM_INL T* arenaArray(Arena& a, size_t n) { return (T*)a.alloc(sizeof(T) * (n ? n
 struct DevCounters {
   unsigned long long reads, headerProbes, bucketFetches, hitsFetched, candidatesExtended, pathAlignerCalls, pathAlignerNodes,
       quickAccepts, blocksOut, alignmentsOut, refWindowBytes, readBytes;
+  unsigned long long t[16];  // XM_PROFILE builds only: shader-clock ticks per phase, summed over lanes
 };
+
+#if defined(XM_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define XM_TIC(var) unsigned long long var = clock64()
+#define XM_TOC(dc, slot, var) do { if (dc) (dc)->t[slot] += clock64() - var; } while (0)
+#else
+#define XM_TIC(var) do { } while (0)
+#define XM_TOC(dc, slot, var) do { } while (0)
+#endif
+enum { T_TOTAL = 0, T_PYRAMID = 1, T_WALK = 2, T_HITS = 3, T_STRAIGHT = 4, T_ANALYZE = 5, T_PATH = 6, T_PATH_INIT = 7, T_BLOCK = 8, T_MATCHER_INDEX = 9, T_CONFIDENT = 10, T_OUTER = 11 };
 
 }  // namespace xm

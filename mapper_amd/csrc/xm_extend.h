@@ -129,6 +129,7 @@ XM_INL int matcherEncodeBlock(const Matcher& m, const SeqView& s, int index) {  
   return sum;
 }
 XM_NOINL void matcherIndexSection(Matcher& m, const ExtEnv& e, int sectionIndex, int16_t* section) {  // :40-77
+  XM_TIC(t0);
   for (int i = 0; i < m.numPossibilities; i++) section[i] = M_NO_MATCHES;
   int previousEncoded = M_UNKNOWN;
   int startIndex = m.referenceStart + sectionIndex * m.sectionLength;
@@ -147,6 +148,7 @@ XM_NOINL void matcherIndexSection(Matcher& m, const ExtEnv& e, int sectionIndex,
     section[encoded] = (existing == M_NO_MATCHES) ? (int16_t)(i - m.referenceStart) : (int16_t)M_MULTIPLE;
     previousEncoded = encoded;
   }
+  XM_TOC(e.dc, T_MATCHER_INDEX, t0);
 }
 // getSection :203-215; returns -1 for a "null" entry (a section skipped by an earlier jump), else the section slot
 XM_INL int matcherGetSection(Matcher& m, const ExtEnv& e, int index) {
@@ -233,19 +235,26 @@ struct PathAligner {
   int32_t nNodes, maxNodes;
   int32_t* hash; int32_t hashMask;  // (x,y) -> latest node index + 1
   // prioritizedNodes: bucket per exact double key; list entries in insertion order
+  // buckets are never recycled (a removed key cannot reappear: new estimates are clamped to the active key); lookup by exact
+  // key bits through an open-addressing hash, priorities.poll() through a binary min-heap of bucket ids
   double* bkey; int32_t* bhead; int32_t* btail; int32_t nBuckets, maxBuckets;
+  int32_t* bhash; int32_t bhashMask; int32_t* heap; int32_t heapSize;
   int16_t* lx; int16_t* ly; int32_t* lnext; int32_t nList;
   // problem
   Params parameters;
   const ExtEnv* e;
-  Analysis* analysis;
+  // register-resident copies (the struct is only used inside pathAlign with every method force-inlined, so it never
+  // has to live in scratch memory)
+  const uint8_t* qBase; int32_t qLen; bool qRc; const uint8_t* rBase;
+  bool confident; double maxInsExt, maxDelExt;
+  bool overflow; int32_t predictedBestOffset; unsigned long long nodesPut;
   int32_t startIndexA, endIndexA, startIndexB, endIndexB, textALength, textBLength;
   int32_t startX, startY, goalX, goalY, diagonal, stepDelta;
   double maxInterestingPenalty, activePenalty;
   bool mayQueryExtendPastEndOfReference, searchReverse;
 
-  XM_INL uint8_t charA(int i) const { return e->query.at(startIndexA + i); }
-  XM_INL uint8_t charB(int i) const { return e->reference.at(startIndexB + i); }
+  XM_INL uint8_t charA(int i) const { int k = startIndexA + i; return qRc ? bpComplement(qBase[qLen - 1 - k]) : qBase[k]; }
+  XM_INL uint8_t charB(int i) const { return rBase[startIndexB + i]; }
   XM_INL int signedDist(int x, int y) const { return x - y - diagonal; }
 
   XM_INL int findNode(int x, int y) const {  // getNode :541-553
@@ -274,15 +283,15 @@ struct PathAligner {
     }
   }
   XM_INL double estimateOverallPenalty(int x, int y, double pen, double insX, double insY, uint8_t fl) const {  // :475-521
-    if (!analysis->confidentAboutBestOffset) return pen;
+    if (!confident) return pen;
     int sd = signedDist(x, y);
     if (fl & 1) {
       if (sd * stepDelta > 0) {
         double ext = fabs(sd * parameters.InsertionExtension_Penalty);
-        if (ext > analysis->maxInsertionExtensionPenalty) return disallowed;
+        if (ext > maxInsExt) return disallowed;
       } else {
         double ext = fabs(sd * parameters.DeletionExtension_Penalty);
-        if (ext > analysis->maxDeletionExtensionPenalty) return disallowed;
+        if (ext > maxDelExt) return disallowed;
       }
       if (fl & 2) return pen;
       double indelPenalty = dmin(parameters.InsertionStart_Penalty + parameters.InsertionExtension_Penalty, parameters.DeletionStart_Penalty + parameters.DeletionExtension_Penalty);
@@ -290,26 +299,43 @@ struct PathAligner {
     }
     if (sd * stepDelta < 0) {
       double ext = fabs(sd * parameters.InsertionExtension_Penalty);
-      if (ext > analysis->maxInsertionExtensionPenalty) return disallowed;
+      if (ext > maxInsExt) return disallowed;
       double startP = dmin(parameters.InsertionStart_Penalty, insX - pen);
       return pen + startP + ext;
     } else {
       double ext = fabs(sd * parameters.DeletionExtension_Penalty);
-      if (ext > analysis->maxDeletionExtensionPenalty) return disallowed;
+      if (ext > maxDelExt) return disallowed;
       double startP = dmin(parameters.DeletionStart_Penalty, insY - pen);
       return pen + startP + ext;
     }
   }
-  XM_NOINL void putNode(int x, int y, double pen, double insX, double insY, uint8_t fl) {  // :446-473
+  XM_INL void putNode(int x, int y, double pen, double insX, double insY, uint8_t fl) {  // :446-473
     double est = estimateOverallPenalty(x, y, pen, insX, insY, fl);
     if (est < activePenalty) est = activePenalty;
-    if (nNodes >= maxNodes) { *e->status = XM_ST_OVERFLOW; return; }
+    if (nNodes >= maxNodes) { overflow = true; return; }
     int b = -1;
-    for (int i = 0; i < nBuckets; i++) if (bkey[i] == est) { b = i; break; }
+    uint64_t kb;
+    __builtin_memcpy(&kb, &est, 8);
+    uint32_t h = (uint32_t)((kb ^ (kb >> 29)) * 0x9E3779B97F4A7C15ull >> 40) & (uint32_t)bhashMask;
+    while (true) {
+      int32_t v = bhash[h];
+      if (v == 0) break;
+      if (bkey[v - 1] == est) { b = v - 1; break; }
+      h = (h + 1) & (uint32_t)bhashMask;
+    }
     if (b < 0) {
-      if (nBuckets >= maxBuckets) { *e->status = XM_ST_OVERFLOW; return; }
+      if (nBuckets >= maxBuckets) { overflow = true; return; }
       b = nBuckets++;
       bkey[b] = est; bhead[b] = -1; btail[b] = -1;
+      bhash[h] = b + 1;
+      int i = heapSize++;  // sift up
+      while (i > 0) {
+        int parent = (i - 1) >> 1;
+        if (bkey[heap[parent]] <= est) break;
+        heap[i] = heap[parent];
+        i = parent;
+      }
+      heap[i] = b;
     }
     int li = nList++;
     lx[li] = (int16_t)x; ly[li] = (int16_t)y; lnext[li] = -1;
@@ -318,9 +344,9 @@ struct PathAligner {
     int idx = nNodes++;
     nx[idx] = (int16_t)x; ny[idx] = (int16_t)y; npen[idx] = pen; nix[idx] = insX; niy[idx] = insY; nfl[idx] = fl;
     saveNode(idx);
-    if (e->dc) e->dc->pathAlignerNodes++;
+    nodesPut++;
   }
-  XM_NOINL void update(int x, int y) {  // :555-571 + computeUpdated :573-719
+  XM_INL void update(int x, int y) {  // :555-571 + computeUpdated :573-719
     if (x <= 0 || x > textALength) return;
     if (y <= 0 || y > textBLength) return;
     int existing = findNode(x, y);
@@ -383,7 +409,7 @@ struct PathAligner {
   }
   XM_INL bool chooseSearchReverse() const {  // :17-53
     int sumMis = 0, numMis = 0, sumMatch = 0, numMatch = 0;
-    int offset = analysis->predictedBestOffset;
+    int offset = predictedBestOffset;
     int s = imax(startIndexA, startIndexB - offset);
     int t = imin(endIndexA, endIndexB - offset);
     int length = t - s;
@@ -406,13 +432,17 @@ XM_INL bool paCanRemoveSection(const ABlock& b) {  // :358-366
 
 // PathAligner.align :55-293.  false = null
 XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, const Params& params, Analysis& analysis, SeqAl& out) {
+  XM_TIC(tPath);
   Arena& tmp = *e.tmp;
   size_t mark = tmp.used;
   const Caps& caps = *e.caps;
   PathAligner pa;
   pa.e = &e;
-  pa.analysis = &analysis;
   pa.parameters = params;
+  pa.qBase = e.query.base; pa.qLen = e.query.len; pa.qRc = e.query.rc != 0; pa.rBase = e.reference.base;
+  pa.confident = analysis.confidentAboutBestOffset; pa.maxInsExt = analysis.maxInsertionExtensionPenalty; pa.maxDelExt = analysis.maxDeletionExtensionPenalty;
+  pa.predictedBestOffset = analysis.predictedBestOffset; pa.overflow = false; pa.nodesPut = 0;
+  const int referenceLen = e.reference.len;
   pa.maxNodes = caps.maxNodes;
   pa.nx = arenaArray<int16_t>(tmp, caps.maxNodes); pa.ny = arenaArray<int16_t>(tmp, caps.maxNodes);
   pa.npen = arenaArray<double>(tmp, caps.maxNodes); pa.nix = arenaArray<double>(tmp, caps.maxNodes); pa.niy = arenaArray<double>(tmp, caps.maxNodes);
@@ -421,9 +451,13 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, c
   pa.hashMask = caps.nodeHash - 1;
   pa.maxBuckets = caps.maxBuckets;
   pa.bkey = arenaArray<double>(tmp, caps.maxBuckets); pa.bhead = arenaArray<int32_t>(tmp, caps.maxBuckets); pa.btail = arenaArray<int32_t>(tmp, caps.maxBuckets);
+  pa.bhash = arenaArray<int32_t>(tmp, caps.bucketHash); pa.bhashMask = caps.bucketHash - 1;
+  pa.heap = arenaArray<int32_t>(tmp, caps.maxBuckets); pa.heapSize = 0;
   pa.lx = arenaArray<int16_t>(tmp, caps.maxNodes); pa.ly = arenaArray<int16_t>(tmp, caps.maxNodes); pa.lnext = arenaArray<int32_t>(tmp, caps.maxNodes);
   if (tmp.overflow) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
   for (int i = 0; i < caps.nodeHash; i++) pa.hash[i] = 0;
+  for (int i = 0; i < caps.bucketHash; i++) pa.bhash[i] = 0;
+  XM_TOC(e.dc, T_PATH_INIT, tPath);
   pa.nNodes = 0; pa.nBuckets = 0; pa.nList = 0;
   pa.activePenalty = 0;
   if (e.dc) e.dc->pathAlignerCalls++;
@@ -436,7 +470,7 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, c
   pa.stepDelta = 1;
   pa.searchReverse = pa.chooseSearchReverse();
   if (pa.searchReverse) { pa.stepDelta = -1; pa.mayQueryExtendPastEndOfReference = pa.startIndexB == 0; }
-  else { pa.stepDelta = 1; pa.mayQueryExtendPastEndOfReference = pa.endIndexB == e.reference.len; }
+  else { pa.stepDelta = 1; pa.mayQueryExtendPastEndOfReference = pa.endIndexB == referenceLen; }
   int width = pa.textALength + 2, height = pa.endIndexB - pa.startIndexB + 2;
   if (pa.searchReverse) { pa.startX = width - 1; pa.startY = height - 1; pa.goalX = 1; pa.goalY = 1; }
   else { pa.startX = 0; pa.startY = 0; pa.goalX = width - 2; pa.goalY = height - 2; }
@@ -445,38 +479,59 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, c
     double startingInsertionStartPenalty = params.getStartingInsertionStartPenalty();
     if (!pa.mayQueryExtendPastEndOfReference) startingInsertionStartPenalty = disallowed;
     int initialDeletionCount = imax(0, pa.textBLength - pa.textALength) + 1;
-    for (int i = 0; i < initialDeletionCount && !*e.status; i++) pa.putNode(pa.startX, pa.startY + i * pa.stepDelta, 0, startingInsertionStartPenalty, disallowed, 0);
+    for (int i = 0; i < initialDeletionCount && !pa.overflow; i++) pa.putNode(pa.startX, pa.startY + i * pa.stepDelta, 0, startingInsertionStartPenalty, disallowed, 0);
   } else {
     int initialInsertionCount = imax(0, pa.textALength - pa.textBLength) + 1;
-    for (int i = 0; i < initialInsertionCount && !*e.status; i++) pa.putNode(pa.startX + i * pa.stepDelta, pa.startY, 0, disallowed, disallowed, 0);
+    for (int i = 0; i < initialInsertionCount && !pa.overflow; i++) pa.putNode(pa.startX + i * pa.stepDelta, pa.startY, 0, disallowed, disallowed, 0);
   }
   if (pa.mayQueryExtendPastEndOfReference) {
     int initialInsertionCount = j2i(analysis.maxInsertionExtensionPenalty / params.DeletionExtension_Penalty);
-    for (int i = 1; i < initialInsertionCount && !*e.status; i++) pa.putNode(pa.startX + i * pa.stepDelta, pa.startY, i * params.UnalignedPenalty, disallowed, disallowed, 0);
+    for (int i = 1; i < initialInsertionCount && !pa.overflow; i++) pa.putNode(pa.startX + i * pa.stepDelta, pa.startY, i * params.UnalignedPenalty, disallowed, disallowed, 0);
   }
   bool haveLast = false;
   int lastX = 0, lastY = 0;
+  // every exit below goes through `leave` so that the locally accumulated counters and the overflow flag are published once
+  auto leave = [&](bool r) -> bool {
+    if (pa.overflow) *e.status = XM_ST_OVERFLOW;
+    if (e.dc) e.dc->pathAlignerNodes += pa.nodesPut;
+    pa.nodesPut = 0;
+    tmp.used = mark;
+    return r && !pa.overflow;
+  };
   while (!haveLast) {
-    if (*e.status) { tmp.used = mark; return false; }
+    if (pa.overflow) return leave(false);
     // priorities.poll(): smallest live key
-    int b = -1;
-    for (int i = 0; i < pa.nBuckets; i++) if (b < 0 || pa.bkey[i] < pa.bkey[b]) b = i;
-    if (b < 0) { *e.status = XM_ST_INTERNAL; tmp.used = mark; return false; }  // Java: NullPointerException
+    if (pa.heapSize < 1) { *e.status = XM_ST_INTERNAL; return leave(false); }  // Java: NullPointerException
+    int b = pa.heap[0];
     pa.activePenalty = pa.bkey[b];
     int li = pa.bhead[b];
     while (li >= 0) {
       int x = pa.lx[li], y = pa.ly[li];
-      if (pa.activePenalty > pa.maxInterestingPenalty + 0.000001) { tmp.used = mark; return false; }
+      if (pa.activePenalty > pa.maxInterestingPenalty + 0.000001) return leave(false);
       if (x == pa.goalX) { haveLast = true; lastX = x; lastY = y; break; }
-      pa.update(x + pa.stepDelta, y);  // explore :722-729
-      pa.update(x, y + pa.stepDelta);
-      pa.update(x + pa.stepDelta, y + pa.stepDelta);
-      if (*e.status) { tmp.used = mark; return false; }
+      for (int mv = 0; mv < 3; mv++) {  // explore :722-729: (x+d, y), (x, y+d), (x+d, y+d)
+        int ux = (mv == 1) ? x : x + pa.stepDelta;
+        int uy = (mv == 0) ? y : y + pa.stepDelta;
+        pa.update(ux, uy);
+      }
+      if (pa.overflow) return leave(false);
       li = pa.lnext[li];
     }
-    // prioritizedNodes.remove(activePenalty): swap-remove the bucket
-    pa.nBuckets--;
-    pa.bkey[b] = pa.bkey[pa.nBuckets]; pa.bhead[b] = pa.bhead[pa.nBuckets]; pa.btail[b] = pa.btail[pa.nBuckets];
+    // prioritizedNodes.remove(activePenalty) + the poll(): pop the heap root (the active bucket is still the minimum: every key
+    // inserted meanwhile is >= activePenalty and distinct keys are distinct buckets)
+    {
+      int last = pa.heap[--pa.heapSize];
+      int i = 0;
+      while (true) {
+        int l = 2 * i + 1, r = l + 1;
+        if (l >= pa.heapSize) break;
+        int c = (r < pa.heapSize && pa.bkey[pa.heap[r]] < pa.bkey[pa.heap[l]]) ? r : l;
+        if (pa.bkey[pa.heap[c]] >= pa.bkey[last]) break;
+        pa.heap[i] = pa.heap[c];
+        i = c;
+      }
+      if (pa.heapSize > 0) pa.heap[i] = last;
+    }
   }
   // traceback :195-264
   int i = lastX, j = lastY;
@@ -484,7 +539,7 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, c
   const int sd = pa.stepDelta;
   const int sA = pa.startIndexA, sB = pa.startIndexB;
   while (i != pa.startX && j != pa.startY) {
-    if (nb >= caps.maxBlocks) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+    if (nb >= caps.maxBlocks) { pa.overflow = true; return leave(false); }
     int node = pa.findNode(i, j);
     double bestPenalty = pa.npen[node], insertXPenalty = pa.nix[node], insertYPenalty = pa.niy[node];
     ABlock blk;
@@ -527,7 +582,7 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, c
     }
     out.blocks[nb++] = blk;
   }
-  tmp.used = mark;  // the search structures are dead from here on
+  leave(true);  // the search structures are dead from here on
   if (!pa.searchReverse) for (int a = 0, b2 = nb - 1; a < b2; a++, b2--) { ABlock t = out.blocks[a]; out.blocks[a] = out.blocks[b2]; out.blocks[b2] = t; }
   if (nb < 1) return false;
   // justify :307-352
@@ -575,7 +630,9 @@ XM_INL bool straightAlign(const ExtEnv& e, const Section& qs, const Section& rs,
   ABlock simpleBlock[1];
   SeqAl simple;
   simple.blocks = simpleBlock;
+  XM_TIC(tS);
   straightAlignment(e, qs, rs, p, an, simple);
+  XM_TOC(e.dc, T_STRAIGHT, tS);
   double simpleTotal = simple.alignedPenalty;
   double maxInterestingPenalty = secLen(qs) * p.MaxErrorRate;
   double indelPenalty = dmin(p.getStartingInsertionStartPenalty() + p.InsertionExtension_Penalty, p.DeletionStart_Penalty + p.DeletionExtension_Penalty);
@@ -657,6 +714,7 @@ XM_INL double hbaManyDeletions(int numMismatches, double totalPenalty, const Par
 // analyzePenalty :94-283.  storeSlot: where a matcher created for a matcher-less analysis lives (A for the outer
 // HashBlock_Aligner, B for the inner one); temporaries go to slot T.
 XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, Matcher* storeSlot) {
+  XM_TIC(tA);
   Arena& tmp = *e.tmp;
   size_t mark = tmp.used;
   PenaltyAnalysis result;
@@ -749,6 +807,7 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qs, c
   int mostPopularOffset = counts.mostPopularKey;
   int mostPopularOffset_count = counts.mostPopularCount;
   tmp.used = mark;
+  XM_TOC(e.dc, T_ANALYZE, tA);
   double indelPenalty = hbaMinIndelPenaltyForBlockMismatches(numMismatches, p);
   result.minPossiblePenalty = indelPenalty;
   bool couldDiffer = mostPopularOffset_count < 1 || an.lastCheckedOffset != mostPopularOffset;
@@ -804,7 +863,12 @@ XM_INL bool hashBlockAlign(const ExtEnv& e, const Section& qs, Section rs, const
 
 // ---------------------------------------------------------------- the inner chain: straight3 -> pathAligner, hashBlock<2>, straight2
 struct NextPath {
-  XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const { return pathAlign(e, qs, rs, p, an, out); }
+  XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const {
+    XM_TIC(t0);
+    bool r = pathAlign(e, qs, rs, p, an, out);
+    XM_TOC(e.dc, T_PATH, t0);
+    return r;
+  }
 };
 struct NextStraight3 {
   XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const { return straightAlign(e, qs, rs, p, an, out, NextPath()); }
@@ -969,10 +1033,16 @@ XM_NOINL bool blockAlign(const ExtEnv& e, const Section& qs, const Section& rs, 
 
 // ---------------------------------------------------------------- the outer chain (M/QueryMatch_Aligner.java:18-29)
 struct NextBlock {
-  XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const { return blockAlign(e, qs, rs, p, an, out); }
+  XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const {
+    XM_TIC(t0);
+    bool r = blockAlign(e, qs, rs, p, an, out);
+    XM_TOC(e.dc, T_BLOCK, t0);
+    return r;
+  }
 };
 struct NextHashBlock1 {
   XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const {
+    if (!e.caps->heavyAllowed) { *e.status = XM_ST_NEED_HEAVY; return false; }
     // SkipHighAmbiguity_Aligner :13-28
     int numAmbiguities = 0;
     for (int i = rs.start; i < rs.end; i++) if (bpIsAmbiguous(e.reference.at(i))) numAmbiguities++;
@@ -981,7 +1051,10 @@ struct NextHashBlock1 {
   }
 };
 XM_NOINL bool outerChain(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) {
-  return straightAlign(e, qs, rs, p, an, out, NextHashBlock1());
+  XM_TIC(t0);
+  bool r = straightAlign(e, qs, rs, p, an, out, NextHashBlock1());
+  XM_TOC(e.dc, T_OUTER, t0);
+  return r;
 }
 
 }  // namespace xm

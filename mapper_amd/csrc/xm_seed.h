@@ -160,8 +160,10 @@ struct Pyramid {
   int32_t* levelStart;  // levelStart[k] (k>=1) = first block of level k; levelStart[nBuilt+1] = used
   int32_t nBuilt, used, cap, maxLevels;
   int32_t* status;
+  DevCounters* dc;
 
   XM_INL void init(const SeqView& s, PBlock* b, int cap_, int32_t* ls, int maxLevels_, int32_t* st) {
+    dc = nullptr;
     seq = s; blocks = b; cap = cap_; levelStart = ls; maxLevels = maxLevels_; nBuilt = 0; used = 0; status = st;
     levelStart[1] = 0;
   }
@@ -169,6 +171,7 @@ struct Pyramid {
   XM_INL PBlock blockAt(int level, int i) const { return level == 0 ? level0Block(seq.at(i), i) : blocks[levelStart[level] + i]; }
 
   XM_NOINL void ensure(int level) {  // M/HashBlock_Pyramid.java:15-24 + HashBlock_ParentRow.maybeMakeBlock
+    XM_TIC(t0);
     while (nBuilt < level) {
       if (nBuilt + 2 >= maxLevels) { *status = XM_ST_OVERFLOW; return; }
       int prev = nBuilt;
@@ -189,6 +192,7 @@ struct Pyramid {
       used = w;
       levelStart[nBuilt + 1] = w;
     }
+    XM_TOC(dc, T_PYRAMID, t0);
   }
   // first block of `level` whose start > pos (HashBlock_Row.getAfter)
   XM_INL bool getAfter(int level, int pos, PBlock& out) {
@@ -414,6 +418,7 @@ XM_INL int pathMaxNumMatchesAllowed(Comp& c, const SeedEnv& e, const QBlock& b) 
 }
 // :143-195.  returns false when the path is exhausted
 XM_NOINL bool pathAdvance(Comp& c, const SeedEnv& e) {
+  XM_TIC(t0);
   int singleLen = c.path.cur.len;
   if (maxGapmerNumBasepairsUsed(singleLen) < e.ix->minInterestingSize && e.ix->enableGapmers) {
     pathMoveUpOrRight(c);
@@ -434,6 +439,7 @@ XM_NOINL bool pathAdvance(Comp& c, const SeedEnv& e) {
     }
   }
   // skipMultiblocks (:130-140) is a no-op: reads with ambiguous bases are rejected up front (XM_ST_AMBIGUOUS)
+  XM_TOC(e.dc, T_WALK, t0);
   return c.path.curExists && *e.status == 0;
 }
 // getNextInterestingBlock :27-50 (+ getNextBlockWithGoodNumberOfMatches :68-96, recentlySeen :52-65)
@@ -615,6 +621,7 @@ XM_NOINL bool compStep(Comp& c, const SeedEnv& e) {
   if (c.nHistory >= e.caps->maxHistory) { *e.status = XM_ST_OVERFLOW; return false; }
   c.history[c.nHistory++] = qb;
   const IndexView& ix = *e.ix;
+  XM_TIC(tHits);
   for (int h = 0; h < nHits; h++) {
     RefPos rp = fetchHit(ix, first + h, invert, qb.len);
     SeqView refSeq = refView(ix, rp.contig, rp.rc != 0);
@@ -654,6 +661,7 @@ XM_NOINL bool compStep(Comp& c, const SeedEnv& e) {
     compUpdateMatches(c, e, fm, qb, nHits);
     if (*e.status) return false;
   }
+  XM_TOC(e.dc, T_HITS, tHits);
   if (qb.start >= c.maxNonoverlappingBlockVisited) {
     c.maxNonoverlappingBlockVisited = qb.end();
     c.numNonoverlappingBlocksVisited++;

@@ -471,6 +471,7 @@ XM_INL double penaltyLowerBound(const ReadCtx& cx, int numMismatchedHashblocks) 
 
 XM_NOINL bool quicklyConfidentInBestAlignment(ReadCtx& cx, QMAligner& a, int alIdx, const QMatch& m) {  // :494-587
   if (alIdx < 0) return false;
+  XM_TIC(t0);
   const QAl& al = a.good[alIdx];
   for (int k = 0; k < al.nSeq; k++) if (saHasIndel(al.seq[k])) return false;
   int contig = m.c[0].contig;
@@ -492,6 +493,7 @@ XM_NOINL bool quicklyConfidentInBestAlignment(ReadCtx& cx, QMAligner& a, int alI
   if (mayContainDuplicationInRange(*cx.ix, contig, windowStart, windowEnd)) hasNearbyDuplication = true;
   else if (matchStart <= interestingWindow) hasNearbyDuplication = true;
   else if (matchEnd >= cx.ix->contigLen[contig] - interestingWindow) hasNearbyDuplication = true;
+  XM_TOC(cx.dc, T_CONFIDENT, t0);
   if (hasNearbyDuplication) return false;
   for (int k = 0; k < al.nSeq; k++) if (saHasAmbiguous(cx, al.seq[k])) return false;
   return true;
@@ -511,6 +513,7 @@ XM_INL void compInit(ReadCtx& cx, Comp& c, const SeqView& query, const SeqView& 
   c.all.items = arenaArray<int16_t>(A, k.maxCounters);
   if (A.overflow) { cx.status = XM_ST_OVERFLOW; return; }
   c.pyr.init(query, blocks, k.maxPyramidBlocks, ls, k.maxLevels, &cx.status);
+  c.pyr.dc = cx.dc;
   pathInit(c.path);
   c.query = query; c.rcQuery = rcQuery;
   c.nCounters = 0; c.nGood = 0; c.foundGood = false; c.done = false; c.nHistory = 0; c.pendHead = c.pendTail = 0;
@@ -689,14 +692,16 @@ XM_INL void resultWrite(const ReadResult& rr, OutWriter& w, DevCounters* dc) {
 }
 
 // Carve a lane's arena and align one read.  `arena` must be 16-byte aligned.
-XM_INL void runRead(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* arena, size_t arenaBytes, DevCounters* dc, ReadResult& rr) {
-  cx.ix = ix; cx.caps = makeCaps(scale); cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
+XM_INL void runRead(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* arena, size_t arenaBytes, DevCounters* dc, ReadResult& rr, bool heavyAllowed = true) {
+  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed ? 1 : 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
   cx.params.StartingInsertionStartFree = 0;
   size_t persistBytes = arenaBytes * 5 / 12;
   persistBytes &= ~(size_t)15;
   cx.persist.init(arena, persistBytes);
   cx.tmp.init((uint8_t*)arena + persistBytes, arenaBytes - persistBytes);
+  XM_TIC(t0);
   alignRead(cx, rr);
+  XM_TOC(dc, T_TOTAL, t0);
 }
 
 }  // namespace xm

@@ -303,6 +303,14 @@ int xmo_kat_local_align(int chain, const char* queryText, const char* refText, c
   } catch (std::exception& e) { g_error = e.what(); return 3; }
 }
 
+// T/BasepairsTest.java:9-45: AlignmentParameters.getPenalty(byte, byte) on IUPAC letters
+double xmo_kat_base_penalty(char a, char b, double mutationPenalty, double ambiguityPenalty) {
+  AlignmentParameters p;
+  p.MutationPenalty = mutationPenalty;
+  p.AmbiguityPenalty = ambiguityPenalty;
+  return p.getPenalty(Basepairs::encode(a), Basepairs::encode(b));
+}
+
 // T/HashBlock_Test.java:30-92 checkSymmetry; returns 0 when every block is symmetric, else a failure code
 int xmo_kat_hash_symmetry(const char* text) {
   try {

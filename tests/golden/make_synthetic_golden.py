@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/synthetic_golden.json: SHA-256 digests of the oracle's result streams on seeded synthetic batches
+(the batches are regenerated from the seeds by mapper_amd.synth, so only the digests need to be stored)."""
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import oracle_lib as o  # noqa: E402
+from helpers import se_batch, pe_batch  # noqa: E402
+from mapper_amd import synth  # noqa: E402
+
+
+def digest(s):
+    h = hashlib.sha256()
+    for a in (s.int_off, s.dbl_off, s.ints, np.asarray(s.dbls).view(np.int64)):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def cases():
+    ref = synth.synthetic_reference(400_000, seed=0xEC011)
+    reads, _, _ = synth.synthetic_single_end(ref, 4000, seed=0x5EED0001)
+    m1, m2, _, _, _ = synth.synthetic_paired_end(ref, 1500, seed=0x5EED0002)
+    return ref, {"single_end_4000": se_batch(reads), "paired_end_1500": pe_batch(m1, m2)}
+
+
+if __name__ == "__main__":
+    ref, batches = cases()
+    R = o.OracleReference([("ecoli_syn", ref)])
+    out = {"reference": "synthetic_reference(400000, seed=0xEC011)", "params": "Mapper.main defaults", "digests": {}}
+    for name, b in batches.items():
+        s = R.align(b, o.make_params())
+        out["digests"][name] = {"sha256": digest(s), "num_ints": int(len(s.ints)), "num_dbls": int(len(s.dbls))}
+    with open(os.path.join(ROOT, "tests", "golden", "synthetic_golden.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(out)

@@ -1,0 +1,65 @@
+"""Shared helpers of the test-suite."""
+import json
+import os
+import numpy as np
+
+import oracle_lib
+from mapper_amd import api, sam, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KAT = json.load(open(os.path.join(ROOT, "tests", "golden", "kat_reference.json")))
+
+
+def streams_equal(a, b):
+    """bit-exact equality of two result streams (ints, doubles compared by bit pattern, offsets)."""
+    return (np.array_equal(a.int_off, b.int_off) and np.array_equal(a.dbl_off, b.dbl_off) and np.array_equal(a.ints, b.ints)
+            and np.array_equal(np.asarray(a.dbls).view(np.int64), np.asarray(b.dbls).view(np.int64)))
+
+
+def first_difference(a, b, n):
+    for q in range(n):
+        x = api.decode_streams(a.ints, a.dbls, a.int_off, a.dbl_off, q)
+        y = api.decode_streams(b.ints, b.dbls, b.int_off, b.dbl_off, q)
+        fx = [[(al.penalty, [(s.contig, s.reference_reversed, [(k.startA, k.startB, k.lengthA, k.lengthB) for k in s.sections]) for s in al.components]) for al in c] for c in x]
+        fy = [[(al.penalty, [(s.contig, s.reference_reversed, [(k.startA, k.startB, k.lengthA, k.lengthB) for k in s.sections]) for s in al.components]) for al in c] for c in y]
+        if fx != fy:
+            return "query %d: %r != %r" % (q, fx, fy)
+    return None
+
+
+def se_batch(reads):
+    nq, L = reads.shape
+    mc = np.ones(nq, np.int32)
+    mo = np.zeros(2 * nq, np.int64); mo[0::2] = np.arange(nq, dtype=np.int64) * L
+    ml = np.zeros(2 * nq, np.int32); ml[0::2] = L
+    return oracle_lib.QueryBatch.from_arrays(mc, mo, ml, np.ascontiguousarray(reads.reshape(-1)), np.zeros(nq), np.ones(nq))
+
+
+def pe_batch(m1, m2, expected=100.0, dev=50.0):
+    nq, L = m1.shape
+    codes = np.ascontiguousarray(np.concatenate([m1, m2], axis=1).reshape(-1))
+    mc = np.full(nq, 2, np.int32)
+    mo = np.zeros(2 * nq, np.int64); mo[0::2] = np.arange(nq, dtype=np.int64) * 2 * L; mo[1::2] = mo[0::2] + L
+    ml = np.full(2 * nq, L, np.int32)
+    return oracle_lib.QueryBatch.from_arrays(mc, mo, ml, codes, np.full(nq, expected), np.full(nq, dev))
+
+
+def check_align_case(case, comps, ref_codes):
+    """Checks the expectations a reference JUnit case pins on the decoded QueryAlignments (list of components)."""
+    e = case["expect"]
+    top = comps[0] if len(comps) == 1 else []
+    assert len(top) == e["num"], "%s: expected %d alignments, got %d" % (case["name"], e["num"], len(top))
+    if "alignedB0" in e:
+        s = top[0].components[0]
+        q = api.encode(case["mates"][0])
+        if s.reference_reversed:
+            q = api.reverse_complement(q)
+        assert s.aligned_text(q, ref_codes)[1] == e["alignedB0"], case["name"]
+    if "startsB" in e:
+        got = sorted([s.start_index_b() for s in al.components] for al in top)
+        # the order of equal-penalty alignments comes from a HashSet in the reference (QueryMatch_Aligner.java:86-92): compared as a set
+        assert got == sorted(e["startsB"]), case["name"]
+
+
+def sam_text(query, comps, names):
+    return "".join(line + "\n" for line in sam.records(query, comps, names))

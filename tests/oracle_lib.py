@@ -98,6 +98,8 @@ def lib():
         L.xmo_result_free.argtypes = [C.POINTER(_Result)]
         L.xmo_kat_local_align.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_double, C.c_double, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_double)]
         L.xmo_kat_hash_symmetry.argtypes = [C.c_char_p]
+        L.xmo_kat_base_penalty.argtypes = [C.c_char, C.c_char, C.c_double, C.c_double]
+        L.xmo_kat_base_penalty.restype = C.c_double
         L.xmo_kat_counting_path.argtypes = [C.c_char_p, C.c_char_p, C.c_double, C.c_int, C.c_void_p, C.c_int]
         L.xmo_kat_paths_counter.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.xmo_kat_db_order_independent.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int]

@@ -1,0 +1,143 @@
+"""CPU tier (no GPU): the product's host-side index builder (through the real C ABI, host_only=1) and the kernel sources
+compiled for the host (tests/hostsim, a test harness — the shipped library has no CPU path) against the oracle."""
+import os
+import re
+import numpy as np
+import pytest
+
+import oracle_lib as o
+import hostsim_lib as hs
+from helpers import KAT, streams_equal, first_difference, se_batch, pe_batch, check_align_case
+from mapper_amd import api, synth, _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_exports_every_declared_symbol():
+    """libxmapper_hip.so loads on a machine without GPU and exports every function include/xmapper_hip.h declares."""
+    header = open(os.path.join(ROOT, "include", "xmapper_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(xm_[a-z_]+)\s*\(", header)))
+    assert len(declared) >= 12
+    lib = _capi.lib()
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert sorted(_capi.EXPORTS) == declared
+
+
+def test_library_refuses_to_align_without_gpu_index():
+    """The product fails loudly instead of falling back to a CPU path."""
+    db = api.ReferenceDatabase([("r", synth.synthetic_reference(5000))], host_only=True)
+    with pytest.raises(RuntimeError, match="GPU only|host_only"):
+        db.align_batch([api.Query("ACGTACGTACGTACGTACGTACGTACGT")], api.AlignmentParameters())
+    db.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 33, 150, 400])
+def test_read_pyramid_matches_oracle(n):
+    rng = np.random.default_rng(n)
+    codes = np.array([1, 2, 4, 8], dtype=np.uint8)[rng.integers(0, 4, n)]
+    a, b = o.pyramid_dump(codes), hs.pyramid_dump(codes)
+    assert a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode,contigs", [("mapper", [120_000]), ("api", [3000]), ("mapper", [40_000, 25_000, 700])])
+def test_index_builder_matches_oracle(mode, contigs):
+    """Every PackedMap (capacity, per-bucket counts / overfull marks, packed positions) and the duplication keys of the host
+    builder in libxmapper_hip.so equal the oracle's literal restatement of HashBlock_Database / DuplicationDetector."""
+    refs = [("c%d" % i, synth.synthetic_reference(n, seed=0xEC011 + i)) for i, n in enumerate(contigs)]
+    R = o.OracleReference(refs, mode=mode)
+    R.align(["ACGTACGTACGTAGCATCGACTAGCAGCATCGAC"], o.make_params())  # triggers prepare()
+    P = api.ReferenceDatabase(refs, mode=mode, host_only=True)
+    mn, mx = R.index_info()
+    info = P.info()
+    assert info["min_interesting_size"] == mn and info["max_hashed_length"] == mx
+    for L in range(0, mx + 1):
+        ta, tb = R.table(L), P.table(L)
+        assert ta["capacity"] == tb["capacity"] and ta["maxCount"] == tb["maxCount"], L
+        assert np.array_equal(ta["counts"], tb["counts"]), L
+        assert np.array_equal(ta["positions"], tb["positions"]), L
+    for c in range(len(refs)):
+        assert np.array_equal(R.dup_keys(c), P.dup_keys(c))
+    # lazy growth (Readable_HashBlock_Database.java:108-113) gives the same tables as hashing them up front
+    R.require_size(mx + 20)
+    P.ensure_length(R.index_info()[1])
+    for L in range(mx + 1, R.index_info()[1] + 1):
+        ta, tb = R.table(L), P.table(L)
+        assert ta["capacity"] == tb["capacity"] and np.array_equal(ta["counts"], tb["counts"]) and np.array_equal(ta["positions"], tb["positions"]), L
+    P.close()
+
+
+def test_ambiguous_reference_is_rejected_loudly():
+    with pytest.raises(RuntimeError, match="non-ACGT"):
+        api.ReferenceDatabase([("r", "ACGTNACGTACGTACGATCGATCGACTGACTAGC")], host_only=True)
+
+
+@pytest.mark.parametrize("case", [c for c in KAT["align_cases"] if set(c["reference"]) <= set("ACGT")], ids=lambda c: c["name"])
+def test_kernel_logic_on_reference_kats(case):
+    """The reference's own AlignerWorker_Test cases through the kernel sources (host-simulated): expectations hold and the
+    result streams are bit-identical to the oracle's."""
+    R = o.OracleReference([("reference-0", case["reference"])], mode="api")
+    S = hs.SimReference([("reference-0", case["reference"])], mode="api")
+    q = [(case["mates"], case["expectedInner"], case["deviation"])]
+    p = o.make_params(case["params"])
+    sa, sb = R.align(q, p), S.align(q, p)
+    assert streams_equal(sa, sb), first_difference(sa, sb, 1)
+    check_align_case(case, api.decode_streams(sb.ints, sb.dbls, sb.int_off, sb.dbl_off, 0), o.encode(case["reference"]))
+
+
+def test_kernel_logic_single_end_synthetic():
+    ref = synth.synthetic_reference(200_000)
+    reads, starts, strand = synth.synthetic_single_end(ref, 3000)
+    b = se_batch(reads)
+    R = o.OracleReference([("ecoli_syn", ref)])
+    S = hs.SimReference([("ecoli_syn", ref)])
+    p = o.make_params()
+    sa, sb = R.align(b, p), S.align(b, p)
+    assert streams_equal(sa, sb), first_difference(sa, sb, len(reads))
+    # sanity of the workload itself: nearly every synthetic read maps back to where it came from
+    ok = 0
+    for q in range(len(reads)):
+        comps = sa.query(q)
+        if comps[0]:
+            s0 = comps[0][0]["sequences"][0]
+            if abs((s0["blocks"][0][1] - s0["blocks"][0][0]) - int(starts[q])) <= 3 and s0["referenceReversed"] == int(strand[q]):
+                ok += 1
+    assert ok >= 0.99 * len(reads)
+
+
+def test_kernel_logic_paired_end_synthetic():
+    ref = synth.synthetic_reference(300_000)
+    m1, m2, _, _, _ = synth.synthetic_paired_end(ref, 1500)
+    b = pe_batch(m1, m2)
+    R = o.OracleReference([("ecoli_syn", ref)])
+    S = hs.SimReference([("ecoli_syn", ref)])
+    p = o.make_params()
+    sa, sb = R.align(b, p), S.align(b, p)
+    assert streams_equal(sa, sb), first_difference(sa, sb, len(m1))
+
+
+def test_kernel_logic_edge_cases():
+    """ragged / tiny / unalignable reads, reads hanging over contig ends, repeats, multi-contig reference, long reads."""
+    rng = np.random.default_rng(3)
+    c0 = synth.synthetic_reference(60_000, seed=11)
+    c1 = synth.synthetic_reference(9_000, seed=12)
+    rep = np.tile(synth.synthetic_reference(500, seed=13), 8)   # tandem repeat contig
+    contigs = api.sort_reference([("c0", c0), ("c1", c1), ("rep", rep)])
+    queries = []
+    for L in (1, 2, 7, 12, 20, 33, 75, 151, 400, 1000):
+        s = int(rng.integers(0, len(c0) - L))
+        queries.append(([c0[s:s + L].copy()], 0.0, 1.0))
+    queries.append(([np.concatenate([c1[-40:], np.array([1, 2, 4, 8] * 10, dtype=np.uint8)])], 0.0, 1.0))  # hangs over a contig end
+    queries.append(([np.concatenate([np.array([8, 4, 2, 1] * 8, dtype=np.uint8), c1[:60]])], 0.0, 1.0))      # hangs over a contig start
+    queries.append(([rep[100:250].copy()], 0.0, 1.0))                                                          # many equally good placements
+    queries.append(([np.full(150, 1, dtype=np.uint8)], 0.0, 1.0))                                              # poly-A, matches nowhere
+    queries.append(([np.array([1, 2, 4, 8], dtype=np.uint8)[rng.integers(0, 4, 150)]], 0.0, 1.0))              # random, unalignable
+    queries.append(([c0[5000:5150].copy(), api.reverse_complement(c0[5300:5450])], 100.0, 50.0))               # proper pair
+    queries.append(([c0[5000:5150].copy(), api.reverse_complement(c1[300:450])], 100.0, 50.0))                 # mates on different contigs
+    queries.append(([c0[5000:5150].copy(), api.reverse_complement(c0[5100:5250])], 100.0, 50.0))               # overlapping mates
+    b = o.QueryBatch(queries)
+    R = o.OracleReference(contigs)
+    S = hs.SimReference(contigs)
+    for params in (o.make_params(), o.make_params(MaxNumMatches=3), o.make_params(Max_PenaltySpan=2.0, MaxErrorRate=0.15)):
+        sa, sb = R.align(b, params), S.align(b, params)
+        assert streams_equal(sa, sb), first_difference(sa, sb, len(queries))

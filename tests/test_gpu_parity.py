@@ -1,0 +1,160 @@
+"""GPU tier: libxmapper_hip.so through its C ABI (mapper_amd.api) against the oracle, the committed golden vectors and
+size-independent properties at BASELINE.json's full size.  Run with -m gpu on an MI355X."""
+import json
+import os
+import sys
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from helpers import KAT, streams_equal, first_difference, se_batch, pe_batch, check_align_case, sam_text
+from mapper_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+
+def gpu_align(db, batch, params=None):
+    r = db.align_arrays(batch.mate_count, batch.mate_offset, batch.mate_length, batch.codes, batch.expected_inner, batch.deviation,
+                        params or api.AlignmentParameters())
+    return o.Streams(r.ints, r.dbls, r.int_off, r.dbl_off, r.counters), r
+
+
+def to_api_params(d):
+    return api.AlignmentParameters(**{k: v for k, v in d.items()})
+
+
+@pytest.mark.parametrize("case", [c for c in KAT["align_cases"] if set(c["reference"]) <= set("ACGT")], ids=lambda c: c["name"])
+def test_reference_kats_on_gpu(case):
+    """T/AlignerWorker_Test.java through Api.alignOnce's mirror: expectations of the reference's test + bit-identical to the oracle."""
+    db = api.newDatabase(case["reference"])
+    b = o.QueryBatch([(case["mates"], case["expectedInner"], case["deviation"])])
+    got, _ = gpu_align(db, b, to_api_params(case["params"]))
+    want = o.OracleReference([("reference-0", case["reference"])], mode="api").align(b, o.make_params(case["params"]))
+    assert streams_equal(got, want), first_difference(got, want, 1)
+    check_align_case(case, api.decode_streams(got.ints, got.dbls, got.int_off, got.dbl_off, 0), o.encode(case["reference"]))
+    db.close()
+
+
+@pytest.mark.parametrize("case", KAT["sam_cases"], ids=[c["name"] for c in KAT["sam_cases"]])
+def test_sam_bodies_on_gpu(case):
+    """T/SamWriter_Test.java:18-94 with the alignments computed on the GPU."""
+    db = api.ReferenceDatabase([("ref", case["reference"])], dup=(1, 2, 2, 1))
+    mates = [m[1] for m in case["mates"]]
+    q = api.Query(*mates, expected_inner_distance=case.get("expectedInner", 0.0), spacing_deviation_per_unit_penalty=case.get("deviation", 1.0),
+                  names=[m[0] for m in case["mates"]])
+    comps = db.align_batch([q], to_api_params(KAT["align_cases"][0]["params"])).query_alignments(0)
+    assert sorted(sam_text(q, comps, ["ref"]).splitlines()) == sorted(case["sam"].splitlines())
+    db.close()
+
+
+def test_golden_digests_and_oracle_parity():
+    """Committed golden vectors (tests/golden/synthetic_golden.json, made by the oracle) + live oracle comparison."""
+    import hashlib
+    from make_synthetic_golden import cases, digest
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "synthetic_golden.json")))
+    ref, batches = cases()
+    db = api.ReferenceDatabase([("ecoli_syn", ref)])
+    R = o.OracleReference([("ecoli_syn", ref)])
+    for name, b in batches.items():
+        got, _ = gpu_align(db, b)
+        assert digest(got) == golden["digests"][name]["sha256"], name
+        want = R.align(b, o.make_params(), threads=os.cpu_count())
+        assert streams_equal(got, want), first_difference(got, want, b.nq)
+    del hashlib
+    db.close()
+
+
+def test_edge_cases_on_gpu():
+    rng = np.random.default_rng(3)
+    c0 = synth.synthetic_reference(60_000, seed=11)
+    c1 = synth.synthetic_reference(9_000, seed=12)
+    rep = np.tile(synth.synthetic_reference(500, seed=13), 8)
+    contigs = api.sort_reference([("c0", c0), ("c1", c1), ("rep", rep)])
+    queries = []
+    for L in (1, 2, 7, 12, 20, 33, 75, 151, 400, 1000):
+        s = int(rng.integers(0, len(c0) - L))
+        queries.append(([c0[s:s + L].copy()], 0.0, 1.0))
+    queries.append(([np.concatenate([c1[-40:], np.array([1, 2, 4, 8] * 10, dtype=np.uint8)])], 0.0, 1.0))
+    queries.append(([np.concatenate([np.array([8, 4, 2, 1] * 8, dtype=np.uint8), c1[:60]])], 0.0, 1.0))
+    queries.append(([rep[100:250].copy()], 0.0, 1.0))
+    queries.append(([np.full(150, 1, dtype=np.uint8)], 0.0, 1.0))
+    queries.append(([np.array([1, 2, 4, 8], dtype=np.uint8)[rng.integers(0, 4, 150)]], 0.0, 1.0))
+    queries.append(([c0[5000:5150].copy(), api.reverse_complement(c0[5300:5450])], 100.0, 50.0))
+    queries.append(([c0[5000:5150].copy(), api.reverse_complement(c1[300:450])], 100.0, 50.0))
+    queries.append(([c0[5000:5150].copy(), api.reverse_complement(c0[5100:5250])], 100.0, 50.0))
+    b = o.QueryBatch(queries)
+    db = api.ReferenceDatabase(contigs)
+    R = o.OracleReference(contigs)
+    for kw in ({}, {"MaxNumMatches": 3}, {"Max_PenaltySpan": 2.0, "MaxErrorRate": 0.15}):
+        got, _ = gpu_align(db, b, api.AlignmentParameters(**kw))
+        want = R.align(b, o.make_params(**kw))
+        assert streams_equal(got, want), first_difference(got, want, len(queries))
+    # empty batch
+    empty = o.QueryBatch([])
+    r = db.align_arrays(empty.mate_count, empty.mate_offset, empty.mate_length, empty.codes, empty.expected_inner, empty.deviation, api.AlignmentParameters())
+    assert len(r.ints) == 0 and list(r.int_off) == [0]
+    db.close()
+
+
+def test_read_with_ambiguous_base_fails_loudly():
+    db = api.ReferenceDatabase([("r", synth.synthetic_reference(20_000))])
+    with pytest.raises(RuntimeError, match="non-ACGT"):
+        db.align_batch([api.Query("ACGTACGTACGTANGTACGTACGTACGTACGTACGT")], api.AlignmentParameters())
+    db.close()
+
+
+def test_seed_probe_matches_host_tables():
+    """xm_seed_probe (bulk PackedMap.get on the device) against the bucket contents the oracle holds."""
+    ref = synth.synthetic_reference(300_000)
+    db = api.ReferenceDatabase([("ecoli_syn", ref)])
+    R = o.OracleReference([("ecoli_syn", ref)])
+    R.align(["ACGTACGTACGTAGCATCGACTAGCAGCATCGAC"], o.make_params())
+    rng = np.random.default_rng(5)
+    info = db.info()
+    for L in (info["min_interesting_size"], 12, 16, 24, info["max_hashed_length"]):
+        t = R.table(L)
+        keys = rng.integers(-2**31, 2**31 - 1, 4096).astype(np.int32)
+        counts, pos, _ = db.seed_probe(np.full(len(keys), L, np.int32), keys, max_per_probe=8)
+        starts = np.concatenate([[0], np.cumsum(np.maximum(t["counts"], 0))])
+        for i, k in enumerate(keys):
+            bucket = int(k) % t["capacity"]
+            c = int(t["counts"][bucket])
+            want = -1 if (c < 0 or c > t["maxCount"]) else c
+            assert counts[i] == want
+            if want > 0:
+                assert list(pos[i, :min(want, 8)]) == list(t["positions"][starts[bucket]:starts[bucket] + min(want, 8)])
+    db.close()
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1] at full size (1,000,000 x 150 bp vs 5 Mb): properties that need no oracle run."""
+    ref = synth.synthetic_reference(5_000_000)
+    reads, starts, strand = synth.synthetic_single_end(ref, 1_000_000)
+    db = api.ReferenceDatabase([("ecoli_syn", ref)], max_query_length=150)
+    b = se_batch(reads)
+    a1, r1 = gpu_align(db, b)
+    a2, _ = gpu_align(db, b)
+    assert streams_equal(a1, a2), "two runs of the same batch differ (non-determinism)"
+    # batch-composition invariance: a read's result does not depend on what else is in the batch
+    sub = se_batch(reads[250_000:300_000])
+    a3, _ = gpu_align(db, sub)
+    lo, hi = a1.int_off[250_000], a1.int_off[300_000]
+    assert np.array_equal(a3.ints, a1.ints[lo:hi])
+    # every read of this workload maps back to its origin (ungapped offset of the first block, strand)
+    io = a1.int_off[:-1]
+    nal = a1.ints[io + 1]
+    assert (nal >= 1).mean() > 0.995
+    one = nal >= 1
+    contig_rev = a1.ints[io[one] + 5]
+    start_a = a1.ints[io[one] + 7]
+    start_b = a1.ints[io[one] + 8]
+    assert (np.abs((start_b - start_a) - starts[one]) <= 3).mean() > 0.99
+    assert (contig_rev == strand[one]).mean() > 0.995
+    # the oracle agrees bit for bit on a slice that finishes in seconds
+    R = o.OracleReference([("ecoli_syn", ref)])
+    n = 60_000
+    want = R.align(se_batch(reads[:n]), o.make_params(), threads=os.cpu_count())
+    assert np.array_equal(want.ints, a1.ints[:a1.int_off[n]]) and np.array_equal(want.dbls.view(np.int64), a1.dbls[:a1.dbl_off[n]].view(np.int64))
+    db.close()
