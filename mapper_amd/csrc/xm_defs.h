@@ -142,7 +142,7 @@ struct Caps {
   int32_t scale;
   int32_t heavyAllowed;  // 0: light pass (a read that reaches the gapped chain stops with XM_ST_NEED_HEAVY)
   int32_t maxLevels, maxPyramidBlocks, maxHistory, maxCounters, maxPending, maxQM, maxGoodAlignments, maxBlocks,
-      maxNodes, nodeHash, maxBuckets, bucketHash, matcherEntries, maxSections, maxPieces, maxCountMap, maxJoined;
+      maxNodes, nodeHash, gridCap, maxBuckets, bucketHash, matcherEntries, maxSections, maxPieces, maxCountMap, maxJoined;
 };
 XM_INL Caps makeCaps(int scale) {
   Caps c;
@@ -158,6 +158,7 @@ XM_INL Caps makeCaps(int scale) {
   c.maxBlocks = 16 * scale;
   c.maxNodes = 1536 * scale;
   c.nodeHash = 4096 * scale;  // power of two >= 2 * maxNodes
+  c.gridCap = 10000 * scale;  // cells of PathAligner's dense (x,y) grid; larger problems use the hash
   c.maxBuckets = 512 * scale;
   c.bucketHash = 2048 * scale;  // power of two >= 4 * maxBuckets
   c.matcherEntries = 6144 * scale;

@@ -65,10 +65,10 @@ struct ExtEnv {  // everything the chain needs
 };
 
 // ---------------------------------------------------------------- penalties (M/AlignmentParameters.java)
-XM_INL double blockPenalty(const ExtEnv& e, const Params& p, const ABlock& b) {  // :106-126
+XM_INL double blockPenalty(const SeqView& q, const SeqView& r, const Params& p, const ABlock& b) {  // :106-126
   double penalty = 0;
   if (b.lenA == b.lenB) {
-    for (int i = 0; i < b.lenA; i++) penalty += p.getPenalty(e.query.at(b.startA + i), e.reference.at(b.startB + i));
+    for (int i = 0; i < b.lenA; i++) penalty += p.getPenalty(q.at(b.startA + i), r.at(b.startB + i));
   } else if (b.lenA > 0) {
     penalty += p.InsertionStart_Penalty;
     penalty += p.InsertionExtension_Penalty * b.lenA;
@@ -79,12 +79,17 @@ XM_INL double blockPenalty(const ExtEnv& e, const Params& p, const ABlock& b) { 
   return penalty;
 }
 // newSequenceAlignment :73-95 over out.blocks[0..nb)
-XM_INL void finishSeqAl(const ExtEnv& e, const Params& p, SeqAl& out, bool referenceReversed) {
+XM_INL void finishSeqAl(const ExtEnv& e, const Params& pIn, SeqAl& out, bool referenceReversed) {
+  const Params p = pIn;
+  const SeqView q = e.query, r = e.reference;
+  const ABlock* const blocks = out.blocks;
+  const int nbL = out.nb;
   int alignedQueryLength = 0;
   double totalPenalty = 0;
-  for (int i = 0; i < out.nb; i++) {
-    totalPenalty += blockPenalty(e, p, out.blocks[i]);
-    alignedQueryLength += out.blocks[i].lenA;
+  for (int i = 0; i < nbL; i++) {
+    const ABlock b = blocks[i];
+    totalPenalty += blockPenalty(q, r, p, b);
+    alignedQueryLength += b.lenA;
   }
   if (out.nb > 0 && p.StartingInsertionStartFree && out.blocks[0].lenB == 0) totalPenalty -= p.InsertionStart_Penalty;
   double alignedPenalty = totalPenalty;
@@ -128,7 +133,10 @@ XM_INL int matcherEncodeBlock(const Matcher& m, const SeqView& s, int index) {  
   }
   return sum;
 }
-XM_NOINL void matcherIndexSection(Matcher& m, const ExtEnv& e, int sectionIndex, int16_t* section) {  // :40-77
+// GPU note: everything below takes the sequences and the matcher BY VALUE / as locals.  Structures reached through a pointer
+// (ExtEnv, Matcher in the arena) cost a dependent memory round trip per field on this hardware, and the compiler must reload
+// them after every store it cannot disambiguate; locals stay in registers.
+XM_NOINL void matcherIndexSection(const Matcher m, const SeqView ref, int sectionIndex, int16_t* section, DevCounters* dc) {  // :40-77
   XM_TIC(t0);
   for (int i = 0; i < m.numPossibilities; i++) section[i] = M_NO_MATCHES;
   int previousEncoded = M_UNKNOWN;
@@ -137,9 +145,9 @@ XM_NOINL void matcherIndexSection(Matcher& m, const ExtEnv& e, int sectionIndex,
   for (int i = startIndex; i < endIndex; i++) {
     int encoded;
     if (previousEncoded == M_UNKNOWN) {
-      encoded = matcherEncodeBlock(m, e.reference, i);
+      encoded = matcherEncodeBlock(m, ref, i);
     } else {
-      uint8_t nextChar = e.reference.at(i + m.blockLength - 1);
+      uint8_t nextChar = ref.at(i + m.blockLength - 1);
       if (bpIsAmbiguous(nextChar)) encoded = M_UNKNOWN;
       else encoded = ((previousEncoded * 4) & m.maxPossibility) + encodedCharToInt(nextChar);
     }
@@ -148,40 +156,55 @@ XM_NOINL void matcherIndexSection(Matcher& m, const ExtEnv& e, int sectionIndex,
     section[encoded] = (existing == M_NO_MATCHES) ? (int16_t)(i - m.referenceStart) : (int16_t)M_MULTIPLE;
     previousEncoded = encoded;
   }
-  XM_TOC(e.dc, T_MATCHER_INDEX, t0);
+  XM_TOC(dc, T_MATCHER_INDEX, t0);
 }
 // getSection :203-215; returns -1 for a "null" entry (a section skipped by an earlier jump), else the section slot
-XM_INL int matcherGetSection(Matcher& m, const ExtEnv& e, int index) {
+XM_INL int matcherGetSection(Matcher& m, const SeqView& ref, int index, bool& overflow, DevCounters* dc) {
   if (m.nSections > index) return m.present[index] ? index : -1;
-  if (index >= m.maxSections || (long long)(index + 1) * m.numPossibilities > m.tableCap) { *e.status = XM_ST_OVERFLOW; return -1; }
+  if (index >= m.maxSections || (long long)(index + 1) * m.numPossibilities > m.tableCap) { overflow = true; return -1; }
   while (m.nSections <= index) m.present[m.nSections++] = 0;
   m.present[index] = 1;
-  matcherIndexSection(m, e, index, m.tables + (size_t)index * m.numPossibilities);
+  matcherIndexSection(m, ref, index, m.tables + (size_t)index * m.numPossibilities, dc);
   return index;
 }
-XM_INL bool matcherCanPositionsMatch(const Matcher& m, const ExtEnv& e, int queryIndex, int referenceIndex) {  // :159-171
+XM_INL bool matcherCanPositionsMatch(const Matcher& m, const SeqView& query, const SeqView& ref, int queryIndex, int referenceIndex) {  // :159-171
   if (referenceIndex + m.blockLength > m.referenceStart + m.referenceLength) return false;
-  for (int i = 0; i < m.blockLength; i++) if (!bpCanMatch(e.query.at(queryIndex + i), e.reference.at(referenceIndex + i))) return false;
+  for (int i = 0; i < m.blockLength; i++) if (!bpCanMatch(query.at(queryIndex + i), ref.at(referenceIndex + i))) return false;
   return true;
 }
-XM_NOINL int matcherLookup(Matcher& m, const ExtEnv& e, int queryIndex, int minReferenceIndex, int maxReferenceIndex) {  // :98-141
+// encodeBlock(query, index) with a one-entry rolling cache (consecutive block starts differ by one base)
+struct EncodeCache { int32_t index, code; };
+XM_INL int matcherEncodeQuery(const Matcher& m, const SeqView& query, int index, EncodeCache& c) {
+  int code;
+  if (c.code >= 0 && index == c.index + 1 && index + m.blockLength <= query.len) {
+    uint8_t here = query.at(index + m.blockLength - 1);
+    code = bpIsAmbiguous(here) ? (int)M_UNKNOWN : (((c.code * 4) & m.maxPossibility) + encodedCharToInt(here));
+  } else {
+    code = matcherEncodeBlock(m, query, index);
+  }
+  c.index = index;
+  c.code = code;
+  return code;
+}
+XM_INL int matcherLookup(Matcher& m, const SeqView& query, const SeqView& ref, int queryIndex, int minReferenceIndex, int maxReferenceIndex, EncodeCache& cache,
+                         bool& overflow, DevCounters* dc) {  // :98-141
   if (minReferenceIndex < 0) return M_UNKNOWN;
-  if (maxReferenceIndex > e.reference.len) return M_UNKNOWN;
-  int encoded = matcherEncodeBlock(m, e.query, queryIndex);
+  if (maxReferenceIndex > ref.len) return M_UNKNOWN;
+  int encoded = matcherEncodeQuery(m, query, queryIndex, cache);
   if (encoded < 0) return M_UNKNOWN;
   int matched = M_NO_MATCHES;
   int minSectionIndex = imax(0, matcherSectionIndex(m, minReferenceIndex));
   int maxSection = imin(m.maxSectionIndex, matcherSectionIndex(m, maxReferenceIndex));
   for (int sectionIndex = minSectionIndex; sectionIndex <= maxSection; sectionIndex++) {
-    int slot = matcherGetSection(m, e, sectionIndex);
-    if (*e.status) return M_UNKNOWN;
+    int slot = matcherGetSection(m, ref, sectionIndex, overflow, dc);
+    if (overflow) return M_UNKNOWN;
     int lookedUp;
     if (m.sectionLength < 3) {  // scanSection :143-157
       lookedUp = M_NO_MATCHES;
       int startIndex = m.referenceStart + sectionIndex * m.sectionLength;
       int endIndex = startIndex + m.sectionLength;
       for (int i = startIndex; i < endIndex; i++) {
-        if (matcherCanPositionsMatch(m, e, queryIndex, i)) {
+        if (matcherCanPositionsMatch(m, query, ref, queryIndex, i)) {
           if (lookedUp == M_NO_MATCHES) lookedUp = i; else { lookedUp = M_MULTIPLE; break; }
         }
       }
@@ -228,13 +251,21 @@ struct CountMap {
 };
 
 // ---------------------------------------------------------------- PathAligner (M/PathAligner.java)
+struct PNode {  // AlignmentNode, 32 bytes = two 16-byte loads
+  double pen, insX, insY;
+  int16_t x, y;
+  uint8_t fl;  // 1 reachedMainDiagonal, 2 reachedOtherDiagonal
+  uint8_t pad[3];
+};
+
 struct PathAligner {
   static constexpr double disallowed = 1000000.0;
-  // node pool (SoA)
-  int16_t* nx; int16_t* ny; double* npen; double* nix; double* niy; uint8_t* nfl;  // fl: 1 reachedMain, 2 reachedOther
-  int32_t nNodes, maxNodes;
+  // locatedNodes: (x,y) -> latest node.  Dense grid of node indices when (textA+2)*(textB+2) fits (the four neighbour lookups of
+  // an update are then four INDEPENDENT loads, issued together), open-addressing hash otherwise.
+  PNode* nodes; int32_t nNodes, maxNodes;
+  int32_t* grid; int32_t gridH, gridW; bool useGrid;
   int32_t* hash; int32_t hashMask;  // (x,y) -> latest node index + 1
-  // prioritizedNodes: bucket per exact double key; list entries in insertion order
+  // prioritizedNodes: bucket per exact double key; list entries in insertion order.
   // buckets are never recycled (a removed key cannot reappear: new estimates are clamped to the active key); lookup by exact
   // key bits through an open-addressing hash, priorities.poll() through a binary min-heap of bucket ids
   double* bkey; int32_t* bhead; int32_t* btail; int32_t nBuckets, maxBuckets;
@@ -257,28 +288,38 @@ struct PathAligner {
   XM_INL uint8_t charB(int i) const { return rBase[startIndexB + i]; }
   XM_INL int signedDist(int x, int y) const { return x - y - diagonal; }
 
-  XM_INL int findNode(int x, int y) const {  // getNode :541-553
-    if (x < 0 || y < 0) return -1;
+  XM_INL int findNodeHash(int x, int y) const {
     uint32_t key = ((uint32_t)x << 16) | (uint32_t)(y & 0xFFFF);
     uint32_t h = (key * 2654435761u) & (uint32_t)hashMask;
     while (true) {
       int32_t v = hash[h];
       if (v == 0) return -1;
       int idx = v - 1;
-      if (nx[idx] == x && ny[idx] == y) return idx;
+      if (nodes[idx].x == x && nodes[idx].y == y) return idx;
       h = (h + 1) & (uint32_t)hashMask;
     }
   }
-  XM_INL void saveNode(int idx) {  // :523-539 (overwrites the node at (x,y))
-    int x = nx[idx], y = ny[idx];
+  XM_INL int findNode(int x, int y) const {  // getNode :541-553
+    if (x < 0 || y < 0) return -1;
+    if (useGrid) {
+      if (x >= gridW || y >= gridH) return -1;
+      return grid[x * gridH + y] - 1;
+    }
+    return findNodeHash(x, y);
+  }
+  XM_INL void saveNode(int idx, int x, int y) {  // :523-539 (overwrites the node at (x,y))
     if (x < 0 || y < 0) return;
+    if (useGrid) {
+      if (x < gridW && y < gridH) grid[x * gridH + y] = idx + 1;
+      return;
+    }
     uint32_t key = ((uint32_t)x << 16) | (uint32_t)(y & 0xFFFF);
     uint32_t h = (key * 2654435761u) & (uint32_t)hashMask;
     while (true) {
       int32_t v = hash[h];
       if (v == 0) { hash[h] = idx + 1; return; }
       int o = v - 1;
-      if (nx[o] == x && ny[o] == y) { hash[h] = idx + 1; return; }
+      if (nodes[o].x == x && nodes[o].y == y) { hash[h] = idx + 1; return; }
       h = (h + 1) & (uint32_t)hashMask;
     }
   }
@@ -342,22 +383,29 @@ struct PathAligner {
     if (btail[b] >= 0) lnext[btail[b]] = li; else bhead[b] = li;
     btail[b] = li;
     int idx = nNodes++;
-    nx[idx] = (int16_t)x; ny[idx] = (int16_t)y; npen[idx] = pen; nix[idx] = insX; niy[idx] = insY; nfl[idx] = fl;
-    saveNode(idx);
+    PNode n;
+    n.pen = pen; n.insX = insX; n.insY = insY; n.x = (int16_t)x; n.y = (int16_t)y; n.fl = fl; n.pad[0] = n.pad[1] = n.pad[2] = 0;
+    nodes[idx] = n;
+    saveNode(idx, x, y);
     nodesPut++;
   }
   XM_INL void update(int x, int y) {  // :555-571 + computeUpdated :573-719
     if (x <= 0 || x > textALength) return;
     if (y <= 0 || y > textBLength) return;
-    int existing = findNode(x, y);
-    int left = findNode(x - stepDelta, y);
-    int up = findNode(x, y - stepDelta);
-    int diag = findNode(x - stepDelta, y - stepDelta);
+    // the four lookups first (independent loads), then the four nodes (index 0 stands in for "null": node 0 always exists)
+    const int existing = findNode(x, y);
+    const int left = findNode(x - stepDelta, y);
+    const int up = findNode(x, y - stepDelta);
+    const int diag = findNode(x - stepDelta, y - stepDelta);
+    const PNode nE = nodes[existing >= 0 ? existing : 0];
+    const PNode nL = nodes[left >= 0 ? left : 0];
+    const PNode nU = nodes[up >= 0 ? up : 0];
+    const PNode nD = nodes[diag >= 0 ? diag : 0];
     double insertXPenalty = disallowed, insertYPenalty = disallowed, overlayPenalty = disallowed;
-    if (diag >= 0) overlayPenalty = npen[diag] + parameters.getPenalty(charA(x - 1), charB(y - 1));
+    if (diag >= 0) overlayPenalty = nD.pen + parameters.getPenalty(charA(x - 1), charB(y - 1));
     if (left >= 0) {
       if (y == goalY && mayQueryExtendPastEndOfReference) {
-        insertXPenalty = npen[left] + parameters.UnalignedPenalty;
+        insertXPenalty = nL.pen + parameters.UnalignedPenalty;
       } else {
         bool allowed = true;
         int prevA = x - 1 - stepDelta, prevB = y - 1;
@@ -372,8 +420,8 @@ struct PathAligner {
             else if (bpIsFullyAmbiguous(a) || bpIsFullyAmbiguous(b)) allowed = false;
           }
         }
-        double newInsertX = allowed ? npen[left] + parameters.InsertionStart_Penalty + parameters.InsertionExtension_Penalty : disallowed;
-        double extendInsertX = nix[left] + parameters.InsertionExtension_Penalty;
+        double newInsertX = allowed ? nL.pen + parameters.InsertionStart_Penalty + parameters.InsertionExtension_Penalty : disallowed;
+        double extendInsertX = nL.insX + parameters.InsertionExtension_Penalty;
         insertXPenalty = dmin(extendInsertX, newInsertX);
       }
     }
@@ -391,17 +439,17 @@ struct PathAligner {
           else if (bpIsFullyAmbiguous(a) || bpIsFullyAmbiguous(b)) allowed = false;
         }
       }
-      double newInsertY = allowed ? npen[up] + parameters.DeletionStart_Penalty + parameters.DeletionExtension_Penalty : disallowed;
-      double extendInsertY = niy[up] + parameters.DeletionExtension_Penalty;
+      double newInsertY = allowed ? nU.pen + parameters.DeletionStart_Penalty + parameters.DeletionExtension_Penalty : disallowed;
+      double extendInsertY = nU.insY + parameters.DeletionExtension_Penalty;
       insertYPenalty = dmin(extendInsertY, newInsertY);
     }
     double bestPenalty = dmin(dmin(overlayPenalty, insertXPenalty), insertYPenalty);
-    if (existing < 0 || bestPenalty < npen[existing] || insertXPenalty < nix[existing] || insertYPenalty < niy[existing]) {
+    if (existing < 0 || bestPenalty < nE.pen || insertXPenalty < nE.insX || insertYPenalty < nE.insY) {
       uint8_t fl = 0;
       if (bestPenalty != disallowed) {
-        if (bestPenalty == overlayPenalty) fl = nfl[diag];
-        else if (bestPenalty == insertXPenalty) fl = nfl[left];
-        else fl = nfl[up];
+        if (bestPenalty == overlayPenalty) fl = nD.fl;
+        else if (bestPenalty == insertXPenalty) fl = nL.fl;
+        else fl = nU.fl;
         if (iabs(signedDist(x, y)) == 0) fl |= 1; else fl |= 2;
       }
       putNode(x, y, bestPenalty, insertXPenalty, insertYPenalty, fl);
@@ -431,11 +479,16 @@ XM_INL bool paCanRemoveSection(const ABlock& b) {  // :358-366
 }
 
 // PathAligner.align :55-293.  false = null
-XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, const Params& params, Analysis& analysis, SeqAl& out) {
+XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qsIn, const Section& rsIn, const Params& paramsIn, Analysis& analysis, SeqAl& out) {
   XM_TIC(tPath);
+  // by-value copies: anything read through a reference inside a loop that also stores would be re-loaded (and waited for) on
+  // every iteration, because the compiler cannot prove the store does not alias it
+  const Section qs = qsIn, rs = rsIn;
+  const Params params = paramsIn;
   Arena& tmp = *e.tmp;
   size_t mark = tmp.used;
-  const Caps& caps = *e.caps;
+  const Caps caps = *e.caps;
+  ABlock* const outBlocks = out.blocks;
   PathAligner pa;
   pa.e = &e;
   pa.parameters = params;
@@ -444,19 +497,24 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, c
   pa.predictedBestOffset = analysis.predictedBestOffset; pa.overflow = false; pa.nodesPut = 0;
   const int referenceLen = e.reference.len;
   pa.maxNodes = caps.maxNodes;
-  pa.nx = arenaArray<int16_t>(tmp, caps.maxNodes); pa.ny = arenaArray<int16_t>(tmp, caps.maxNodes);
-  pa.npen = arenaArray<double>(tmp, caps.maxNodes); pa.nix = arenaArray<double>(tmp, caps.maxNodes); pa.niy = arenaArray<double>(tmp, caps.maxNodes);
-  pa.nfl = arenaArray<uint8_t>(tmp, caps.maxNodes);
-  pa.hash = arenaArray<int32_t>(tmp, caps.nodeHash);
-  pa.hashMask = caps.nodeHash - 1;
+  pa.nodes = arenaArray<PNode>(tmp, caps.maxNodes);
+  pa.gridW = secLen(qs) + 2; pa.gridH = secLen(rs) + 2;
+  pa.useGrid = (long long)pa.gridW * pa.gridH <= (long long)caps.gridCap;
+  pa.grid = nullptr; pa.hash = nullptr; pa.hashMask = 0;
+  if (pa.useGrid) pa.grid = arenaArray<int32_t>(tmp, (size_t)pa.gridW * pa.gridH);
+  else { pa.hash = arenaArray<int32_t>(tmp, caps.nodeHash); pa.hashMask = caps.nodeHash - 1; }
   pa.maxBuckets = caps.maxBuckets;
   pa.bkey = arenaArray<double>(tmp, caps.maxBuckets); pa.bhead = arenaArray<int32_t>(tmp, caps.maxBuckets); pa.btail = arenaArray<int32_t>(tmp, caps.maxBuckets);
   pa.bhash = arenaArray<int32_t>(tmp, caps.bucketHash); pa.bhashMask = caps.bucketHash - 1;
   pa.heap = arenaArray<int32_t>(tmp, caps.maxBuckets); pa.heapSize = 0;
   pa.lx = arenaArray<int16_t>(tmp, caps.maxNodes); pa.ly = arenaArray<int16_t>(tmp, caps.maxNodes); pa.lnext = arenaArray<int32_t>(tmp, caps.maxNodes);
   if (tmp.overflow) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
-  for (int i = 0; i < caps.nodeHash; i++) pa.hash[i] = 0;
-  for (int i = 0; i < caps.bucketHash; i++) pa.bhash[i] = 0;
+  {
+    int32_t* const h1 = pa.useGrid ? pa.grid : pa.hash; const int n1 = pa.useGrid ? pa.gridW * pa.gridH : caps.nodeHash;
+    for (int i = 0; i < n1; i++) h1[i] = 0;
+    int32_t* const h2 = pa.bhash; const int n2 = caps.bucketHash;
+    for (int i = 0; i < n2; i++) h2[i] = 0;
+  }
   XM_TOC(e.dc, T_PATH_INIT, tPath);
   pa.nNodes = 0; pa.nBuckets = 0; pa.nList = 0;
   pa.activePenalty = 0;
@@ -541,15 +599,15 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, c
   while (i != pa.startX && j != pa.startY) {
     if (nb >= caps.maxBlocks) { pa.overflow = true; return leave(false); }
     int node = pa.findNode(i, j);
-    double bestPenalty = pa.npen[node], insertXPenalty = pa.nix[node], insertYPenalty = pa.niy[node];
+    double bestPenalty = pa.nodes[node].pen, insertXPenalty = pa.nodes[node].insX, insertYPenalty = pa.nodes[node].insY;
     ABlock blk;
     if (bestPenalty == insertXPenalty) {
       int oldI = i;
       i -= sd;
       while (i != pa.startX) {
         int other = pa.findNode(i, j);
-        double otherNew = pa.npen[other] + params.InsertionStart_Penalty + params.InsertionExtension_Penalty;
-        double otherExtend = pa.nix[other] + params.InsertionExtension_Penalty;
+        double otherNew = pa.nodes[other].pen + params.InsertionStart_Penalty + params.InsertionExtension_Penalty;
+        double otherExtend = pa.nodes[other].insX + params.InsertionExtension_Penalty;
         if (otherNew < otherExtend) break;
         i -= sd;
       }
@@ -560,8 +618,8 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, c
       j -= sd;
       while (j != pa.startY) {
         int other = pa.findNode(i, j);
-        double otherNew = pa.npen[other] + params.DeletionStart_Penalty + params.DeletionExtension_Penalty;
-        double otherExtend = pa.niy[other] + params.DeletionExtension_Penalty;
+        double otherNew = pa.nodes[other].pen + params.DeletionStart_Penalty + params.DeletionExtension_Penalty;
+        double otherExtend = pa.nodes[other].insY + params.DeletionExtension_Penalty;
         if (otherNew < otherExtend) break;
         j -= sd;
       }
@@ -573,28 +631,29 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, c
       j -= sd;
       while (i != pa.startX && j != pa.startY) {
         int other = pa.findNode(i, j);
-        if (pa.npen[other] == pa.nix[other] || pa.npen[other] == pa.niy[other]) break;
+        if (pa.nodes[other].pen == pa.nodes[other].insX || pa.nodes[other].pen == pa.nodes[other].insY) break;
         i -= sd;
         j -= sd;
       }
       if (pa.searchReverse) blk = ABlock{sA + oldI - 1, sB + oldJ - 1, i - oldI, j - oldJ};
       else blk = ABlock{sA + i, sB + j, oldI - i, oldJ - j};
     }
-    out.blocks[nb++] = blk;
+    outBlocks[nb++] = blk;
   }
   leave(true);  // the search structures are dead from here on
-  if (!pa.searchReverse) for (int a = 0, b2 = nb - 1; a < b2; a++, b2--) { ABlock t = out.blocks[a]; out.blocks[a] = out.blocks[b2]; out.blocks[b2] = t; }
+  if (!pa.searchReverse) for (int a = 0, b2 = nb - 1; a < b2; a++, b2--) { ABlock t = outBlocks[a]; outBlocks[a] = outBlocks[b2]; outBlocks[b2] = t; }
   if (nb < 1) return false;
   // justify :307-352
-  ABlock* s = out.blocks;
+  ABlock* s = outBlocks;
+  const SeqView jq = e.query, jr = e.reference;
   for (int k = 1; k < nb - 1; k++) {
     while (true) {
       ABlock left = s[k - 1], middle = s[k], right = s[k + 1];
       if ((middle.lenA > 0) == (middle.lenB > 0)) break;
       if (left.lenA == 0 || left.lenB == 0) break;
       if (right.lenA == 0 || right.lenB == 0) break;
-      if (middle.lenA > 0) { if (e.query.at(abEndA(left) - 1) != e.query.at(abEndA(middle) - 1)) break; }
-      else { if (e.reference.at(abEndB(left) - 1) != e.reference.at(abEndB(middle) - 1)) break; }
+      if (middle.lenA > 0) { if (jq.at(abEndA(left) - 1) != jq.at(abEndA(middle) - 1)) break; }
+      else { if (jr.at(abEndB(left) - 1) != jr.at(abEndB(middle) - 1)) break; }
       s[k - 1] = ABlock{left.startA, left.startB, left.lenA - 1, left.lenB - 1};
       s[k] = ABlock{middle.startA - 1, middle.startB - 1, middle.lenA, middle.lenB};
       s[k + 1] = ABlock{right.startA - 1, right.startB - 1, right.lenA + 1, right.lenB + 1};
@@ -713,14 +772,20 @@ XM_INL double hbaManyDeletions(int numMismatches, double totalPenalty, const Par
 
 // analyzePenalty :94-283.  storeSlot: where a matcher created for a matcher-less analysis lives (A for the outer
 // HashBlock_Aligner, B for the inner one); temporaries go to slot T.
-XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, Matcher* storeSlot) {
+XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qsIn, const Section& rsIn, const Params& pIn, Analysis& an, Matcher* storeSlot) {
   XM_TIC(tA);
+  const Section qs = qsIn, rs = rsIn;  // by value (see pathAlign)
+  const Params p = pIn;
   Arena& tmp = *e.tmp;
   size_t mark = tmp.used;
   PenaltyAnalysis result;
   result.minPossiblePenalty = 0; result.maxInsertionExtensionPenalty = 0; result.maxDeletionExtensionPenalty = 0;
   result.offsetWithMostHashblockMatches = 0; result.numHashBlockMatchesWithBestOffset = 0;
   Matcher* matcher = an.matcher;
+  const SeqView query = e.query, reference = e.reference;  // register-resident copies
+  DevCounters* const dc = e.dc;
+  bool overflow = false;
+  EncodeCache cache; cache.index = -2; cache.code = -1;
   double maxInterestingPenalty = p.MaxErrorRate * secLen(qs);
   int numMismatches = 0;
   int maxNonmatchingBlockEnd = qs.start;
@@ -739,12 +804,13 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qs, c
     matcher = slot;
     if (!an.matcher) an.matcher = matcher;
   }
-  int blockLength = matcher->blockLength;
+  Matcher mm = *matcher;  // by value: scalars stay in registers, tables/present are pointers into the arena
+  int blockLength = mm.blockLength;
   int maxBlockStart = qs.end - blockLength;
   for (int blockStartIndex = qs.start; blockStartIndex <= maxBlockStart; blockStartIndex++) {
     if (blockStartIndex >= maxNonmatchingBlockEnd) {
-      int position = matcherLookup(*matcher, e, blockStartIndex, blockStartIndex + minPossibleOffset, blockStartIndex + maxPossibleOffset + 1);
-      if (*e.status) { tmp.used = mark; return result; }
+      int position = matcherLookup(mm, query, reference, blockStartIndex, blockStartIndex + minPossibleOffset, blockStartIndex + maxPossibleOffset + 1, cache, overflow, dc);
+      if (overflow) break;
       int offset = position - blockStartIndex;
       if (position == M_UNKNOWN || position == M_MULTIPLE) continue;
       if (position == M_NO_MATCHES) {
@@ -757,7 +823,7 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qs, c
       int reverseCount = imin(blockStartIndex - maxNonmatchingBlockEnd, otherStartIndex);
       bool foundMismatch = false;
       for (int i = 1; i <= reverseCount; i++) {
-        if (!bpCanMatch(e.query.at(blockStartIndex - i), e.reference.at(otherStartIndex - i))) {
+        if (!bpCanMatch(query.at(blockStartIndex - i), reference.at(otherStartIndex - i))) {
           numMismatches++;
           foundMismatch = true;
           maxNonmatchingBlockEnd = blockStartIndex + blockLength;
@@ -768,8 +834,8 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qs, c
         int forwardShift = qs.end - blockStartIndex;
         for (int i = blockLength; i < forwardShift; i++) {
           int indexA = blockStartIndex + i, indexB = otherStartIndex + i;
-          uint8_t ca = e.query.at(indexA);
-          uint8_t cb = (indexB < rs.end) ? e.reference.at(indexB) : (uint8_t)0;
+          uint8_t ca = query.at(indexA);
+          uint8_t cb = (indexB < rs.end) ? reference.at(indexB) : (uint8_t)0;
           if (!bpCanMatch(ca, cb)) {
             numMismatches++;
             foundMismatch = true;
@@ -782,8 +848,8 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qs, c
         int forwardShift2 = maxNonmatchingBlockEnd - blockStartIndex - blockLength;
         for (int i = blockLength; i < forwardShift2; i++) {
           int indexA = blockStartIndex + i;
-          int lookupResult = matcherLookup(*matcher, e, indexA, indexA + minPossibleOffset, indexA + maxPossibleOffset + 1);
-          if (*e.status) { tmp.used = mark; return result; }
+          int lookupResult = matcherLookup(mm, query, reference, indexA, indexA + minPossibleOffset, indexA + maxPossibleOffset + 1, cache, overflow, dc);
+          if (overflow) break;
           int offset2 = lookupResult - indexA;
           if (lookupResult >= 0 && offset2 == offset) {
             numOther++;
@@ -801,9 +867,12 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qs, c
       } else {
         counts.add(offset, 1);
       }
-      if (*e.status) { tmp.used = mark; return result; }
+      if (overflow) break;
     }
   }
+  matcher->nSections = mm.nSections;  // write back the only scalar that changes
+  if (overflow) *e.status = XM_ST_OVERFLOW;
+  if (*e.status) { tmp.used = mark; return result; }
   int mostPopularOffset = counts.mostPopularKey;
   int mostPopularOffset_count = counts.mostPopularCount;
   tmp.used = mark;
@@ -917,10 +986,12 @@ XM_INL bool baTryMerge(const ExtEnv& e, const SeqAl& left, const SeqAl& right, c
   return true;
 }
 
-XM_NOINL bool blockAlign(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) {  // :17-36
+XM_NOINL bool blockAlign(const ExtEnv& e, const Section& qsIn, const Section& rsIn, const Params& pIn, Analysis& an, SeqAl& out) {  // :17-36
+  const Section qs = qsIn, rs = rsIn;
+  const Params p = pIn;
   Arena& tmp = *e.tmp;
   size_t mark = tmp.used;
-  const Caps& caps = *e.caps;
+  const Caps caps = *e.caps;
   double maxInterestingPenalty = p.MaxErrorRate * secLen(qs);
   // initialAlignments :39-96
   double maxInterestingPenaltyWholeQuery = p.MaxErrorRate * e.query.len;  // (sic) uses query.getLength()

@@ -172,22 +172,29 @@ struct Pyramid {
 
   XM_NOINL void ensure(int level) {  // M/HashBlock_Pyramid.java:15-24 + HashBlock_ParentRow.maybeMakeBlock
     XM_TIC(t0);
+    // locals: members reached through `this` would be re-loaded after every block store (possible aliasing)
+    PBlock* const blk = blocks;
+    const int capL = cap;
+    const SeqView sq = seq;
     while (nBuilt < level) {
       if (nBuilt + 2 >= maxLevels) { *status = XM_ST_OVERFLOW; return; }
       int prev = nBuilt;
       int n = count(prev);
       int w = used;
+      const int base = prev == 0 ? 0 : levelStart[prev];
+      bool ovf = false;
       if (n > 1) {
-        PBlock L = blockAt(prev, 0);
+        PBlock L = prev == 0 ? level0Block(sq.at(0), 0) : blk[base];
         for (int i = 0; i + 1 < n; i++) {
-          PBlock R = blockAt(prev, i + 1);
+          PBlock R = prev == 0 ? level0Block(sq.at(i + 1), i + 1) : blk[base + i + 1];
           if (shouldMergeBlocks(L, R)) {
-            if (w >= cap) { *status = XM_ST_OVERFLOW; return; }
-            blocks[w++] = mergeBlocks(L, R);
+            if (w >= capL) { ovf = true; break; }
+            blk[w++] = mergeBlocks(L, R);
           }
           L = R;
         }
       }
+      if (ovf) { *status = XM_ST_OVERFLOW; return; }
       nBuilt++;
       used = w;
       levelStart[nBuilt + 1] = w;
