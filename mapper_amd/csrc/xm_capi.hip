@@ -419,11 +419,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     std::vector<int32_t> status((size_t)nq, -1), intLen((size_t)nq, 0), dblLen((size_t)nq, 0);
     std::vector<int64_t> intOffA((size_t)nq, 0), dblOffA((size_t)nq, 0);
     // per-query result slices gathered across launches
-    std::vector<std::vector<int32_t>> lateInts;
-    std::vector<std::vector<double>> lateDbls;
-    std::vector<int64_t> lateIndex((size_t)nq, -1);
-    std::vector<int32_t> arenaInts;
-    std::vector<double> arenaDbls;
+    std::vector<std::vector<int32_t>> passInts;   // the result arena of every pass is kept; a read points into the pass that finished it
+    std::vector<std::vector<double>> passDbls;
+    std::vector<int32_t> passOf((size_t)nq, -1);
 
     // Passes: (1) light pass over every read at scale 1: reads that reach the gapped extension chain stop with
     // XM_ST_NEED_HEAVY instead of serialising their wave; (2) full pass over exactly those reads; (3..) reads whose scratch
@@ -495,12 +493,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         int32_t code = st[(size_t)q];
         if (code == XM_OK) {
           status[(size_t)q] = 0;
-          if (first) { intOffA[(size_t)q] = io[(size_t)q]; dblOffA[(size_t)q] = dofs[(size_t)q]; intLen[(size_t)q] = il[(size_t)q]; dblLen[(size_t)q] = dl[(size_t)q]; }
-          else {
-            lateIndex[(size_t)q] = (int64_t)lateInts.size();
-            lateInts.emplace_back(hi.begin() + io[(size_t)q], hi.begin() + io[(size_t)q] + il[(size_t)q]);
-            lateDbls.emplace_back(hd.begin() + dofs[(size_t)q], hd.begin() + dofs[(size_t)q] + dl[(size_t)q]);
-          }
+          intOffA[(size_t)q] = io[(size_t)q]; dblOffA[(size_t)q] = dofs[(size_t)q]; intLen[(size_t)q] = il[(size_t)q]; dblLen[(size_t)q] = dl[(size_t)q];
+          passOf[(size_t)q] = (int32_t)passInts.size();
         } else if (code == XM_ST_NEED_HEAVY) nextHeavy.push_back(q);
         else if (code == XM_ST_OVERFLOW) nextScale.push_back(q);
         else if (code == XM_ST_OUT_OVERFLOW) nextOut.push_back(q);
@@ -508,8 +502,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         else if (code == XM_ST_NEED_GROW) throw std::runtime_error("Failed to align query " + std::to_string(q) + ": gapmer longer than the hashed lengths");
         else throw std::runtime_error("Failed to align query " + std::to_string(q) + ": the reference implementation would have thrown here (status " + std::to_string(code) + ")");
       };
-      if (first) { for (int64_t q = 0; q < nq; q++) consider(q); arenaInts.swap(hi); arenaDbls.swap(hd); }
+      if (first) { for (int64_t q = 0; q < nq; q++) consider(q); }
       else for (int64_t q : todo) consider(q);
+      passInts.push_back(std::move(hi));
+      passDbls.push_back(std::move(hd));
       first = false;
       pendingHeavy.insert(pendingHeavy.end(), nextHeavy.begin(), nextHeavy.end());
       pendingScale.insert(pendingScale.end(), nextScale.begin(), nextScale.end());
@@ -542,23 +538,19 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     int64_t ti = 0, td = 0;
     for (int64_t q = 0; q < nq; q++) {
       res->int_off[q] = ti; res->dbl_off[q] = td;
-      if (lateIndex[(size_t)q] >= 0) { ti += (int64_t)lateInts[(size_t)lateIndex[(size_t)q]].size(); td += (int64_t)lateDbls[(size_t)lateIndex[(size_t)q]].size(); }
-      else { ti += intLen[(size_t)q]; td += dblLen[(size_t)q]; }
+      ti += intLen[(size_t)q]; td += dblLen[(size_t)q];
     }
     res->int_off[nq] = ti; res->dbl_off[nq] = td;
     res->num_ints = ti; res->num_dbls = td;
     res->ints = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ti ? ti : 1));
     res->dbls = (double*)malloc(sizeof(double) * (size_t)(td ? td : 1));
     for (int64_t q = 0; q < nq; q++) {
-      if (lateIndex[(size_t)q] >= 0) {
-        const auto& vi = lateInts[(size_t)lateIndex[(size_t)q]];
-        const auto& vd = lateDbls[(size_t)lateIndex[(size_t)q]];
-        if (!vi.empty()) memcpy(res->ints + res->int_off[q], vi.data(), vi.size() * sizeof(int32_t));
-        if (!vd.empty()) memcpy(res->dbls + res->dbl_off[q], vd.data(), vd.size() * sizeof(double));
-      } else {
-        if (intLen[(size_t)q]) memcpy(res->ints + res->int_off[q], arenaInts.data() + intOffA[(size_t)q], (size_t)intLen[(size_t)q] * sizeof(int32_t));
-        if (dblLen[(size_t)q]) memcpy(res->dbls + res->dbl_off[q], arenaDbls.data() + dblOffA[(size_t)q], (size_t)dblLen[(size_t)q] * sizeof(double));
-      }
+      const int32_t* si = passInts[(size_t)passOf[(size_t)q]].data() + intOffA[(size_t)q];
+      const double* sd = passDbls[(size_t)passOf[(size_t)q]].data() + dblOffA[(size_t)q];
+      int32_t* di = res->ints + res->int_off[q];
+      double* dd = res->dbls + res->dbl_off[q];
+      for (int k = 0; k < intLen[(size_t)q]; k++) di[k] = si[k];
+      for (int k = 0; k < dblLen[(size_t)q]; k++) dd[k] = sd[k];
     }
     DevCounters dc;
     HIP_CHECK(hipMemcpy(&dc, idx->dCounters.p, sizeof(dc), hipMemcpyDeviceToHost));

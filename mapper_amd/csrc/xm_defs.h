@@ -194,7 +194,11 @@ struct DevCounters {
 
 #if defined(XM_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define XM_TIC(var) unsigned long long var = clock64()
+#if XM_PROFILE == 2  // wave time: only the lowest active lane of the wave counts (per-lane sum / wave time = mean active lanes)
+#define XM_TOC(dc, slot, var) do { unsigned long long m_ = __ballot(1); if ((dc) && (int)__lane_id() == __ffsll((long long)m_) - 1) (dc)->t[slot] += clock64() - var; } while (0)
+#else
 #define XM_TOC(dc, slot, var) do { if (dc) (dc)->t[slot] += clock64() - var; } while (0)
+#endif
 #else
 #define XM_TIC(var) do { } while (0)
 #define XM_TOC(dc, slot, var) do { } while (0)
