@@ -56,10 +56,23 @@ __device__ __forceinline__ void addCounters(DevCounters* g, const DevCounters& l
   for (int i = 0; i < 16; i++) if (l.t[i]) atomicAdd(&g->t[i], l.t[i]);
 }
 
+static long long envInt(const char* name, long long dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoll(v) : dflt;
+}
+
+#ifndef XM_WAVES_PER_SIMD
+#define XM_WAVES_PER_SIMD 4  // 128 registers per lane: the path is latency-bound, four waves per SIMD hide more of it than the spills cost
+#endif
+
 // One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
-__global__ void __launch_bounds__(256) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed,
+__global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed, int lanesPerWave,
                                                        uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters) {
-  unsigned long long lane = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // lanesPerWave < 64 (gapped pass): the extension chain diverges so much that a wave runs its reads nearly one after another, so
+  // spreading them over more, partly filled waves shortens the critical path; the idle lanes own no scratch arena
+  const int laneInWave = (int)(threadIdx.x & 63u);
+  if (laneInWave >= lanesPerWave) return;
+  unsigned long long lane = ((unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (unsigned)lanesPerWave + (unsigned)laneInWave;
   uint8_t* arena = arenas + lane * arenaBytes;
   DevCounters local;
   memset(&local, 0, sizeof(local));
@@ -440,16 +453,30 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       if (nTodo == 0) break;
       // lanes: enough waves to cover memory latency, bounded by the scratch budget
       size_t arenaBytes = arenaUnit * (size_t)scale;
-      long long maxLanesByMem = (long long)((48ull << 30) / arenaBytes);
-      long long lanes = (long long)idx->numCUs * 256 * (scale == 1 ? 2 : 1);
+      // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped pass
+      // is serialised by divergence inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  Scratch: up to 200 GiB
+      // of the 288 GiB HBM (never more than 3/4 of what is free).  The XM_* variables are experiment knobs.
+      static const long long scratchGiBWanted = envInt("XM_SCRATCH_GIB", 200);
+      static const long long lightWaves = envInt("XM_LIGHT_WAVES", 8), fullWaves = envInt("XM_FULL_WAVES", 4);
+      static const long long fullLpw = envInt("XM_FULL_LPW", 32), lightLpw = envInt("XM_LIGHT_LPW", 64);
+      long long scratchGiB = scratchGiBWanted;
+      {
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+          long long avail = (long long)(((freeB + idx->dArenas.n) / 4 * 3) >> 30);
+          if (scratchGiB > avail) scratchGiB = avail < 1 ? 1 : avail;
+        }
+      }
+      const int lpw = (int)(heavy ? fullLpw : lightLpw);  // active lanes per wave
+      long long maxLanesByMem = (long long)(((unsigned long long)scratchGiB << 30) / arenaBytes);
+      long long lanes = (long long)idx->numCUs * 4 * lpw * (heavy ? fullWaves : lightWaves);
       if (lanes > maxLanesByMem) lanes = maxLanesByMem;
       if (lanes > nTodo) lanes = nTodo;
-      lanes = ((lanes + 63) / 64) * 64;
-      if (lanes < 64) lanes = 64;
-      int block = 256;
-      if (lanes < block) block = (int)lanes;
-      int grid = (int)((lanes + block - 1) / block);
-      lanes = (long long)grid * block;
+      long long nWaves = (lanes + lpw - 1) / lpw;
+      if (nWaves < 1) nWaves = 1;
+      int block = nWaves < 4 ? (int)nWaves * 64 : 256;
+      int grid = (int)((nWaves * 64 + block - 1) / block);
+      lanes = (long long)grid * (block / 64) * lpw;
       idx->dArenas.ensure((size_t)lanes * arenaBytes);
       idx->dOutInts.ensure((size_t)intCap); idx->dOutDbls.ensure((size_t)dblCap);
       if (!first) {
@@ -459,7 +486,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       HIP_CHECK(hipMemsetAsync(idx->dCursors.p, 0, sizeof(unsigned long long) * 4, s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
       HIP_CHECK(hipEventRecord(e0, s));
-      hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, first ? (const int64_t*)nullptr : idx->dTodo.p, nTodo, scale, heavy ? 1 : 0,
+      hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, first ? (const int64_t*)nullptr : idx->dTodo.p, nTodo, scale, heavy ? 1 : 0, lpw,
                          idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
