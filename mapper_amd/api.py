@@ -210,8 +210,7 @@ class ReferenceDatabase:
         res = C.POINTER(_capi.XmResult)()
         if self._L.xm_align_batch(self._h, C.byref(p), C.byref(b), C.byref(res)):
             raise RuntimeError("Failed to align: " + self._L.xm_last_error().decode())
-        d = _capi.copy_result(res.contents)
-        self._L.xm_result_free(res)
+        d = _capi.view_result(self._L, res)
         return BatchResult(d)
 
     def upload_arrays(self, mate_count, mate_offset, mate_length, codes, expected_inner, deviation):
@@ -225,8 +224,7 @@ class ReferenceDatabase:
         res = C.POINTER(_capi.XmResult)()
         if self._L.xm_align_resident(self._h, C.byref(p), C.byref(res)):
             raise RuntimeError("Failed to align: " + self._L.xm_last_error().decode())
-        d = _capi.copy_result(res.contents)
-        self._L.xm_result_free(res)
+        d = _capi.view_result(self._L, res)
         return BatchResult(d)
 
     def align_batch(self, queries, parameters):

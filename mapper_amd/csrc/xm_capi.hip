@@ -114,6 +114,92 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
   addCounters(counters, local);
 }
 
+// ---------------------------------------------------------------- pass bookkeeping on the device
+// After every pass the reads are sorted into the work lists of the passes still to come; only the list sizes travel to the host.
+struct PassCtl {
+  unsigned long long nHeavy, nScale[2], nOut[2];
+  unsigned long long errQuery;  // smallest query index whose status is an error (~0 = none)
+};
+
+__global__ void __launch_bounds__(256) xm_classify_kernel(const int64_t* todo, long long nTodo, const int32_t* status, int64_t* listHeavy, int64_t* listScale, int64_t* listOut,
+                                                          PassCtl* ctl, int ts, int to) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nTodo) return;
+  int64_t q = todo ? todo[i] : (int64_t)i;
+  int32_t st = status[q];
+  if (st == XM_OK) return;
+  if (st == XM_ST_NEED_HEAVY) listHeavy[atomicAdd(&ctl->nHeavy, 1ull)] = q;
+  else if (st == XM_ST_OVERFLOW) listScale[atomicAdd(&ctl->nScale[ts], 1ull)] = q;
+  else if (st == XM_ST_OUT_OVERFLOW) listOut[atomicAdd(&ctl->nOut[to], 1ull)] = q;
+  else atomicMin(&ctl->errQuery, (unsigned long long)q);
+}
+
+// Exclusive prefix sums of the per-query stream lengths (query order), three small kernels: block totals, scan of the totals,
+// final offsets.  4096 queries per block.
+constexpr int XM_SCAN_PER_THREAD = 16;
+constexpr int XM_SCAN_PER_BLOCK = 256 * XM_SCAN_PER_THREAD;
+
+__device__ __forceinline__ void blockReduce2(long long& a, long long& b, long long* shA, long long* shB) {
+  shA[threadIdx.x] = a; shB[threadIdx.x] = b;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) { shA[threadIdx.x] += shA[threadIdx.x + d]; shB[threadIdx.x] += shB[threadIdx.x + d]; }
+    __syncthreads();
+  }
+  a = shA[0]; b = shB[0];
+}
+
+__global__ void __launch_bounds__(256) xm_scan_totals_kernel(long long nq, const int32_t* intLen, const int32_t* dblLen, long long* blockI, long long* blockD) {
+  __shared__ long long shA[256], shB[256];
+  long long base = (long long)blockIdx.x * XM_SCAN_PER_BLOCK + (long long)threadIdx.x * XM_SCAN_PER_THREAD;
+  long long a = 0, b = 0;
+  for (int k = 0; k < XM_SCAN_PER_THREAD; k++) if (base + k < nq) { a += intLen[base + k]; b += dblLen[base + k]; }
+  blockReduce2(a, b, shA, shB);
+  if (threadIdx.x == 0) { blockI[blockIdx.x] = a; blockD[blockIdx.x] = b; }
+}
+
+__global__ void xm_scan_blocks_kernel(long long nBlocks, long long nq, long long* blockI, long long* blockD, int64_t* finalIntOff, int64_t* finalDblOff) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long long a = 0, b = 0;
+  for (long long i = 0; i < nBlocks; i++) { long long x = blockI[i], y = blockD[i]; blockI[i] = a; blockD[i] = b; a += x; b += y; }
+  finalIntOff[nq] = a; finalDblOff[nq] = b;
+}
+
+__global__ void __launch_bounds__(256) xm_scan_final_kernel(long long nq, const int32_t* intLen, const int32_t* dblLen, const long long* blockI, const long long* blockD,
+                                                            int64_t* finalIntOff, int64_t* finalDblOff) {
+  __shared__ long long shA[256], shB[256];
+  long long base = (long long)blockIdx.x * XM_SCAN_PER_BLOCK + (long long)threadIdx.x * XM_SCAN_PER_THREAD;
+  long long a = 0, b = 0;
+  for (int k = 0; k < XM_SCAN_PER_THREAD; k++) if (base + k < nq) { a += intLen[base + k]; b += dblLen[base + k]; }
+  shA[threadIdx.x] = a; shB[threadIdx.x] = b;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {  // inclusive Hillis-Steele scan of the 256 thread totals
+    long long x = 0, y = 0;
+    if ((int)threadIdx.x >= d) { x = shA[threadIdx.x - d]; y = shB[threadIdx.x - d]; }
+    __syncthreads();
+    shA[threadIdx.x] += x; shB[threadIdx.x] += y;
+    __syncthreads();
+  }
+  long long offA = blockI[blockIdx.x] + shA[threadIdx.x] - a, offB = blockD[blockIdx.x] + shB[threadIdx.x] - b;
+  for (int k = 0; k < XM_SCAN_PER_THREAD; k++) if (base + k < nq) {
+    finalIntOff[base + k] = offA; finalDblOff[base + k] = offB;
+    offA += intLen[base + k]; offB += dblLen[base + k];
+  }
+}
+
+// canonical streams: every query's slice copied from where its pass left it to its place in query order
+__global__ void __launch_bounds__(256) xm_gather_kernel(long long nq, const int64_t* srcIntOff, const int64_t* srcDblOff, const int32_t* intLen, const int32_t* dblLen,
+                                                        const int64_t* finalIntOff, const int64_t* finalDblOff, const int32_t* srcInts, const double* srcDbls,
+                                                        int32_t* dstInts, double* dstDbls) {
+  long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const int32_t* si = srcInts + srcIntOff[q]; int32_t* di = dstInts + finalIntOff[q];
+  const double* sd = srcDbls + srcDblOff[q]; double* dd = dstDbls + finalDblOff[q];
+  int ni = intLen[q], nd = dblLen[q];
+  for (int k = 0; k < ni; k++) di[k] = si[k];
+  for (int k = 0; k < nd; k++) dd[k] = sd[k];
+}
+
 // PackedMap.getNumMatchesLowerBound + PackedMap.get for a batch of (used length, key): one lane per probe.
 __global__ void __launch_bounds__(256) xm_seed_probe_kernel(IndexView ix, long long n, const int32_t* usedLength, const int32_t* keys, int maxPerProbe,
                                                             int32_t* counts, int64_t* outPositions) {
@@ -145,7 +231,70 @@ struct DevBuf {
     n = count ? count : 1;
     HIP_CHECK(hipMalloc((void**)&p, n * sizeof(T)));
   }
+  // grow to `count`, keeping the first `keep` elements
+  void growKeep(size_t count, size_t keep, hipStream_t s) {
+    if (count <= n && p) return;
+    T* np = nullptr;
+    HIP_CHECK(hipMalloc((void**)&np, count * sizeof(T)));
+    if (p && keep) HIP_CHECK(hipMemcpyAsync(np, p, (keep < n ? keep : n) * sizeof(T), hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (p) (void)hipFree(p);
+    p = np; n = count;
+  }
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  ~DevBuf() { release(); }
+};
+
+// Result streams live in pinned host memory (the final device-to-host copy is then one DMA per stream); the buffers are recycled
+// through a process-wide pool because pinning is far more expensive than the copy itself.
+struct PinnedPool {
+  struct Buf { void* p; size_t bytes; };
+  std::mutex mu;
+  std::vector<Buf> idle;
+  size_t idleBytes = 0;
+  void* get(size_t bytes, size_t* got) {
+    if (bytes < 64) bytes = 64;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      int best = -1;
+      for (int i = 0; i < (int)idle.size(); i++)
+        if (idle[i].bytes >= bytes && idle[i].bytes <= bytes * 2 + 4096 && (best < 0 || idle[i].bytes < idle[best].bytes)) best = i;
+      if (best >= 0) {
+        Buf b = idle[best];
+        idle.erase(idle.begin() + best);
+        idleBytes -= b.bytes;
+        *got = b.bytes;
+        return b.p;
+      }
+    }
+    void* p = nullptr;
+    size_t want = bytes + bytes / 8;  // headroom so that the next, slightly larger batch reuses it
+    HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocPortable));
+    *got = want;
+    return p;
+  }
+  void put(void* p, size_t bytes) {
+    if (!p) return;
+    std::vector<Buf> drop;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      idle.push_back(Buf{p, bytes});
+      idleBytes += bytes;
+      while (idleBytes > (4ull << 30) && !idle.empty()) {  // oldest first
+        drop.push_back(idle.front());
+        idleBytes -= idle.front().bytes;
+        idle.erase(idle.begin());
+      }
+    }
+    for (auto& b : drop) (void)hipHostFree(b.p);
+  }
+};
+static PinnedPool* g_pinned = new PinnedPool();  // never destroyed: the HIP runtime may be gone before static destructors run
+
+// xm_result plus what xm_result_free needs to know about its buffers
+struct ResultBox {
+  xm_result pub;
+  size_t bytesInts, bytesDbls, bytesIntOff, bytesDblOff;
 };
 
 }  // namespace
@@ -172,6 +321,11 @@ struct xm_index {
   DevBuf<int64_t> dMateOffset, dIntOff, dDblOff, dTodo;
   DevBuf<double> dExpected, dDeviation, dOutDbls;
   DevBuf<unsigned long long> dCursors;  // [0],[1] result cursors, [2] next item
+  DevBuf<int64_t> dListHeavy, dListScale[2], dListOut[2], dFinalIntOff, dFinalDblOff;
+  DevBuf<PassCtl> dCtl;
+  DevBuf<long long> dBlockI, dBlockD;
+  DevBuf<int32_t> dFinalInts;
+  DevBuf<double> dFinalDbls;
   DevBuf<DevCounters> dCounters;
   int numCUs = 0;
   int64_t residentNq = -1;   // batch kept in HBM by xm_batch_upload
@@ -322,8 +476,10 @@ int64_t xm_index_dup_keys(const xm_index* idx, int32_t contig, int32_t* out, int
 
 void xm_result_free(xm_result* r) {
   if (!r) return;
-  free(r->ints); free(r->dbls); free(r->int_off); free(r->dbl_off);
-  free(r);
+  ResultBox* box = (ResultBox*)r;  // pub is the first member
+  g_pinned->put(r->ints, box->bytesInts); g_pinned->put(r->dbls, box->bytesDbls);
+  g_pinned->put(r->int_off, box->bytesIntOff); g_pinned->put(r->dbl_off, box->bytesDblOff);
+  free(box);
 }
 
 // validation + Readable_HashBlock_Database growth + host-to-device copy of one batch; the batch stays resident in HBM
@@ -402,16 +558,18 @@ int xm_align_batch(xm_index* idx, const xm_params* p, const xm_query_batch* b, x
 }
 
 static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** out) {
-  {
+  ResultBox* box = (ResultBox*)calloc(1, sizeof(ResultBox));
+  xm_result* res = &box->pub;
+  try {
     const int64_t nq = idx->residentNq;
     HIP_CHECK(hipSetDevice(idx->device));
     hipStream_t s = idx->stream;
-    xm_result* res = (xm_result*)calloc(1, sizeof(xm_result));
     res->num_queries = nq;
-    res->int_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq + 1));
-    res->dbl_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq + 1));
+    res->int_off = (int64_t*)g_pinned->get(sizeof(int64_t) * (size_t)(nq + 1), &box->bytesIntOff);
+    res->dbl_off = (int64_t*)g_pinned->get(sizeof(int64_t) * (size_t)(nq + 1), &box->bytesDblOff);
     if (nq == 0) {
-      res->ints = (int32_t*)malloc(4); res->dbls = (double*)malloc(8); res->int_off[0] = res->dbl_off[0] = 0;
+      res->ints = (int32_t*)g_pinned->get(4, &box->bytesInts); res->dbls = (double*)g_pinned->get(8, &box->bytesDbls);
+      res->int_off[0] = res->dbl_off[0] = 0;
       *out = res;
       return 0;
     }
@@ -426,32 +584,34 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     params.MaxNumMatches = p->MaxNumMatches; params.StartingInsertionStartFree = 0;
 
     idx->dStatus.ensure((size_t)nq); idx->dIntOff.ensure((size_t)nq); idx->dDblOff.ensure((size_t)nq); idx->dIntLen.ensure((size_t)nq); idx->dDblLen.ensure((size_t)nq);
-    idx->dCursors.ensure(4); idx->dCounters.ensure(1);
+    idx->dCursors.ensure(4); idx->dCounters.ensure(1); idx->dCtl.ensure(1);
+    idx->dListHeavy.ensure((size_t)nq);
     HIP_CHECK(hipMemsetAsync(idx->dCounters.p, 0, sizeof(DevCounters), s));
-
-    std::vector<int32_t> status((size_t)nq, -1), intLen((size_t)nq, 0), dblLen((size_t)nq, 0);
-    std::vector<int64_t> intOffA((size_t)nq, 0), dblOffA((size_t)nq, 0);
-    // per-query result slices gathered across launches
-    std::vector<std::vector<int32_t>> passInts;   // the result arena of every pass is kept; a read points into the pass that finished it
-    std::vector<std::vector<double>> passDbls;
-    std::vector<int32_t> passOf((size_t)nq, -1);
+    HIP_CHECK(hipMemsetAsync(idx->dCursors.p, 0, sizeof(unsigned long long) * 4, s));
+    PassCtl ctl0;
+    memset(&ctl0, 0, sizeof(ctl0));
+    ctl0.errQuery = ~0ull;
+    HIP_CHECK(hipMemcpyAsync(idx->dCtl.p, &ctl0, sizeof(ctl0), hipMemcpyHostToDevice, s));
 
     // Passes: (1) light pass over every read at scale 1: reads that reach the gapped extension chain stop with
     // XM_ST_NEED_HEAVY instead of serialising their wave; (2) full pass over exactly those reads; (3..) reads whose scratch
-    // overflowed are rerun in full mode with 4x, 16x, ... the scratch.  All passes run on the GPU.
-    std::vector<int64_t> todo;  // empty on the first pass = all reads
-    std::vector<int64_t> pendingHeavy, pendingScale;
+    // overflowed are rerun in full mode with 4x, 16x, ... the scratch.  All passes run on the GPU; the work lists of the later
+    // passes are built on the GPU too (xm_classify_kernel), and every pass appends to the same result arenas.
+    const int64_t* todo = nullptr;  // device list of the current pass; null on the first pass = all reads
+    long long nTodo = nq;
+    unsigned long long pendingHeavy = 0, pendingScale = 0;
+    int ts = 0, to = 0;  // which of the two scale / out lists receives new entries
     int scale = 1, overflowScale = 1;
-    bool first = true, heavy = false;
+    bool heavy = false;
     unsigned long long intCap = (unsigned long long)nq * 40 + 4096, dblCap = (unsigned long long)nq * 12 + 4096;
+    idx->dOutInts.ensure((size_t)intCap); idx->dOutDbls.ensure((size_t)dblCap);
+    intCap = idx->dOutInts.n; dblCap = idx->dOutDbls.n;
+    unsigned long long cursors[4] = {0, 0, 0, 0};
     double kernelMs = 0;
     int launches = 0;
     int64_t rerun = 0;
     const size_t arenaUnit = 288 * 1024;
-    while (true) {
-      long long nTodo = first ? (long long)nq : (long long)todo.size();
-      if (nTodo == 0) break;
-      // lanes: enough waves to cover memory latency, bounded by the scratch budget
+    while (nTodo > 0) {
       size_t arenaBytes = arenaUnit * (size_t)scale;
       // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped pass
       // is serialised by divergence inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  Scratch: up to 200 GiB
@@ -478,109 +638,93 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       int grid = (int)((nWaves * 64 + block - 1) / block);
       lanes = (long long)grid * (block / 64) * lpw;
       idx->dArenas.ensure((size_t)lanes * arenaBytes);
-      idx->dOutInts.ensure((size_t)intCap); idx->dOutDbls.ensure((size_t)dblCap);
-      if (!first) {
-        idx->dTodo.ensure(todo.size());
-        HIP_CHECK(hipMemcpyAsync(idx->dTodo.p, todo.data(), sizeof(int64_t) * todo.size(), hipMemcpyHostToDevice, s));
-      }
-      HIP_CHECK(hipMemsetAsync(idx->dCursors.p, 0, sizeof(unsigned long long) * 4, s));
+      idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq);
+      HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
       HIP_CHECK(hipEventRecord(e0, s));
-      hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, first ? (const int64_t*)nullptr : idx->dTodo.p, nTodo, scale, heavy ? 1 : 0, lpw,
+      hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, todo, nTodo, scale, heavy ? 1 : 0, lpw,
                          idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
+      hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,
+                         idx->dListOut[to].p, idx->dCtl.p, ts, to);
+      HIP_CHECK(hipGetLastError());
+      PassCtl ctl;
+      HIP_CHECK(hipMemcpyAsync(&ctl, idx->dCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(cursors, idx->dCursors.p, sizeof(cursors), hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
       HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       kernelMs += ms;
       if (launches < 8) res->counters[12 + (launches < 4 ? launches : 3)] += (int64_t)(ms * 1000.0);  // per-pass kernel microseconds (passes 1,2,3,4+)
       launches++;
-      // ---- D2H
-      HIP_CHECK(hipEventRecord(e0, s));
-      unsigned long long cursors[4];
-      HIP_CHECK(hipMemcpy(cursors, idx->dCursors.p, sizeof(cursors), hipMemcpyDeviceToHost));
-      std::vector<int32_t> st((size_t)nq), il((size_t)nq), dl((size_t)nq);
-      std::vector<int64_t> io((size_t)nq), dofs((size_t)nq);
-      HIP_CHECK(hipMemcpy(st.data(), idx->dStatus.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
-      HIP_CHECK(hipMemcpy(il.data(), idx->dIntLen.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
-      HIP_CHECK(hipMemcpy(dl.data(), idx->dDblLen.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
-      HIP_CHECK(hipMemcpy(io.data(), idx->dIntOff.p, sizeof(int64_t) * (size_t)nq, hipMemcpyDeviceToHost));
-      HIP_CHECK(hipMemcpy(dofs.data(), idx->dDblOff.p, sizeof(int64_t) * (size_t)nq, hipMemcpyDeviceToHost));
-      size_t usedI = (size_t)std::min<unsigned long long>(cursors[0], intCap), usedD = (size_t)std::min<unsigned long long>(cursors[1], dblCap);
-      std::vector<int32_t> hi(usedI ? usedI : 1);
-      std::vector<double> hd(usedD ? usedD : 1);
-      if (usedI) HIP_CHECK(hipMemcpy(hi.data(), idx->dOutInts.p, sizeof(int32_t) * usedI, hipMemcpyDeviceToHost));
-      if (usedD) HIP_CHECK(hipMemcpy(hd.data(), idx->dOutDbls.p, sizeof(double) * usedD, hipMemcpyDeviceToHost));
-      HIP_CHECK(hipEventRecord(e1, s));
-      HIP_CHECK(hipStreamSynchronize(s));
-      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-      res->d2h_ms += ms;
-      std::vector<int64_t> nextScale, nextOut, nextHeavy;
-      auto consider = [&](int64_t q) {
-        int32_t code = st[(size_t)q];
-        if (code == XM_OK) {
-          status[(size_t)q] = 0;
-          intOffA[(size_t)q] = io[(size_t)q]; dblOffA[(size_t)q] = dofs[(size_t)q]; intLen[(size_t)q] = il[(size_t)q]; dblLen[(size_t)q] = dl[(size_t)q];
-          passOf[(size_t)q] = (int32_t)passInts.size();
-        } else if (code == XM_ST_NEED_HEAVY) nextHeavy.push_back(q);
-        else if (code == XM_ST_OVERFLOW) nextScale.push_back(q);
-        else if (code == XM_ST_OUT_OVERFLOW) nextOut.push_back(q);
-        else if (code == XM_ST_AMBIGUOUS) throw std::runtime_error("Failed to align query " + std::to_string(q) + ": it contains a non-ACGT base (MultiHashBlock path is not supported by this build)");
-        else if (code == XM_ST_NEED_GROW) throw std::runtime_error("Failed to align query " + std::to_string(q) + ": gapmer longer than the hashed lengths");
-        else throw std::runtime_error("Failed to align query " + std::to_string(q) + ": the reference implementation would have thrown here (status " + std::to_string(code) + ")");
-      };
-      if (first) { for (int64_t q = 0; q < nq; q++) consider(q); }
-      else for (int64_t q : todo) consider(q);
-      passInts.push_back(std::move(hi));
-      passDbls.push_back(std::move(hd));
-      first = false;
-      pendingHeavy.insert(pendingHeavy.end(), nextHeavy.begin(), nextHeavy.end());
-      pendingScale.insert(pendingScale.end(), nextScale.begin(), nextScale.end());
-      if (!nextOut.empty()) {  // result arena too small: rerun those reads with the same settings and room to spare
-        todo.swap(nextOut);
-        intCap = intCap * 4 + 65536; dblCap = dblCap * 4 + 65536;
-        rerun += (int64_t)todo.size();
+      if (ctl.errQuery != ~0ull) {
+        int32_t code = 0;
+        HIP_CHECK(hipMemcpy(&code, idx->dStatus.p + ctl.errQuery, sizeof(code), hipMemcpyDeviceToHost));
+        std::string q = std::to_string(ctl.errQuery);
+        if (code == XM_ST_AMBIGUOUS) throw std::runtime_error("Failed to align query " + q + ": it contains a non-ACGT base (MultiHashBlock path is not supported by this build)");
+        if (code == XM_ST_NEED_GROW) throw std::runtime_error("Failed to align query " + q + ": gapmer longer than the hashed lengths");
+        throw std::runtime_error("Failed to align query " + q + ": the reference implementation would have thrown here (status " + std::to_string(code) + ")");
+      }
+      pendingHeavy = ctl.nHeavy;
+      pendingScale = ctl.nScale[ts];
+      if (ctl.nOut[to] > 0) {  // result arena too small: rerun those reads with the same settings and room to spare
+        todo = idx->dListOut[to].p; nTodo = (long long)ctl.nOut[to];
+        to ^= 1;
+        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nOut[to], 0, sizeof(unsigned long long), s));
+        unsigned long long keepI = std::min(cursors[0], intCap), keepD = std::min(cursors[1], dblCap);
+        unsigned long long newI = std::max(intCap * 4 + 65536, cursors[0] * 2), newD = std::max(dblCap * 4 + 65536, cursors[1] * 2);
+        idx->dOutInts.growKeep((size_t)newI, (size_t)keepI, s); idx->dOutDbls.growKeep((size_t)newD, (size_t)keepD, s);
+        intCap = idx->dOutInts.n; dblCap = idx->dOutDbls.n;
+        rerun += nTodo;
         continue;
       }
-      if (!pendingHeavy.empty()) {
-        todo.swap(pendingHeavy);
-        pendingHeavy.clear();
+      if (pendingHeavy > 0) {
         // the full pass runs at scale 4 straight away: far fewer lanes are needed than in the light pass, and most reads whose
         // gapped search outgrows the scale-1 scratch then finish here instead of costing one more (latency-bound) pass
+        todo = idx->dListHeavy.p; nTodo = (long long)pendingHeavy;
+        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nHeavy, 0, sizeof(unsigned long long), s));  // (a full pass never adds to this list)
         scale = 4;
         if (overflowScale < 4) overflowScale = 4;
         heavy = true;
         continue;
       }
-      if (pendingScale.empty()) break;
-      todo.swap(pendingScale);
-      pendingScale.clear();
-      rerun += (int64_t)todo.size();
+      if (pendingScale == 0) break;
+      todo = idx->dListScale[ts].p; nTodo = (long long)pendingScale;
+      ts ^= 1;
+      HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nScale[ts], 0, sizeof(unsigned long long), s));
+      rerun += nTodo;
       overflowScale *= 4;
       scale = overflowScale;
       heavy = true;
       if (scale > 4096) throw std::runtime_error("Failed to align: scratch scale limit reached (query needs more than 4096x the default scratch)");
     }
-    // ---- canonical streams in query order
-    int64_t ti = 0, td = 0;
-    for (int64_t q = 0; q < nq; q++) {
-      res->int_off[q] = ti; res->dbl_off[q] = td;
-      ti += intLen[(size_t)q]; td += dblLen[(size_t)q];
-    }
-    res->int_off[nq] = ti; res->dbl_off[nq] = td;
-    res->num_ints = ti; res->num_dbls = td;
-    res->ints = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ti ? ti : 1));
-    res->dbls = (double*)malloc(sizeof(double) * (size_t)(td ? td : 1));
-    for (int64_t q = 0; q < nq; q++) {
-      const int32_t* si = passInts[(size_t)passOf[(size_t)q]].data() + intOffA[(size_t)q];
-      const double* sd = passDbls[(size_t)passOf[(size_t)q]].data() + dblOffA[(size_t)q];
-      int32_t* di = res->ints + res->int_off[q];
-      double* dd = res->dbls + res->dbl_off[q];
-      for (int k = 0; k < intLen[(size_t)q]; k++) di[k] = si[k];
-      for (int k = 0; k < dblLen[(size_t)q]; k++) dd[k] = sd[k];
-    }
+    // ---- canonical streams in query order: offsets by prefix sum, slices gathered on the device, one copy per stream to the host
+    HIP_CHECK(hipEventRecord(e0, s));
+    const long long nBlocks = (nq + XM_SCAN_PER_BLOCK - 1) / XM_SCAN_PER_BLOCK;
+    idx->dBlockI.ensure((size_t)nBlocks); idx->dBlockD.ensure((size_t)nBlocks);
+    idx->dFinalIntOff.ensure((size_t)nq + 1); idx->dFinalDblOff.ensure((size_t)nq + 1);
+    const size_t usedI = (size_t)std::min(cursors[0], intCap), usedD = (size_t)std::min(cursors[1], dblCap);  // upper bounds of the totals
+    idx->dFinalInts.ensure(usedI); idx->dFinalDbls.ensure(usedD);
+    hipLaunchKernelGGL(xm_scan_totals_kernel, dim3((unsigned)nBlocks), dim3(256), 0, s, (long long)nq, idx->dIntLen.p, idx->dDblLen.p, idx->dBlockI.p, idx->dBlockD.p);
+    hipLaunchKernelGGL(xm_scan_blocks_kernel, dim3(1), dim3(64), 0, s, nBlocks, (long long)nq, idx->dBlockI.p, idx->dBlockD.p, idx->dFinalIntOff.p, idx->dFinalDblOff.p);
+    hipLaunchKernelGGL(xm_scan_final_kernel, dim3((unsigned)nBlocks), dim3(256), 0, s, (long long)nq, idx->dIntLen.p, idx->dDblLen.p, idx->dBlockI.p, idx->dBlockD.p,
+                       idx->dFinalIntOff.p, idx->dFinalDblOff.p);
+    hipLaunchKernelGGL(xm_gather_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, (long long)nq, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p,
+                       idx->dFinalIntOff.p, idx->dFinalDblOff.p, idx->dOutInts.p, idx->dOutDbls.p, idx->dFinalInts.p, idx->dFinalDbls.p);
+    HIP_CHECK(hipGetLastError());
+    res->ints = (int32_t*)g_pinned->get(sizeof(int32_t) * (usedI ? usedI : 1), &box->bytesInts);
+    res->dbls = (double*)g_pinned->get(sizeof(double) * (usedD ? usedD : 1), &box->bytesDbls);
+    HIP_CHECK(hipMemcpyAsync(res->int_off, idx->dFinalIntOff.p, sizeof(int64_t) * (size_t)(nq + 1), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(res->dbl_off, idx->dFinalDblOff.p, sizeof(int64_t) * (size_t)(nq + 1), hipMemcpyDeviceToHost, s));
+    if (usedI) HIP_CHECK(hipMemcpyAsync(res->ints, idx->dFinalInts.p, sizeof(int32_t) * usedI, hipMemcpyDeviceToHost, s));
+    if (usedD) HIP_CHECK(hipMemcpyAsync(res->dbls, idx->dFinalDbls.p, sizeof(double) * usedD, hipMemcpyDeviceToHost, s));
     DevCounters dc;
-    HIP_CHECK(hipMemcpy(&dc, idx->dCounters.p, sizeof(dc), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpyAsync(&dc, idx->dCounters.p, sizeof(dc), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipEventRecord(e1, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    res->d2h_ms = ms;
+    res->num_ints = res->int_off[nq]; res->num_dbls = res->dbl_off[nq];
     res->counters[0] = (int64_t)dc.reads; res->counters[1] = (int64_t)dc.headerProbes; res->counters[2] = (int64_t)dc.bucketFetches; res->counters[3] = (int64_t)dc.hitsFetched;
     res->counters[4] = (int64_t)dc.candidatesExtended; res->counters[5] = (int64_t)dc.pathAlignerCalls; res->counters[6] = (int64_t)dc.pathAlignerNodes;
     res->counters[7] = (int64_t)dc.quickAccepts; res->counters[8] = (int64_t)dc.alignmentsOut; res->counters[9] = (int64_t)dc.refWindowBytes; res->counters[10] = (int64_t)dc.readBytes;
@@ -590,6 +734,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     res->kernel_launches = launches;
     *out = res;
     return 0;
+  } catch (...) {
+    xm_result_free(res);
+    throw;
   }
 }
 
