@@ -258,11 +258,41 @@ struct PNode {  // AlignmentNode, 32 bytes = two 16-byte loads
   uint8_t pad[3];
 };
 
-struct PathAligner {
+// Two storage modes share one implementation (template parameter LDS):
+//  - LDS == false: every search structure lives in the lane's scratch arena in HBM (any size up to the scale's capacities);
+//  - LDS == true: the lookup structures (cell hash, bucket table, bucket heap, node lists, both texts) live in the wave's slot of the
+//    CU's local data share and only the 32-byte node payloads stay in HBM.  The gapped search is a chain of dependent lookups that
+//    only one or two lanes of a wave execute at a time, so its cost is the latency of each lookup: ~100 cycles in LDS, >1000 in HBM.
+//    The slot is sized for the piece-wise searches BlockAligner issues (<= 960 nodes, <= 112 distinct priorities, texts <= 64 x 128);
+//    a search that outgrows it is redone in HBM mode.  One slot per wave: pathAlignAny runs the lanes of a wave through it in turn.
+constexpr int XM_PAL_HASH = 2048, XM_PAL_NODES = 960, XM_PAL_BUCKETS = 112, XM_PAL_BHASH = 256, XM_PAL_TEXTA = 64, XM_PAL_TEXTB = 128;
+constexpr int XM_PAL_OFF_HASH = 0;                                      // uint16[2048]: node index + 1
+constexpr int XM_PAL_OFF_XY = XM_PAL_OFF_HASH + XM_PAL_HASH * 2;        // uint16[960]: x << 8 | y of node i (= list entry i)
+constexpr int XM_PAL_OFF_NEXT = XM_PAL_OFF_XY + XM_PAL_NODES * 2;       // uint16[960]: next list entry, 0xFFFF = none
+constexpr int XM_PAL_OFF_BKEY = XM_PAL_OFF_NEXT + XM_PAL_NODES * 2;     // double[112]
+constexpr int XM_PAL_OFF_BHEAD = XM_PAL_OFF_BKEY + XM_PAL_BUCKETS * 8;  // uint16[112]
+constexpr int XM_PAL_OFF_BTAIL = XM_PAL_OFF_BHEAD + XM_PAL_BUCKETS * 2; // uint16[112]
+constexpr int XM_PAL_OFF_BHASH = XM_PAL_OFF_BTAIL + XM_PAL_BUCKETS * 2; // uint8[256]: bucket + 1
+constexpr int XM_PAL_OFF_HEAP = XM_PAL_OFF_BHASH + XM_PAL_BHASH;        // uint8[112]
+constexpr int XM_PAL_OFF_TEXTA = XM_PAL_OFF_HEAP + XM_PAL_BUCKETS;      // uint8[64]
+constexpr int XM_PAL_OFF_TEXTB = XM_PAL_OFF_TEXTA + XM_PAL_TEXTA;       // uint8[128]
+constexpr int XM_PAL_SLOT_BYTES = (XM_PAL_OFF_TEXTB + XM_PAL_TEXTB + 63) / 64 * 64;
+static_assert(XM_PAL_OFF_BKEY % 8 == 0, "bucket keys must be 8-byte aligned");
+static_assert(XM_PAL_SLOT_BYTES * 4 <= 40 * 1024, "four waves per workgroup, four workgroups per CU, 160 KB of LDS");
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__shared__ __attribute__((aligned(16))) uint8_t xm_pal_lds[4 * XM_PAL_SLOT_BYTES];
+XM_INL uint8_t* palSlot() { return xm_pal_lds + (threadIdx.x >> 6) * XM_PAL_SLOT_BYTES; }
+#else
+XM_INL uint8_t* palSlot() { static thread_local double slot[XM_PAL_SLOT_BYTES / 8]; return (uint8_t*)slot; }  // host simulation (tests only)
+#endif
+
+template <bool LDS>
+struct PathAlignerT {
   static constexpr double disallowed = 1000000.0;
-  // locatedNodes: (x,y) -> latest node.  Dense grid of node indices when (textA+2)*(textB+2) fits (the four neighbour lookups of
-  // an update are then four INDEPENDENT loads, issued together), open-addressing hash otherwise.
-  PNode* nodes; int32_t nNodes, maxNodes;
+  PNode* nodes; int32_t nNodes, maxNodes;  // node i is also list entry i (putNode appends exactly one of each)
+  // locatedNodes: (x,y) -> latest node.  HBM mode: dense grid of node indices when (textA+2)*(textB+2) fits (the four neighbour
+  // lookups of an update are then four INDEPENDENT loads, issued together), open-addressing hash otherwise.  LDS mode: hash.
   int32_t* grid; int32_t gridH, gridW; bool useGrid;
   int32_t* hash; int32_t hashMask;  // (x,y) -> latest node index + 1
   // prioritizedNodes: bucket per exact double key; list entries in insertion order.
@@ -270,10 +300,13 @@ struct PathAligner {
   // key bits through an open-addressing hash, priorities.poll() through a binary min-heap of bucket ids
   double* bkey; int32_t* bhead; int32_t* btail; int32_t nBuckets, maxBuckets;
   int32_t* bhash; int32_t bhashMask; int32_t* heap; int32_t heapSize;
-  int16_t* lx; int16_t* ly; int32_t* lnext; int32_t nList;
+  int16_t* lx; int16_t* ly; int32_t* lnext;
+  // LDS mode
+  uint16_t* Lhash; uint16_t* Lxy; uint16_t* Lnext; double* Lbkey; uint16_t* Lbhead; uint16_t* Lbtail; uint8_t* Lbhash; uint8_t* Lheap;
+  uint8_t* LtextA; uint8_t* LtextB;
+  bool ldsOverflow;
   // problem
   Params parameters;
-  const ExtEnv* e;
   // register-resident copies (the struct is only used inside pathAlign with every method force-inlined, so it never
   // has to live in scratch memory)
   const uint8_t* qBase; int32_t qLen; bool qRc; const uint8_t* rBase;
@@ -284,9 +317,25 @@ struct PathAligner {
   double maxInterestingPenalty, activePenalty;
   bool mayQueryExtendPastEndOfReference, searchReverse;
 
-  XM_INL uint8_t charA(int i) const { int k = startIndexA + i; return qRc ? bpComplement(qBase[qLen - 1 - k]) : qBase[k]; }
-  XM_INL uint8_t charB(int i) const { return rBase[startIndexB + i]; }
+  XM_INL uint8_t charAGlobal(int i) const { int k = startIndexA + i; return qRc ? bpComplement(qBase[qLen - 1 - k]) : qBase[k]; }
+  XM_INL uint8_t charBGlobal(int i) const { return rBase[startIndexB + i]; }
+  XM_INL uint8_t charA(int i) const { if constexpr (LDS) return LtextA[i]; else return charAGlobal(i); }
+  XM_INL uint8_t charB(int i) const { if constexpr (LDS) return LtextB[i]; else return charBGlobal(i); }
   XM_INL int signedDist(int x, int y) const { return x - y - diagonal; }
+
+  // ---- storage accessors
+  XM_INL double bucketKey(int b) const { if constexpr (LDS) return Lbkey[b]; else return bkey[b]; }
+  XM_INL int bucketHead(int b) const { if constexpr (LDS) { uint16_t v = Lbhead[b]; return v == 0xFFFF ? -1 : (int)v; } else return bhead[b]; }
+  XM_INL int bucketTail(int b) const { if constexpr (LDS) { uint16_t v = Lbtail[b]; return v == 0xFFFF ? -1 : (int)v; } else return btail[b]; }
+  XM_INL void setBucketHead(int b, int v) { if constexpr (LDS) Lbhead[b] = (uint16_t)v; else bhead[b] = v; }
+  XM_INL void setBucketTail(int b, int v) { if constexpr (LDS) Lbtail[b] = (uint16_t)v; else btail[b] = v; }
+  XM_INL int heapAt(int i) const { if constexpr (LDS) return Lheap[i]; else return heap[i]; }
+  XM_INL void setHeap(int i, int b) { if constexpr (LDS) Lheap[i] = (uint8_t)b; else heap[i] = b; }
+  XM_INL int listNext(int li) const { if constexpr (LDS) { uint16_t v = Lnext[li]; return v == 0xFFFF ? -1 : (int)v; } else return lnext[li]; }
+  XM_INL void setListNext(int li, int v) { if constexpr (LDS) Lnext[li] = (uint16_t)v; else lnext[li] = v; }
+  XM_INL int listX(int li) const { if constexpr (LDS) return Lxy[li] >> 8; else return lx[li]; }
+  XM_INL int listY(int li) const { if constexpr (LDS) return Lxy[li] & 0xFF; else return ly[li]; }
+  XM_INL void setListXY(int li, int x, int y) { if constexpr (LDS) Lxy[li] = (uint16_t)((x << 8) | y); else { lx[li] = (int16_t)x; ly[li] = (int16_t)y; } }
 
   XM_INL int findNodeHash(int x, int y) const {
     uint32_t key = ((uint32_t)x << 16) | (uint32_t)(y & 0xFFFF);
@@ -299,28 +348,52 @@ struct PathAligner {
       h = (h + 1) & (uint32_t)hashMask;
     }
   }
+  XM_INL static uint32_t ldsCellHash(uint32_t key) { return (key * 2654435761u) >> 21; }  // top 11 bits: XM_PAL_HASH == 2048
   XM_INL int findNode(int x, int y) const {  // getNode :541-553
     if (x < 0 || y < 0) return -1;
-    if (useGrid) {
+    if constexpr (LDS) {
       if (x >= gridW || y >= gridH) return -1;
-      return grid[x * gridH + y] - 1;
+      const uint32_t key = ((uint32_t)x << 8) | (uint32_t)y;
+      uint32_t h = ldsCellHash(key);
+      while (true) {
+        uint32_t v = Lhash[h];
+        if (v == 0) return -1;
+        if (Lxy[v - 1] == key) return (int)v - 1;
+        h = (h + 1) & (XM_PAL_HASH - 1);
+      }
+    } else {
+      if (useGrid) {
+        if (x >= gridW || y >= gridH) return -1;
+        return grid[x * gridH + y] - 1;
+      }
+      return findNodeHash(x, y);
     }
-    return findNodeHash(x, y);
   }
-  XM_INL void saveNode(int idx, int x, int y) {  // :523-539 (overwrites the node at (x,y))
+  XM_INL void saveNode(int idx, int x, int y) {  // :523-539 (overwrites the node at (x,y)); node idx's list entry is already written
     if (x < 0 || y < 0) return;
-    if (useGrid) {
-      if (x < gridW && y < gridH) grid[x * gridH + y] = idx + 1;
-      return;
-    }
-    uint32_t key = ((uint32_t)x << 16) | (uint32_t)(y & 0xFFFF);
-    uint32_t h = (key * 2654435761u) & (uint32_t)hashMask;
-    while (true) {
-      int32_t v = hash[h];
-      if (v == 0) { hash[h] = idx + 1; return; }
-      int o = v - 1;
-      if (nodes[o].x == x && nodes[o].y == y) { hash[h] = idx + 1; return; }
-      h = (h + 1) & (uint32_t)hashMask;
+    if constexpr (LDS) {
+      if (x >= gridW || y >= gridH) return;
+      const uint32_t key = ((uint32_t)x << 8) | (uint32_t)y;
+      uint32_t h = ldsCellHash(key);
+      while (true) {
+        uint32_t v = Lhash[h];
+        if (v == 0 || Lxy[v - 1] == key) { Lhash[h] = (uint16_t)(idx + 1); return; }
+        h = (h + 1) & (XM_PAL_HASH - 1);
+      }
+    } else {
+      if (useGrid) {
+        if (x < gridW && y < gridH) grid[x * gridH + y] = idx + 1;
+        return;
+      }
+      uint32_t key = ((uint32_t)x << 16) | (uint32_t)(y & 0xFFFF);
+      uint32_t h = (key * 2654435761u) & (uint32_t)hashMask;
+      while (true) {
+        int32_t v = hash[h];
+        if (v == 0) { hash[h] = idx + 1; return; }
+        int o = v - 1;
+        if (nodes[o].x == x && nodes[o].y == y) { hash[h] = idx + 1; return; }
+        h = (h + 1) & (uint32_t)hashMask;
+      }
     }
   }
   XM_INL double estimateOverallPenalty(int x, int y, double pen, double insX, double insY, uint8_t fl) const {  // :475-521
@@ -353,36 +426,52 @@ struct PathAligner {
   XM_INL void putNode(int x, int y, double pen, double insX, double insY, uint8_t fl) {  // :446-473
     double est = estimateOverallPenalty(x, y, pen, insX, insY, fl);
     if (est < activePenalty) est = activePenalty;
-    if (nNodes >= maxNodes) { overflow = true; return; }
+    if (nNodes >= maxNodes) { if constexpr (LDS) ldsOverflow = true; overflow = true; return; }
+    if constexpr (LDS) {
+      if ((x | y) < 0 || x > 255 || y > 255) { ldsOverflow = true; overflow = true; return; }  // does not pack into a list entry
+    }
     int b = -1;
     uint64_t kb;
     __builtin_memcpy(&kb, &est, 8);
-    uint32_t h = (uint32_t)((kb ^ (kb >> 29)) * 0x9E3779B97F4A7C15ull >> 40) & (uint32_t)bhashMask;
-    while (true) {
-      int32_t v = bhash[h];
-      if (v == 0) break;
-      if (bkey[v - 1] == est) { b = v - 1; break; }
-      h = (h + 1) & (uint32_t)bhashMask;
+    const uint32_t mixed = (uint32_t)((kb ^ (kb >> 29)) * 0x9E3779B97F4A7C15ull >> 40);
+    uint32_t h;
+    if constexpr (LDS) {
+      h = mixed & (XM_PAL_BHASH - 1);
+      while (true) {
+        uint32_t v = Lbhash[h];
+        if (v == 0) break;
+        if (Lbkey[v - 1] == est) { b = (int)v - 1; break; }
+        h = (h + 1) & (XM_PAL_BHASH - 1);
+      }
+    } else {
+      h = mixed & (uint32_t)bhashMask;
+      while (true) {
+        int32_t v = bhash[h];
+        if (v == 0) break;
+        if (bkey[v - 1] == est) { b = v - 1; break; }
+        h = (h + 1) & (uint32_t)bhashMask;
+      }
     }
     if (b < 0) {
-      if (nBuckets >= maxBuckets) { overflow = true; return; }
+      if (nBuckets >= maxBuckets) { if constexpr (LDS) ldsOverflow = true; overflow = true; return; }
       b = nBuckets++;
-      bkey[b] = est; bhead[b] = -1; btail[b] = -1;
-      bhash[h] = b + 1;
+      if constexpr (LDS) { Lbkey[b] = est; Lbhead[b] = 0xFFFF; Lbtail[b] = 0xFFFF; Lbhash[h] = (uint8_t)(b + 1); }
+      else { bkey[b] = est; bhead[b] = -1; btail[b] = -1; bhash[h] = b + 1; }
       int i = heapSize++;  // sift up
       while (i > 0) {
         int parent = (i - 1) >> 1;
-        if (bkey[heap[parent]] <= est) break;
-        heap[i] = heap[parent];
+        int pb = heapAt(parent);
+        if (bucketKey(pb) <= est) break;
+        setHeap(i, pb);
         i = parent;
       }
-      heap[i] = b;
+      setHeap(i, b);
     }
-    int li = nList++;
-    lx[li] = (int16_t)x; ly[li] = (int16_t)y; lnext[li] = -1;
-    if (btail[b] >= 0) lnext[btail[b]] = li; else bhead[b] = li;
-    btail[b] = li;
-    int idx = nNodes++;
+    const int idx = nNodes++;  // = list entry
+    setListXY(idx, x, y); setListNext(idx, -1);
+    const int tail = bucketTail(b);
+    if (tail >= 0) setListNext(tail, idx); else setBucketHead(b, idx);
+    setBucketTail(b, idx);
     PNode n;
     n.pen = pen; n.insX = insX; n.insY = insY; n.x = (int16_t)x; n.y = (int16_t)y; n.fl = fl; n.pad[0] = n.pad[1] = n.pad[2] = 0;
     nodes[idx] = n;
@@ -478,8 +567,9 @@ XM_INL bool paCanRemoveSection(const ABlock& b) {  // :358-366
   return false;
 }
 
-// PathAligner.align :55-293.  false = null
-XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qsIn, const Section& rsIn, const Params& paramsIn, Analysis& analysis, SeqAl& out) {
+// PathAligner.align :55-293.  false = null.  LDS mode: *ldsOverflow = true means "does not fit the slot, nothing decided".
+template <bool LDS>
+XM_INL bool pathAlignT(const ExtEnv& e, const Section& qsIn, const Section& rsIn, const Params& paramsIn, Analysis& analysis, SeqAl& out, bool* ldsOverflow) {
   XM_TIC(tPath);
   // by-value copies: anything read through a reference inside a loop that also stores would be re-loaded (and waited for) on
   // every iteration, because the compiler cannot prove the store does not alias it
@@ -489,40 +579,60 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qsIn, const Section& rsI
   size_t mark = tmp.used;
   const Caps caps = *e.caps;
   ABlock* const outBlocks = out.blocks;
-  PathAligner pa;
-  pa.e = &e;
+  PathAlignerT<LDS> pa;
   pa.parameters = params;
   pa.qBase = e.query.base; pa.qLen = e.query.len; pa.qRc = e.query.rc != 0; pa.rBase = e.reference.base;
   pa.confident = analysis.confidentAboutBestOffset; pa.maxInsExt = analysis.maxInsertionExtensionPenalty; pa.maxDelExt = analysis.maxDeletionExtensionPenalty;
-  pa.predictedBestOffset = analysis.predictedBestOffset; pa.overflow = false; pa.nodesPut = 0;
+  pa.predictedBestOffset = analysis.predictedBestOffset; pa.overflow = false; pa.nodesPut = 0; pa.ldsOverflow = false;
   const int referenceLen = e.reference.len;
-  pa.maxNodes = caps.maxNodes;
-  pa.nodes = arenaArray<PNode>(tmp, caps.maxNodes);
   pa.gridW = secLen(qs) + 2; pa.gridH = secLen(rs) + 2;
-  pa.useGrid = (long long)pa.gridW * pa.gridH <= (long long)caps.gridCap;
-  pa.grid = nullptr; pa.hash = nullptr; pa.hashMask = 0;
-  if (pa.useGrid) pa.grid = arenaArray<int32_t>(tmp, (size_t)pa.gridW * pa.gridH);
-  else { pa.hash = arenaArray<int32_t>(tmp, caps.nodeHash); pa.hashMask = caps.nodeHash - 1; }
-  pa.maxBuckets = caps.maxBuckets;
-  pa.bkey = arenaArray<double>(tmp, caps.maxBuckets); pa.bhead = arenaArray<int32_t>(tmp, caps.maxBuckets); pa.btail = arenaArray<int32_t>(tmp, caps.maxBuckets);
-  pa.bhash = arenaArray<int32_t>(tmp, caps.bucketHash); pa.bhashMask = caps.bucketHash - 1;
-  pa.heap = arenaArray<int32_t>(tmp, caps.maxBuckets); pa.heapSize = 0;
-  pa.lx = arenaArray<int16_t>(tmp, caps.maxNodes); pa.ly = arenaArray<int16_t>(tmp, caps.maxNodes); pa.lnext = arenaArray<int32_t>(tmp, caps.maxNodes);
-  if (tmp.overflow) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
-  {
+  pa.grid = nullptr; pa.hash = nullptr; pa.hashMask = 0; pa.useGrid = false;
+  pa.bkey = nullptr; pa.bhead = nullptr; pa.btail = nullptr; pa.bhash = nullptr; pa.bhashMask = 0; pa.heap = nullptr; pa.lx = nullptr; pa.ly = nullptr; pa.lnext = nullptr;
+  pa.Lhash = nullptr; pa.Lxy = nullptr; pa.Lnext = nullptr; pa.Lbkey = nullptr; pa.Lbhead = nullptr; pa.Lbtail = nullptr; pa.Lbhash = nullptr; pa.Lheap = nullptr;
+  pa.LtextA = nullptr; pa.LtextB = nullptr;
+  pa.startIndexA = qs.start; pa.endIndexA = qs.end; pa.startIndexB = rs.start; pa.endIndexB = rs.end;
+  pa.textALength = secLen(qs); pa.textBLength = secLen(rs);
+  if constexpr (LDS) {
+    if (pa.textALength > XM_PAL_TEXTA || pa.textBLength > XM_PAL_TEXTB || pa.textALength < 0 || pa.textBLength < 0) { *ldsOverflow = true; return false; }
+    pa.maxNodes = imin(caps.maxNodes, XM_PAL_NODES);
+    pa.maxBuckets = imin(caps.maxBuckets, XM_PAL_BUCKETS);
+    pa.nodes = arenaArray<PNode>(tmp, pa.maxNodes);
+    if (tmp.overflow) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+    uint8_t* const slot = palSlot();
+    pa.Lhash = (uint16_t*)(slot + XM_PAL_OFF_HASH); pa.Lxy = (uint16_t*)(slot + XM_PAL_OFF_XY); pa.Lnext = (uint16_t*)(slot + XM_PAL_OFF_NEXT);
+    pa.Lbkey = (double*)(slot + XM_PAL_OFF_BKEY); pa.Lbhead = (uint16_t*)(slot + XM_PAL_OFF_BHEAD); pa.Lbtail = (uint16_t*)(slot + XM_PAL_OFF_BTAIL);
+    pa.Lbhash = slot + XM_PAL_OFF_BHASH; pa.Lheap = slot + XM_PAL_OFF_HEAP; pa.LtextA = slot + XM_PAL_OFF_TEXTA; pa.LtextB = slot + XM_PAL_OFF_TEXTB;
+    {
+      uint64_t* const z1 = (uint64_t*)pa.Lhash;
+      for (int i = 0; i < XM_PAL_HASH * 2 / 8; i++) z1[i] = 0;
+      uint64_t* const z2 = (uint64_t*)pa.Lbhash;
+      for (int i = 0; i < XM_PAL_BHASH / 8; i++) z2[i] = 0;
+      for (int i = 0; i < pa.textALength; i++) pa.LtextA[i] = pa.charAGlobal(i);
+      for (int i = 0; i < pa.textBLength; i++) pa.LtextB[i] = pa.charBGlobal(i);
+    }
+  } else {
+    pa.maxNodes = caps.maxNodes;
+    pa.nodes = arenaArray<PNode>(tmp, caps.maxNodes);
+    pa.useGrid = (long long)pa.gridW * pa.gridH <= (long long)caps.gridCap;
+    if (pa.useGrid) pa.grid = arenaArray<int32_t>(tmp, (size_t)pa.gridW * pa.gridH);
+    else { pa.hash = arenaArray<int32_t>(tmp, caps.nodeHash); pa.hashMask = caps.nodeHash - 1; }
+    pa.maxBuckets = caps.maxBuckets;
+    pa.bkey = arenaArray<double>(tmp, caps.maxBuckets); pa.bhead = arenaArray<int32_t>(tmp, caps.maxBuckets); pa.btail = arenaArray<int32_t>(tmp, caps.maxBuckets);
+    pa.bhash = arenaArray<int32_t>(tmp, caps.bucketHash); pa.bhashMask = caps.bucketHash - 1;
+    pa.heap = arenaArray<int32_t>(tmp, caps.maxBuckets);
+    pa.lx = arenaArray<int16_t>(tmp, caps.maxNodes); pa.ly = arenaArray<int16_t>(tmp, caps.maxNodes); pa.lnext = arenaArray<int32_t>(tmp, caps.maxNodes);
+    if (tmp.overflow) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
     int32_t* const h1 = pa.useGrid ? pa.grid : pa.hash; const int n1 = pa.useGrid ? pa.gridW * pa.gridH : caps.nodeHash;
     for (int i = 0; i < n1; i++) h1[i] = 0;
     int32_t* const h2 = pa.bhash; const int n2 = caps.bucketHash;
     for (int i = 0; i < n2; i++) h2[i] = 0;
   }
   XM_TOC(e.dc, T_PATH_INIT, tPath);
-  pa.nNodes = 0; pa.nBuckets = 0; pa.nList = 0;
+  pa.heapSize = 0;
+  pa.nNodes = 0; pa.nBuckets = 0;
   pa.activePenalty = 0;
-  if (e.dc) e.dc->pathAlignerCalls++;
 
   pa.maxInterestingPenalty = secLen(qs) * params.MaxErrorRate;
-  pa.startIndexA = qs.start; pa.endIndexA = qs.end; pa.startIndexB = rs.start; pa.endIndexB = rs.end;
-  pa.textALength = secLen(qs); pa.textBLength = secLen(rs);
   if (pa.textALength + 2 > 32000 || pa.textBLength + 2 > 32000) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
   pa.diagonal = pa.startIndexB - (pa.startIndexA + analysis.predictedBestOffset);
   pa.stepDelta = 1;
@@ -532,7 +642,7 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qsIn, const Section& rsI
   int width = pa.textALength + 2, height = pa.endIndexB - pa.startIndexB + 2;
   if (pa.searchReverse) { pa.startX = width - 1; pa.startY = height - 1; pa.goalX = 1; pa.goalY = 1; }
   else { pa.startX = 0; pa.startY = 0; pa.goalX = width - 2; pa.goalY = height - 2; }
-  const double disallowed = PathAligner::disallowed;
+  const double disallowed = PathAlignerT<LDS>::disallowed;
   if (pa.textBLength >= pa.textALength) {
     double startingInsertionStartPenalty = params.getStartingInsertionStartPenalty();
     if (!pa.mayQueryExtendPastEndOfReference) startingInsertionStartPenalty = disallowed;
@@ -550,21 +660,27 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qsIn, const Section& rsI
   int lastX = 0, lastY = 0;
   // every exit below goes through `leave` so that the locally accumulated counters and the overflow flag are published once
   auto leave = [&](bool r) -> bool {
-    if (pa.overflow) *e.status = XM_ST_OVERFLOW;
-    if (e.dc) e.dc->pathAlignerNodes += pa.nodesPut;
-    pa.nodesPut = 0;
     tmp.used = mark;
+    if constexpr (LDS) {
+      if (pa.ldsOverflow) { *ldsOverflow = true; return false; }  // nothing decided, nothing counted: the HBM-mode search redoes it
+    }
+    if (pa.overflow) *e.status = XM_ST_OVERFLOW;
+#ifdef XM_PA_STATS
+    fprintf(stderr, "PASTAT nodes %d buckets %d gridW %d gridH %d scale %d lds %d\n", pa.nNodes, pa.nBuckets, pa.gridW, pa.gridH, caps.scale, LDS ? 1 : 0);
+#endif
+    if (e.dc) { e.dc->pathAlignerCalls++; e.dc->pathAlignerNodes += pa.nodesPut; }
+    pa.nodesPut = 0;
     return r && !pa.overflow;
   };
   while (!haveLast) {
     if (pa.overflow) return leave(false);
     // priorities.poll(): smallest live key
     if (pa.heapSize < 1) { *e.status = XM_ST_INTERNAL; return leave(false); }  // Java: NullPointerException
-    int b = pa.heap[0];
-    pa.activePenalty = pa.bkey[b];
-    int li = pa.bhead[b];
+    int b = pa.heapAt(0);
+    pa.activePenalty = pa.bucketKey(b);
+    int li = pa.bucketHead(b);
     while (li >= 0) {
-      int x = pa.lx[li], y = pa.ly[li];
+      int x = pa.listX(li), y = pa.listY(li);
       if (pa.activePenalty > pa.maxInterestingPenalty + 0.000001) return leave(false);
       if (x == pa.goalX) { haveLast = true; lastX = x; lastY = y; break; }
       for (int mv = 0; mv < 3; mv++) {  // explore :722-729: (x+d, y), (x, y+d), (x+d, y+d)
@@ -573,22 +689,31 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qsIn, const Section& rsI
         pa.update(ux, uy);
       }
       if (pa.overflow) return leave(false);
-      li = pa.lnext[li];
+      li = pa.listNext(li);
     }
     // prioritizedNodes.remove(activePenalty) + the poll(): pop the heap root (the active bucket is still the minimum: every key
     // inserted meanwhile is >= activePenalty and distinct keys are distinct buckets)
     {
-      int last = pa.heap[--pa.heapSize];
+      const int last = pa.heapAt(--pa.heapSize);
+      const double lastKey = pa.bucketKey(last);
       int i = 0;
       while (true) {
         int l = 2 * i + 1, r = l + 1;
         if (l >= pa.heapSize) break;
-        int c = (r < pa.heapSize && pa.bkey[pa.heap[r]] < pa.bkey[pa.heap[l]]) ? r : l;
-        if (pa.bkey[pa.heap[c]] >= pa.bkey[last]) break;
-        pa.heap[i] = pa.heap[c];
+        int bl = pa.heapAt(l);
+        double kl = pa.bucketKey(bl);
+        int c = l, bc = bl;
+        double kc = kl;
+        if (r < pa.heapSize) {
+          int br = pa.heapAt(r);
+          double kr = pa.bucketKey(br);
+          if (kr < kl) { c = r; bc = br; kc = kr; }
+        }
+        if (kc >= lastKey) break;
+        pa.setHeap(i, bc);
         i = c;
       }
-      if (pa.heapSize > 0) pa.heap[i] = last;
+      if (pa.heapSize > 0) pa.setHeap(i, last);
     }
   }
   // traceback :195-264
@@ -667,6 +792,33 @@ XM_NOINL bool pathAlign(const ExtEnv& e, const Section& qsIn, const Section& rsI
   finishSeqAl(e, params, out, e.query.rc != 0);
   if (out.alignedPenalty > pa.maxInterestingPenalty) return false;
   return true;
+}
+
+XM_NOINL bool pathAlignHbm(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) {
+  return pathAlignT<false>(e, qs, rs, p, an, out, nullptr);
+}
+XM_NOINL bool pathAlignLds(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out, bool* ldsOverflow) {
+  return pathAlignT<true>(e, qs, rs, p, an, out, ldsOverflow);
+}
+
+// LDS-mode search first (the lanes of the wave that arrive here together take the wave's slot one after the other); the searches
+// that do not fit are then redone in HBM mode
+XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) {
+  bool ldsOverflow = false;
+  bool r = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned long long pending = __ballot(1);
+  const int lane = (int)__lane_id();
+  while (pending) {
+    const int leader = __ffsll((long long)pending) - 1;
+    if (lane == leader) r = pathAlignLds(e, qs, rs, p, an, out, &ldsOverflow);
+    pending &= pending - 1;
+  }
+#else
+  r = pathAlignLds(e, qs, rs, p, an, out, &ldsOverflow);
+#endif
+  if (ldsOverflow) r = pathAlignHbm(e, qs, rs, p, an, out);
+  return r;
 }
 
 // ---------------------------------------------------------------- StraightAligner (M/StraightAligner.java)
