@@ -15,6 +15,7 @@
 #include <mutex>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
 
 using namespace xm;
 
@@ -67,7 +68,8 @@ static long long envInt(const char* name, long long dflt) {
 
 // One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed, int lanesPerWave,
-                                                       uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters) {
+                                                       uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters,
+                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit) {
   // lanesPerWave < 64 (gapped pass): the extension chain diverges so much that a wave runs its reads nearly one after another, so
   // spreading them over more, partly filled waves shortens the critical path; the idle lanes own no scratch arena
   const int laneInWave = (int)(threadIdx.x & 63u);
@@ -78,6 +80,13 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
   memset(&local, 0, sizeof(local));
   ReadCtx cx;
   while (true) {
+    if (taperUnit > 0 && laneInWave > 0) {
+      // End of the work list (gapped pass): the lanes of a wave run their reads mostly one after the other, so when the list runs dry
+      // every wave would still hold lanesPerWave unfinished reads and the launch would end with that long serial tail.  The higher
+      // lanes therefore stop taking reads early; the last reads are spread one per wave.
+      long long remaining = nTodo - (long long)__hip_atomic_load(nextItem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (remaining < (long long)laneInWave * taperUnit) break;
+    }
     unsigned long long item = atomicAdd(nextItem, 1ull);
     if ((long long)item >= nTodo) break;
     int64_t q = todo ? todo[item] : (int64_t)item;
@@ -92,7 +101,10 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
     in.deviation = in.nMates > 1 ? batch.deviation[q] : 1.0;
     ReadResult rr;
     DevCounters before = local;
-    runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed != 0);
+    // deferred-search gapped pass (memoBase != null): the read's memo slot carries its finished calls from replay to replay
+    MemoHdr* memo = memoBase ? (MemoHdr*)(memoBase + (size_t)slotOf[q] * XM_MEMO_SLOT_BYTES) : nullptr;
+    if (memo && memoFresh) memoInit(memo);
+    runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed != 0, memo, deferPath != 0);
     int32_t st = cx.status;
     if (st != XM_OK) local = before;  // work of a read that is rerun by a later pass is counted there
     if (st == XM_OK) {
@@ -114,21 +126,46 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
   addCounters(counters, local);
 }
 
+// Every PathAligner search the gapped pass left waiting (MemoHdr, xm_extend.h): one request per lane, every lane in the same code.
+__global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_path_kernel(const int64_t* list, long long n, const int32_t* slotOf, uint8_t* memoBase, int scale, int lanesPerWave,
+                                                      uint8_t* arenas, unsigned long long arenaBytes, unsigned long long* nextItem, DevCounters* counters) {
+  // few searches: spread them over as many waves as the GPU holds (the time of a launch is its longest wave)
+  const int laneInWave = (int)(threadIdx.x & 63u);
+  if (laneInWave >= lanesPerWave) return;
+  unsigned long long lane = ((unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (unsigned)lanesPerWave + (unsigned)laneInWave;
+  DevCounters local;
+  memset(&local, 0, sizeof(local));
+  const Caps caps = makeCaps(scale);
+  while (true) {
+    unsigned long long item = atomicAdd(nextItem, 1ull);
+    if ((long long)item >= n) break;
+    MemoHdr* memo = (MemoHdr*)(memoBase + (size_t)slotOf[list[item]] * XM_MEMO_SLOT_BYTES);
+    Arena tmp;
+    tmp.init(arenas + lane * arenaBytes, (size_t)arenaBytes);
+    memoRunPath(memo, tmp, caps, &local);
+  }
+  addCounters(counters, local);
+}
+
 // ---------------------------------------------------------------- pass bookkeeping on the device
 // After every pass the reads are sorted into the work lists of the passes still to come; only the list sizes travel to the host.
 struct PassCtl {
-  unsigned long long nHeavy, nScale[2], nOut[2];
+  unsigned long long nHeavy, nScale[2], nOut[2], nPath[2];
   unsigned long long errQuery;  // smallest query index whose status is an error (~0 = none)
 };
 
 __global__ void __launch_bounds__(256) xm_classify_kernel(const int64_t* todo, long long nTodo, const int32_t* status, int64_t* listHeavy, int64_t* listScale, int64_t* listOut,
-                                                          PassCtl* ctl, int ts, int to) {
+                                                          int64_t* listPath, int32_t* slotOf, PassCtl* ctl, int ts, int to, int tp) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nTodo) return;
   int64_t q = todo ? todo[i] : (int64_t)i;
   int32_t st = status[q];
   if (st == XM_OK) return;
-  if (st == XM_ST_NEED_HEAVY) listHeavy[atomicAdd(&ctl->nHeavy, 1ull)] = q;
+  if (st == XM_ST_NEED_HEAVY) {
+    unsigned long long slot = atomicAdd(&ctl->nHeavy, 1ull);
+    listHeavy[slot] = q;
+    slotOf[q] = (int32_t)slot;  // the read's memo slot in the gapped pass
+  } else if (st == XM_ST_NEED_PATH) listPath[atomicAdd(&ctl->nPath[tp], 1ull)] = q;
   else if (st == XM_ST_OVERFLOW) listScale[atomicAdd(&ctl->nScale[ts], 1ull)] = q;
   else if (st == XM_ST_OUT_OVERFLOW) listOut[atomicAdd(&ctl->nOut[to], 1ull)] = q;
   else atomicMin(&ctl->errQuery, (unsigned long long)q);
@@ -321,7 +358,9 @@ struct xm_index {
   DevBuf<int64_t> dMateOffset, dIntOff, dDblOff, dTodo;
   DevBuf<double> dExpected, dDeviation, dOutDbls;
   DevBuf<unsigned long long> dCursors;  // [0],[1] result cursors, [2] next item
-  DevBuf<int64_t> dListHeavy, dListScale[2], dListOut[2], dFinalIntOff, dFinalDblOff;
+  DevBuf<int64_t> dListHeavy, dListScale[2], dListOut[2], dListPath[2], dFinalIntOff, dFinalDblOff;
+  DevBuf<int32_t> dSlotOf;
+  DevBuf<uint8_t> dMemo;
   DevBuf<PassCtl> dCtl;
   DevBuf<long long> dBlockI, dBlockD;
   DevBuf<int32_t> dFinalInts;
@@ -593,44 +632,57 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     ctl0.errQuery = ~0ull;
     HIP_CHECK(hipMemcpyAsync(idx->dCtl.p, &ctl0, sizeof(ctl0), hipMemcpyHostToDevice, s));
 
-    // Passes: (1) light pass over every read at scale 1: reads that reach the gapped extension chain stop with
-    // XM_ST_NEED_HEAVY instead of serialising their wave; (2) full pass over exactly those reads; (3..) reads whose scratch
-    // overflowed are rerun in full mode with 4x, 16x, ... the scratch.  All passes run on the GPU; the work lists of the later
-    // passes are built on the GPU too (xm_classify_kernel), and every pass appends to the same result arenas.
+    // Passes, all on the GPU:
+    //  (1) light pass over every read at scale 1: reads that reach the gapped extension chain stop with XM_ST_NEED_HEAVY
+    //      instead of serialising their wave;
+    //  (2) gapped pass over exactly those reads at scale 4, PathAligner searches deferred: chain kernel (a read stops at its
+    //      first search it has no result for) -> xm_path_kernel (all waiting searches, one per lane) -> chain kernel over the
+    //      reads that waited (replay from their memo slots) -> ... until no read waits;
+    //  (3) reads whose scratch overflowed are rerun with inline searches and 16x, 64x, ... the scratch.
+    // The work lists are built on the GPU (xm_classify_kernel); every pass appends to the same result arenas.
     const int64_t* todo = nullptr;  // device list of the current pass; null on the first pass = all reads
     long long nTodo = nq;
-    unsigned long long pendingHeavy = 0, pendingScale = 0;
-    int ts = 0, to = 0;  // which of the two scale / out lists receives new entries
+    unsigned long long pendingHeavy = 0, pendingScale = 0, pendingPath = 0;
+    int ts = 0, to = 0, tp = 0;  // which of the two scale / out / path lists receives new entries
     int scale = 1, overflowScale = 1;
-    bool heavy = false;
+    bool heavy = false, defer = false, memoFresh = false, inlineRest = false;
+    int searchRounds = 0;
     unsigned long long intCap = (unsigned long long)nq * 40 + 4096, dblCap = (unsigned long long)nq * 12 + 4096;
     idx->dOutInts.ensure((size_t)intCap); idx->dOutDbls.ensure((size_t)dblCap);
     intCap = idx->dOutInts.n; dblCap = idx->dOutDbls.n;
+    idx->dSlotOf.ensure((size_t)nq);
     unsigned long long cursors[4] = {0, 0, 0, 0};
     double kernelMs = 0;
     int launches = 0;
     int64_t rerun = 0;
     const size_t arenaUnit = 288 * 1024;
+    static const long long scratchGiBWanted = envInt("XM_SCRATCH_GIB", 200);
+    static const long long lightWaves = envInt("XM_LIGHT_WAVES", 8), fullWaves = envInt("XM_FULL_WAVES", 4), pathWaves = envInt("XM_PATH_WAVES", 4);
+    static const long long fullLpw = envInt("XM_FULL_LPW", 32), lightLpw = envInt("XM_LIGHT_LPW", 64);
+    static const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
+    static const long long taperWaves = envInt("XM_TAPER_PCT", 100);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
+    // a search round costs two launches whose time is the time of one read (a replay, a search) however few reads wait; once the
+    // waiting reads no longer fill the GPU the rest is cheaper inline: one last chain pass, one read per wave
+    static const long long deferMaxRounds = envInt("XM_DEFER_ROUNDS", 3), inlineBelow = envInt("XM_INLINE_BELOW", 8192);
+    auto scratchLanes = [&](size_t arenaBytes) -> long long {  // scratch: up to 200 GiB of the 288 GiB HBM, never more than 3/4 of what is free
+      long long scratchGiB = scratchGiBWanted;
+      size_t freeB = 0, totalB = 0;
+      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+        long long avail = (long long)(((freeB + idx->dArenas.n) / 4 * 3) >> 30);
+        if (scratchGiB > avail) scratchGiB = avail < 1 ? 1 : avail;
+      }
+      return (long long)(((unsigned long long)scratchGiB << 30) / arenaBytes);
+    };
     while (nTodo > 0) {
       size_t arenaBytes = arenaUnit * (size_t)scale;
-      // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped pass
-      // is serialised by divergence inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  Scratch: up to 200 GiB
-      // of the 288 GiB HBM (never more than 3/4 of what is free).  The XM_* variables are experiment knobs.
-      static const long long scratchGiBWanted = envInt("XM_SCRATCH_GIB", 200);
-      static const long long lightWaves = envInt("XM_LIGHT_WAVES", 8), fullWaves = envInt("XM_FULL_WAVES", 4);
-      static const long long fullLpw = envInt("XM_FULL_LPW", 32), lightLpw = envInt("XM_LIGHT_LPW", 64);
-      long long scratchGiB = scratchGiBWanted;
-      {
-        size_t freeB = 0, totalB = 0;
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-          long long avail = (long long)(((freeB + idx->dArenas.n) / 4 * 3) >> 30);
-          if (scratchGiB > avail) scratchGiB = avail < 1 ? 1 : avail;
-        }
-      }
-      const int lpw = (int)(heavy ? fullLpw : lightLpw);  // active lanes per wave
-      long long maxLanesByMem = (long long)(((unsigned long long)scratchGiB << 30) / arenaBytes);
-      long long lanes = (long long)idx->numCUs * 4 * lpw * (heavy ? fullWaves : lightWaves);
-      if (lanes > maxLanesByMem) lanes = maxLanesByMem;
+      // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped chain
+      // diverges inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  The XM_* variables are experiment knobs.
+      // a pass over few reads spreads them over all the wave slots of the GPU (the time of a launch is its longest wave)
+      const long long waveSlots = (long long)idx->numCUs * 4 * (heavy ? fullWaves : lightWaves);
+      int lpw = (int)(heavy ? fullLpw : lightLpw);  // active lanes per wave
+      if (heavy) lpw = (int)std::max(1ll, std::min((long long)lpw, (nTodo + waveSlots - 1) / waveSlots));
+      long long lanes = waveSlots * lpw;
+      lanes = std::min(lanes, scratchLanes(arenaBytes));
       if (lanes > nTodo) lanes = nTodo;
       long long nWaves = (lanes + lpw - 1) / lpw;
       if (nWaves < 1) nWaves = 1;
@@ -638,16 +690,18 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       int grid = (int)((nWaves * 64 + block - 1) / block);
       lanes = (long long)grid * (block / 64) * lpw;
       idx->dArenas.ensure((size_t)lanes * arenaBytes);
-      idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq);
+      idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq); idx->dListPath[tp].ensure(defer ? (size_t)nTodo : 1);
       HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
       HIP_CHECK(hipEventRecord(e0, s));
       hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, todo, nTodo, scale, heavy ? 1 : 0, lpw,
-                         idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p);
+                         idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
+                         defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
+                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,
-                         idx->dListOut[to].p, idx->dCtl.p, ts, to);
+                         idx->dListOut[to].p, idx->dListPath[tp].p, idx->dSlotOf.p, idx->dCtl.p, ts, to, tp);
       HIP_CHECK(hipGetLastError());
       PassCtl ctl;
       HIP_CHECK(hipMemcpyAsync(&ctl, idx->dCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, s));
@@ -655,8 +709,12 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       HIP_CHECK(hipStreamSynchronize(s));
       HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       kernelMs += ms;
-      if (launches < 8) res->counters[12 + (launches < 4 ? launches : 3)] += (int64_t)(ms * 1000.0);  // per-pass kernel microseconds (passes 1,2,3,4+)
+      res->counters[!heavy ? 12 : (defer ? 13 : 15)] += (int64_t)(ms * 1000.0);  // kernel microseconds: light pass / gapped chain passes / inline reruns
       launches++;
+      memoFresh = false;
+      static const bool tracePasses = envInt("XM_TRACE_PASSES", 0) != 0;
+      if (tracePasses) fprintf(stderr, "[xm] pass %d: %s reads %lld scale %d lpw %d waves %lld: %.3f ms -> heavy %llu path %llu scale %llu out %llu\n", launches, !heavy ? "light" : (defer ? "chain" : "inline"),
+                               nTodo, scale, lpw, nWaves, ms, ctl.nHeavy, ctl.nPath[tp], ctl.nScale[ts], ctl.nOut[to]);
       if (ctl.errQuery != ~0ull) {
         int32_t code = 0;
         HIP_CHECK(hipMemcpy(&code, idx->dStatus.p + ctl.errQuery, sizeof(code), hipMemcpyDeviceToHost));
@@ -667,6 +725,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       }
       pendingHeavy = ctl.nHeavy;
       pendingScale = ctl.nScale[ts];
+      pendingPath = ctl.nPath[tp];
       if (ctl.nOut[to] > 0) {  // result arena too small: rerun those reads with the same settings and room to spare
         todo = idx->dListOut[to].p; nTodo = (long long)ctl.nOut[to];
         to ^= 1;
@@ -678,14 +737,52 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         rerun += nTodo;
         continue;
       }
+      if (pendingPath > 0 && (searchRounds >= deferMaxRounds || (long long)pendingPath < inlineBelow)) {
+        // last chain pass: the reads still waiting replay from their memo slots and run their remaining searches inline
+        todo = idx->dListPath[tp].p; nTodo = (long long)pendingPath;
+        tp ^= 1;
+        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nPath[tp], 0, sizeof(unsigned long long), s));
+        inlineRest = true;
+        continue;
+      }
+      if (pendingPath > 0) {  // (defer) run the waiting searches, then replay their reads
+        const long long nPath = (long long)pendingPath;
+        searchRounds++;
+        const long long pslots = (long long)idx->numCUs * 4 * pathWaves;
+        const int plpw = (int)std::max(1ll, std::min(64ll, (nPath + pslots - 1) / pslots));
+        long long pl = std::min(pslots * plpw, scratchLanes(arenaBytes));
+        if (pl > nPath) pl = nPath;
+        long long pWaves = (pl + plpw - 1) / plpw;
+        int pblock = pWaves < 4 ? (int)pWaves * 64 : 256;
+        int pgrid = (int)((pWaves * 64 + pblock - 1) / pblock);
+        idx->dArenas.ensure((size_t)pgrid * (pblock / 64) * plpw * arenaBytes);
+        HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
+        HIP_CHECK(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(xm_path_kernel, dim3(pgrid), dim3(pblock), 0, s, idx->dListPath[tp].p, nPath, idx->dSlotOf.p, idx->dMemo.p, scale, plpw, idx->dArenas.p,
+                           (unsigned long long)arenaBytes, idx->dCursors.p + 2, idx->dCounters.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(e1, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        kernelMs += ms;
+        res->counters[14] += (int64_t)(ms * 1000.0);  // search kernel microseconds
+        if (tracePasses) fprintf(stderr, "[xm] search kernel: %lld searches, %d x %d threads, %d lanes per wave: %.3f ms\n", nPath, pgrid, pblock, plpw, ms);
+        launches++;
+        todo = idx->dListPath[tp].p; nTodo = nPath;
+        tp ^= 1;
+        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nPath[tp], 0, sizeof(unsigned long long), s));
+        continue;
+      }
       if (pendingHeavy > 0) {
-        // the full pass runs at scale 4 straight away: far fewer lanes are needed than in the light pass, and most reads whose
+        // the gapped pass runs at scale 4 straight away: far fewer lanes are needed than in the light pass, and most reads whose
         // gapped search outgrows the scale-1 scratch then finish here instead of costing one more (latency-bound) pass
         todo = idx->dListHeavy.p; nTodo = (long long)pendingHeavy;
-        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nHeavy, 0, sizeof(unsigned long long), s));  // (a full pass never adds to this list)
+        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nHeavy, 0, sizeof(unsigned long long), s));  // (a gapped pass never adds to this list)
         scale = 4;
         if (overflowScale < 4) overflowScale = 4;
         heavy = true;
+        defer = deferSearches;
+        if (defer) { idx->dMemo.ensure((size_t)nTodo * XM_MEMO_SLOT_BYTES); memoFresh = true; }
         continue;
       }
       if (pendingScale == 0) break;
@@ -696,6 +793,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       overflowScale *= 4;
       scale = overflowScale;
       heavy = true;
+      defer = false; inlineRest = false;
       if (scale > 4096) throw std::runtime_error("Failed to align: scratch scale limit reached (query needs more than 4096x the default scratch)");
     }
     // ---- canonical streams in query order: offsets by prefix sum, slices gathered on the device, one copy per stream to the host

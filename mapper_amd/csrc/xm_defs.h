@@ -33,6 +33,7 @@ enum : int32_t {
   XM_ST_NEED_GROW = 4,     // a gapmer uses more bases than the largest hashed length (host must grow the index)
   XM_ST_INTERNAL = 5,      // the reference would have thrown (e.g. TreeMap.subMap fromKey > toKey): whole batch fails
   XM_ST_NEED_HEAVY = 6,    // light pass only: the read needs the gapped extension chain; the full pass reruns it
+  XM_ST_NEED_PATH = 7,     // gapped pass with deferred PathAligner: a search request is waiting in the read's memo slot
 };
 
 // ---------------------------------------------------------------- Java arithmetic
@@ -141,6 +142,7 @@ XM_INL SeqView refView(const IndexView& ix, int contig, bool rc) {
 struct Caps {
   int32_t scale;
   int32_t heavyAllowed;  // 0: light pass (a read that reaches the gapped chain stops with XM_ST_NEED_HEAVY)
+  int32_t deferPath;     // 1: a PathAligner search without a logged result is left as a request (XM_ST_NEED_PATH), needs a memo slot
   int32_t maxLevels, maxPyramidBlocks, maxHistory, maxCounters, maxPending, maxQM, maxGoodAlignments, maxBlocks,
       maxNodes, nodeHash, gridCap, maxBuckets, bucketHash, matcherEntries, maxSections, maxPieces, maxCountMap, maxJoined;
 };
@@ -148,6 +150,7 @@ XM_INL Caps makeCaps(int scale) {
   Caps c;
   c.scale = scale;
   c.heavyAllowed = 1;
+  c.deferPath = 0;
   c.maxLevels = 48 * scale;
   c.maxPyramidBlocks = 1536 * scale;
   c.maxHistory = 192 * scale;

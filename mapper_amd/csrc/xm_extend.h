@@ -62,7 +62,67 @@ struct ExtEnv {  // everything the chain needs
   SeqView reference; // sequenceB (forward contig)
   int32_t contig;
   Matcher* slotA; Matcher* slotB; Matcher* slotT;
+  struct MemoHdr* memo;     // gapped pass with deferred PathAligner searches: the read's memo slot (null = searches run inline)
+  int32_t* memoCursor;      // replay position in the memo log
 };
+
+// ---------------------------------------------------------------- memo slot of a read in the deferred-search gapped pass
+// PathAligner's best-first search is the one part of the chain that only a lane or two of a wave ever reach at the same time,
+// so inside the chain it runs at 1/64 of the machine.  In the gapped pass the chain therefore does not run it: pathAlign()
+// writes a request into the read's memo slot and the read stops with XM_ST_NEED_PATH; xm_path_kernel then runs every waiting
+// search, one per lane and all lanes in the same code; the read is replayed and finds the result in its memo log.  To keep
+// replays short the log also holds the results of the finished enclosing calls (BlockAligner pieces, whole alignMatch calls):
+// a finished call replaces the entries of the calls it made.  A replay is deterministic, so it meets the log entries in order.
+struct MemoHdr {
+  int32_t logBytes, logCap, textCap, hasRequest;
+  // request (PathAligner.align arguments)
+  int32_t qsStart, qsEnd, rsStart, rsEnd, referenceLen, predictedBestOffset, confident, pad;
+  double maxInsExt, maxDelExt;
+  Params params;
+};
+struct MemoEntry {  // followed by nb ABlocks
+  int32_t type, ok, nb, contig, referenceReversed, seqAId, aux, bytes;
+  double totalPenalty, alignedPenalty;
+};
+enum { MEMO_MATCH = 1, MEMO_PIECE = 2, MEMO_PATH = 3 };
+constexpr int XM_MEMO_SLOT_BYTES = 8192, XM_MEMO_TEXT_BYTES = 1024;
+XM_INL uint8_t* memoTexts(MemoHdr* m) { return (uint8_t*)(m + 1); }
+XM_INL uint8_t* memoLog(MemoHdr* m) { return memoTexts(m) + m->textCap; }
+XM_INL void memoInit(MemoHdr* m) {
+  m->logBytes = 0; m->hasRequest = 0; m->textCap = XM_MEMO_TEXT_BYTES;
+  m->logCap = XM_MEMO_SLOT_BYTES - (int)sizeof(MemoHdr) - XM_MEMO_TEXT_BYTES;
+}
+XM_INL int memoPeek(MemoHdr* m, int cursor) {
+  if (cursor >= m->logBytes) return 0;
+  return ((const MemoEntry*)(memoLog(m) + cursor))->type;
+}
+// copies the entry at the cursor into `out` (blocks included) and steps over it
+XM_INL bool memoTake(MemoHdr* m, int32_t& cursor, SeqAl& out, int32_t* aux) {
+  const MemoEntry* en = (const MemoEntry*)(memoLog(m) + cursor);
+  const MemoEntry h = *en;
+  const ABlock* b = (const ABlock*)(en + 1);
+  out.nb = h.nb; out.contig = h.contig; out.referenceReversed = (uint8_t)h.referenceReversed; out.seqAId = (uint8_t)h.seqAId;
+  out.totalPenalty = h.totalPenalty; out.alignedPenalty = h.alignedPenalty;
+  for (int i = 0; i < h.nb; i++) out.blocks[i] = b[i];
+  if (aux) *aux = h.aux;
+  cursor += h.bytes;
+  return h.ok != 0;
+}
+// the finished call that started at `start` replaces everything logged since; returns false when the slot is full
+XM_INL bool memoPut(MemoHdr* m, int32_t& cursor, int start, int type, bool ok, const SeqAl& al, int nb, int aux) {
+  const int bytes = (int)sizeof(MemoEntry) + nb * (int)sizeof(ABlock);
+  if (start + bytes > m->logCap) return false;
+  MemoEntry* en = (MemoEntry*)(memoLog(m) + start);
+  MemoEntry h;
+  h.type = type; h.ok = ok ? 1 : 0; h.nb = nb; h.contig = al.contig; h.referenceReversed = al.referenceReversed; h.seqAId = al.seqAId; h.aux = aux; h.bytes = bytes;
+  h.totalPenalty = al.totalPenalty; h.alignedPenalty = al.alignedPenalty;
+  *en = h;
+  ABlock* b = (ABlock*)(en + 1);
+  for (int i = 0; i < nb; i++) b[i] = al.blocks[i];
+  m->logBytes = start + bytes;
+  cursor = m->logBytes;
+  return true;
+}
 
 // ---------------------------------------------------------------- penalties (M/AlignmentParameters.java)
 XM_INL double blockPenalty(const SeqView& q, const SeqView& r, const Params& p, const ABlock& b) {  // :106-126
@@ -263,11 +323,12 @@ struct PNode {  // AlignmentNode, 32 bytes = two 16-byte loads
 //  - LDS == true: the lookup structures (cell hash, bucket table, bucket heap, node lists, both texts) live in the wave's slot of the
 //    CU's local data share and only the 32-byte node payloads stay in HBM.  The gapped search is a chain of dependent lookups that
 //    only one or two lanes of a wave execute at a time, so its cost is the latency of each lookup: ~100 cycles in LDS, >1000 in HBM.
-//    The slot is sized for the piece-wise searches BlockAligner issues (<= 960 nodes, <= 112 distinct priorities, texts <= 64 x 128);
+//    The slot is sized for the piece-wise searches BlockAligner issues (<= 960 nodes on <= 768 cells, <= 112 distinct priorities,
+//    texts <= 64 x 128);
 //    a search that outgrows it is redone in HBM mode.  One slot per wave: pathAlignAny runs the lanes of a wave through it in turn.
-constexpr int XM_PAL_HASH = 2048, XM_PAL_NODES = 960, XM_PAL_BUCKETS = 112, XM_PAL_BHASH = 256, XM_PAL_TEXTA = 64, XM_PAL_TEXTB = 128;
-constexpr int XM_PAL_OFF_HASH = 0;                                      // uint16[2048]: node index + 1
-constexpr int XM_PAL_OFF_XY = XM_PAL_OFF_HASH + XM_PAL_HASH * 2;        // uint16[960]: x << 8 | y of node i (= list entry i)
+constexpr int XM_PAL_HASH = 1024, XM_PAL_CELLS = 768, XM_PAL_NODES = 960, XM_PAL_BUCKETS = 112, XM_PAL_BHASH = 256, XM_PAL_TEXTA = 64, XM_PAL_TEXTB = 128;
+constexpr int XM_PAL_OFF_HASH = 0;                                      // uint32[1024]: (x << 8 | y) << 16 | node index + 1; at most 768 cells
+constexpr int XM_PAL_OFF_XY = XM_PAL_OFF_HASH + XM_PAL_HASH * 4;        // uint16[960]: x << 8 | y of node i (= list entry i)
 constexpr int XM_PAL_OFF_NEXT = XM_PAL_OFF_XY + XM_PAL_NODES * 2;       // uint16[960]: next list entry, 0xFFFF = none
 constexpr int XM_PAL_OFF_BKEY = XM_PAL_OFF_NEXT + XM_PAL_NODES * 2;     // double[112]
 constexpr int XM_PAL_OFF_BHEAD = XM_PAL_OFF_BKEY + XM_PAL_BUCKETS * 8;  // uint16[112]
@@ -287,9 +348,19 @@ XM_INL uint8_t* palSlot() { return xm_pal_lds + (threadIdx.x >> 6) * XM_PAL_SLOT
 XM_INL uint8_t* palSlot() { static thread_local double slot[XM_PAL_SLOT_BYTES / 8]; return (uint8_t*)slot; }  // host simulation (tests only)
 #endif
 
+// XM_PROFILE builds: where a search step spends its time (hash lookups / node loads / arithmetic / putNode), summed into t[12..15]
+#if defined(XM_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define XM_PA_TIC(var) unsigned long long var = clock64()
+#define XM_PA_TOC(field, var) do { __builtin_amdgcn_s_waitcnt(0); unsigned long long n_ = clock64(); field += n_ - var; var = n_; } while (0)
+#else
+#define XM_PA_TIC(var) do { } while (0)
+#define XM_PA_TOC(field, var) do { } while (0)
+#endif
+
 template <bool LDS>
 struct PathAlignerT {
   static constexpr double disallowed = 1000000.0;
+  unsigned long long tLook, tLoad, tCompute, tPut;
   PNode* nodes; int32_t nNodes, maxNodes;  // node i is also list entry i (putNode appends exactly one of each)
   // locatedNodes: (x,y) -> latest node.  HBM mode: dense grid of node indices when (textA+2)*(textB+2) fits (the four neighbour
   // lookups of an update are then four INDEPENDENT loads, issued together), open-addressing hash otherwise.  LDS mode: hash.
@@ -302,7 +373,7 @@ struct PathAlignerT {
   int32_t* bhash; int32_t bhashMask; int32_t* heap; int32_t heapSize;
   int16_t* lx; int16_t* ly; int32_t* lnext;
   // LDS mode
-  uint16_t* Lhash; uint16_t* Lxy; uint16_t* Lnext; double* Lbkey; uint16_t* Lbhead; uint16_t* Lbtail; uint8_t* Lbhash; uint8_t* Lheap;
+  uint32_t* Lhash; int32_t nCells; uint16_t* Lxy; uint16_t* Lnext; double* Lbkey; uint16_t* Lbhead; uint16_t* Lbtail; uint8_t* Lbhash; uint8_t* Lheap;
   uint8_t* LtextA; uint8_t* LtextB;
   bool ldsOverflow;
   // problem
@@ -348,19 +419,20 @@ struct PathAlignerT {
       h = (h + 1) & (uint32_t)hashMask;
     }
   }
-  XM_INL static uint32_t ldsCellHash(uint32_t key) { return (key * 2654435761u) >> 21; }  // top 11 bits: XM_PAL_HASH == 2048
+  // LDS cell hash: one 32-bit word per cell, key and node index together, so a lookup is one LDS read unless it collides
+  XM_INL static uint32_t ldsCellHash(uint32_t key) { return (key * 2654435761u) >> 22; }  // top 10 bits: XM_PAL_HASH == 1024
+  XM_INL void ldsResolve(uint32_t key, uint32_t& h, uint32_t& v) const {  // from the first probe (h, v) to the cell's slot or the empty slot that ends its run
+    while (v != 0 && (v >> 16) != key) { h = (h + 1) & (XM_PAL_HASH - 1); v = Lhash[h]; }
+  }
   XM_INL int findNode(int x, int y) const {  // getNode :541-553
     if (x < 0 || y < 0) return -1;
     if constexpr (LDS) {
       if (x >= gridW || y >= gridH) return -1;
       const uint32_t key = ((uint32_t)x << 8) | (uint32_t)y;
       uint32_t h = ldsCellHash(key);
-      while (true) {
-        uint32_t v = Lhash[h];
-        if (v == 0) return -1;
-        if (Lxy[v - 1] == key) return (int)v - 1;
-        h = (h + 1) & (XM_PAL_HASH - 1);
-      }
+      uint32_t v = Lhash[h];
+      ldsResolve(key, h, v);
+      return (int)(v & 0xFFFFu) - 1;
     } else {
       if (useGrid) {
         if (x >= gridW || y >= gridH) return -1;
@@ -369,17 +441,20 @@ struct PathAlignerT {
       return findNodeHash(x, y);
     }
   }
-  XM_INL void saveNode(int idx, int x, int y) {  // :523-539 (overwrites the node at (x,y)); node idx's list entry is already written
+  // :523-539 (overwrites the node at (x,y)).  LDS mode: slot >= 0 is the cell's slot as ldsResolve left it (the caller just looked the cell up)
+  XM_INL void saveNode(int idx, int x, int y, int slot = -1) {
     if (x < 0 || y < 0) return;
     if constexpr (LDS) {
       if (x >= gridW || y >= gridH) return;
       const uint32_t key = ((uint32_t)x << 8) | (uint32_t)y;
-      uint32_t h = ldsCellHash(key);
-      while (true) {
-        uint32_t v = Lhash[h];
-        if (v == 0 || Lxy[v - 1] == key) { Lhash[h] = (uint16_t)(idx + 1); return; }
-        h = (h + 1) & (XM_PAL_HASH - 1);
+      uint32_t h, v;
+      if (slot >= 0) { h = (uint32_t)slot; v = Lhash[h]; }
+      else { h = ldsCellHash(key); v = Lhash[h]; ldsResolve(key, h, v); }
+      if (v == 0) {
+        if (nCells >= XM_PAL_CELLS) { ldsOverflow = true; overflow = true; return; }
+        nCells++;
       }
+      Lhash[h] = (key << 16) | (uint32_t)(idx + 1);
     } else {
       if (useGrid) {
         if (x < gridW && y < gridH) grid[x * gridH + y] = idx + 1;
@@ -423,7 +498,7 @@ struct PathAlignerT {
       return pen + startP + ext;
     }
   }
-  XM_INL void putNode(int x, int y, double pen, double insX, double insY, uint8_t fl) {  // :446-473
+  XM_INL void putNode(int x, int y, double pen, double insX, double insY, uint8_t fl, int cellSlot = -1) {  // :446-473
     double est = estimateOverallPenalty(x, y, pen, insX, insY, fl);
     if (est < activePenalty) est = activePenalty;
     if (nNodes >= maxNodes) { if constexpr (LDS) ldsOverflow = true; overflow = true; return; }
@@ -475,21 +550,36 @@ struct PathAlignerT {
     PNode n;
     n.pen = pen; n.insX = insX; n.insY = insY; n.x = (int16_t)x; n.y = (int16_t)y; n.fl = fl; n.pad[0] = n.pad[1] = n.pad[2] = 0;
     nodes[idx] = n;
-    saveNode(idx, x, y);
+    saveNode(idx, x, y, cellSlot);
     nodesPut++;
   }
   XM_INL void update(int x, int y) {  // :555-571 + computeUpdated :573-719
     if (x <= 0 || x > textALength) return;
     if (y <= 0 || y > textBLength) return;
     // the four lookups first (independent loads), then the four nodes (index 0 stands in for "null": node 0 always exists)
-    const int existing = findNode(x, y);
-    const int left = findNode(x - stepDelta, y);
-    const int up = findNode(x, y - stepDelta);
-    const int diag = findNode(x - stepDelta, y - stepDelta);
+    XM_PA_TIC(t0);
+    int existing, left, up, diag, cellSlot = -1;
+    if constexpr (LDS) {
+      // all four cells are inside the grid here; the four first probes are independent LDS reads, issued together
+      const uint32_t xs = (uint32_t)(x - stepDelta), ys = (uint32_t)(y - stepDelta);
+      const uint32_t kE = ((uint32_t)x << 8) | (uint32_t)y, kL = (xs << 8) | (uint32_t)y, kU = ((uint32_t)x << 8) | ys, kD = (xs << 8) | ys;
+      uint32_t hE = ldsCellHash(kE), hL = ldsCellHash(kL), hU = ldsCellHash(kU), hD = ldsCellHash(kD);
+      uint32_t vE = Lhash[hE], vL = Lhash[hL], vU = Lhash[hU], vD = Lhash[hD];
+      ldsResolve(kE, hE, vE); ldsResolve(kL, hL, vL); ldsResolve(kU, hU, vU); ldsResolve(kD, hD, vD);
+      existing = (int)(vE & 0xFFFFu) - 1; left = (int)(vL & 0xFFFFu) - 1; up = (int)(vU & 0xFFFFu) - 1; diag = (int)(vD & 0xFFFFu) - 1;
+      cellSlot = (int)hE;
+    } else {
+      existing = findNode(x, y);
+      left = findNode(x - stepDelta, y);
+      up = findNode(x, y - stepDelta);
+      diag = findNode(x - stepDelta, y - stepDelta);
+    }
+    XM_PA_TOC(tLook, t0);
     const PNode nE = nodes[existing >= 0 ? existing : 0];
     const PNode nL = nodes[left >= 0 ? left : 0];
     const PNode nU = nodes[up >= 0 ? up : 0];
     const PNode nD = nodes[diag >= 0 ? diag : 0];
+    XM_PA_TOC(tLoad, t0);
     double insertXPenalty = disallowed, insertYPenalty = disallowed, overlayPenalty = disallowed;
     if (diag >= 0) overlayPenalty = nD.pen + parameters.getPenalty(charA(x - 1), charB(y - 1));
     if (left >= 0) {
@@ -541,7 +631,11 @@ struct PathAlignerT {
         else fl = nU.fl;
         if (iabs(signedDist(x, y)) == 0) fl |= 1; else fl |= 2;
       }
-      putNode(x, y, bestPenalty, insertXPenalty, insertYPenalty, fl);
+      XM_PA_TOC(tCompute, t0);
+      putNode(x, y, bestPenalty, insertXPenalty, insertYPenalty, fl, cellSlot);
+      XM_PA_TOC(tPut, t0);
+    } else {
+      XM_PA_TOC(tCompute, t0);
     }
   }
   XM_INL bool chooseSearchReverse() const {  // :17-53
@@ -567,24 +661,34 @@ XM_INL bool paCanRemoveSection(const ABlock& b) {  // :358-366
   return false;
 }
 
-// PathAligner.align :55-293.  false = null.  LDS mode: *ldsOverflow = true means "does not fit the slot, nothing decided".
+// What PathAligner.align is given: the two texts (as views), the sections, the parameters and the analysis scalars
+struct PaProblem {
+  const uint8_t* qBase; int32_t qLen; bool qRc; const uint8_t* rBase; int32_t referenceLen;
+  Section qs, rs;
+  Params params;
+  bool confident; double maxInsExt, maxDelExt; int32_t predictedBestOffset;
+};
+
+// PathAligner.align :55-293 up to and including justify: the search, the traceback and the final block list (outBlocks[0..nbOut)).
+// false = null (or *status set).  LDS mode: *ldsOverflow = true means "does not fit the slot, nothing decided".
 template <bool LDS>
-XM_INL bool pathAlignT(const ExtEnv& e, const Section& qsIn, const Section& rsIn, const Params& paramsIn, Analysis& analysis, SeqAl& out, bool* ldsOverflow) {
+XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, int32_t* status, DevCounters* dc, ABlock* const outBlocks, int32_t& nbOut, bool* ldsOverflow) {
   XM_TIC(tPath);
   // by-value copies: anything read through a reference inside a loop that also stores would be re-loaded (and waited for) on
   // every iteration, because the compiler cannot prove the store does not alias it
-  const Section qs = qsIn, rs = rsIn;
-  const Params params = paramsIn;
-  Arena& tmp = *e.tmp;
+  const PaProblem pr = prIn;
+  const Section qs = pr.qs, rs = pr.rs;
+  const Params params = pr.params;
   size_t mark = tmp.used;
-  const Caps caps = *e.caps;
-  ABlock* const outBlocks = out.blocks;
+  const Caps caps = capsIn;
+  nbOut = 0;
   PathAlignerT<LDS> pa;
   pa.parameters = params;
-  pa.qBase = e.query.base; pa.qLen = e.query.len; pa.qRc = e.query.rc != 0; pa.rBase = e.reference.base;
-  pa.confident = analysis.confidentAboutBestOffset; pa.maxInsExt = analysis.maxInsertionExtensionPenalty; pa.maxDelExt = analysis.maxDeletionExtensionPenalty;
-  pa.predictedBestOffset = analysis.predictedBestOffset; pa.overflow = false; pa.nodesPut = 0; pa.ldsOverflow = false;
-  const int referenceLen = e.reference.len;
+  pa.qBase = pr.qBase; pa.qLen = pr.qLen; pa.qRc = pr.qRc; pa.rBase = pr.rBase;
+  pa.confident = pr.confident; pa.maxInsExt = pr.maxInsExt; pa.maxDelExt = pr.maxDelExt;
+  pa.predictedBestOffset = pr.predictedBestOffset; pa.overflow = false; pa.nodesPut = 0; pa.ldsOverflow = false;
+  pa.tLook = pa.tLoad = pa.tCompute = pa.tPut = 0;
+  const int referenceLen = pr.referenceLen;
   pa.gridW = secLen(qs) + 2; pa.gridH = secLen(rs) + 2;
   pa.grid = nullptr; pa.hash = nullptr; pa.hashMask = 0; pa.useGrid = false;
   pa.bkey = nullptr; pa.bhead = nullptr; pa.btail = nullptr; pa.bhash = nullptr; pa.bhashMask = 0; pa.heap = nullptr; pa.lx = nullptr; pa.ly = nullptr; pa.lnext = nullptr;
@@ -597,14 +701,14 @@ XM_INL bool pathAlignT(const ExtEnv& e, const Section& qsIn, const Section& rsIn
     pa.maxNodes = imin(caps.maxNodes, XM_PAL_NODES);
     pa.maxBuckets = imin(caps.maxBuckets, XM_PAL_BUCKETS);
     pa.nodes = arenaArray<PNode>(tmp, pa.maxNodes);
-    if (tmp.overflow) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+    if (tmp.overflow) { *status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
     uint8_t* const slot = palSlot();
-    pa.Lhash = (uint16_t*)(slot + XM_PAL_OFF_HASH); pa.Lxy = (uint16_t*)(slot + XM_PAL_OFF_XY); pa.Lnext = (uint16_t*)(slot + XM_PAL_OFF_NEXT);
+    pa.Lhash = (uint32_t*)(slot + XM_PAL_OFF_HASH); pa.nCells = 0; pa.Lxy = (uint16_t*)(slot + XM_PAL_OFF_XY); pa.Lnext = (uint16_t*)(slot + XM_PAL_OFF_NEXT);
     pa.Lbkey = (double*)(slot + XM_PAL_OFF_BKEY); pa.Lbhead = (uint16_t*)(slot + XM_PAL_OFF_BHEAD); pa.Lbtail = (uint16_t*)(slot + XM_PAL_OFF_BTAIL);
     pa.Lbhash = slot + XM_PAL_OFF_BHASH; pa.Lheap = slot + XM_PAL_OFF_HEAP; pa.LtextA = slot + XM_PAL_OFF_TEXTA; pa.LtextB = slot + XM_PAL_OFF_TEXTB;
     {
       uint64_t* const z1 = (uint64_t*)pa.Lhash;
-      for (int i = 0; i < XM_PAL_HASH * 2 / 8; i++) z1[i] = 0;
+      for (int i = 0; i < XM_PAL_HASH * 4 / 8; i++) z1[i] = 0;
       uint64_t* const z2 = (uint64_t*)pa.Lbhash;
       for (int i = 0; i < XM_PAL_BHASH / 8; i++) z2[i] = 0;
       for (int i = 0; i < pa.textALength; i++) pa.LtextA[i] = pa.charAGlobal(i);
@@ -621,20 +725,20 @@ XM_INL bool pathAlignT(const ExtEnv& e, const Section& qsIn, const Section& rsIn
     pa.bhash = arenaArray<int32_t>(tmp, caps.bucketHash); pa.bhashMask = caps.bucketHash - 1;
     pa.heap = arenaArray<int32_t>(tmp, caps.maxBuckets);
     pa.lx = arenaArray<int16_t>(tmp, caps.maxNodes); pa.ly = arenaArray<int16_t>(tmp, caps.maxNodes); pa.lnext = arenaArray<int32_t>(tmp, caps.maxNodes);
-    if (tmp.overflow) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+    if (tmp.overflow) { *status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
     int32_t* const h1 = pa.useGrid ? pa.grid : pa.hash; const int n1 = pa.useGrid ? pa.gridW * pa.gridH : caps.nodeHash;
     for (int i = 0; i < n1; i++) h1[i] = 0;
     int32_t* const h2 = pa.bhash; const int n2 = caps.bucketHash;
     for (int i = 0; i < n2; i++) h2[i] = 0;
   }
-  XM_TOC(e.dc, T_PATH_INIT, tPath);
+  XM_TOC(dc, T_PATH_INIT, tPath);
   pa.heapSize = 0;
   pa.nNodes = 0; pa.nBuckets = 0;
   pa.activePenalty = 0;
 
   pa.maxInterestingPenalty = secLen(qs) * params.MaxErrorRate;
-  if (pa.textALength + 2 > 32000 || pa.textBLength + 2 > 32000) { *e.status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
-  pa.diagonal = pa.startIndexB - (pa.startIndexA + analysis.predictedBestOffset);
+  if (pa.textALength + 2 > 32000 || pa.textBLength + 2 > 32000) { *status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+  pa.diagonal = pa.startIndexB - (pa.startIndexA + pr.predictedBestOffset);
   pa.stepDelta = 1;
   pa.searchReverse = pa.chooseSearchReverse();
   if (pa.searchReverse) { pa.stepDelta = -1; pa.mayQueryExtendPastEndOfReference = pa.startIndexB == 0; }
@@ -653,7 +757,7 @@ XM_INL bool pathAlignT(const ExtEnv& e, const Section& qsIn, const Section& rsIn
     for (int i = 0; i < initialInsertionCount && !pa.overflow; i++) pa.putNode(pa.startX + i * pa.stepDelta, pa.startY, 0, disallowed, disallowed, 0);
   }
   if (pa.mayQueryExtendPastEndOfReference) {
-    int initialInsertionCount = j2i(analysis.maxInsertionExtensionPenalty / params.DeletionExtension_Penalty);
+    int initialInsertionCount = j2i(pr.maxInsExt / params.DeletionExtension_Penalty);
     for (int i = 1; i < initialInsertionCount && !pa.overflow; i++) pa.putNode(pa.startX + i * pa.stepDelta, pa.startY, i * params.UnalignedPenalty, disallowed, disallowed, 0);
   }
   bool haveLast = false;
@@ -664,18 +768,21 @@ XM_INL bool pathAlignT(const ExtEnv& e, const Section& qsIn, const Section& rsIn
     if constexpr (LDS) {
       if (pa.ldsOverflow) { *ldsOverflow = true; return false; }  // nothing decided, nothing counted: the HBM-mode search redoes it
     }
-    if (pa.overflow) *e.status = XM_ST_OVERFLOW;
+    if (pa.overflow) *status = XM_ST_OVERFLOW;
 #ifdef XM_PA_STATS
     fprintf(stderr, "PASTAT nodes %d buckets %d gridW %d gridH %d scale %d lds %d\n", pa.nNodes, pa.nBuckets, pa.gridW, pa.gridH, caps.scale, LDS ? 1 : 0);
 #endif
-    if (e.dc) { e.dc->pathAlignerCalls++; e.dc->pathAlignerNodes += pa.nodesPut; }
+    if (dc) { dc->pathAlignerCalls++; dc->pathAlignerNodes += pa.nodesPut; }
+#if defined(XM_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    if (dc) { dc->t[12] += pa.tLook; dc->t[13] += pa.tLoad; dc->t[14] += pa.tCompute; dc->t[15] += pa.tPut; }
+#endif
     pa.nodesPut = 0;
     return r && !pa.overflow;
   };
   while (!haveLast) {
     if (pa.overflow) return leave(false);
     // priorities.poll(): smallest live key
-    if (pa.heapSize < 1) { *e.status = XM_ST_INTERNAL; return leave(false); }  // Java: NullPointerException
+    if (pa.heapSize < 1) { *status = XM_ST_INTERNAL; return leave(false); }  // Java: NullPointerException
     int b = pa.heapAt(0);
     pa.activePenalty = pa.bucketKey(b);
     int li = pa.bucketHead(b);
@@ -683,6 +790,7 @@ XM_INL bool pathAlignT(const ExtEnv& e, const Section& qsIn, const Section& rsIn
       int x = pa.listX(li), y = pa.listY(li);
       if (pa.activePenalty > pa.maxInterestingPenalty + 0.000001) return leave(false);
       if (x == pa.goalX) { haveLast = true; lastX = x; lastY = y; break; }
+#pragma unroll 1  // one copy of update() in the loop: the code of this search has to stay in the instruction cache
       for (int mv = 0; mv < 3; mv++) {  // explore :722-729: (x+d, y), (x, y+d), (x+d, y+d)
         int ux = (mv == 1) ? x : x + pa.stepDelta;
         int uy = (mv == 0) ? y : y + pa.stepDelta;
@@ -770,7 +878,9 @@ XM_INL bool pathAlignT(const ExtEnv& e, const Section& qsIn, const Section& rsIn
   if (nb < 1) return false;
   // justify :307-352
   ABlock* s = outBlocks;
-  const SeqView jq = e.query, jr = e.reference;
+  SeqView jq, jr;
+  jq.base = pr.qBase; jq.len = pr.qLen; jq.rc = pr.qRc ? 1 : 0; jq.id = 0;
+  jr.base = pr.rBase; jr.len = pr.referenceLen; jr.rc = 0; jr.id = 0;
   for (int k = 1; k < nb - 1; k++) {
     while (true) {
       ABlock left = s[k - 1], middle = s[k], right = s[k + 1];
@@ -786,39 +896,102 @@ XM_INL bool pathAlignT(const ExtEnv& e, const Section& qsIn, const Section& rsIn
   }
   int drop = 0;
   while (drop < nb && paCanRemoveSection(s[drop])) drop++;
-  if (drop >= nb) { *e.status = XM_ST_INTERNAL; return false; }  // Java: IndexOutOfBoundsException
+  if (drop >= nb) { *status = XM_ST_INTERNAL; return false; }  // Java: IndexOutOfBoundsException
   if (drop > 0) { for (int k = drop; k < nb; k++) s[k - drop] = s[k]; nb -= drop; }
-  out.nb = nb;
-  finishSeqAl(e, params, out, e.query.rc != 0);
-  if (out.alignedPenalty > pa.maxInterestingPenalty) return false;
+  nbOut = nb;
   return true;
 }
 
-XM_NOINL bool pathAlignHbm(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) {
-  return pathAlignT<false>(e, qs, rs, p, an, out, nullptr);
+XM_NOINL bool pathSearchHbm(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb) {
+  return pathSearchT<false>(pr, tmp, caps, status, dc, outBlocks, nb, nullptr);
 }
-XM_NOINL bool pathAlignLds(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out, bool* ldsOverflow) {
-  return pathAlignT<true>(e, qs, rs, p, an, out, ldsOverflow);
+XM_NOINL bool pathSearchLds(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool* ldsOverflow) {
+  return pathSearchT<true>(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow);
 }
 
-// LDS-mode search first (the lanes of the wave that arrive here together take the wave's slot one after the other); the searches
-// that do not fit are then redone in HBM mode
-XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) {
-  bool ldsOverflow = false;
-  bool r = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-  unsigned long long pending = __ballot(1);
-  const int lane = (int)__lane_id();
-  while (pending) {
-    const int leader = __ffsll((long long)pending) - 1;
-    if (lane == leader) r = pathAlignLds(e, qs, rs, p, an, out, &ldsOverflow);
-    pending &= pending - 1;
+// The search of a request left in a memo slot (xm_path_kernel: one request per lane).  The request carries the two texts, so the
+// views address them directly; the result goes to the end of the log, where the replay of the read will look for it.
+XM_INL void memoRunPath(MemoHdr* m, Arena& tmp, const Caps& caps, DevCounters* dc) {
+  PaProblem pr;
+  pr.qs = Section{m->qsStart, m->qsEnd}; pr.rs = Section{m->rsStart, m->rsEnd};
+  const uint8_t* textA = memoTexts(m);
+  const uint8_t* textB = textA + (m->qsEnd - m->qsStart);
+  pr.qBase = textA - m->qsStart; pr.qLen = m->qsEnd; pr.qRc = false;  // at(i) = base[i] for the section's positions
+  pr.rBase = textB - m->rsStart; pr.referenceLen = m->referenceLen;
+  pr.params = m->params;
+  pr.confident = m->confident != 0; pr.maxInsExt = m->maxInsExt; pr.maxDelExt = m->maxDelExt; pr.predictedBestOffset = m->predictedBestOffset;
+  size_t mark = tmp.used;
+  ABlock* blocks = arenaArray<ABlock>(tmp, caps.maxBlocks);
+  int32_t st = tmp.overflow ? (int32_t)XM_ST_OVERFLOW : (int32_t)XM_OK;
+  int32_t nb = 0;
+  bool found = false;
+  if (!st) found = pathSearchHbm(pr, tmp, caps, &st, dc, blocks, nb);
+  SeqAl al;
+  al.blocks = blocks; al.nb = 0; al.contig = 0; al.referenceReversed = 0; al.seqAId = 0; al.totalPenalty = 0; al.alignedPenalty = 0;
+  int32_t cursor = 0;
+  if (!memoPut(m, cursor, m->logBytes, MEMO_PATH, found, al, found ? nb : 0, st)) {
+    // no room for the blocks: the replay must still find an entry, and it will send the read to the inline rerun
+    al.nb = 0;
+    m->logBytes = m->logBytes < m->logCap - (int)sizeof(MemoEntry) ? m->logBytes : m->logCap - (int)sizeof(MemoEntry);
+    memoPut(m, cursor, m->logBytes, MEMO_PATH, false, al, 0, XM_ST_OVERFLOW);
   }
+  m->hasRequest = 0;
+  tmp.used = mark;
+}
+
+// PathAligner.align.  Inline mode: LDS-mode search first (the lanes of the wave that arrive here together take the wave's slot
+// one after the other), the searches that do not fit are then redone in HBM mode.  With a memo slot (see MemoHdr): a logged result
+// is used; without one the search is deferred (caps.deferPath) or, in the last chain pass of a batch, run inline.
+XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) {
+  int32_t nb = 0;
+  bool found = false;
+  if (e.memo && memoPeek(e.memo, *e.memoCursor) == MEMO_PATH) {
+    int32_t st = 0;
+    found = memoTake(e.memo, *e.memoCursor, out, &st);
+    nb = out.nb;
+    if (st) { *e.status = st; return false; }
+  } else if (e.memo && e.caps->deferPath) {
+    MemoHdr* const m = e.memo;
+    {
+      const int la = secLen(qs), lb = secLen(rs);
+      if (la < 0 || lb < 0 || la + lb > m->textCap) { *e.status = XM_ST_OVERFLOW; return false; }  // rerun with inline searches
+      m->qsStart = qs.start; m->qsEnd = qs.end; m->rsStart = rs.start; m->rsEnd = rs.end; m->referenceLen = e.reference.len;
+      m->predictedBestOffset = an.predictedBestOffset; m->confident = an.confidentAboutBestOffset ? 1 : 0; m->pad = 0;
+      m->maxInsExt = an.maxInsertionExtensionPenalty; m->maxDelExt = an.maxDeletionExtensionPenalty;
+      m->params = p;
+      uint8_t* t = memoTexts(m);
+      const SeqView q = e.query, r = e.reference;
+      for (int i = 0; i < la; i++) t[i] = q.at(qs.start + i);
+      for (int i = 0; i < lb; i++) t[la + i] = r.at(rs.start + i);
+      m->hasRequest = 1;
+      *e.status = XM_ST_NEED_PATH;
+      return false;
+    }
+  } else {
+    PaProblem pr;
+    pr.qBase = e.query.base; pr.qLen = e.query.len; pr.qRc = e.query.rc != 0; pr.rBase = e.reference.base; pr.referenceLen = e.reference.len;
+    pr.qs = qs; pr.rs = rs; pr.params = p;
+    pr.confident = an.confidentAboutBestOffset; pr.maxInsExt = an.maxInsertionExtensionPenalty; pr.maxDelExt = an.maxDeletionExtensionPenalty;
+    pr.predictedBestOffset = an.predictedBestOffset;
+    bool ldsOverflow = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long pending = __ballot(1);
+    const int lane = (int)__lane_id();
+    while (pending) {
+      const int leader = __ffsll((long long)pending) - 1;
+      if (lane == leader) found = pathSearchLds(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow);
+      pending &= pending - 1;
+    }
 #else
-  r = pathAlignLds(e, qs, rs, p, an, out, &ldsOverflow);
+    found = pathSearchLds(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow);
 #endif
-  if (ldsOverflow) r = pathAlignHbm(e, qs, rs, p, an, out);
-  return r;
+    if (ldsOverflow) found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb);
+  }
+  if (!found || *e.status) return false;
+  out.nb = nb;
+  finishSeqAl(e, p, out, e.query.rc != 0);
+  if (out.alignedPenalty > secLen(qs) * p.MaxErrorRate) return false;
+  return true;
 }
 
 // ---------------------------------------------------------------- StraightAligner (M/StraightAligner.java)
@@ -1102,7 +1275,18 @@ XM_NOINL bool innerChain(const ExtEnv& e, const Section& qs, const Section& rs, 
 }
 
 // ---------------------------------------------------------------- BlockAligner (M/BlockAligner.java)
-XM_NOINL bool baAlignPiece(const ExtEnv& e, const Section& qs, const Section& rs, double maxPenalty, const Params& p, bool firstPiece, const Analysis& parent, SeqAl& out) {  // :215-249
+XM_NOINL bool baAlignPieceBody(const ExtEnv& e, const Section& qs, const Section& rs, double maxPenalty, const Params& p, bool firstPiece, const Analysis& parent, SeqAl& out);
+// deferred-search pass: a piece that finished in an earlier replay is taken from the memo log; a piece that finishes now is logged
+XM_INL bool baAlignPiece(const ExtEnv& e, const Section& qs, const Section& rs, double maxPenalty, const Params& p, bool firstPiece, const Analysis& parent, SeqAl& out) {
+  if (!e.memo) return baAlignPieceBody(e, qs, rs, maxPenalty, p, firstPiece, parent, out);
+  if (memoPeek(e.memo, *e.memoCursor) == MEMO_PIECE) return memoTake(e.memo, *e.memoCursor, out, nullptr);
+  const int start = *e.memoCursor;
+  bool r = baAlignPieceBody(e, qs, rs, maxPenalty, p, firstPiece, parent, out);
+  if (*e.status) return false;
+  if (!memoPut(e.memo, *e.memoCursor, start, MEMO_PIECE, r, out, r ? out.nb : 0, 0)) { *e.status = XM_ST_OVERFLOW; return false; }
+  return r;
+}
+XM_NOINL bool baAlignPieceBody(const ExtEnv& e, const Section& qs, const Section& rs, double maxPenalty, const Params& p, bool firstPiece, const Analysis& parent, SeqAl& out) {  // :215-249
   if (maxPenalty < 0) return false;
   Section sub = rs;
   if (parent.confidentAboutBestOffset) {

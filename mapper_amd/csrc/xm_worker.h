@@ -46,6 +46,8 @@ struct ReadCtx {
   SeedEnv seed;
   Comp comps[2];
   PathsCounter pc;
+  MemoHdr* memo;        // deferred-search gapped pass: this read's memo slot (xm_extend.h), else null
+  int32_t memoCursor;
 };
 
 XM_INL SeqView queryView(const ReadCtx& cx, uint8_t seqAId) {
@@ -87,10 +89,31 @@ XM_INL void makeExtEnv(ReadCtx& cx, ExtEnv& e, const SeqView& query, int contig)
   e.reference = refView(*cx.ix, contig, false);
   e.contig = contig;
   e.slotA = e.slotB = e.slotT = nullptr;
+  e.memo = cx.memo; e.memoCursor = &cx.memoCursor;
 }
 
 // alignMatch :412-462 (fromHashblockMatch is always true).  The matcher slots live in tmp for the duration of the call.
-XM_NOINL bool qmaAlignMatch(ReadCtx& cx, const SeqView& seqA, int contig, int offset, const Params& params, SeqAl& out) {
+XM_NOINL bool qmaAlignMatchBody(ReadCtx& cx, const SeqView& seqA, int contig, int offset, const Params& params, SeqAl& out);
+// deferred-search pass: an alignMatch call that finished in an earlier replay is taken from the memo log
+XM_INL bool qmaAlignMatch(ReadCtx& cx, const SeqView& seqA, int contig, int offset, const Params& params, SeqAl& out) {
+  if (!cx.memo) return qmaAlignMatchBody(cx, seqA, contig, offset, params, out);
+  if (memoPeek(cx.memo, cx.memoCursor) == MEMO_MATCH) {
+    if (cx.dc) {  // the skipped body's share of the traffic counters
+      int refLen = cx.ix->contigLen[contig];
+      int startB = imax(0, offset), endB = imin(offset + seqA.len, refLen);
+      double mip = (endB - startB) * params.MaxErrorRate;
+      int maxShift = j2i(dmax(0.0, (mip - params.DeletionStart_Penalty) / params.DeletionExtension_Penalty));
+      cx.dc->refWindowBytes += (unsigned long long)((imin(endB + maxShift, refLen) - imax(0, startB - maxShift) + 1) / 2);
+    }
+    return memoTake(cx.memo, cx.memoCursor, out, nullptr);
+  }
+  const int start = cx.memoCursor;
+  bool r = qmaAlignMatchBody(cx, seqA, contig, offset, params, out);
+  if (cx.status) return false;
+  if (!memoPut(cx.memo, cx.memoCursor, start, MEMO_MATCH, r, out, r ? out.nb : 0, 0)) { cx.status = XM_ST_OVERFLOW; return false; }
+  return r;
+}
+XM_NOINL bool qmaAlignMatchBody(ReadCtx& cx, const SeqView& seqA, int contig, int offset, const Params& params, SeqAl& out) {
   size_t mark = cx.tmp.used;
   ExtEnv e;
   makeExtEnv(cx, e, seqA, contig);
@@ -692,8 +715,10 @@ XM_INL void resultWrite(const ReadResult& rr, OutWriter& w, DevCounters* dc) {
 }
 
 // Carve a lane's arena and align one read.  `arena` must be 16-byte aligned.
-XM_INL void runRead(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* arena, size_t arenaBytes, DevCounters* dc, ReadResult& rr, bool heavyAllowed = true) {
-  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed ? 1 : 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
+XM_INL void runRead(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* arena, size_t arenaBytes, DevCounters* dc, ReadResult& rr, bool heavyAllowed = true,
+                    MemoHdr* memo = nullptr, bool deferPath = false) {
+  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed ? 1 : 0; cx.caps.deferPath = (memo && deferPath) ? 1 : 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
+  cx.memo = memo; cx.memoCursor = 0;
   cx.params.StartingInsertionStartFree = 0;
   size_t persistBytes = arenaBytes * 5 / 12;
   persistBytes &= ~(size_t)15;

@@ -13,6 +13,6 @@ mc = np.ones(nq, np.int32); mo = np.zeros(2 * nq, np.int64); mo[0::2] = np.arang
 codes = np.ascontiguousarray(reads.reshape(-1))
 for rep in range(2):
     r = db.align_arrays(mc, mo, ml, codes, np.zeros(nq), np.ones(nq), api.AlignmentParameters())
-names = ["TOTAL", "PYRAMID", "WALK", "HITS", "STRAIGHT", "ANALYZE", "PATH", "PATH_INIT", "BLOCK", "MATCHER_INDEX", "CONFIDENT", "OUTER", "s12", "s13", "s14", "s15"]
-print(label, "nq", nq, "kernel ms %.2f" % r.kernel_ms, "pass us", list(r.counters[12:16]), flush=True)
+names = ["TOTAL", "PYRAMID", "WALK", "HITS", "STRAIGHT", "ANALYZE", "PATH", "PATH_INIT", "BLOCK", "MATCHER_INDEX", "CONFIDENT", "OUTER", "PA_LOOK", "PA_LOAD", "PA_COMPUTE", "PA_PUT"]
+print(label, "nq", nq, "kernel ms %.2f" % r.kernel_ms, "launches", r.kernel_launches, "us light/chain/search/inline", list(r.counters[12:16]), "reruns", r.counters[11], "PA calls/nodes", r.counters[5:7], flush=True)
 print(label, "Mticks", {n: round(x / 1e6, 1) for n, x in zip(names, r.prof)}, flush=True)

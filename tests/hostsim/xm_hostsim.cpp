@@ -78,15 +78,40 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       for (int m = 0; m < 2; m++) { in.mate[m] = b->codes + b->mate_offset[q * 2 + m]; in.mateLen[m] = m < in.nMates ? b->mate_length[q * 2 + m] : 0; }
       in.expectedInner = in.nMates > 1 ? b->expected_inner[q] : 0.0;
       in.deviation = in.nMates > 1 ? b->deviation[q] : 1.0;
+      // the product's pass sequence for one read: light pass at scale 1; reads that need the gapped chain rerun at scale 4 with
+      // deferred PathAligner searches (chain pass -> search "kernel" -> replay ...); scratch overflow -> inline reruns at 16x, 64x...
+      // XMSIM_INLINE=1: plain inline run at scale 1, 4, 16... (the first implementation's sequence)
+      static const bool inlineOnly = getenv("XMSIM_INLINE") && atoi(getenv("XMSIM_INLINE")) != 0;
       int scale = 1;
+      int stage = inlineOnly ? 2 : 0;  // 0 light, 1 deferred gapped, 2 inline
+      std::vector<double> memoBuf(XM_MEMO_SLOT_BYTES / 8);
+      MemoHdr* memo = (MemoHdr*)memoBuf.data();
+      static const int deferRounds = getenv("XMSIM_DEFER_ROUNDS") ? atoi(getenv("XMSIM_DEFER_ROUNDS")) : 2;  // then searches run inline, as the product's last chain pass
+      int rounds = 0;
       while (true) {
         size_t bytes = (size_t)288 * 1024 * (size_t)scale;
         arena.resize(bytes + 64);
         uint8_t* a = (uint8_t*)(((uintptr_t)arena.data() + 15) & ~(uintptr_t)15);
         ReadResult rr;
         DevCounters before = dc;
-        runRead(cx, &idx->view, params, in, scale, a, bytes, &dc, rr);
-        if (cx.status == XM_ST_OVERFLOW) { dc = before; scale *= 4; rerun++; if (scale > 4096) throw std::runtime_error("scratch scale limit"); continue; }
+        runRead(cx, &idx->view, params, in, scale, a, bytes, &dc, rr, stage != 0, stage == 1 ? memo : nullptr, rounds < deferRounds);
+        if (cx.status == XM_ST_NEED_HEAVY && stage == 0) { dc = before; stage = 1; scale = 4; memoInit(memo); continue; }
+        if (cx.status == XM_ST_NEED_PATH && stage == 1) {
+          dc = before;
+          if (!memo->hasRequest) throw std::runtime_error("NEED_PATH without a request");
+          Arena tmp;
+          tmp.init(a, bytes);
+          Caps caps = makeCaps(scale);
+          memoRunPath(memo, tmp, caps, &dc);
+          rounds++;
+          continue;
+        }
+        if (cx.status == XM_ST_OVERFLOW) {
+          dc = before; rerun++;
+          if (stage == 0) { stage = 2; scale = 4; } else { stage = 2; scale *= 4; }
+          if (scale > 4096) throw std::runtime_error("scratch scale limit");
+          continue;
+        }
         if (cx.status != XM_OK) throw std::runtime_error("Failed to align query " + std::to_string(q) + " (status " + std::to_string(cx.status) + ")");
         int64_t ni, nd;
         resultSize(rr, ni, nd);
