@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
     // deferred-search gapped pass (memoBase != null): the read's memo slot carries its finished calls from replay to replay
     MemoHdr* memo = memoBase ? (MemoHdr*)(memoBase + (size_t)slotOf[q] * XM_MEMO_SLOT_BYTES) : nullptr;
     if (memo && memoFresh) memoInit(memo);
-    runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed != 0, memo, deferPath != 0);
+    runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed, memo, deferPath != 0);
     int32_t st = cx.status;
     if (st != XM_OK) local = before;  // work of a read that is rerun by a later pass is counted there
     if (st == XM_OK) {
@@ -660,6 +660,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     static const long long lightWaves = envInt("XM_LIGHT_WAVES", 8), fullWaves = envInt("XM_FULL_WAVES", 4), pathWaves = envInt("XM_PATH_WAVES", 4);
     static const long long fullLpw = envInt("XM_FULL_LPW", 32), lightLpw = envInt("XM_LIGHT_LPW", 64);
     static const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
+    static const long long lightLevel = envInt("XM_LIGHT_LEVEL", 0);  // what the light pass still does itself (Caps::heavyAllowed)
     static const long long taperWaves = envInt("XM_TAPER_PCT", 100);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
     // a search round costs two launches whose time is the time of one read (a replay, a search) however few reads wait; once the
     // waiting reads no longer fill the GPU the rest is cheaper inline: one last chain pass, one read per wave
@@ -694,7 +695,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
       HIP_CHECK(hipEventRecord(e0, s));
-      hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, todo, nTodo, scale, heavy ? 1 : 0, lpw,
+      hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
                          idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
                          defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
                          heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll);

@@ -14,10 +14,16 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define XM_HD __host__ __device__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XM_GLOBAL(T) T __attribute__((address_space(1)))  // pointer known to address HBM: global_load/store instead of flat
+#else
+#define XM_GLOBAL(T) T
+#endif
 #define XM_INL __host__ __device__ __forceinline__
 #define XM_NOINL __host__ __device__ __noinline__
 #else
 #define XM_HD
+#define XM_GLOBAL(T) T
 #define XM_INL inline
 #define XM_NOINL
 #endif
@@ -81,7 +87,8 @@ struct SeqView {
   int32_t len;
   uint8_t rc;
   uint8_t id;  // identity (Java object identity): queries: mate*2+rc, 4 = joined; references: unused
-  XM_INL uint8_t at(int i) const { return rc ? bpComplement(base[len - 1 - i]) : base[i]; }
+  // (reads, reference and joined mates all live in HBM: the loads are global_load, which the compiler can keep several of in flight)
+  XM_INL uint8_t at(int i) const { XM_GLOBAL(const uint8_t)* const g = (XM_GLOBAL(const uint8_t)*)base; return rc ? bpComplement(g[len - 1 - i]) : g[i]; }
 };
 
 // ---------------------------------------------------------------- AlignmentParameters (M/AlignmentParameters.java:8-35)
@@ -141,7 +148,8 @@ XM_INL SeqView refView(const IndexView& ix, int contig, bool rc) {
 // ---------------------------------------------------------------- capacities (scale s = 1, 4, 16, ...)
 struct Caps {
   int32_t scale;
-  int32_t heavyAllowed;  // 0: light pass (a read that reaches the gapped chain stops with XM_ST_NEED_HEAVY)
+  int32_t heavyAllowed;  // how far into the gapped chain a read may go before it stops with XM_ST_NEED_HEAVY: 0 = not at all (stops
+                         // before HashBlock_Aligner), 1 = up to BlockAligner (the hash-block analysis runs, the piece-wise alignment does not), 2 = all
   int32_t deferPath;     // 1: a PathAligner search without a logged result is left as a request (XM_ST_NEED_PATH), needs a memo slot
   int32_t maxLevels, maxPyramidBlocks, maxHistory, maxCounters, maxPending, maxQM, maxGoodAlignments, maxBlocks,
       maxNodes, nodeHash, gridCap, maxBuckets, bucketHash, matcherEntries, maxSections, maxPieces, maxCountMap, maxJoined;
@@ -149,7 +157,7 @@ struct Caps {
 XM_INL Caps makeCaps(int scale) {
   Caps c;
   c.scale = scale;
-  c.heavyAllowed = 1;
+  c.heavyAllowed = 2;
   c.deferPath = 0;
   c.maxLevels = 48 * scale;
   c.maxPyramidBlocks = 1536 * scale;

@@ -1441,6 +1441,7 @@ XM_NOINL bool blockAlign(const ExtEnv& e, const Section& qsIn, const Section& rs
 // ---------------------------------------------------------------- the outer chain (M/QueryMatch_Aligner.java:18-29)
 struct NextBlock {
   XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const {
+    if (e.caps->heavyAllowed < 2) { *e.status = XM_ST_NEED_HEAVY; return false; }
     XM_TIC(t0);
     bool r = blockAlign(e, qs, rs, p, an, out);
     XM_TOC(e.dc, T_BLOCK, t0);
@@ -1449,7 +1450,7 @@ struct NextBlock {
 };
 struct NextHashBlock1 {
   XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const {
-    if (!e.caps->heavyAllowed) { *e.status = XM_ST_NEED_HEAVY; return false; }
+    if (e.caps->heavyAllowed < 1) { *e.status = XM_ST_NEED_HEAVY; return false; }
     // SkipHighAmbiguity_Aligner :13-28
     int numAmbiguities = 0;
     for (int i = rs.start; i < rs.end; i++) if (bpIsAmbiguous(e.reference.at(i))) numAmbiguities++;

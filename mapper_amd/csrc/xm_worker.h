@@ -715,9 +715,9 @@ XM_INL void resultWrite(const ReadResult& rr, OutWriter& w, DevCounters* dc) {
 }
 
 // Carve a lane's arena and align one read.  `arena` must be 16-byte aligned.
-XM_INL void runRead(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* arena, size_t arenaBytes, DevCounters* dc, ReadResult& rr, bool heavyAllowed = true,
+XM_INL void runRead(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* arena, size_t arenaBytes, DevCounters* dc, ReadResult& rr, int heavyAllowed = 2,
                     MemoHdr* memo = nullptr, bool deferPath = false) {
-  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed ? 1 : 0; cx.caps.deferPath = (memo && deferPath) ? 1 : 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
+  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed; cx.caps.deferPath = (memo && deferPath) ? 1 : 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
   cx.memo = memo; cx.memoCursor = 0;
   cx.params.StartingInsertionStartFree = 0;
   size_t persistBytes = arenaBytes * 5 / 12;

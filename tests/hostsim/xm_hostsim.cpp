@@ -88,13 +88,14 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       MemoHdr* memo = (MemoHdr*)memoBuf.data();
       static const int deferRounds = getenv("XMSIM_DEFER_ROUNDS") ? atoi(getenv("XMSIM_DEFER_ROUNDS")) : 2;  // then searches run inline, as the product's last chain pass
       int rounds = 0;
+      static const int lightLevel = getenv("XMSIM_LIGHT_LEVEL") ? atoi(getenv("XMSIM_LIGHT_LEVEL")) : 0;
       while (true) {
         size_t bytes = (size_t)288 * 1024 * (size_t)scale;
         arena.resize(bytes + 64);
         uint8_t* a = (uint8_t*)(((uintptr_t)arena.data() + 15) & ~(uintptr_t)15);
         ReadResult rr;
         DevCounters before = dc;
-        runRead(cx, &idx->view, params, in, scale, a, bytes, &dc, rr, stage != 0, stage == 1 ? memo : nullptr, rounds < deferRounds);
+        runRead(cx, &idx->view, params, in, scale, a, bytes, &dc, rr, stage != 0 ? 2 : lightLevel, stage == 1 ? memo : nullptr, rounds < deferRounds);
         if (cx.status == XM_ST_NEED_HEAVY && stage == 0) { dc = before; stage = 1; scale = 4; memoInit(memo); continue; }
         if (cx.status == XM_ST_NEED_PATH && stage == 1) {
           dc = before;
