@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (configs[1]: 1,000,000)")
     ap.add_argument("--ref-len", type=int, default=5_000_000)
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--seed-probes", type=int, default=16_000_000, help="bucket-header probes of the seed-lookup micro-benchmark (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads of the same workload timed on the host cores (0 = skip)")
     args = ap.parse_args()
 
@@ -116,6 +117,31 @@ def main():
                    "sample": "first %d reads of the same batch, oracle (C++ port of the Java path) with one worker thread per host core, index build excluded; "
                              "GPU result bit-identical on the sample: %s" % (n, same)}
 
+        # seed-lookup micro-kernel: bulk PackedMap.get on the device, bytes = 8 per bucket-header probe + B_pos per
+        # fetched position, next to the measured random-64 B-sector ceiling of this GPU
+        seed = None
+        if args.seed_probes > 0:
+            rng = np.random.default_rng(12345)
+            lo, hi = info["min_interesting_size"], info["max_hashed_length"]
+            used = rng.integers(lo, hi + 1, size=args.seed_probes, dtype=np.int32)
+            keys = rng.integers(-2**31, 2**31 - 1, size=args.seed_probes, dtype=np.int64).astype(np.int32)
+            db.seed_probe(used[:4096], keys[:4096], 0)
+            counts, _, ms_hdr = db.seed_probe(used, keys, 0)
+            sectors_per_s, gather_ms = api.measure_random_gather(4 << 30, 1 << 26, local_rank)
+            n2 = args.seed_probes // 4
+            c2, _, ms_pos = db.seed_probe(used[:n2], keys[:n2], 4)
+            fetched = int(np.minimum(np.maximum(c2, 0), 4).sum())
+            hdr_gbs = 8.0 * args.seed_probes / (ms_hdr * 1e-3) / 1e9
+            seed = {"kernel": "xm_seed_probe_kernel", "probes": args.seed_probes, "kernel_ms": round(ms_hdr, 4),
+                    "probes_per_s": round(args.seed_probes / (ms_hdr * 1e-3), 1), "achieved": round(hdr_gbs, 2), "unit": "GB/s", "peak": 8000.0,
+                    "frac": round(hdr_gbs / 8000.0, 5),
+                    "random_64B_gather_ceiling_sectors_per_s": round(sectors_per_s, 1),
+                    "frac_of_gather_ceiling": round(args.seed_probes / (ms_hdr * 1e-3) / sectors_per_s, 4),
+                    "with_positions": {"probes": n2, "positions_fetched": fetched, "kernel_ms": round(ms_pos, 4),
+                                       "achieved_GBps": round((8.0 * n2 + pos_bytes * fetched) / (ms_pos * 1e-3) / 1e9, 2)},
+                    "note": "algorithmic bytes: 8 B header per probe (+ %d B per fetched position); every probe touches one random 64 B sector, so the "
+                            "sector ceiling (%.1f G sectors/s = %.0f GB/s of sector traffic) is the bound that applies" % (pos_bytes, sectors_per_s / 1e9, sectors_per_s * 64 / 1e9)}
+
         value = world * nq * args.steps / elapsed / 1e6
         line = {
             "metric": "M reads/s aligned (150 bp)", "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
@@ -130,6 +156,7 @@ def main():
                          "kernel_ms_per_step": round(kernel_ms / args.steps, 3), "launches_per_step": launches / args.steps,
                          "result_d2h_ms_per_step": round(d2h_ms / args.steps, 3)},
             "cpu_baseline": cpu,
+            "seed_probe": seed,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

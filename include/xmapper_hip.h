@@ -131,6 +131,11 @@ int xm_align_resident(xm_index* index, const xm_params* params, xm_result** out)
  * not reverse-complemented).  Device-resident micro-kernel used for the seed-lookup roofline measurement. */
 int xm_seed_probe(xm_index* index, int64_t n, const int32_t* used_length, const int32_t* keys, int32_t max_per_probe, int32_t* counts, int64_t* out_positions, double* kernel_ms);
 
+/* Measurement helper for the seed-lookup roofline (SURVEY.md section 8d asks for the achieved rate next to "a measured random-64 B-gather
+ * ceiling on the same GPU"): `accesses` reads of one random 64-byte sector each from a zero-filled device table of table_bytes;
+ * kernel_ms = best of two timed launches.  No reference counterpart. */
+int xm_measure_random_gather(int device, int64_t table_bytes, int64_t accesses, double* kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -255,6 +255,15 @@ class ReferenceDatabase:
         return counts, pos, ms.value
 
 
+def measure_random_gather(table_bytes=4 << 30, accesses=1 << 26, device=0):
+    """Random 64-byte-sector reads per second the GPU sustains (xm_measure_random_gather) -> (sectors/s, kernel ms)."""
+    L = _capi.lib()
+    ms = C.c_double()
+    if L.xm_measure_random_gather(device, table_bytes, accesses, C.byref(ms)):
+        raise RuntimeError(L.xm_last_error().decode())
+    return accesses / (ms.value * 1e-3), ms.value
+
+
 def sort_reference(contigs):
     """Mapper.sortAndComplementReference (Mapper.java:1151-1172): length-descending, stable within equal lengths."""
     return sorted(contigs, key=lambda c: -len(c[1]))

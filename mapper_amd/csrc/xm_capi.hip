@@ -257,6 +257,25 @@ __global__ void __launch_bounds__(256) xm_seed_probe_kernel(IndexView ix, long l
   for (int j = 0; j < m; j++) outPositions[i * maxPerProbe + j] = ix.posIs64 ? (int64_t)ix.positions64[first + j] : (int64_t)ix.positions32[first + j];
 }
 
+// Measurement helper: one random 64-byte sector per access out of a table far larger than the caches, 16 bytes of it read.
+// The sectors/s this reaches is the ceiling a hash-probe kernel (one 8-byte bucket header per probe) can be held against.
+__global__ void __launch_bounds__(256) xm_random_gather_kernel(const uint4* table, unsigned long long nSectors, long long nAccesses, int perThread, unsigned long long seed,
+                                                               unsigned int* sink) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  for (int k = 0; k < perThread; k++) {
+    long long a = t * perThread + k;
+    if (a >= nAccesses) break;
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(a + 1);  // SplitMix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    uint4 v = table[(z % nSectors) * 4];
+    acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;  // keeps the loads alive
+}
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -656,15 +675,15 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     int launches = 0;
     int64_t rerun = 0;
     const size_t arenaUnit = 288 * 1024;
-    static const long long scratchGiBWanted = envInt("XM_SCRATCH_GIB", 200);
-    static const long long lightWaves = envInt("XM_LIGHT_WAVES", 8), fullWaves = envInt("XM_FULL_WAVES", 4), pathWaves = envInt("XM_PATH_WAVES", 4);
-    static const long long fullLpw = envInt("XM_FULL_LPW", 32), lightLpw = envInt("XM_LIGHT_LPW", 64);
-    static const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
-    static const long long lightLevel = envInt("XM_LIGHT_LEVEL", 0);  // what the light pass still does itself (Caps::heavyAllowed)
-    static const long long taperWaves = envInt("XM_TAPER_PCT", 100);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
+    const long long scratchGiBWanted = envInt("XM_SCRATCH_GIB", 200);
+    const long long lightWaves = envInt("XM_LIGHT_WAVES", 8), fullWaves = envInt("XM_FULL_WAVES", 4), pathWaves = envInt("XM_PATH_WAVES", 4);
+    const long long fullLpw = envInt("XM_FULL_LPW", 32), lightLpw = envInt("XM_LIGHT_LPW", 64);
+    const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
+    const long long lightLevel = envInt("XM_LIGHT_LEVEL", 0);  // what the light pass still does itself (Caps::heavyAllowed)
+    const long long taperWaves = envInt("XM_TAPER_PCT", 100);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
     // a search round costs two launches whose time is the time of one read (a replay, a search) however few reads wait; once the
     // waiting reads no longer fill the GPU the rest is cheaper inline: one last chain pass, one read per wave
-    static const long long deferMaxRounds = envInt("XM_DEFER_ROUNDS", 3), inlineBelow = envInt("XM_INLINE_BELOW", 8192);
+    const long long deferMaxRounds = envInt("XM_DEFER_ROUNDS", 3), inlineBelow = envInt("XM_INLINE_BELOW", 8192);
     auto scratchLanes = [&](size_t arenaBytes) -> long long {  // scratch: up to 200 GiB of the 288 GiB HBM, never more than 3/4 of what is free
       long long scratchGiB = scratchGiBWanted;
       size_t freeB = 0, totalB = 0;
@@ -713,7 +732,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       res->counters[!heavy ? 12 : (defer ? 13 : 15)] += (int64_t)(ms * 1000.0);  // kernel microseconds: light pass / gapped chain passes / inline reruns
       launches++;
       memoFresh = false;
-      static const bool tracePasses = envInt("XM_TRACE_PASSES", 0) != 0;
+      const bool tracePasses = envInt("XM_TRACE_PASSES", 0) != 0;
       if (tracePasses) fprintf(stderr, "[xm] pass %d: %s reads %lld scale %d lpw %d waves %lld: %.3f ms -> heavy %llu path %llu scale %llu out %llu\n", launches, !heavy ? "light" : (defer ? "chain" : "inline"),
                                nTodo, scale, lpw, nWaves, ms, ctl.nHeavy, ctl.nPath[tp], ctl.nScale[ts], ctl.nOut[to]);
       if (ctl.errQuery != ~0ull) {
@@ -865,6 +884,38 @@ int xm_seed_probe(xm_index* idx, int64_t n, const int32_t* usedLength, const int
     dUsed.release(); dKeys.release(); dCounts.release(); dPos.release();
     return 0;
   } catch (std::exception& e) { return fail(std::string("xm_seed_probe: ") + e.what()); }
+}
+
+int xm_measure_random_gather(int device, int64_t table_bytes, int64_t accesses, double* kernel_ms) {
+  try {
+    HIP_CHECK(hipSetDevice(device));
+    if (table_bytes < 4096 || accesses < 1) return fail("xm_measure_random_gather: bad arguments");
+    DevBuf<uint4> table;
+    DevBuf<unsigned int> sink;
+    const size_t nSectors = (size_t)table_bytes / 64;
+    table.ensure(nSectors * 4);
+    sink.ensure(1);
+    HIP_CHECK(hipMemset(table.p, 0, nSectors * 64));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    const int perThread = 4;
+    const long long threads = (accesses + perThread - 1) / perThread;
+    float best = 0;
+    for (int rep = 0; rep < 3; rep++) {  // first repetition warms up
+      HIP_CHECK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(xm_random_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, table.p, (unsigned long long)nSectors, (long long)accesses, perThread,
+                         0x5EED0000ull + rep, sink.p);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipEventRecord(e1, 0));
+      HIP_CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep > 0 && (best == 0 || ms < best)) best = ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (kernel_ms) *kernel_ms = best;
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_measure_random_gather: ") + e.what()); }
 }
 
 }  // extern "C"

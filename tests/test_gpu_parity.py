@@ -66,6 +66,36 @@ def test_golden_digests_and_oracle_parity():
     db.close()
 
 
+PASS_SHAPES = [
+    {"XM_DEFER_PATH": "1"},                                                     # deferred PathAligner searches, default hand-over to the inline last pass
+    {"XM_DEFER_PATH": "1", "XM_DEFER_ROUNDS": "1000", "XM_INLINE_BELOW": "0"},  # every search through xm_path_kernel
+    {"XM_LIGHT_LEVEL": "1"},                                                    # light pass keeps the hash-block analysis
+    {"XM_TAPER_PCT": "0", "XM_FULL_LPW": "64"},                                 # no end-of-list taper, full waves in the gapped pass
+    {"XM_LIGHT_WAVES": "2", "XM_FULL_WAVES": "1", "XM_SCRATCH_GIB": "2"},       # few lanes: every lane aligns many reads in turn
+]
+
+
+@pytest.mark.parametrize("env", PASS_SHAPES, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_pass_shapes_do_not_change_results(env, monkeypatch):
+    """The pass sequence and launch shapes are scheduling only: every variant must return the oracle's streams bit for bit
+    (single-end with indels and a paired batch, so that the gapped chain, PathAligner and the join path all run)."""
+    ref = synth.synthetic_reference(300_000, seed=77)
+    reads, _, _ = synth.synthetic_single_end(ref, 6000, seed=78, indel_prob=0.3)
+    b = se_batch(reads)
+    m1, m2 = synth.synthetic_paired_end(ref, 1500, seed=79)[:2]
+    pb = pe_batch(m1, m2, 100.0, 50.0)
+    R = o.OracleReference([("r", ref)])
+    want, wantp = R.align(b, o.make_params()), R.align(pb, o.make_params())
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    db = api.ReferenceDatabase([("r", ref)])
+    got, _ = gpu_align(db, b)
+    assert streams_equal(got, want), first_difference(got, want, len(reads))
+    gotp, _ = gpu_align(db, pb)
+    assert streams_equal(gotp, wantp), first_difference(gotp, wantp, 1500)
+    db.close()
+
+
 def test_edge_cases_on_gpu():
     rng = np.random.default_rng(3)
     c0 = synth.synthetic_reference(60_000, seed=11)
