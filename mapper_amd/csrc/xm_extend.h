@@ -343,7 +343,7 @@ static_assert(XM_PAL_SLOT_BYTES * 4 <= 40 * 1024, "four waves per workgroup, fou
 
 #if defined(__HIP_DEVICE_COMPILE__)
 __shared__ __attribute__((aligned(16))) uint8_t xm_pal_lds[4 * XM_PAL_SLOT_BYTES];
-XM_INL uint8_t* palSlot() { return xm_pal_lds + (threadIdx.x >> 6) * XM_PAL_SLOT_BYTES; }
+XM_INL uint8_t* palSlot() { return xm_pal_lds + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * XM_PAL_SLOT_BYTES; }
 #else
 XM_INL uint8_t* palSlot() { static thread_local double slot[XM_PAL_SLOT_BYTES / 8]; return (uint8_t*)slot; }  // host simulation (tests only)
 #endif
@@ -661,6 +661,22 @@ XM_INL bool paCanRemoveSection(const ABlock& b) {  // :358-366
   return false;
 }
 
+// LDS-mode searches run one lane at a time (pathAlign's loop over the lanes of the wave), so everything the search computes is the
+// same in all its active lanes.  Passing the inputs through readfirstlane tells the compiler so: branches become scalar branches
+// (no exec-mask bookkeeping) and the integer bookkeeping moves to the scalar unit.
+#if defined(__HIP_DEVICE_COMPILE__)
+XM_INL int32_t uniI(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+XM_INL uint64_t uniU64(uint64_t v) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+#else
+XM_INL int32_t uniI(int32_t v) { return v; }
+XM_INL uint64_t uniU64(uint64_t v) { return v; }
+#endif
+XM_INL double uniD(double v) { uint64_t b; __builtin_memcpy(&b, &v, 8); b = uniU64(b); __builtin_memcpy(&v, &b, 8); return v; }
+template <typename T> XM_INL T* uniP(T* p) { return (T*)uniU64((uint64_t)p); }
+
 // What PathAligner.align is given: the two texts (as views), the sections, the parameters and the analysis scalars
 struct PaProblem {
   const uint8_t* qBase; int32_t qLen; bool qRc; const uint8_t* rBase; int32_t referenceLen;
@@ -672,15 +688,28 @@ struct PaProblem {
 // PathAligner.align :55-293 up to and including justify: the search, the traceback and the final block list (outBlocks[0..nbOut)).
 // false = null (or *status set).  LDS mode: *ldsOverflow = true means "does not fit the slot, nothing decided".
 template <bool LDS>
-XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, int32_t* status, DevCounters* dc, ABlock* const outBlocks, int32_t& nbOut, bool* ldsOverflow) {
+XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, int32_t* status, DevCounters* dc, ABlock* const outBlocksIn, int32_t& nbOut, bool* ldsOverflow) {
   XM_TIC(tPath);
   // by-value copies: anything read through a reference inside a loop that also stores would be re-loaded (and waited for) on
   // every iteration, because the compiler cannot prove the store does not alias it
-  const PaProblem pr = prIn;
+  PaProblem pr = prIn;
+  Caps caps = capsIn;
+  ABlock* outBlocks = outBlocksIn;
+  if constexpr (LDS) {
+    pr.qBase = uniP(pr.qBase); pr.rBase = uniP(pr.rBase); pr.qLen = uniI(pr.qLen); pr.qRc = uniI(pr.qRc ? 1 : 0) != 0; pr.referenceLen = uniI(pr.referenceLen);
+    pr.qs.start = uniI(pr.qs.start); pr.qs.end = uniI(pr.qs.end); pr.rs.start = uniI(pr.rs.start); pr.rs.end = uniI(pr.rs.end);
+    Params& q = pr.params;
+    q.MutationPenalty = uniD(q.MutationPenalty); q.InsertionStart_Penalty = uniD(q.InsertionStart_Penalty); q.InsertionExtension_Penalty = uniD(q.InsertionExtension_Penalty);
+    q.DeletionStart_Penalty = uniD(q.DeletionStart_Penalty); q.DeletionExtension_Penalty = uniD(q.DeletionExtension_Penalty); q.MaxErrorRate = uniD(q.MaxErrorRate);
+    q.UnalignedPenalty = uniD(q.UnalignedPenalty); q.AmbiguityPenalty = uniD(q.AmbiguityPenalty); q.Max_PenaltySpan = uniD(q.Max_PenaltySpan);
+    q.MaxNumMatches = uniI(q.MaxNumMatches); q.StartingInsertionStartFree = uniI(q.StartingInsertionStartFree);
+    pr.confident = uniI(pr.confident ? 1 : 0) != 0; pr.maxInsExt = uniD(pr.maxInsExt); pr.maxDelExt = uniD(pr.maxDelExt); pr.predictedBestOffset = uniI(pr.predictedBestOffset);
+    caps.maxNodes = uniI(caps.maxNodes); caps.maxBuckets = uniI(caps.maxBuckets); caps.maxBlocks = uniI(caps.maxBlocks);
+    outBlocks = uniP(outBlocks);
+  }
   const Section qs = pr.qs, rs = pr.rs;
   const Params params = pr.params;
   size_t mark = tmp.used;
-  const Caps caps = capsIn;
   nbOut = 0;
   PathAlignerT<LDS> pa;
   pa.parameters = params;
@@ -700,7 +729,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
     if (pa.textALength > XM_PAL_TEXTA || pa.textBLength > XM_PAL_TEXTB || pa.textALength < 0 || pa.textBLength < 0) { *ldsOverflow = true; return false; }
     pa.maxNodes = imin(caps.maxNodes, XM_PAL_NODES);
     pa.maxBuckets = imin(caps.maxBuckets, XM_PAL_BUCKETS);
-    pa.nodes = arenaArray<PNode>(tmp, pa.maxNodes);
+    pa.nodes = uniP(arenaArray<PNode>(tmp, pa.maxNodes));
     if (tmp.overflow) { *status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
     uint8_t* const slot = palSlot();
     pa.Lhash = (uint32_t*)(slot + XM_PAL_OFF_HASH); pa.nCells = 0; pa.Lxy = (uint16_t*)(slot + XM_PAL_OFF_XY); pa.Lnext = (uint16_t*)(slot + XM_PAL_OFF_NEXT);

@@ -12,7 +12,7 @@
 namespace xm {
 
 // ---------------------------------------------------------------- pyramid
-struct PBlock {  // 16 bytes
+struct alignas(16) PBlock {  // 16 bytes, moved as one 16-byte word
   uint16_t start, len;
   int32_t fwd, rev;
   uint8_t flags;  // 1 requestMergeLeft, 2 requestMergeRight, 4 nextRequestMergeLeft, 8 nextRequestMergeRight
@@ -20,6 +20,21 @@ struct PBlock {  // 16 bytes
   int16_t extraGap;
 };
 enum : uint8_t { F_RML = 1, F_RMR = 2, F_NRML = 4, F_NRMR = 8 };
+// one 16-byte memory operation per block instead of one per field group (each lane's pyramid is in its own arena, so every
+// memory instruction of a wave touches 64 different lines: the instruction count is what the memory pipeline sees)
+struct alignas(16) PBlockWord { uint32_t w[4]; };
+XM_INL PBlock pbUnpack(const PBlockWord& v) {
+  PBlock b;
+  b.start = (uint16_t)(v.w[0] & 0xFFFFu); b.len = (uint16_t)(v.w[0] >> 16); b.fwd = (int32_t)v.w[1]; b.rev = (int32_t)v.w[2];
+  b.flags = (uint8_t)(v.w[3] & 0xFFu); b.gapDir = (int8_t)((v.w[3] >> 8) & 0xFFu); b.extraGap = (int16_t)(v.w[3] >> 16);
+  return b;
+}
+XM_INL PBlockWord pbPack(const PBlock& b) {
+  PBlockWord v;
+  v.w[0] = (uint32_t)b.start | ((uint32_t)b.len << 16); v.w[1] = (uint32_t)b.fwd; v.w[2] = (uint32_t)b.rev;
+  v.w[3] = (uint32_t)b.flags | ((uint32_t)(uint8_t)b.gapDir << 8) | ((uint32_t)(uint16_t)b.extraGap << 16);
+  return v;
+}
 
 XM_INL int maxGapmerNumBasepairsUsed(int startingLength) { return startingLength + startingLength * 9 / 8 + 1; }  // M/HashBlock.java:11-13
 
@@ -184,7 +199,7 @@ struct Pyramid {
       const int base = prev == 0 ? 0 : levelStart[prev];
       bool ovf = false;
       if (n > 1 && prev == 0) {  // level 1 from the bases themselves
-        XM_GLOBAL(PBlock)* const dst = (XM_GLOBAL(PBlock)*)blk;
+        XM_GLOBAL(PBlockWord)* const dst = (XM_GLOBAL(PBlockWord)*)blk;
         PBlock L = level0Block(sq.at(0), 0);
         for (int i0 = 0; i0 + 1 < n && !ovf; i0 += 8) {
           uint8_t codes[8];
@@ -197,7 +212,7 @@ struct Pyramid {
               const PBlock R = level0Block(codes[k], i0 + 1 + k);
               if (shouldMergeBlocks(L, R)) {
                 if (w >= capL) ovf = true;
-                else dst[w++] = mergeBlocks(L, R);
+                else dst[w++] = pbPack(mergeBlocks(L, R));
               }
               L = R;
             }
@@ -206,21 +221,21 @@ struct Pyramid {
       } else if (n > 1) {
         // The new level is appended behind the level it is made from, so the blocks read never alias the blocks written: eight
         // reads are issued together (one memory round trip instead of eight dependent ones; the lane's arena is in HBM)
-        XM_GLOBAL(const PBlock)* const src = (XM_GLOBAL(const PBlock)*)(blk + base);
-        XM_GLOBAL(PBlock)* const dst = (XM_GLOBAL(PBlock)*)blk;
-        PBlock L = src[0];
+        XM_GLOBAL(const PBlockWord)* const src = (XM_GLOBAL(const PBlockWord)*)(blk + base);
+        XM_GLOBAL(PBlockWord)* const dst = (XM_GLOBAL(PBlockWord)*)blk;
+        PBlock L = pbUnpack(src[0]);
         for (int i0 = 0; i0 + 1 < n && !ovf; i0 += 8) {
-          PBlock buf[8];
+          PBlockWord buf[8];
           const int m = imin(8, n - 1 - i0);
 #pragma unroll
           for (int k = 0; k < 8; k++) buf[k] = src[i0 + 1 + (k < m ? k : 0)];
 #pragma unroll
           for (int k = 0; k < 8; k++) {
             if (k < m && !ovf) {
-              const PBlock R = buf[k];
+              const PBlock R = pbUnpack(buf[k]);
               if (shouldMergeBlocks(L, R)) {
                 if (w >= capL) ovf = true;
-                else dst[w++] = mergeBlocks(L, R);
+                else dst[w++] = pbPack(mergeBlocks(L, R));
               }
               L = R;
             }
