@@ -11,7 +11,7 @@
 
 namespace xm {
 
-struct ABlock { int32_t startA, startB, lenA, lenB; };  // AlignedBlock
+struct alignas(16) ABlock { int32_t startA, startB, lenA, lenB; };  // AlignedBlock; moved as one 16-byte word
 XM_INL int abEndA(const ABlock& b) { return b.startA + b.lenA; }
 XM_INL int abEndB(const ABlock& b) { return b.startB + b.lenB; }
 XM_INL int abIndelType(const ABlock& b) { return b.lenA == b.lenB ? 0 : (b.lenA > b.lenB ? 1 : 2); }
@@ -198,7 +198,14 @@ XM_INL int matcherEncodeBlock(const Matcher& m, const SeqView& s, int index) {  
 // them after every store it cannot disambiguate; locals stay in registers.
 XM_NOINL void matcherIndexSection(const Matcher m, const SeqView ref, int sectionIndex, int16_t* section, DevCounters* dc) {  // :40-77
   XM_TIC(t0);
-  for (int i = 0; i < m.numPossibilities; i++) section[i] = M_NO_MATCHES;
+  {  // numPossibilities is a power of four >= 64 and the tables are 16-byte aligned: fill with 16-byte stores
+    struct alignas(16) W { uint32_t w[4]; };
+    W* const t = (W*)section;
+    W v;
+    v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0xFFFFFFFFu;  // M_NO_MATCHES (-1) in every int16
+    const int nW = m.numPossibilities / 8;
+    for (int i = 0; i < nW; i++) t[i] = v;
+  }
   int previousEncoded = M_UNKNOWN;
   int startIndex = m.referenceStart + sectionIndex * m.sectionLength;
   int endIndex = imin(startIndex + m.sectionLength, m.referenceStart + m.referenceLength - m.blockLength);

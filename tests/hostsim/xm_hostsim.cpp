@@ -84,8 +84,8 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       static const bool inlineOnly = getenv("XMSIM_INLINE") && atoi(getenv("XMSIM_INLINE")) != 0;
       int scale = 1;
       int stage = inlineOnly ? 2 : 0;  // 0 light, 1 deferred gapped, 2 inline
-      std::vector<double> memoBuf(XM_MEMO_SLOT_BYTES / 8);
-      MemoHdr* memo = (MemoHdr*)memoBuf.data();
+      std::vector<double> memoBuf(XM_MEMO_SLOT_BYTES / 8 + 2);
+      MemoHdr* memo = (MemoHdr*)(((uintptr_t)memoBuf.data() + 15) & ~(uintptr_t)15);
       static const int deferRounds = getenv("XMSIM_DEFER_ROUNDS") ? atoi(getenv("XMSIM_DEFER_ROUNDS")) : 2;  // then searches run inline, as the product's last chain pass
       int rounds = 0;
       static const int lightLevel = getenv("XMSIM_LIGHT_LEVEL") ? atoi(getenv("XMSIM_LIGHT_LEVEL")) : 0;
