@@ -69,9 +69,10 @@ static long long envInt(const char* name, long long dflt) {
 // One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed, int lanesPerWave,
                                                        uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters,
-                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit) {
+                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync) {
   // lanesPerWave < 64 (gapped pass): the extension chain diverges so much that a wave runs its reads nearly one after another, so
   // spreading them over more, partly filled waves shortens the critical path; the idle lanes own no scratch arena
+  xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
   const int laneInWave = (int)(threadIdx.x & 63u);
   if (laneInWave >= lanesPerWave) return;
   unsigned long long lane = ((unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (unsigned)lanesPerWave + (unsigned)laneInWave;
@@ -87,8 +88,21 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
       long long remaining = nTodo - (long long)__hip_atomic_load(nextItem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (remaining < (long long)laneInWave * taperUnit) break;
     }
-    unsigned long long item = atomicAdd(nextItem, 1ull);
-    if ((long long)item >= nTodo) break;
+    unsigned long long item;
+    if (waveSync) {
+      // Light pass: the lanes of a wave take their next reads together and meet again before the following batch, so that the
+      // pyramids are built and the index is walked in step (lanes that each fetched a new read whenever they finished drifted apart,
+      // and most of the wave then executed one read at a time)
+      unsigned long long first = 0;
+      if (laneInWave == 0) first = atomicAdd(nextItem, (unsigned long long)lanesPerWave);
+      first = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)first);
+      if ((long long)first >= nTodo) break;
+      item = first + (unsigned)laneInWave;
+      if ((long long)item >= nTodo) continue;  // (the next batch is past the end for everybody)
+    } else {
+      item = atomicAdd(nextItem, 1ull);
+      if ((long long)item >= nTodo) break;
+    }
     int64_t q = todo ? todo[item] : (int64_t)item;
     ReadIn in;
     in.nMates = batch.mateCount[q];
@@ -679,6 +693,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const long long lightWaves = envInt("XM_LIGHT_WAVES", 8), fullWaves = envInt("XM_FULL_WAVES", 4), pathWaves = envInt("XM_PATH_WAVES", 4);
     const long long fullLpw = envInt("XM_FULL_LPW", 32), lightLpw = envInt("XM_LIGHT_LPW", 64);
     const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
+    const bool lightSync = envInt("XM_LIGHT_SYNC", 0) != 0;  // lanes of a light-pass wave take reads together (measured: no gain)
     const long long lightLevel = envInt("XM_LIGHT_LEVEL", 0);  // what the light pass still does itself (Caps::heavyAllowed)
     const long long taperWaves = envInt("XM_TAPER_PCT", 100);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
     // a search round costs two launches whose time is the time of one read (a replay, a search) however few reads wait; once the
@@ -717,7 +732,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
                          idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
                          defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
-                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll);
+                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, (!heavy && lightSync) ? 1 : 0);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,

@@ -64,6 +64,67 @@ XM_INL bool shouldMergeBlocks(const B& l, const B& r) {  // M/HashBlock_ParentRo
   return (l.flags & F_RMR) || (r.flags & F_RML);
 }
 
+// The merge flags and the gap direction of a merged block (M/HashBlock.java:192-259) depend on five small facts only: which parent
+// anchors (L.fwd vs R.rev), the order of the merged hashes, the two "next" flags of either parent and the order of the parents'
+// lengths.  The rule is evaluated once per combination at compile time; a merge then costs two hashes and one table read (the
+// branchy rule itself was ~3/4 of the instructions of building a read's pyramid).
+//   anchor: 0 none, 1 left parent, 2 right parent;  fr: 0 fwd<rev, 1 equal, 2 fwd>rev;  aBits/oBits: bit0 nextRequestMergeLeft,
+//   bit1 nextRequestMergeRight of the anchor / the other parent;  lc: 0 L.len<R.len, 1 equal, 2 L.len>R.len
+//   result: bits 0-3 the four flags, bits 4-5 gapDirection + 1
+constexpr uint8_t mergeRule(int anchor, int fr, int aBits, int oBits, int lc) {
+  bool rml = true, rmr = true, nrml = true, nrmr = true;
+  if (anchor != 0 && fr != 1) {
+    bool anchorIsRight = anchor == 2;
+    bool isReverse = fr == 0;
+    bool invert = isReverse == anchorIsRight;
+    bool aL = (aBits & 1) != 0, aR = (aBits & 2) != 0;
+    if (aL && aR) { if (anchorIsRight) aR = false; else aL = false; }
+    bool oL = (oBits & 1) != 0, oR = (oBits & 2) != 0;
+    if (oL && oR) { if (!anchorIsRight) oL = false; else oR = false; }  // otherParent == rightParent <=> anchor is left
+    rml = aL != invert;
+    rmr = aR != invert;
+    nrml = oL != invert;
+    nrmr = oR != invert;
+  }
+  if (lc != 1) {
+    rml = lc == 2;
+    rmr = !rml;
+    nrml = !rml;
+    nrmr = !nrml;
+  }
+  if (fr != 1) {
+    if (rml && rmr) { rml = fr == 2; rmr = !rml; }
+    if (nrml && nrmr) { nrml = rml; nrmr = !nrml; }
+  }
+  int gd = 0;
+  if (rml != rmr) gd = rml ? 1 : -1;
+  else if (anchor != 0) gd = (anchor == 2) ? 1 : -1;
+  return (uint8_t)((rml ? F_RML : 0) | (rmr ? F_RMR : 0) | (nrml ? F_NRML : 0) | (nrmr ? F_NRMR : 0) | ((gd + 1) << 4));
+}
+struct MergeRuleTable { uint8_t v[3 * 3 * 4 * 4 * 3]; };
+constexpr MergeRuleTable makeMergeRuleTable() {
+  MergeRuleTable t{};
+  for (int anchor = 0; anchor < 3; anchor++) for (int fr = 0; fr < 3; fr++) for (int a = 0; a < 4; a++) for (int o = 0; o < 4; o++) for (int lc = 0; lc < 3; lc++)
+    t.v[(((anchor * 3 + fr) * 4 + a) * 4 + o) * 3 + lc] = mergeRule(anchor, fr, a, o, lc);
+  return t;
+}
+static constexpr MergeRuleTable kMergeRuleHost = makeMergeRuleTable();
+#if defined(__HIPCC__)
+static __device__ const MergeRuleTable kMergeRuleDev = makeMergeRuleTable();
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// the kernel copies the table into LDS before anything else (xmLoadMergeRule): a table read is then ~64 cycles, next to the hashes
+__shared__ uint8_t xm_merge_rule_lds[sizeof(MergeRuleTable)];
+XM_INL void xmLoadMergeRule() {
+  for (int i = (int)threadIdx.x; i < (int)sizeof(MergeRuleTable); i += (int)blockDim.x) xm_merge_rule_lds[i] = kMergeRuleDev.v[i];
+  __syncthreads();
+}
+XM_INL uint8_t mergeRuleLookup(int idx) { return xm_merge_rule_lds[idx]; }
+#else
+XM_INL void xmLoadMergeRule() {}
+XM_INL uint8_t mergeRuleLookup(int idx) { return kMergeRuleHost.v[idx]; }
+#endif
+
 template <typename B>
 XM_INL B mergeBlocks(const B& L, const B& R) {  // M/HashBlock.java:20-44,192-259
   B b;
@@ -72,39 +133,14 @@ XM_INL B mergeBlocks(const B& L, const B& R) {  // M/HashBlock.java:20-44,192-25
   b.len = (decltype(b.len))len;
   b.fwd = mergeHash(L.len, L.fwd, R.len, R.fwd);
   b.rev = mergeHash(R.len, R.rev, L.len, L.rev);
-  bool rml = true, rmr = true, nrml = true, nrmr = true;
-  int anchor = 0;  // 0 none, 1 left parent, 2 right parent
-  if (L.fwd != R.rev) anchor = (L.fwd > R.rev) ? 2 : 1;
-  if (anchor != 0 && b.fwd != b.rev) {
-    const B& A = (anchor == 2) ? R : L;
-    const B& O = (anchor == 2) ? L : R;
-    bool anchorIsRight = anchor == 2;
-    bool isReverse = b.fwd < b.rev;
-    bool invert = isReverse == anchorIsRight;
-    bool aL = (A.flags & F_NRML) != 0, aR = (A.flags & F_NRMR) != 0;
-    if (aL && aR) { if (anchorIsRight) aR = false; else aL = false; }
-    bool oL = (O.flags & F_NRML) != 0, oR = (O.flags & F_NRMR) != 0;
-    if (oL && oR) { if (!anchorIsRight) oL = false; else oR = false; }  // otherParent == rightParent <=> anchor is left
-    rml = aL != invert;
-    rmr = aR != invert;
-    nrml = oL != invert;
-    nrmr = oR != invert;
-  }
-  if (L.len != R.len) {
-    rml = L.len > R.len;
-    rmr = !rml;
-    nrml = !rml;
-    nrmr = !nrml;
-  }
-  if (b.fwd != b.rev) {
-    if (rml && rmr) { rml = b.fwd > b.rev; rmr = !rml; }
-    if (nrml && nrmr) { nrml = rml; nrmr = !nrml; }
-  }
-  b.flags = (uint8_t)((rml ? F_RML : 0) | (rmr ? F_RMR : 0) | (nrml ? F_NRML : 0) | (nrmr ? F_NRMR : 0));
-  int gd = 0;
-  if (rml != rmr) gd = rml ? 1 : -1;
-  else if (L.fwd != R.rev) gd = (L.fwd > R.rev) ? 1 : -1;
-  b.gapDir = (int8_t)gd;
+  const int anchor = (L.fwd != R.rev) ? ((L.fwd > R.rev) ? 2 : 1) : 0;  // 0 none, 1 left parent, 2 right parent
+  const int fr = (b.fwd < b.rev) ? 0 : ((b.fwd == b.rev) ? 1 : 2);
+  const int lc = (L.len < R.len) ? 0 : ((L.len == R.len) ? 1 : 2);
+  const int lBits = (L.flags >> 2) & 3, rBits = (R.flags >> 2) & 3;  // F_NRML = 4, F_NRMR = 8
+  const int aBits = (anchor == 2) ? rBits : lBits, oBits = (anchor == 2) ? lBits : rBits;
+  const uint8_t rule = mergeRuleLookup((((anchor * 3 + fr) * 4 + aBits) * 4 + oBits) * 3 + lc);
+  b.flags = (uint8_t)(rule & 15);
+  b.gapDir = (int8_t)((int)(rule >> 4) - 1);
   b.extraGap = (int16_t)(((int)L.len + (int)R.len - len) / 4);
   return b;
 }
