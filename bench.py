@@ -142,6 +142,16 @@ def main():
                     "note": "algorithmic bytes: 8 B header per probe (+ %d B per fetched position); every probe touches one random 64 B sector, so the "
                             "sector ceiling (%.1f G sectors/s = %.0f GB/s of sector traffic) is the bound that applies" % (pos_bytes, sectors_per_s / 1e9, sectors_per_s * 64 / 1e9)}
 
+        # HBM bytes per launch from the PMC passes committed with this round's profiles (same command, scripts/gpu_profile_round.sh);
+        # only quoted for the workload they were collected on
+        traffic = None
+        try:
+            if (args.reads, args.ref_len, args.read_len) == (1_000_000, 5_000_000, 150):
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))
+                traffic = int(pm["hbm_bytes_per_launch"]["mean_over_the_two_launches_of_a_step"])
+        except Exception:
+            traffic = None
+
         value = world * nq * args.steps / elapsed / 1e6
         line = {
             "metric": "M reads/s aligned (150 bp)", "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
@@ -151,7 +161,7 @@ def main():
                        "reads_per_gpu": nq, "read_len": args.read_len, "reference_len": args.ref_len, "parallelism": "reads sharded x%d" % world,
                        "aligned_reads": aligned, "index_build_s": round(index_build_s, 3), "index_bytes": info["index_bytes"]},
             "roofline": {"bound": "hbm", "kernel": "xm_align_kernel", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 6), "traffic": None,
+                         "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                          "algorithmic_bytes_per_step": int(alg_bytes), "bytes_per_read": round(alg_bytes / nq, 1),
                          "kernel_ms_per_step": round(kernel_ms / args.steps, 3), "launches_per_step": launches / args.steps,
                          "result_d2h_ms_per_step": round(d2h_ms / args.steps, 3)},
