@@ -1,0 +1,259 @@
+"""Command-line harness in the shape of `java -jar x-mapper.jar` (Mapper.main, Mapper.java:37-453; Mapper.run :639-812) for the part
+of it that this repository accelerates: reference + queries in, alignments out as SAM.
+
+    python -m mapper_amd --reference ref.fasta --queries reads.fastq --out-sam out.sam
+    python -m mapper_amd --reference ref.fasta --paired-queries r1.fq r2.fq --spacing 100 50 --out-sam out.sam --out-unaligned un.fasta
+
+SURVEY.md section 8(f) rank 1.  What is pinned by the reference: the flag names and their defaults (Mapper.java:82-453), the
+derivation of AlignmentParameters from them (:409-453), reference sorting (:1151-1172), the SAM record format
+(SamWriter_Test.java) and the statistics lines of Mapper.run (:786-796).  The SAM header, `--out-unaligned` and the other writers
+live in the un-vendored QuickVariants module: the header written here is the minimal SAM-spec one and is marked [unpinned]; the
+VCF / mutations / ancestry / refs-map-count outputs stay with the Java host and are refused here with a message saying so.
+"""
+import gzip
+import sys
+
+import numpy as np
+
+from . import api, sam
+
+JAVA_HOST_ONLY = {"--out-vcf": 1, "--out-mutations": 1, "--out-ancestor": 1, "--out-refs-map-count": 1, "--cache-dir": 1,
+                  "--distinguish-query-ends": 1, "--split-queries-past-size": 1, "--infer-ancestors": 0, "--verify-consistent-db": 0,
+                  "--vcf-exclude-non-mutations": 0, "--vcf-omit-support-reads": 0}
+IGNORED = {"--verbose": 0, "-v": 0, "-vv": 0, "--verbose-alignment": 0, "--verbose-reference": 0, "--verbosity-auto": 0, "--num-threads": 1,
+           "--no-infer-ancestors": 0, "--allow-duplicate-contig-names": 0, "--version": 0}
+
+
+class UsageError(Exception):
+    pass
+
+
+def _open(path):
+    return gzip.open(path, "rt") if path.endswith(".gz") else open(path, "r")
+
+
+def read_sequences(path):
+    """FASTA or FASTQ (optionally .gz) -> list of (name, text, quality or None).  The name is the header up to the first blank."""
+    out = []
+    with _open(path) as f:
+        lines = f.read().splitlines()
+    i, n = 0, len(lines)
+    while i < n:
+        line = lines[i].rstrip("\r")
+        if not line:
+            i += 1
+            continue
+        if line[0] == ">":
+            name = line[1:].split()[0] if len(line) > 1 else ""
+            i += 1
+            parts = []
+            while i < n and not lines[i].startswith(">"):
+                parts.append(lines[i].strip())
+                i += 1
+            out.append((name, "".join(parts).upper(), None))
+        elif line[0] == "@":
+            name = line[1:].split()[0] if len(line) > 1 else ""
+            seq = lines[i + 1].strip().upper()
+            qual = lines[i + 3].strip() if i + 3 < n else ""
+            i += 4
+            out.append((name, seq, qual))
+        else:
+            raise ValueError("%s: line %d is neither a FASTA nor a FASTQ header" % (path, i + 1))
+    return out
+
+
+def parse_args(argv):
+    """Mapper.main's flag loop (Mapper.java:82-385) for the flags of this path."""
+    o = dict(references=[], queries=[], paired=[], out_sam=None, out_unaligned=None, no_output=False, enable_gapmers=True,
+             mutationPenalty=-1.0, indelStart_penalty=1.5, indelExtension_penalty=0.5, additional_insertionExtension_penalty=-1.0,
+             maxErrorRate=-1.0, ambiguityPenalty=-1.0, maxNumMatches=2**31 - 1, max_penaltySpan=-1.0, device=0,
+             paired_without_spacing=False, help=False)
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        if a == "--help":
+            o["help"] = True
+        elif a == "--reference":
+            o["references"].append(argv[i + 1]); i += 1
+        elif a == "--queries":
+            o["queries"].append(argv[i + 1]); i += 1
+        elif a == "--paired-queries":
+            left, right = argv[i + 1], argv[i + 2]
+            i += 2
+            expected, deviation = 100.0, 50.0  # Mapper.java:41-42
+            if i + 1 < len(argv) and argv[i + 1] == "--spacing":
+                expected, deviation = float(argv[i + 2]), float(argv[i + 3])
+                i += 3
+            else:
+                o["paired_without_spacing"] = True
+            o["paired"].append((left, right, expected, deviation))
+        elif a == "--out-sam":
+            o["out_sam"] = argv[i + 1]; i += 1
+        elif a == "--out-unaligned":
+            o["out_unaligned"] = argv[i + 1]; i += 1
+        elif a == "--no-output":
+            o["no_output"] = True
+        elif a == "--no-gapmers":
+            o["enable_gapmers"] = False
+        elif a == "--new-indel-penalty":
+            o["indelStart_penalty"] = float(argv[i + 1]); i += 1
+        elif a == "--extend-indel-penalty":
+            o["indelExtension_penalty"] = float(argv[i + 1]); i += 1
+        elif a == "--additional-extend-insertion-penalty":
+            o["additional_insertionExtension_penalty"] = float(argv[i + 1]); i += 1
+        elif a == "--snp-penalty":
+            o["mutationPenalty"] = float(argv[i + 1]); i += 1
+            if o["mutationPenalty"] <= 0:
+                raise UsageError("--snp-penalty must be > 0")
+        elif a == "--max-penalty":
+            o["maxErrorRate"] = float(argv[i + 1]); i += 1
+            if o["maxErrorRate"] < 0:
+                raise UsageError("--max-penalty must be >= 0")
+        elif a == "--max-penalty-span":
+            o["max_penaltySpan"] = float(argv[i + 1]); i += 1
+            if o["max_penaltySpan"] < 0:
+                raise UsageError("--max-penalty-span must be >= 0")
+        elif a == "--ambiguity-penalty":
+            o["ambiguityPenalty"] = float(argv[i + 1]); i += 1
+            if o["ambiguityPenalty"] < 0:
+                raise UsageError("--ambiguity-penalty must be >= 0")
+        elif a == "--max-num-matches":
+            o["maxNumMatches"] = int(argv[i + 1]); i += 1
+        elif a == "--device":  # (not a Mapper flag) which GPU
+            o["device"] = int(argv[i + 1]); i += 1
+        elif a == "--spacing":
+            raise UsageError("--spacing is not a top-level argument: try --paired-queries <queries> <queries2> --spacing <expected> <distancePerPenalty>")
+        elif a in JAVA_HOST_ONLY:
+            raise UsageError("%s is handled by the Java host (VCF / mutation / ancestry / cache subsystems are outside the accelerated path, SURVEY.md section 8)" % a)
+        elif a in IGNORED:
+            i += IGNORED[a]
+        else:
+            raise UsageError("Unrecognized argument: " + a)
+        i += 1
+    return o
+
+
+def derive_parameters(o):
+    """Mapper.java:386-453: validation and the defaults that depend on other flags."""
+    if len(o["references"]) < 1:
+        raise UsageError("--reference is required")
+    if len(o["queries"]) + len(o["paired"]) < 1:
+        raise UsageError("--queries or --paired-queries is required")
+    if o["out_sam"] is None and o["out_unaligned"] is None and not o["no_output"]:
+        raise UsageError("No output specified. Try --out-sam <output path>, or if you really don't want to generate an output file, --no-output")
+    if o["maxErrorRate"] >= 0 and o["mutationPenalty"] >= 0 and o["paired_without_spacing"]:
+        raise UsageError("Customized alignment penalties (--snp-penalty) and penalty threshold (--max-penalty) without customizing spacing penalty "
+                         "between paired-end queries: please specify --spacing explicitly")
+    maxErrorRate = o["maxErrorRate"] if o["maxErrorRate"] >= 0 else 0.1
+    mutationPenalty = o["mutationPenalty"] if o["mutationPenalty"] > 0 else 1.0
+    if o["indelExtension_penalty"] <= 0:
+        raise UsageError("--extend-indel-penalty must be > 0")
+    if o["indelStart_penalty"] <= 0:
+        raise UsageError("--new-indel-penalty must be > 0")
+    if o["maxNumMatches"] < 1:
+        raise UsageError("--max-num-matches must be >= 1")
+    span = o["max_penaltySpan"] if o["max_penaltySpan"] >= 0 else mutationPenalty / 2
+    ambiguity = o["ambiguityPenalty"] if o["ambiguityPenalty"] >= 0 else maxErrorRate
+    additional = o["additional_insertionExtension_penalty"] if o["additional_insertionExtension_penalty"] >= 0 else ambiguity
+    return api.AlignmentParameters(MutationPenalty=mutationPenalty, DeletionStart_Penalty=o["indelStart_penalty"], DeletionExtension_Penalty=o["indelExtension_penalty"],
+                                   InsertionStart_Penalty=o["indelStart_penalty"], InsertionExtension_Penalty=o["indelExtension_penalty"] + additional,
+                                   MaxErrorRate=maxErrorRate, AmbiguityPenalty=ambiguity, UnalignedPenalty=ambiguity, MaxNumMatches=o["maxNumMatches"],
+                                   Max_PenaltySpan=span)
+
+
+def load_queries(o):
+    """-> list of (api.Query, qualities or None) in input order: --queries files first, then --paired-queries files, as Mapper.main adds them."""
+    out = []
+    for path in o["queries"]:
+        for name, text, qual in read_sequences(path):
+            out.append((api.Query(text, name=name), [qual]))
+    for left, right, expected, deviation in o["paired"]:
+        ls, rs = read_sequences(left), read_sequences(right)
+        if len(ls) != len(rs):
+            raise UsageError("paired query files have different numbers of reads: %s %d, %s %d" % (left, len(ls), right, len(rs)))
+        for (n1, t1, q1), (n2, t2, q2) in zip(ls, rs):
+            out.append((api.Query(t1, t2, expected_inner_distance=expected, spacing_deviation_per_unit_penalty=deviation, names=[n1, n2]), [q1, q2]))
+    return out
+
+
+def java_float(x):
+    """Float.toString of (float)x for the statistics lines: shortest decimal that round-trips the 32-bit value."""
+    t = str(np.float32(x))
+    return t if ("." in t or "e" in t or "n" in t) else t + ".0"
+
+
+def sam_header(contigs):
+    """[unpinned: SamWriter is un-vendored] minimal SAM-spec header: @HD, one @SQ per contig in the order of the reference files, @PG."""
+    lines = ["@HD\tVN:1.6\tSO:unsorted"]
+    lines += ["@SQ\tSN:%s\tLN:%d" % (name, len(text)) for name, text in contigs]
+    lines.append("@PG\tID:xmapper-mi355x\tPN:xmapper-mi355x")
+    return lines
+
+
+def run(argv, out=sys.stdout):
+    o = parse_args(argv)
+    if o["help"] or not argv:
+        out.write(__doc__ + "\n")
+        return 0
+    params = derive_parameters(o)
+    contigs = []
+    for path in o["references"]:
+        contigs += [(name, text) for name, text, _ in read_sequences(path)]
+    out.write("%d reference files:\n" % len(o["references"]))
+    for path in o["references"]:
+        out.write("Reference path = %s\n" % path)
+    queries = load_queries(o)
+    ordered = api.sort_reference(contigs)  # Mapper.sortAndComplementReference: alignment results refer to this order
+    names = [n for n, _ in ordered]
+    db = api.ReferenceDatabase(ordered, mode="mapper", enable_gapmers=o["enable_gapmers"], device=o["device"],
+                               max_query_length=max([len(s) for q, _ in queries for s in q.sequences] + [1]))
+    result = db.align_batch([q for q, _ in queries], params)
+    sam_out = None
+    if o["out_sam"]:
+        sam_out = sys.stdout if o["out_sam"] == "-" else open(o["out_sam"], "w")
+        sam_out.write("\n".join(sam_header(contigs)) + "\n")
+    un_out = open(o["out_unaligned"], "w") if o["out_unaligned"] else None
+    num_aligned = total_len = num_indels = 0
+    total_penalty = 0.0
+    for qi, (q, quals) in enumerate(queries):
+        comps = result.query_alignments(qi)
+        aligned = any(len(c) > 0 for c in comps)
+        if aligned:
+            num_aligned += 1
+            for comp in comps:  # AlignmentCounter [QuickVariants, inferred]: every reported alignment's aligned length, penalty and indels
+                for al in comp:
+                    for k, sa in enumerate(al.components):
+                        total_len += sum(b.lengthA for b in sa.sections)
+                        num_indels += sum(1 for b in sa.sections if b.lengthA != b.lengthB)
+                    total_penalty += al.penalty
+            if sam_out:
+                for line in sam.records(q, comps, names):
+                    sam_out.write(line + "\n")
+        elif un_out:  # [unpinned format] the query as it came in: FASTQ when it had qualities, else FASTA
+            for name, seq, qual in zip(q.names, q.sequences, quals):
+                text = api.decode(seq)
+                un_out.write("@%s\n%s\n+\n%s\n" % (name, text, qual) if qual is not None else ">%s\n%s\n" % (name, text))
+    if sam_out and sam_out is not sys.stdout:
+        sam_out.close()
+    if un_out:
+        un_out.close()
+    n = len(queries)
+    out.write("\nStatistics: \n")
+    out.write(" Alignment rate                : %d%% of queries (%d/%d)\n" % (num_aligned * 100 // n if n else 0, num_aligned, n))
+    if total_len:
+        out.write(" Average penalty               : %s per base (%d/%d) in aligned queries\n" % (java_float(total_penalty / total_len), int(total_penalty), total_len))
+        out.write(" Num indels                    : %s per base (%d/%d) in aligned queries\n" % (java_float(num_indels / total_len), num_indels, total_len))
+    db.close()
+    return 0
+
+
+def main(argv=None):
+    try:
+        return run(sys.argv[1:] if argv is None else argv)
+    except UsageError as e:
+        sys.stderr.write("Error: %s\n" % e)
+        return 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
