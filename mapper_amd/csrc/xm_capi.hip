@@ -69,7 +69,7 @@ static long long envInt(const char* name, long long dflt) {
 // One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed, int lanesPerWave,
                                                        uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters,
-                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync) {
+                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync, long long firstStride) {
   // lanesPerWave < 64 (gapped pass): the extension chain diverges so much that a wave runs its reads nearly one after another, so
   // spreading them over more, partly filled waves shortens the critical path; the idle lanes own no scratch arena
   xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
@@ -80,28 +80,40 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
   DevCounters local;
   memset(&local, 0, sizeof(local));
   ReadCtx cx;
+  // Gapped pass: the list starts with the reads that look expensive.  The first read of every lane is dealt out lane-major (items
+  // 0..waves-1 to lane 0 of every wave, the next `waves` items to lane 1, ...), so that every wave gets the same number of them and
+  // they all start at once; after that the lanes draw from the counter, which the host has set behind the dealt items.
+  bool dealt = firstStride > 0;
+  const long long waveIndex = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   while (true) {
-    if (taperUnit > 0 && laneInWave > 0) {
-      // End of the work list (gapped pass): the lanes of a wave run their reads mostly one after the other, so when the list runs dry
-      // every wave would still hold lanesPerWave unfinished reads and the launch would end with that long serial tail.  The higher
-      // lanes therefore stop taking reads early; the last reads are spread one per wave.
-      long long remaining = nTodo - (long long)__hip_atomic_load(nextItem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (remaining < (long long)laneInWave * taperUnit) break;
-    }
     unsigned long long item;
-    if (waveSync) {
-      // Light pass: the lanes of a wave take their next reads together and meet again before the following batch, so that the
-      // pyramids are built and the index is walked in step (lanes that each fetched a new read whenever they finished drifted apart,
-      // and most of the wave then executed one read at a time)
-      unsigned long long first = 0;
-      if (laneInWave == 0) first = atomicAdd(nextItem, (unsigned long long)lanesPerWave);
-      first = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)first);
-      if ((long long)first >= nTodo) break;
-      item = first + (unsigned)laneInWave;
-      if ((long long)item >= nTodo) continue;  // (the next batch is past the end for everybody)
+    const long long mine = (long long)laneInWave * firstStride + waveIndex;
+    if (dealt && mine < nTodo) {
+      dealt = false;
+      item = (unsigned long long)mine;
     } else {
-      item = atomicAdd(nextItem, 1ull);
-      if ((long long)item >= nTodo) break;
+      dealt = false;
+      if (taperUnit > 0 && laneInWave > 0) {
+        // End of the work list (gapped pass): the lanes of a wave run their reads mostly one after the other, so when the list runs dry
+        // every wave would still hold lanesPerWave unfinished reads and the launch would end with that long serial tail.  The higher
+        // lanes therefore stop taking reads early; the last reads are spread one per wave.
+        long long remaining = nTodo - (long long)__hip_atomic_load(nextItem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (remaining < (long long)laneInWave * taperUnit) break;
+      }
+      if (waveSync) {
+        // Light pass: the lanes of a wave take their next reads together and meet again before the following batch, so that the
+        // pyramids are built and the index is walked in step (lanes that each fetched a new read whenever they finished drifted apart,
+        // and most of the wave then executed one read at a time)
+        unsigned long long first = 0;
+        if (laneInWave == 0) first = atomicAdd(nextItem, (unsigned long long)lanesPerWave);
+        first = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)first);
+        if ((long long)first >= nTodo) break;
+        item = first + (unsigned)laneInWave;
+        if ((long long)item >= nTodo) continue;  // (the next batch is past the end for everybody)
+      } else {
+        item = atomicAdd(nextItem, 1ull);
+        if ((long long)item >= nTodo) break;
+      }
     }
     int64_t q = todo ? todo[item] : (int64_t)item;
     ReadIn in;
@@ -135,6 +147,11 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
         out.intOff[q] = (int64_t)io; out.dblOff[q] = (int64_t)dofs; out.intLen[q] = (int32_t)ni; out.dblLen[q] = (int32_t)nd;
       }
     }
+    if (st == XM_ST_NEED_HEAVY) {  // bits 8..15: cost hint (penalty x 8, capped) for the order of the gapped pass
+      float h = cx.heavyHint * 8.0f;
+      int hi = h > 255.0f ? 255 : (h > 0.0f ? (int)h : 0);
+      st |= hi << 8;
+    }
     out.status[q] = st;
   }
   addCounters(counters, local);
@@ -164,25 +181,37 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_path_kernel(const i
 // ---------------------------------------------------------------- pass bookkeeping on the device
 // After every pass the reads are sorted into the work lists of the passes still to come; only the list sizes travel to the host.
 struct PassCtl {
-  unsigned long long nHeavy, nScale[2], nOut[2], nPath[2];
+  unsigned long long nHeavy, nHeavyLate, nScale[2], nOut[2], nPath[2];
   unsigned long long errQuery;  // smallest query index whose status is an error (~0 = none)
 };
 
 __global__ void __launch_bounds__(256) xm_classify_kernel(const int64_t* todo, long long nTodo, const int32_t* status, int64_t* listHeavy, int64_t* listScale, int64_t* listOut,
-                                                          int64_t* listPath, int32_t* slotOf, PassCtl* ctl, int ts, int to, int tp) {
+                                                          int64_t* listPath, int64_t* listHeavyLate, int hintThreshold, PassCtl* ctl, int ts, int to, int tp) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nTodo) return;
   int64_t q = todo ? todo[i] : (int64_t)i;
-  int32_t st = status[q];
+  const int32_t word = status[q];
+  const int32_t st = word & 0xFF;
   if (st == XM_OK) return;
   if (st == XM_ST_NEED_HEAVY) {
-    unsigned long long slot = atomicAdd(&ctl->nHeavy, 1ull);
-    listHeavy[slot] = q;
-    slotOf[q] = (int32_t)slot;  // the read's memo slot in the gapped pass
+    // reads whose straight alignment was bad enough for an indel go to the front of the gapped pass: they are the long ones, and a
+    // launch ends with its longest wave (longest-processing-time-first)
+    if ((word >> 8) >= hintThreshold) listHeavy[atomicAdd(&ctl->nHeavy, 1ull)] = q;
+    else listHeavyLate[atomicAdd(&ctl->nHeavyLate, 1ull)] = q;
   } else if (st == XM_ST_NEED_PATH) listPath[atomicAdd(&ctl->nPath[tp], 1ull)] = q;
   else if (st == XM_ST_OVERFLOW) listScale[atomicAdd(&ctl->nScale[ts], 1ull)] = q;
   else if (st == XM_ST_OUT_OVERFLOW) listOut[atomicAdd(&ctl->nOut[to], 1ull)] = q;
   else atomicMin(&ctl->errQuery, (unsigned long long)q);
+}
+
+// the gapped pass's work list: expensive-looking reads first, then the others; a read's position is its memo slot
+__global__ void __launch_bounds__(256) xm_heavy_list_kernel(int64_t* listHeavy, long long nFront, const int64_t* listLate, long long nLate, int32_t* slotOf) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nFront + nLate) return;
+  int64_t q;
+  if (i < nFront) q = listHeavy[i];
+  else { q = listLate[i - nFront]; listHeavy[i] = q; }
+  slotOf[q] = (int32_t)i;
 }
 
 // Exclusive prefix sums of the per-query stream lengths (query order), three small kernels: block totals, scan of the totals,
@@ -391,7 +420,7 @@ struct xm_index {
   DevBuf<int64_t> dMateOffset, dIntOff, dDblOff, dTodo;
   DevBuf<double> dExpected, dDeviation, dOutDbls;
   DevBuf<unsigned long long> dCursors;  // [0],[1] result cursors, [2] next item
-  DevBuf<int64_t> dListHeavy, dListScale[2], dListOut[2], dListPath[2], dFinalIntOff, dFinalDblOff;
+  DevBuf<int64_t> dListHeavy, dListHeavyLate, dListScale[2], dListOut[2], dListPath[2], dFinalIntOff, dFinalDblOff;
   DevBuf<int32_t> dSlotOf;
   DevBuf<uint8_t> dMemo;
   DevBuf<PassCtl> dCtl;
@@ -657,7 +686,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
 
     idx->dStatus.ensure((size_t)nq); idx->dIntOff.ensure((size_t)nq); idx->dDblOff.ensure((size_t)nq); idx->dIntLen.ensure((size_t)nq); idx->dDblLen.ensure((size_t)nq);
     idx->dCursors.ensure(4); idx->dCounters.ensure(1); idx->dCtl.ensure(1);
-    idx->dListHeavy.ensure((size_t)nq);
+    idx->dListHeavy.ensure((size_t)nq); idx->dListHeavyLate.ensure((size_t)nq);
     HIP_CHECK(hipMemsetAsync(idx->dCounters.p, 0, sizeof(DevCounters), s));
     HIP_CHECK(hipMemsetAsync(idx->dCursors.p, 0, sizeof(unsigned long long) * 4, s));
     PassCtl ctl0;
@@ -695,6 +724,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
     const bool lightSync = envInt("XM_LIGHT_SYNC", 0) != 0;  // lanes of a light-pass wave take reads together (measured: no gain)
     const long long lightLevel = envInt("XM_LIGHT_LEVEL", 0);  // what the light pass still does itself (Caps::heavyAllowed)
+    const long long heavyHintThreshold = envInt("XM_HEAVY_HINT", 0);  // straight-alignment penalty x 8 from which a read is put first in the gapped pass and dealt out evenly (0: no order; measured: no gain, the pass is bound by the work per wave, not by its balance)
     const long long taperWaves = envInt("XM_TAPER_PCT", 100);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
     // a search round costs two launches whose time is the time of one read (a replay, a search) however few reads wait; once the
     // waiting reads no longer fill the GPU the rest is cheaper inline: one last chain pass, one read per wave
@@ -726,17 +756,20 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       lanes = (long long)grid * (block / 64) * lpw;
       idx->dArenas.ensure((size_t)lanes * arenaBytes);
       idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq); idx->dListPath[tp].ensure(defer ? (size_t)nTodo : 1);
-      HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
+      // gapped pass with an ordered list: the first read of every lane is dealt out (kernel), the counter starts behind those items
+      const long long firstStride = (heavy && !defer && heavyHintThreshold > 0 && scale == 4) ? (long long)grid * (block / 64) : 0;
+      const unsigned long long firstItem = (unsigned long long)std::min((long long)nTodo, firstStride * lpw);
+      HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 2, &firstItem, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
       HIP_CHECK(hipEventRecord(e0, s));
       hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
                          idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
                          defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
-                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, (!heavy && lightSync) ? 1 : 0);
+                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, (!heavy && lightSync) ? 1 : 0, firstStride);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,
-                         idx->dListOut[to].p, idx->dListPath[tp].p, idx->dSlotOf.p, idx->dCtl.p, ts, to, tp);
+                         idx->dListOut[to].p, idx->dListPath[tp].p, idx->dListHeavyLate.p, (int)heavyHintThreshold, idx->dCtl.p, ts, to, tp);
       HIP_CHECK(hipGetLastError());
       PassCtl ctl;
       HIP_CHECK(hipMemcpyAsync(&ctl, idx->dCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, s));
@@ -753,12 +786,13 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       if (ctl.errQuery != ~0ull) {
         int32_t code = 0;
         HIP_CHECK(hipMemcpy(&code, idx->dStatus.p + ctl.errQuery, sizeof(code), hipMemcpyDeviceToHost));
+        code &= 0xFF;
         std::string q = std::to_string(ctl.errQuery);
         if (code == XM_ST_AMBIGUOUS) throw std::runtime_error("Failed to align query " + q + ": it contains a non-ACGT base (MultiHashBlock path is not supported by this build)");
         if (code == XM_ST_NEED_GROW) throw std::runtime_error("Failed to align query " + q + ": gapmer longer than the hashed lengths");
         throw std::runtime_error("Failed to align query " + q + ": the reference implementation would have thrown here (status " + std::to_string(code) + ")");
       }
-      pendingHeavy = ctl.nHeavy;
+      pendingHeavy = ctl.nHeavy + ctl.nHeavyLate;
       pendingScale = ctl.nScale[ts];
       pendingPath = ctl.nPath[tp];
       if (ctl.nOut[to] > 0) {  // result arena too small: rerun those reads with the same settings and room to spare
@@ -811,8 +845,11 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       if (pendingHeavy > 0) {
         // the gapped pass runs at scale 4 straight away: far fewer lanes are needed than in the light pass, and most reads whose
         // gapped search outgrows the scale-1 scratch then finish here instead of costing one more (latency-bound) pass
+        hipLaunchKernelGGL(xm_heavy_list_kernel, dim3((unsigned)((pendingHeavy + 255) / 256)), dim3(256), 0, s, idx->dListHeavy.p, (long long)ctl.nHeavy, idx->dListHeavyLate.p,
+                           (long long)ctl.nHeavyLate, idx->dSlotOf.p);
+        HIP_CHECK(hipGetLastError());
         todo = idx->dListHeavy.p; nTodo = (long long)pendingHeavy;
-        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nHeavy, 0, sizeof(unsigned long long), s));  // (a gapped pass never adds to this list)
+        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nHeavy, 0, 2 * sizeof(unsigned long long), s));  // nHeavy, nHeavyLate (a gapped pass never adds to these lists)
         scale = 4;
         if (overflowScale < 4) overflowScale = 4;
         heavy = true;

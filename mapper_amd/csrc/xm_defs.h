@@ -59,6 +59,7 @@ XM_INL double jmaxd(double a, double b) {  // Math.max incl. NaN propagation
   return a > b ? a : b;
 }
 XM_INL int imin(int a, int b) { return a < b ? a : b; }
+XM_INL int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 XM_INL int imax(int a, int b) { return a > b ? a : b; }
 XM_INL int iabs(int a) { return a < 0 ? -a : a; }
 XM_INL double jnextUp(double d) {  // Math.nextUp

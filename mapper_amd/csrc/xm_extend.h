@@ -62,6 +62,7 @@ struct ExtEnv {  // everything the chain needs
   SeqView reference; // sequenceB (forward contig)
   int32_t contig;
   Matcher* slotA; Matcher* slotB; Matcher* slotT;
+  float* heavyHint;         // light pass: where a read that stops with XM_ST_NEED_HEAVY leaves its cost hint
   struct MemoHdr* memo;     // gapped pass with deferred PathAligner searches: the read's memo slot (null = searches run inline)
   int32_t* memoCursor;      // replay position in the memo log
 };
@@ -395,8 +396,12 @@ struct PathAlignerT {
   double maxInterestingPenalty, activePenalty;
   bool mayQueryExtendPastEndOfReference, searchReverse;
 
-  XM_INL uint8_t charAGlobal(int i) const { int k = startIndexA + i; return qRc ? bpComplement(qBase[qLen - 1 - k]) : qBase[k]; }
-  XM_INL uint8_t charBGlobal(int i) const { return rBase[startIndexB + i]; }
+  XM_INL uint8_t charAGlobal(int i) const {
+    XM_GLOBAL(const uint8_t)* const g = (XM_GLOBAL(const uint8_t)*)qBase;
+    int k = startIndexA + i;
+    return qRc ? bpComplement(g[qLen - 1 - k]) : g[k];
+  }
+  XM_INL uint8_t charBGlobal(int i) const { return ((XM_GLOBAL(const uint8_t)*)rBase)[startIndexB + i]; }
   XM_INL uint8_t charA(int i) const { if constexpr (LDS) return LtextA[i]; else return charAGlobal(i); }
   XM_INL uint8_t charB(int i) const { if constexpr (LDS) return LtextB[i]; else return charBGlobal(i); }
   XM_INL int signedDist(int x, int y) const { return x - y - diagonal; }
@@ -587,8 +592,14 @@ struct PathAlignerT {
     const PNode nU = nodes[up >= 0 ? up : 0];
     const PNode nD = nodes[diag >= 0 ? diag : 0];
     XM_PA_TOC(tLoad, t0);
+    // the six bases the three transitions can look at (three consecutive ones of either text): read up front, together, instead of
+    // one dependent read per branch; indices outside a text are clamped for the read and never used (the range tests below stay)
+    const int ia = x - 1, ib = y - 1;
+    const uint8_t a0 = charA(ia), b0 = charB(ib);
+    const uint8_t aPrev = charA(iclamp(ia - stepDelta, 0, textALength - 1)), aNext = charA(iclamp(ia + stepDelta, 0, textALength - 1));
+    const uint8_t bPrev = charB(iclamp(ib - stepDelta, 0, textBLength - 1)), bNext = charB(iclamp(ib + stepDelta, 0, textBLength - 1));
     double insertXPenalty = disallowed, insertYPenalty = disallowed, overlayPenalty = disallowed;
-    if (diag >= 0) overlayPenalty = nD.pen + parameters.getPenalty(charA(x - 1), charB(y - 1));
+    if (diag >= 0) overlayPenalty = nD.pen + parameters.getPenalty(a0, b0);
     if (left >= 0) {
       if (y == goalY && mayQueryExtendPastEndOfReference) {
         insertXPenalty = nL.pen + parameters.UnalignedPenalty;
@@ -596,12 +607,12 @@ struct PathAlignerT {
         bool allowed = true;
         int prevA = x - 1 - stepDelta, prevB = y - 1;
         if (prevA >= 0 && prevA < textALength && prevB >= 0 && prevB < textBLength) {
-          if (!bpCanMatch(charA(prevA), charB(prevB))) allowed = false;
+          if (!bpCanMatch(aPrev, b0)) allowed = false;
         }
         if (allowed) {
           int nextA = x - 1, nextB = y - 1 + stepDelta;
           if (nextA >= 0 && nextA < textALength && nextB >= 0 && nextB < textBLength) {
-            uint8_t a = charA(nextA), b = charB(nextB);
+            uint8_t a = a0, b = bNext;
             if (parameters.getPenalty(a, b) == 0) allowed = false;
             else if (bpIsFullyAmbiguous(a) || bpIsFullyAmbiguous(b)) allowed = false;
           }
@@ -615,12 +626,12 @@ struct PathAlignerT {
       bool allowed = true;
       int prevA = x - 1, prevB = y - 1 - stepDelta;
       if (prevA >= 0 && prevA < textALength && prevB >= 0 && prevB < textBLength) {
-        if (!bpCanMatch(charA(prevA), charB(prevB))) allowed = false;
+        if (!bpCanMatch(a0, bPrev)) allowed = false;
       }
       if (allowed) {
         int nextA = x - 1 + stepDelta, nextB = y - 1;
         if (nextA >= 0 && nextA < textALength && nextB >= 0 && nextB < textBLength) {
-          uint8_t a = charA(nextA), b = charB(nextB);
+          uint8_t a = aNext, b = b0;
           if (parameters.getPenalty(a, b) == 0) allowed = false;
           else if (bpIsFullyAmbiguous(a) || bpIsFullyAmbiguous(b)) allowed = false;
         }
@@ -747,8 +758,20 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
       for (int i = 0; i < XM_PAL_HASH * 4 / 8; i++) z1[i] = 0;
       uint64_t* const z2 = (uint64_t*)pa.Lbhash;
       for (int i = 0; i < XM_PAL_BHASH / 8; i++) z2[i] = 0;
-      for (int i = 0; i < pa.textALength; i++) pa.LtextA[i] = pa.charAGlobal(i);
-      for (int i = 0; i < pa.textBLength; i++) pa.LtextB[i] = pa.charBGlobal(i);
+      for (int i0 = 0; i0 < pa.textALength; i0 += 8) {  // eight loads in flight per round
+        uint8_t c[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = pa.charAGlobal(imin(i0 + k, pa.textALength - 1));
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (i0 + k < pa.textALength) pa.LtextA[i0 + k] = c[k];
+      }
+      for (int i0 = 0; i0 < pa.textBLength; i0 += 8) {
+        uint8_t c[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = pa.charBGlobal(imin(i0 + k, pa.textBLength - 1));
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (i0 + k < pa.textBLength) pa.LtextB[i0 + k] = c[k];
+      }
     }
   } else {
     pa.maxNodes = caps.maxNodes;
@@ -1486,7 +1509,13 @@ struct NextBlock {
 };
 struct NextHashBlock1 {
   XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const {
-    if (e.caps->heavyAllowed < 1) { *e.status = XM_ST_NEED_HEAVY; return false; }
+    if (e.caps->heavyAllowed < 1) {
+      // cost hint for the gapped pass: the penalty of the straight alignment that was not good enough (p.MaxErrorRate is that
+      // alignment's error rate here, StraightAligner :59-61).  A read with an indel mismatches on one whole side of it.
+      if (e.heavyHint) *e.heavyHint = (float)(p.MaxErrorRate * secLen(qs));
+      *e.status = XM_ST_NEED_HEAVY;
+      return false;
+    }
     // SkipHighAmbiguity_Aligner :13-28
     int numAmbiguities = 0;
     for (int i = rs.start; i < rs.end; i++) if (bpIsAmbiguous(e.reference.at(i))) numAmbiguities++;

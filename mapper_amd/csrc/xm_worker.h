@@ -48,6 +48,7 @@ struct ReadCtx {
   PathsCounter pc;
   MemoHdr* memo;        // deferred-search gapped pass: this read's memo slot (xm_extend.h), else null
   int32_t memoCursor;
+  float heavyHint;      // light pass: largest straight-alignment penalty among the candidates that needed the gapped chain
 };
 
 XM_INL SeqView queryView(const ReadCtx& cx, uint8_t seqAId) {
@@ -90,6 +91,7 @@ XM_INL void makeExtEnv(ReadCtx& cx, ExtEnv& e, const SeqView& query, int contig)
   e.contig = contig;
   e.slotA = e.slotB = e.slotT = nullptr;
   e.memo = cx.memo; e.memoCursor = &cx.memoCursor;
+  e.heavyHint = &cx.heavyHint;
 }
 
 // alignMatch :412-462 (fromHashblockMatch is always true).  The matcher slots live in tmp for the duration of the call.
@@ -718,7 +720,7 @@ XM_INL void resultWrite(const ReadResult& rr, OutWriter& w, DevCounters* dc) {
 XM_INL void runRead(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* arena, size_t arenaBytes, DevCounters* dc, ReadResult& rr, int heavyAllowed = 2,
                     MemoHdr* memo = nullptr, bool deferPath = false) {
   cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed; cx.caps.deferPath = (memo && deferPath) ? 1 : 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
-  cx.memo = memo; cx.memoCursor = 0;
+  cx.memo = memo; cx.memoCursor = 0; cx.heavyHint = 0;
   cx.params.StartingInsertionStartFree = 0;
   size_t persistBytes = arenaBytes * 5 / 12;
   persistBytes &= ~(size_t)15;

@@ -72,6 +72,7 @@ PASS_SHAPES = [
     {"XM_LIGHT_LEVEL": "1"},                                                    # light pass keeps the hash-block analysis
     {"XM_TAPER_PCT": "0", "XM_FULL_LPW": "64"},                                 # no end-of-list taper, full waves in the gapped pass
     {"XM_LIGHT_WAVES": "2", "XM_FULL_WAVES": "1", "XM_SCRATCH_GIB": "2"},       # few lanes: every lane aligns many reads in turn
+    {"XM_HEAVY_HINT": "64", "XM_LIGHT_SYNC": "1"},                              # gapped pass ordered by the cost hint and dealt out; wave-synchronous light batches
 ]
 
 
