@@ -369,6 +369,7 @@ template <bool LDS>
 struct PathAlignerT {
   static constexpr double disallowed = 1000000.0;
   unsigned long long tLook, tLoad, tCompute, tPut;
+  int32_t lastBucket, lastTail; double lastKey;  // the bucket the previous node went to
   PNode* nodes; int32_t nNodes, maxNodes;  // node i is also list entry i (putNode appends exactly one of each)
   // locatedNodes: (x,y) -> latest node.  HBM mode: dense grid of node indices when (textA+2)*(textB+2) fits (the four neighbour
   // lookups of an update are then four INDEPENDENT loads, issued together), open-addressing hash otherwise.  LDS mode: hash.
@@ -518,6 +519,11 @@ struct PathAlignerT {
       if ((x | y) < 0 || x > 255 || y > 255) { ldsOverflow = true; overflow = true; return; }  // does not pack into a list entry
     }
     int b = -1;
+    int tail = -1;
+    // most nodes go where the previous one went (estimates are clamped to the active key): the last bucket and its tail are kept in
+    // registers, which saves the three dependent lookups below for them
+    if (lastBucket >= 0 && est == lastKey) { b = lastBucket; tail = lastTail; }
+    else {
     uint64_t kb;
     __builtin_memcpy(&kb, &est, 8);
     const uint32_t mixed = (uint32_t)((kb ^ (kb >> 29)) * 0x9E3779B97F4A7C15ull >> 40);
@@ -553,12 +559,16 @@ struct PathAlignerT {
         i = parent;
       }
       setHeap(i, b);
+    } else {
+      tail = bucketTail(b);
+    }
+    lastBucket = b; lastKey = est;
     }
     const int idx = nNodes++;  // = list entry
     setListXY(idx, x, y); setListNext(idx, -1);
-    const int tail = bucketTail(b);
     if (tail >= 0) setListNext(tail, idx); else setBucketHead(b, idx);
     setBucketTail(b, idx);
+    lastTail = idx;
     PNode n;
     n.pen = pen; n.insX = insX; n.insY = insY; n.x = (int16_t)x; n.y = (int16_t)y; n.fl = fl; n.pad[0] = n.pad[1] = n.pad[2] = 0;
     nodes[idx] = n;
@@ -735,6 +745,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
   pa.confident = pr.confident; pa.maxInsExt = pr.maxInsExt; pa.maxDelExt = pr.maxDelExt;
   pa.predictedBestOffset = pr.predictedBestOffset; pa.overflow = false; pa.nodesPut = 0; pa.ldsOverflow = false;
   pa.tLook = pa.tLoad = pa.tCompute = pa.tPut = 0;
+  pa.lastBucket = -1; pa.lastTail = -1; pa.lastKey = 0;
   const int referenceLen = pr.referenceLen;
   pa.gridW = secLen(qs) + 2; pa.gridH = secLen(rs) + 2;
   pa.grid = nullptr; pa.hash = nullptr; pa.hashMask = 0; pa.useGrid = false;
