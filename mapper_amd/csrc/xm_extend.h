@@ -455,13 +455,13 @@ struct PathAlignerT {
     }
   }
   // :523-539 (overwrites the node at (x,y)).  LDS mode: slot >= 0 is the cell's slot as ldsResolve left it (the caller just looked the cell up)
-  XM_INL void saveNode(int idx, int x, int y, int slot = -1) {
+  XM_INL void saveNode(int idx, int x, int y, int slot = -1, bool slotTaken = false) {
     if (x < 0 || y < 0) return;
     if constexpr (LDS) {
       if (x >= gridW || y >= gridH) return;
       const uint32_t key = ((uint32_t)x << 8) | (uint32_t)y;
       uint32_t h, v;
-      if (slot >= 0) { h = (uint32_t)slot; v = Lhash[h]; }
+      if (slot >= 0) { h = (uint32_t)slot; v = slotTaken ? 1u : 0u; }  // (the caller's lookup already knows whether the cell exists)
       else { h = ldsCellHash(key); v = Lhash[h]; ldsResolve(key, h, v); }
       if (v == 0) {
         if (nCells >= XM_PAL_CELLS) { ldsOverflow = true; overflow = true; return; }
@@ -511,7 +511,7 @@ struct PathAlignerT {
       return pen + startP + ext;
     }
   }
-  XM_INL void putNode(int x, int y, double pen, double insX, double insY, uint8_t fl, int cellSlot = -1) {  // :446-473
+  XM_INL void putNode(int x, int y, double pen, double insX, double insY, uint8_t fl, int cellSlot = -1, bool cellTaken = false) {  // :446-473
     double est = estimateOverallPenalty(x, y, pen, insX, insY, fl);
     if (est < activePenalty) est = activePenalty;
     if (nNodes >= maxNodes) { if constexpr (LDS) ldsOverflow = true; overflow = true; return; }
@@ -550,15 +550,19 @@ struct PathAlignerT {
       b = nBuckets++;
       if constexpr (LDS) { Lbkey[b] = est; Lbhead[b] = 0xFFFF; Lbtail[b] = 0xFFFF; Lbhash[h] = (uint8_t)(b + 1); }
       else { bkey[b] = est; bhead[b] = -1; btail[b] = -1; bhash[h] = b + 1; }
-      int i = heapSize++;  // sift up
-      while (i > 0) {
-        int parent = (i - 1) >> 1;
-        int pb = heapAt(parent);
-        if (bucketKey(pb) <= est) break;
-        setHeap(i, pb);
-        i = parent;
+      if constexpr (LDS) {
+        heapSize++;  // LDS mode keeps no heap (the search loop scans the <= 112 keys): heapSize counts the live buckets
+      } else {
+        int i = heapSize++;  // sift up
+        while (i > 0) {
+          int parent = (i - 1) >> 1;
+          int pb = heapAt(parent);
+          if (bucketKey(pb) <= est) break;
+          setHeap(i, pb);
+          i = parent;
+        }
+        setHeap(i, b);
       }
-      setHeap(i, b);
     } else {
       tail = bucketTail(b);
     }
@@ -572,7 +576,7 @@ struct PathAlignerT {
     PNode n;
     n.pen = pen; n.insX = insX; n.insY = insY; n.x = (int16_t)x; n.y = (int16_t)y; n.fl = fl; n.pad[0] = n.pad[1] = n.pad[2] = 0;
     nodes[idx] = n;
-    saveNode(idx, x, y, cellSlot);
+    saveNode(idx, x, y, cellSlot, cellTaken);
     nodesPut++;
   }
   XM_INL void update(int x, int y) {  // :555-571 + computeUpdated :573-719
@@ -660,7 +664,7 @@ struct PathAlignerT {
         if (iabs(signedDist(x, y)) == 0) fl |= 1; else fl |= 2;
       }
       XM_PA_TOC(tCompute, t0);
-      putNode(x, y, bestPenalty, insertXPenalty, insertYPenalty, fl, cellSlot);
+      putNode(x, y, bestPenalty, insertXPenalty, insertYPenalty, fl, cellSlot, existing >= 0);
       XM_PA_TOC(tPut, t0);
     } else {
       XM_PA_TOC(tCompute, t0);
@@ -853,7 +857,16 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
     if (pa.overflow) return leave(false);
     // priorities.poll(): smallest live key
     if (pa.heapSize < 1) { *status = XM_ST_INTERNAL; return leave(false); }  // Java: NullPointerException
-    int b = pa.heapAt(0);
+    int b;
+    if constexpr (LDS) {
+      // the live bucket with the smallest key: a scan of the keys (independent LDS reads, a removed bucket's key is +inf) is shorter
+      // than the dependent reads of a heap for this few buckets
+      b = 0;
+      double best = pa.Lbkey[0];
+      for (int k = 1; k < pa.nBuckets; k++) { const double key = pa.Lbkey[k]; if (key < best) { best = key; b = k; } }
+    } else {
+      b = pa.heapAt(0);
+    }
     pa.activePenalty = pa.bucketKey(b);
     int li = pa.bucketHead(b);
     while (li >= 0) {
@@ -871,7 +884,11 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
     }
     // prioritizedNodes.remove(activePenalty) + the poll(): pop the heap root (the active bucket is still the minimum: every key
     // inserted meanwhile is >= activePenalty and distinct keys are distinct buckets)
-    {
+    if constexpr (LDS) {
+      pa.Lbkey[b] = HUGE_VAL;
+      pa.heapSize--;
+      if (pa.lastBucket == b) pa.lastBucket = -1;
+    } else {
       const int last = pa.heapAt(--pa.heapSize);
       const double lastKey = pa.bucketKey(last);
       int i = 0;
