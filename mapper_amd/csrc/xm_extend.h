@@ -210,19 +210,40 @@ XM_NOINL void matcherIndexSection(const Matcher m, const SeqView ref, int sectio
   int previousEncoded = M_UNKNOWN;
   int startIndex = m.referenceStart + sectionIndex * m.sectionLength;
   int endIndex = imin(startIndex + m.sectionLength, m.referenceStart + m.referenceLength - m.blockLength);
-  for (int i = startIndex; i < endIndex; i++) {
-    int encoded;
-    if (previousEncoded == M_UNKNOWN) {
-      encoded = matcherEncodeBlock(m, ref, i);
-    } else {
-      uint8_t nextChar = ref.at(i + m.blockLength - 1);
-      if (bpIsAmbiguous(nextChar)) encoded = M_UNKNOWN;
-      else encoded = ((previousEncoded * 4) & m.maxPossibility) + encodedCharToInt(nextChar);
+  // Eight positions per round: their codes first (registers), then the eight table entries with independent loads (one memory round
+  // trip instead of eight dependent ones: the table is in the lane's arena in HBM), then the updates in position order; a position
+  // whose code already occurred earlier in the same round takes that position's result instead of the stale table entry.
+  XM_GLOBAL(int16_t)* const table = (XM_GLOBAL(int16_t)*)section;
+  for (int i0 = startIndex; i0 < endIndex; i0 += 8) {
+    int enc[8];
+    int16_t cur[8], neu[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int i = i0 + k;
+      int encoded = M_UNKNOWN;
+      if (i < endIndex) {
+        if (previousEncoded == M_UNKNOWN) {
+          encoded = matcherEncodeBlock(m, ref, i);
+        } else {
+          uint8_t nextChar = ref.at(i + m.blockLength - 1);
+          if (bpIsAmbiguous(nextChar)) encoded = M_UNKNOWN;
+          else encoded = ((previousEncoded * 4) & m.maxPossibility) + encodedCharToInt(nextChar);
+        }
+        if (encoded != M_UNKNOWN) previousEncoded = encoded;  // (sic) an unknown block leaves previousEncoded at its stale value
+      }
+      enc[k] = encoded;
     }
-    if (encoded == M_UNKNOWN) continue;  // (sic) previousEncoded keeps its stale value
-    int16_t existing = section[encoded];
-    section[encoded] = (existing == M_NO_MATCHES) ? (int16_t)(i - m.referenceStart) : (int16_t)M_MULTIPLE;
-    previousEncoded = encoded;
+#pragma unroll
+    for (int k = 0; k < 8; k++) cur[k] = enc[k] >= 0 ? table[enc[k]] : (int16_t)M_NO_MATCHES;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int16_t existing = cur[k];
+#pragma unroll
+      for (int j = 0; j < k; j++) if (enc[j] >= 0 && enc[j] == enc[k]) existing = neu[j];
+      neu[k] = (existing == M_NO_MATCHES) ? (int16_t)(i0 + k - m.referenceStart) : (int16_t)M_MULTIPLE;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (enc[k] >= 0) table[enc[k]] = neu[k];
   }
   XM_TOC(dc, T_MATCHER_INDEX, t0);
 }
