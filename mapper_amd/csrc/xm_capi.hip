@@ -430,6 +430,7 @@ struct xm_index {
   DevBuf<DevCounters> dCounters;
   int numCUs = 0;
   int64_t residentNq = -1;   // batch kept in HBM by xm_batch_upload
+  int residentMaxLen = 0;    // longest mate of that batch
   double residentH2dMs = 0;
 
   void upload() {
@@ -621,6 +622,7 @@ static void uploadBatchLocked(xm_index* idx, const xm_query_batch* b) {
     idx->residentH2dMs = ms;
   }
   idx->residentNq = nq;
+  idx->residentMaxLen = maxLen;
 }
 
 static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** out);
@@ -706,7 +708,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     long long nTodo = nq;
     unsigned long long pendingHeavy = 0, pendingScale = 0, pendingPath = 0;
     int ts = 0, to = 0, tp = 0;  // which of the two scale / out / path lists receives new entries
-    int scale = 1, overflowScale = 1;
+    // the scratch capacities are sized for ~150-300 bp mates at scale 1; batches of longer reads start at a larger scale instead of
+    // sending every read through a pass that can only overflow
+    int scale = idx->residentMaxLen <= 320 ? 1 : (idx->residentMaxLen <= 1280 ? 4 : 16), overflowScale = scale;
+    const int gappedScale = scale < 4 ? 4 : scale * 4;
     bool heavy = false, defer = false, memoFresh = false, inlineRest = false;
     int searchRounds = 0;
     unsigned long long intCap = (unsigned long long)nq * 40 + 4096, dblCap = (unsigned long long)nq * 12 + 4096;
@@ -757,7 +762,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       idx->dArenas.ensure((size_t)lanes * arenaBytes);
       idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq); idx->dListPath[tp].ensure(defer ? (size_t)nTodo : 1);
       // gapped pass with an ordered list: the first read of every lane is dealt out (kernel), the counter starts behind those items
-      const long long firstStride = (heavy && !defer && heavyHintThreshold > 0 && scale == 4) ? (long long)grid * (block / 64) : 0;
+      const long long firstStride = (heavy && !defer && heavyHintThreshold > 0 && scale == gappedScale) ? (long long)grid * (block / 64) : 0;
       const unsigned long long firstItem = (unsigned long long)std::min((long long)nTodo, firstStride * lpw);
       HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 2, &firstItem, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
@@ -850,8 +855,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         HIP_CHECK(hipGetLastError());
         todo = idx->dListHeavy.p; nTodo = (long long)pendingHeavy;
         HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nHeavy, 0, 2 * sizeof(unsigned long long), s));  // nHeavy, nHeavyLate (a gapped pass never adds to these lists)
-        scale = 4;
-        if (overflowScale < 4) overflowScale = 4;
+        scale = gappedScale;
+        if (overflowScale < gappedScale) overflowScale = gappedScale;
         heavy = true;
         defer = deferSearches;
         if (defer) { idx->dMemo.ensure((size_t)nTodo * XM_MEMO_SLOT_BYTES); memoFresh = true; }

@@ -97,6 +97,21 @@ def test_pass_shapes_do_not_change_results(env, monkeypatch):
     db.close()
 
 
+def test_long_reads_on_gpu():
+    """1,000 bp queries (BASELINE.json configs[4] splits its 10 kb reads into these) with long-read-like errors and 400 bp reads: the batch starts
+    at a larger scratch scale, the searches outgrow the LDS slot and run in HBM mode; results must still be the oracle's."""
+    ref = synth.synthetic_reference(400_000, seed=31)
+    R = o.OracleReference([("r", ref)])
+    for L, n, sub, ind in ((1000, 300, 0.05, 0.9), (400, 1500, 0.02, 0.3)):
+        reads = synth.synthetic_single_end(ref, n, read_len=L, sub_rate=sub, indel_prob=ind, seed=32 + L)[0]
+        b = se_batch(reads)
+        db = api.ReferenceDatabase([("r", ref)], max_query_length=L)
+        got, _ = gpu_align(db, b)
+        want = R.align(b, o.make_params())
+        assert streams_equal(got, want), first_difference(got, want, n)
+        db.close()
+
+
 def test_edge_cases_on_gpu():
     rng = np.random.default_rng(3)
     c0 = synth.synthetic_reference(60_000, seed=11)
