@@ -141,3 +141,21 @@ def test_kernel_logic_edge_cases():
     for params in (o.make_params(), o.make_params(MaxNumMatches=3), o.make_params(Max_PenaltySpan=2.0, MaxErrorRate=0.15)):
         sa, sb = R.align(b, params), S.align(b, params)
         assert streams_equal(sa, sb), first_difference(sa, sb, len(queries))
+
+
+def test_committed_golden_digests_on_cpu():
+    """tests/golden/synthetic_golden.json (digests of the oracle's result streams on seeded batches, made by
+    tests/golden/make_synthetic_golden.py): the oracle still produces them, and so does the kernel logic in the host simulation — in the
+    product's pass sequence and with every PathAligner search deferred to the search "kernel"."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_synthetic_golden import cases, digest
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synthetic_golden.json")))
+    ref, batches = cases()
+    R = o.OracleReference([("ecoli_syn", ref)])
+    S = hs.SimReference([("ecoli_syn", ref)])
+    for name, b in batches.items():
+        want = golden["digests"][name]["sha256"]
+        assert digest(R.align(b, o.make_params(), threads=os.cpu_count())) == want, "oracle: " + name
+        assert digest(S.align(b, o.make_params())) == want, "host simulation: " + name
