@@ -205,8 +205,54 @@ XM_INL int withGapAndExtension(const B& b, const SeqView& seq, QBlock& out) {
   return 2;
 }
 
+// ---------------------------------------------------------------- reads with ambiguous bases (M/MultiHashBlock.java, M/ConditionalHashBlock.java,
+// M/SequenceCondition.java, the multi branch of M/HashBlock_ParentRow.java:69-191, M/HashBlock_BaseRow.java:20-49)
+// A block that covers an ambiguous base is a list of possibilities, each either a HashBlock or "no block", under a condition
+// (position -> base).  The walk never probes such a block (HashBlockPath.skipMultiblocks) but it has to know where they are, and
+// whether one exists depends on the full expansion, so the rule is restated as written.  Only reads that contain a non-ACGT base
+// take this path; it keeps the possibilities in a pool in the lane's arena.
+constexpr uint8_t F_MULTI = 0x80;   // PBlock::flags of a stored multi block: fwd = first possibility in the pool, rev = their number
+constexpr int XM_MAX_COMBINATIONS = 64;  // HashBlock_ParentRow.maxNumCombinationsToExpand
+constexpr int XM_MAX_AMBIGUOUS = 128;    // ambiguous bases per mate this representation holds
+// SequenceCondition: a set of (position -> base) constraints.  Its only operation is intersect (:22-94): null if the two sets disagree
+// on a position, else their union (the reference returns the larger operand when one contains the other, which is the union too).
+// A position is identified by its rank among the mate's ambiguous bases, so a condition is three bit sets: which ranks are
+// constrained, and the two bits of the base (A C G T = 0 1 2 3) for each.
+struct Cond {
+  uint64_t mask[2], lo[2], hi[2];
+  XM_INL void clear() { mask[0] = mask[1] = lo[0] = lo[1] = hi[0] = hi[1] = 0; }
+  XM_INL void setOnly(int rank, int base) {
+    clear();
+    const int w = rank >> 6;
+    const uint64_t bit = 1ull << (rank & 63);
+    mask[w] = bit;
+    if (base & 1) lo[w] = bit;
+    if (base & 2) hi[w] = bit;
+  }
+};
+struct Poss {  // ConditionalHashBlock
+  PBlock block;
+  Cond cond;
+  int32_t hasBlock;
+};
+XM_INL bool condIntersect(const Cond& a, const Cond& b, Cond& out) {  // false = conflict (Java null)
+  for (int w = 0; w < 2; w++) {
+    const uint64_t common = a.mask[w] & b.mask[w];
+    if (common & ((a.lo[w] ^ b.lo[w]) | (a.hi[w] ^ b.hi[w]))) return false;
+  }
+  for (int w = 0; w < 2; w++) { out.mask[w] = a.mask[w] | b.mask[w]; out.lo[w] = a.lo[w] | b.lo[w]; out.hi[w] = a.hi[w] | b.hi[w]; }
+  return true;
+}
+struct MultiStore {
+  int16_t* ambPos; int32_t nAmb;  // positions of the mate's ambiguous bases, ascending (rank = index)
+  Poss* pool; int32_t poolUsed, poolCap;
+  Poss* options;  // mergeOptions of the block being made: up to XM_MAX_COMBINATIONS + 1 from expand + one per left option
+  int32_t optionsCap;
+};
+
 struct Pyramid {
   SeqView seq;
+  MultiStore* ms;       // null: the sequence is plain ACGT (every block is a single HashBlock)
   PBlock* blocks;       // levels >= 1, concatenated
   int32_t* levelStart;  // levelStart[k] (k>=1) = first block of level k; levelStart[nBuilt+1] = used
   int32_t nBuilt, used, cap, maxLevels;
@@ -215,13 +261,133 @@ struct Pyramid {
 
   XM_INL void init(const SeqView& s, PBlock* b, int cap_, int32_t* ls, int maxLevels_, int32_t* st) {
     dc = nullptr;
+    ms = nullptr;
     seq = s; blocks = b; cap = cap_; levelStart = ls; maxLevels = maxLevels_; nBuilt = 0; used = 0; status = st;
     levelStart[1] = 0;
+  }
+
+  // ---- multi mode: uniform view of a level's entries (level 0 is computed from the bases)
+  XM_INL PBlock entryAt(int level, int i) const {
+    if (level > 0) return blocks[levelStart[level] + i];
+    uint8_t code = seq.at(i);
+    PBlock b = level0Block(code, i);
+    if (bpIsAmbiguous(code)) { b.flags = F_MULTI; b.fwd = 0; b.rev = 0; }
+    return b;
+  }
+  XM_INL int numPoss(int level, const PBlock& e) const {
+    if (!(e.flags & F_MULTI)) return 1;
+    if (level > 0) return e.rev;
+    return bpPop(seq.at(e.start));
+  }
+  XM_INL Poss possAt(int level, const PBlock& e, int k) const {  // getPossibilities()[k]
+    Poss p;
+    if (!(e.flags & F_MULTI)) { p.block = e; p.cond.clear(); p.hasBlock = 1; return p; }  // (this, ALWAYS), M/HashBlock.java:352-356
+    if (level > 0) return ms->pool[e.fwd + k];
+    uint8_t code = seq.at(e.start);  // HashBlock_BaseRow.get: one possibility per base the code can stand for, in A C G T order
+    int seen = 0;
+    uint8_t option = 1;
+    for (int bit = 0; bit < 4; bit++) {
+      uint8_t o = (uint8_t)(1 << bit);
+      if (code & o) { if (seen == k) { option = o; break; } seen++; }
+    }
+    p.block = level0Block(option, e.start);
+    int lo = 0, hi = ms->nAmb - 1;  // rank of this position
+    while (lo < hi) { int mid = (lo + hi) >> 1; if ((int)ms->ambPos[mid] < (int)e.start) lo = mid + 1; else hi = mid; }
+    p.cond.setOnly(lo, option == 1 ? 0 : option == 2 ? 1 : option == 4 ? 2 : 3);
+    p.hasBlock = 1;
+    return p;
+  }
+  // HashBlock_ParentRow.expand :137-191 for one left possibility; the recursion (a right possibility without a block passes the search
+  // on to the block after it) runs on an explicit stack.  false = capacity exceeded
+  XM_INL bool multiExpand(int prev, int n, const PBlock& leftBlock, const Cond& leftCond, int i, int& nOpt) {
+    struct Frame { int32_t j, opt; Cond cond; bool found; };
+    Frame st[24];
+    int sp = 0;
+    st[0].j = i; st[0].opt = 0; st[0].cond = leftCond; st[0].found = false;
+    while (sp >= 0) {
+      Frame& f = st[sp];
+      const int nextIdx = f.j + 1;
+      if (nextIdx >= n) { sp--; continue; }
+      const PBlock next = entryAt(prev, nextIdx);
+      if (f.opt >= numPoss(prev, next)) { sp--; continue; }
+      const Poss ro = possAt(prev, next, f.opt);
+      f.opt++;
+      Cond ic;
+      if (!condIntersect(f.cond, ro.cond, ic)) { if (f.found) sp--; continue; }
+      f.found = true;
+      if (nOpt > XM_MAX_COMBINATIONS) return true;  // every enclosing call returns at its next intersection without adding anything
+      if (!ro.hasBlock) {
+        if (sp + 1 >= 24) return false;
+        sp++;
+        st[sp].j = nextIdx; st[sp].opt = 0; st[sp].cond = ic; st[sp].found = false;
+        continue;
+      }
+      if (nOpt >= ms->optionsCap) return false;
+      Poss& o = ms->options[nOpt++];
+      o.cond = ic;
+      if (shouldMergeBlocks(leftBlock, ro.block)) { o.block = mergeBlocks(leftBlock, ro.block); o.hasBlock = 1; }
+      else { o.block = leftBlock; o.hasBlock = 0; }
+    }
+    return true;
+  }
+  // one level in multi mode: maybeMakeBlock :69-127 for every block of the level below, in order
+  XM_INL void buildLevelMulti() {
+    const int prev = nBuilt;
+    const int n = count(prev);
+    int w = used;
+    for (int i = 0; i + 1 < n; i++) {
+      const PBlock L = entryAt(prev, i), R = entryAt(prev, i + 1);
+      if (!((L.flags | R.flags) & F_MULTI)) {
+        if (shouldMergeBlocks(L, R)) {
+          if (w >= cap) { *status = XM_ST_OVERFLOW; return; }
+          blocks[w++] = mergeBlocks(L, R);
+        }
+        continue;
+      }
+      int nOpt = 0;
+      const int nl = numPoss(prev, L);
+      for (int k = 0; k < nl; k++) {
+        const Poss lo = possAt(prev, L, k);
+        if (lo.hasBlock) {
+          if (!multiExpand(prev, n, lo.block, lo.cond, i, nOpt)) { *status = XM_ST_OVERFLOW; return; }
+        } else {
+          if (nOpt >= ms->optionsCap) { *status = XM_ST_OVERFLOW; return; }
+          Poss& o = ms->options[nOpt++];
+          o = lo;
+        }
+      }
+      if (nOpt > 0 && nOpt <= XM_MAX_COMBINATIONS) {
+        int minStart = -1, maxEnd = -1;
+        for (int k = 0; k < nOpt; k++) if (ms->options[k].hasBlock) {
+          const PBlock& b = ms->options[k].block;
+          if (minStart < 0 || (int)b.start < minStart) minStart = b.start;
+          if ((int)b.start + b.len > maxEnd) maxEnd = (int)b.start + b.len;
+        }
+        if (minStart >= 0) {  // hasNonEmpty
+          if (w >= cap || ms->poolUsed + nOpt > ms->poolCap) { *status = XM_ST_OVERFLOW; return; }
+          PBlock m;
+          m.start = (uint16_t)minStart; m.len = (uint16_t)(maxEnd - minStart); m.fwd = ms->poolUsed; m.rev = nOpt; m.flags = F_MULTI; m.gapDir = 0; m.extraGap = 0;
+          for (int k = 0; k < nOpt; k++) ms->pool[ms->poolUsed++] = ms->options[k];
+          blocks[w++] = m;
+        }
+      }
+    }
+    nBuilt++;
+    used = w;
+    levelStart[nBuilt + 1] = w;
   }
   XM_INL int count(int level) const { return level == 0 ? seq.len : levelStart[level + 1] - levelStart[level]; }
   XM_INL PBlock blockAt(int level, int i) const { return level == 0 ? level0Block(seq.at(i), i) : blocks[levelStart[level] + i]; }
 
+  XM_NOINL void ensureMulti(int level) {
+    while (nBuilt < level) {
+      if (nBuilt + 2 >= maxLevels) { *status = XM_ST_OVERFLOW; return; }
+      buildLevelMulti();
+      if (*status) return;
+    }
+  }
   XM_NOINL void ensure(int level) {  // M/HashBlock_Pyramid.java:15-24 + HashBlock_ParentRow.maybeMakeBlock
+    if (ms) { ensureMulti(level); return; }  // (rare: kept out of the loop below)
     XM_TIC(t0);
     // locals: members reached through `this` would be re-loaded after every block store (possible aliasing)
     PBlock* const blk = blocks;
@@ -290,7 +456,7 @@ struct Pyramid {
     if (level == 0) {
       int p = pos + 1;
       if (p >= seq.len) return false;
-      out = level0Block(seq.at(p), p);
+      out = ms ? entryAt(0, p) : level0Block(seq.at(p), p);
       return true;
     }
     ensure(level);
@@ -307,7 +473,7 @@ struct Pyramid {
   XM_INL bool get(int level, int index, PBlock& out) {  // HashBlock_Row.get
     if (level == 0) {
       if (index >= seq.len) return false;
-      out = level0Block(seq.at(index), index);
+      out = ms ? entryAt(0, index) : level0Block(seq.at(index), index);
       return true;
     }
     if (!getAfter(level, index - 1, out)) return false;
@@ -529,7 +695,10 @@ XM_NOINL bool pathAdvance(Comp& c, const SeedEnv& e) {
       else { if (c.path.batchIndex > 0) pathMoveDown(c); else pathMoveRight(c); }
     }
   }
-  // skipMultiblocks (:130-140) is a no-op: reads with ambiguous bases are rejected up front (XM_ST_AMBIGUOUS)
+  // skipMultiblocks :130-140 (only a read with ambiguous bases has such blocks)
+  while (c.path.curExists && (c.path.cur.flags & F_MULTI) && *e.status == 0) {
+    if (c.path.batchIndex > 0) pathMoveDown(c); else pathMoveRight(c);
+  }
   XM_TOC(e.dc, T_WALK, t0);
   return c.path.curExists && *e.status == 0;
 }

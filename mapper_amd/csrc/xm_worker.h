@@ -524,6 +524,23 @@ XM_NOINL bool quicklyConfidentInBestAlignment(ReadCtx& cx, QMAligner& a, int alI
   return true;
 }
 
+// any base of the mate that is not exactly one of A C G T?  Eight codes per load: a code is unambiguous iff exactly one of its four bits is set
+XM_INL bool mateHasAmbiguousBase(const SeqView& q) {
+  XM_GLOBAL(const uint8_t)* const g = (XM_GLOBAL(const uint8_t)*)q.base;
+  uint64_t bad = 0;
+  int i = 0;
+  for (; i + 8 <= q.len; i += 8) {
+    uint64_t x;
+    __builtin_memcpy(&x, (const void*)(q.base + i), 8);
+    x &= 0x0F0F0F0F0F0F0F0Full;
+    uint64_t pairs = (x & 0x0505050505050505ull) + ((x >> 1) & 0x0505050505050505ull);   // bit counts of the two 2-bit halves
+    uint64_t pop = (pairs & 0x0303030303030303ull) + ((pairs >> 2) & 0x0303030303030303ull);  // per byte: 0..4
+    bad |= pop ^ 0x0101010101010101ull;
+  }
+  for (; i < q.len; i++) if (bpIsAmbiguous(g[i])) bad = 1;
+  return bad != 0;
+}
+
 XM_INL void compInit(ReadCtx& cx, Comp& c, const SeqView& query, const SeqView& rcQuery) {  // M/Counting_HashBlockPath.java:20-37
   const Caps& k = cx.caps;
   Arena& A = cx.persist;
@@ -539,6 +556,21 @@ XM_INL void compInit(ReadCtx& cx, Comp& c, const SeqView& query, const SeqView& 
   if (A.overflow) { cx.status = XM_ST_OVERFLOW; return; }
   c.pyr.init(query, blocks, k.maxPyramidBlocks, ls, k.maxLevels, &cx.status);
   c.pyr.dc = cx.dc;
+  int nAmb = 0;
+  if (mateHasAmbiguousBase(query)) for (int i = 0; i < query.len; i++) if (bpIsAmbiguous(query.at(i))) nAmb++;
+  if (nAmb > 0) {  // blocks over an ambiguous base are lists of possibilities (MultiHashBlock): xm_seed.h, MultiStore
+    if (nAmb > XM_MAX_AMBIGUOUS) { cx.status = XM_ST_AMBIGUOUS; return; }
+    MultiStore* ms = arenaArray<MultiStore>(A, 1);
+    int16_t* ambPos = arenaArray<int16_t>(A, (size_t)nAmb);
+    Poss* pool = arenaArray<Poss>(A, (size_t)128 * k.scale);
+    Poss* options = arenaArray<Poss>(A, 2 * XM_MAX_COMBINATIONS + 8);
+    if (A.overflow) { cx.status = XM_ST_OVERFLOW; return; }
+    int w = 0;
+    for (int i = 0; i < query.len; i++) if (bpIsAmbiguous(query.at(i))) ambPos[w++] = (int16_t)i;
+    ms->ambPos = ambPos; ms->nAmb = nAmb;
+    ms->pool = pool; ms->poolUsed = 0; ms->poolCap = 128 * k.scale; ms->options = options; ms->optionsCap = 2 * XM_MAX_COMBINATIONS + 8;
+    c.pyr.ms = ms;
+  }
   pathInit(c.path);
   c.query = query; c.rcQuery = rcQuery;
   c.nCounters = 0; c.nGood = 0; c.foundGood = false; c.done = false; c.nHistory = 0; c.pendHead = c.pendTail = 0;
@@ -590,8 +622,6 @@ XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr) {
   const ReadIn& in = cx.in;
   if (cx.dc) { cx.dc->reads++; for (int m = 0; m < in.nMates; m++) cx.dc->readBytes += (unsigned long long)((in.mateLen[m] + 1) / 2); }
   rr.nComponents = 1; rr.single[0] = -1; rr.empty[0] = 0; rr.aligner[0] = nullptr;
-  // reads with ambiguous bases need the MultiHashBlock path, which this build does not implement
-  for (int m = 0; m < in.nMates; m++) for (int i = 0; i < in.mateLen[m]; i++) if (bpIsAmbiguous(in.mate[m][i])) { cx.status = XM_ST_AMBIGUOUS; return; }
   for (int m = 0; m < in.nMates; m++) if (in.mateLen[m] > cx.ix->maxHashedLength) { cx.status = XM_ST_NEED_GROW; return; }
   int queryLength = 0;
   for (int m = 0; m < in.nMates; m++) queryLength += in.mateLen[m];

@@ -63,3 +63,18 @@ def check_align_case(case, comps, ref_codes):
 
 def sam_text(query, comps, names):
     return "".join(line + "\n" for line in sam.records(query, comps, names))
+
+
+def sprinkle_ambiguity(reads, seed=3):
+    """Copies of `reads` (code arrays [n, L]) with 0-3 IUPAC ambiguity codes each (N, R, Y, M, K, V, B) and, in every 50th read, a run of 2-11 N's."""
+    rng = np.random.default_rng(seed)
+    out = reads.copy()
+    codes = np.array([15, 15, 15, 5, 10, 3, 12, 7, 14], np.uint8)
+    for q in range(len(out)):
+        k = rng.integers(0, 4)
+        pos = rng.integers(0, out.shape[1], size=k)
+        out[q, pos] = codes[rng.integers(0, len(codes), size=k)]
+        if q % 50 == 0:
+            p0 = rng.integers(0, out.shape[1] - 12)
+            out[q, p0:p0 + rng.integers(2, 12)] = 15
+    return out

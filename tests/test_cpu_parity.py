@@ -7,7 +7,7 @@ import pytest
 
 import oracle_lib as o
 import hostsim_lib as hs
-from helpers import KAT, streams_equal, first_difference, se_batch, pe_batch, check_align_case
+from helpers import KAT, streams_equal, first_difference, se_batch, pe_batch, check_align_case, sprinkle_ambiguity
 from mapper_amd import api, synth, _capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -159,3 +159,18 @@ def test_committed_golden_digests_on_cpu():
         want = golden["digests"][name]["sha256"]
         assert digest(R.align(b, o.make_params(), threads=os.cpu_count())) == want, "oracle: " + name
         assert digest(S.align(b, o.make_params())) == want, "host simulation: " + name
+
+
+def test_kernel_logic_reads_with_ambiguous_bases():
+    """Read-side MultiHashBlock path (blocks over an ambiguous base are lists of conditional possibilities): the kernel logic against the
+    oracle's literal restatement of HashBlock_BaseRow / HashBlock_ParentRow / SequenceCondition, single-end and paired."""
+    ref = synth.synthetic_reference(300_000, seed=41)
+    reads = sprinkle_ambiguity(synth.synthetic_single_end(ref, 5000, seed=42)[0])
+    m1, m2 = synth.synthetic_paired_end(ref, 1000, seed=43)[:2]
+    m1, m2 = sprinkle_ambiguity(m1, 4), sprinkle_ambiguity(m2, 5)
+    R = o.OracleReference([("r", ref)])
+    S = hs.SimReference([("r", ref)])
+    for b, n in ((se_batch(reads), 5000), (pe_batch(m1, m2, 100.0, 50.0), 1000)):
+        want = R.align(b, o.make_params(), threads=os.cpu_count())
+        got = S.align(b, o.make_params())
+        assert streams_equal(got, want), first_difference(got, want, n)
