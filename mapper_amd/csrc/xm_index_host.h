@@ -8,7 +8,8 @@
 // level below, so each contig is hashed level by level over flat arrays; every gapmer becomes a (table, bucket,
 // position) record; each table is then sorted by (bucket, position) and cut into CSR form, a bucket that received
 // more than maxInterestingCountPerKey records being marked overfull (its content is never observable: PackedMap.get
-// returns null for it).
+// returns null for it).  Contigs with ambiguous bases go through a vector-based restatement of the multi-block rule
+// (possibilities under conditions), see nextLevelMulti below.
 #pragma once
 #include "xm_seed.h"
 #include <vector>
@@ -77,9 +78,7 @@ struct HostIndex {
       seqCumStart.push_back(2 * off + lengths[i]);
       for (int64_t k = 0; k < lengths[i]; k++) {
         uint8_t c = codes[i][k];
-        if (c != 1 && c != 2 && c != 4 && c != 8)
-          throw std::runtime_error("reference contig " + names.back() + " has a non-ACGT base at " + std::to_string(k) +
-                                   ": ambiguous reference bases (MultiHashBlock, M/MultiHashBlock.java) are not supported by this build");
+        if (c < 1 || c > 15) throw std::runtime_error("reference contig " + names.back() + " has an invalid base code at " + std::to_string(k));
         refCodes[(size_t)(off + k)] = c;
       }
       off += lengths[i];
@@ -106,7 +105,102 @@ struct HostIndex {
     return result;
   }
 
-  struct Rec { uint32_t bucket; uint64_t pos; };
+  struct Rec { uint32_t bucket; uint64_t pos; uint32_t fromMulti; };
+
+  // ---- contigs with ambiguous bases: blocks over such a base are lists of conditional possibilities (M/MultiHashBlock.java,
+  // M/ConditionalHashBlock.java, M/SequenceCondition.java, the multi branch of M/HashBlock_ParentRow.java:69-191 and
+  // M/HashBlock_BaseRow.java:20-49), restated over vectors; xm_seed.h has the fixed-capacity read-side version of the same rule.
+  typedef std::vector<std::pair<int32_t, uint8_t>> HCond;  // sorted (position, base code)
+  static bool hcondIntersect(const HCond& a, const HCond& b, HCond& out) {  // SequenceCondition.intersect :22-94; false = null
+    if (b.empty()) { out = a; return true; }
+    if (a.empty()) { out = b; return true; }
+    size_t i = 0, j = 0, same = 0;
+    while (i < a.size() && j < b.size()) {
+      if (a[i].first < b[j].first) i++;
+      else if (b[j].first < a[i].first) j++;
+      else { if (a[i].second != b[j].second) return false; same++; i++; j++; }
+    }
+    if (same == a.size()) { out = b; return true; }
+    if (same == b.size()) { out = a; return true; }
+    HCond m;
+    i = j = 0;
+    while (i < a.size() && j < b.size()) {
+      if (a[i].first < b[j].first) m.push_back(a[i++]);
+      else if (b[j].first < a[i].first) m.push_back(b[j++]);
+      else { m.push_back(a[i]); i++; j++; }
+    }
+    while (i < a.size()) m.push_back(a[i++]);
+    while (j < b.size()) m.push_back(b[j++]);
+    out.swap(m);
+    return true;
+  }
+  struct HPoss { HBlock block; bool hasBlock; HCond cond; };
+  struct HEntry {
+    bool multi = false;
+    HBlock single;            // !multi
+    std::vector<HPoss> poss;  // multi
+    int start() const {
+      if (!multi) return single.start;
+      int mn = -1;
+      for (const HPoss& p : poss) if (p.hasBlock && (mn < 0 || p.block.start < mn)) mn = p.block.start;
+      return mn;
+    }
+    int minLength() const {
+      if (!multi) return single.len;
+      int mn = -1;
+      for (const HPoss& p : poss) if (p.hasBlock && (mn < 0 || p.block.len < mn)) mn = p.block.len;
+      return mn;
+    }
+  };
+  static HBlock hblock0(uint8_t code, int index) {
+    PBlock b0 = level0Block(code, 0);
+    HBlock h;
+    h.start = index; h.len = 1; h.fwd = b0.fwd; h.rev = b0.rev; h.flags = b0.flags; h.gapDir = 0; h.extraGap = 0;
+    return h;
+  }
+  static std::vector<HPoss> possibilitiesOf(const HEntry& e) {  // getPossibilities(): a single block is [(this, ALWAYS)]
+    if (e.multi) return e.poss;
+    return std::vector<HPoss>(1, HPoss{e.single, true, HCond()});
+  }
+  static void expandMulti(const std::vector<HEntry>& prev, const HBlock& leftBlock, const HCond& startingCondition, size_t j, std::vector<HPoss>& results) {  // :137-191
+    if (j + 1 >= prev.size()) return;
+    const HEntry& next = prev[j + 1];
+    bool foundAnIntersection = false;
+    for (const HPoss& rightOption : possibilitiesOf(next)) {
+      HCond ic;
+      if (!hcondIntersect(startingCondition, rightOption.cond, ic)) {
+        if (foundAnIntersection) break;
+        continue;
+      }
+      foundAnIntersection = true;
+      if ((int)results.size() > XM_MAX_COMBINATIONS) return;
+      if (!rightOption.hasBlock) { expandMulti(prev, leftBlock, ic, j + 1, results); continue; }
+      if (shouldMergeBlocks(leftBlock, rightOption.block)) results.push_back(HPoss{mergeBlocks(leftBlock, rightOption.block), true, ic});
+      else results.push_back(HPoss{leftBlock, false, ic});
+    }
+  }
+  static std::vector<HEntry> nextLevelMulti(const std::vector<HEntry>& prev) {  // maybeMakeBlock :69-127 for every block of the level below
+    std::vector<HEntry> out;
+    for (size_t i = 0; i + 1 < prev.size(); i++) {
+      const HEntry& L = prev[i];
+      const HEntry& R = prev[i + 1];
+      if (!L.multi && !R.multi) {
+        if (shouldMergeBlocks(L.single, R.single)) { HEntry e; e.single = mergeBlocks(L.single, R.single); out.push_back(e); }
+        continue;
+      }
+      std::vector<HPoss> mergeOptions;
+      for (const HPoss& leftOption : possibilitiesOf(L)) {
+        if (leftOption.hasBlock) expandMulti(prev, leftOption.block, leftOption.cond, i, mergeOptions);
+        else mergeOptions.push_back(HPoss{leftOption.block, false, leftOption.cond});
+      }
+      if (!mergeOptions.empty() && (int)mergeOptions.size() <= XM_MAX_COMBINATIONS) {
+        bool hasNonEmpty = false;
+        for (const HPoss& p : mergeOptions) if (p.hasBlock) hasNonEmpty = true;
+        if (hasNonEmpty) { HEntry e; e.multi = true; e.poss.swap(mergeOptions); out.push_back(e); }
+      }
+    }
+    return out;
+  }
 
   // Hash every gapmer with minLen <= used <= maxLen and append tables [minLen..maxLen].  Tables below minInterestingSize and
   // tables that receive no record are the reference's PackedMap(1, 1) placeholders (M/HashBlock_Database.java:387-393).
@@ -128,40 +222,67 @@ struct HostIndex {
     for (int c = 0; c < numContigs(); c++) {
       SeqView seq = contigView(c, false);
       int n = seq.len;
-      std::vector<HBlock> cur((size_t)n), next;
-      for (int i = 0; i < n; i++) {
-        PBlock b0 = level0Block(seq.base[i], 0);
-        HBlock h;
-        h.start = i; h.len = 1; h.fwd = b0.fwd; h.rev = b0.rev; h.flags = b0.flags; h.gapDir = 0; h.extraGap = 0;
-        cur[(size_t)i] = h;
+      // one block (a single block, or one possibility of a multi block) -> its gapmer -> records
+      auto emit = [&](const HBlock& b, uint32_t fromMulti) {
+        QBlock g;
+        int st;
+        if (enableGapmers) {
+          st = withGapAndExtension(b, seq, g);
+          if (st == 0) return;
+        } else {
+          g.start = b.start; g.len = b.len; g.used = b.len; g.fwd = b.fwd; g.rev = b.rev; g.flags = b.flags;
+        }
+        int used = g.used;
+        if (used < lo || used > maxLen) return;
+        bool rml = (g.flags & F_RML) != 0, rmr = (g.flags & F_RMR) != 0;
+        bool primary = (rml != rmr) ? rml : (g.fwd >= g.rev);     // M/HashBlock.java:329-334
+        bool secondary = (rml != rmr) ? rmr : (g.fwd <= g.rev);   // :336-340
+        int cap = capacity[(size_t)used];
+        if (primary) {  // M/PackedMap.java:107-112
+          int32_t r = g.fwd % cap; if (r < 0) r += cap;
+          recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, false, g.start), fromMulti});
+        }
+        if (secondary) {  // :113-118
+          int32_t r = g.rev % cap; if (r < 0) r += cap;
+          recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, true, n - (g.start + g.len)), fromMulti});
+        }
+      };
+      bool ambiguous = false;
+      for (int i = 0; i < n && !ambiguous; i++) if (bpIsAmbiguous(seq.base[i])) ambiguous = true;
+      if (ambiguous) {
+        std::vector<HEntry> cur((size_t)n);
+        for (int i = 0; i < n; i++) {
+          uint8_t code = seq.base[i];
+          HEntry& e = cur[(size_t)i];
+          if (bpIsAmbiguous(code)) {  // HashBlock_BaseRow.get: one possibility per base the code can stand for, A C G T order
+            e.multi = true;
+            for (int bit = 0; bit < 4; bit++) if (code & (1 << bit)) e.poss.push_back(HPoss{hblock0((uint8_t)(1 << bit), i), true, HCond(1, std::make_pair((int32_t)i, (uint8_t)(1 << bit)))});
+          } else {
+            e.single = hblock0(code, i);
+          }
+        }
+        while (!cur.empty()) {
+          bool anyShort = false;
+          for (const HEntry& e : cur) {
+            if (e.minLength() > maxLen) continue;
+            anyShort = true;
+            if (!e.multi) { if (e.single.len <= maxLen) emit(e.single, 0); }
+            else for (const HPoss& p : e.poss) if (p.hasBlock && p.block.len <= maxLen) emit(p.block, 1);
+          }
+          if (!anyShort) break;
+          std::vector<HEntry> next = nextLevelMulti(cur);
+          cur.swap(next);
+        }
+        continue;
       }
+      std::vector<HBlock> cur((size_t)n), next;
+      for (int i = 0; i < n; i++) cur[(size_t)i] = hblock0(seq.base[i], i);
       while (!cur.empty()) {
         bool anyShort = false;
         for (const HBlock& b : cur) {
           if (b.len > maxLen) continue;  // its gapmer uses at least b.len bases
           anyShort = true;
-          QBlock g;
-          int st;
-          if (enableGapmers) {
-            st = withGapAndExtension(b, seq, g);
-            if (st == 0) continue;
-          } else {
-            g.start = b.start; g.len = b.len; g.used = b.len; g.fwd = b.fwd; g.rev = b.rev; g.flags = b.flags;
-          }
-          int used = g.used;
-          if (used < lo || used > maxLen) continue;
-          bool rml = (g.flags & F_RML) != 0, rmr = (g.flags & F_RMR) != 0;
-          bool primary = (rml != rmr) ? rml : (g.fwd >= g.rev);     // M/HashBlock.java:329-334
-          bool secondary = (rml != rmr) ? rmr : (g.fwd <= g.rev);   // :336-340
-          int cap = capacity[(size_t)used];
-          if (primary) {  // M/PackedMap.java:107-112
-            int32_t r = g.fwd % cap; if (r < 0) r += cap;
-            recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, false, g.start)});
-          }
-          if (secondary) {  // :113-118
-            int32_t r = g.rev % cap; if (r < 0) r += cap;
-            recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, true, n - (g.start + g.len))});
-          }
+          emit(b, 0);
         }
         if (!anyShort) break;
         next.clear();
@@ -179,7 +300,16 @@ struct HostIndex {
       else { t.capacity = capacity[(size_t)L]; t.maxCount = maxCount[(size_t)L]; }
       t.offBase = (int64_t)bucketOff.size();
       t.posBase = (int64_t)positions.size();
-      std::sort(v.begin(), v.end(), [](const Rec& a, const Rec& b) { return a.bucket != b.bucket ? a.bucket < b.bucket : a.pos < b.pos; });
+      std::sort(v.begin(), v.end(), [](const Rec& a, const Rec& b) { return a.bucket != b.bucket ? a.bucket < b.bucket : (a.pos != b.pos ? a.pos < b.pos : a.fromMulti < b.fromMulti); });
+      {  // PackedMap.add with preventDuplicates (:124-153): a record that comes from a multi block is not added when its bucket already holds
+         // that position ([approximation, see DESIGN.md] "already" is taken as: among all single-block records and the earlier multi records)
+        size_t w = 0;
+        for (size_t r = 0; r < v.size(); r++) {
+          if (v[r].fromMulti && w > 0 && v[w - 1].bucket == v[r].bucket && v[w - 1].pos == v[r].pos) continue;
+          v[w++] = v[r];
+        }
+        v.resize(w);
+      }
       size_t i = 0;
       uint64_t stored = 0;
       for (int k = 0; k < t.capacity; k++) {
@@ -285,6 +415,9 @@ struct HostIndex {
             std::string text;
             for (int i = 0; i < prefixLength; i++) text.push_back((char)v.at(p.start + i));
             for (int i = 0; i < prefixLength; i++) text.push_back((char)v.at(p.start + L - prefixLength + i));
+            bool ambiguousText = false;  // :75 isAmbiguousText: positions whose prefix or suffix has a non-ACGT base are left out
+            for (char ch : text) if (bpIsAmbiguous((uint8_t)ch)) ambiguousText = true;
+            if (ambiguousText) continue;
             std::vector<P>& g = byText[text];
             bool dupPos = false;                               // removeDuplicatePositions
             for (const P& q : g) if (q.contig == p.contig && q.rc == p.rc && q.start == p.start) { dupPos = true; break; }

@@ -78,3 +78,16 @@ def sprinkle_ambiguity(reads, seed=3):
             p0 = rng.integers(0, out.shape[1] - 12)
             out[q, p0:p0 + rng.integers(2, 12)] = 15
     return out
+
+
+def ambiguous_reference(n, seed, n_runs=6, n_codes=40):
+    """A synthetic reference (code array) with runs of N (1-40 long) and scattered IUPAC codes."""
+    from mapper_amd import synth
+    ref = synth.synthetic_reference(n, seed=seed).copy()
+    rng = np.random.default_rng(seed)
+    for _ in range(n_runs):
+        p0 = int(rng.integers(0, n - 50))
+        ref[p0:p0 + int(rng.integers(1, 41))] = 15
+    codes = np.array([15, 5, 10, 3, 12, 6, 9, 7, 11, 13, 14], np.uint8)
+    ref[rng.integers(0, n, size=n_codes)] = codes[rng.integers(0, len(codes), size=n_codes)]
+    return ref

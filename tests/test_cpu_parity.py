@@ -7,7 +7,7 @@ import pytest
 
 import oracle_lib as o
 import hostsim_lib as hs
-from helpers import KAT, streams_equal, first_difference, se_batch, pe_batch, check_align_case, sprinkle_ambiguity
+from helpers import KAT, streams_equal, first_difference, se_batch, pe_batch, check_align_case, sprinkle_ambiguity, ambiguous_reference
 from mapper_amd import api, synth, _capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,12 +67,40 @@ def test_index_builder_matches_oracle(mode, contigs):
     P.close()
 
 
-def test_ambiguous_reference_is_rejected_loudly():
-    with pytest.raises(RuntimeError, match="non-ACGT"):
-        api.ReferenceDatabase([("r", "ACGTNACGTACGTACGATCGATCGACTGACTAGC")], host_only=True)
+@pytest.mark.parametrize("mode,n", [("mapper", 60_000), ("api", 4000)])
+def test_index_builder_with_ambiguous_reference_matches_oracle(mode, n):
+    """Reference with N runs and IUPAC codes: the tables the host builder makes from its multi-block restatement (possibilities of every
+    block over an ambiguous base, duplicate suppression of PackedMap.add) equal the oracle's literal HashBlock_Database."""
+    refs = [("amb", ambiguous_reference(n, seed=0xA3B))]
+    R = o.OracleReference(refs, mode=mode)
+    R.align(["ACGTACGTACGTAGCATCGACTAGCAGCATCGAC"], o.make_params())
+    P = api.ReferenceDatabase(refs, mode=mode, host_only=True)
+    mn, mx = R.index_info()
+    info = P.info()
+    assert info["min_interesting_size"] == mn and info["max_hashed_length"] == mx
+    for L in range(0, mx + 1):
+        ta, tb = R.table(L), P.table(L)
+        assert ta["capacity"] == tb["capacity"] and ta["maxCount"] == tb["maxCount"], L
+        assert np.array_equal(ta["counts"], tb["counts"]), L
+        assert np.array_equal(ta["positions"], tb["positions"]), L
+    assert np.array_equal(R.dup_keys(0), P.dup_keys(0))
+    P.close()
 
 
-@pytest.mark.parametrize("case", [c for c in KAT["align_cases"] if set(c["reference"]) <= set("ACGT")], ids=lambda c: c["name"])
+def test_kernel_logic_with_ambiguous_reference():
+    """Reads (plain and with ambiguity codes of their own) against a reference with N runs and IUPAC codes: kernel logic vs oracle."""
+    ref = ambiguous_reference(200_000, seed=0xA3C, n_runs=60, n_codes=600)
+    reads = synth.synthetic_single_end(ref, 4000, seed=51)[0]
+    reads[2000:] = sprinkle_ambiguity(reads[2000:], 6)
+    R = o.OracleReference([("amb", ref)])
+    S = hs.SimReference([("amb", ref)])
+    b = se_batch(reads)
+    want = R.align(b, o.make_params(), threads=os.cpu_count())
+    got = S.align(b, o.make_params())
+    assert streams_equal(got, want), first_difference(got, want, len(reads))
+
+
+@pytest.mark.parametrize("case", KAT["align_cases"], ids=lambda c: c["name"])
 def test_kernel_logic_on_reference_kats(case):
     """The reference's own AlignerWorker_Test cases through the kernel sources (host-simulated): expectations hold and the
     result streams are bit-identical to the oracle's."""

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as o
-from helpers import KAT, streams_equal, first_difference, se_batch, pe_batch, check_align_case, sam_text, sprinkle_ambiguity
+from helpers import KAT, streams_equal, first_difference, se_batch, pe_batch, check_align_case, sam_text, sprinkle_ambiguity, ambiguous_reference
 from mapper_amd import api, synth
 
 pytestmark = pytest.mark.gpu
@@ -25,7 +25,7 @@ def to_api_params(d):
     return api.AlignmentParameters(**{k: v for k, v in d.items()})
 
 
-@pytest.mark.parametrize("case", [c for c in KAT["align_cases"] if set(c["reference"]) <= set("ACGT")], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", KAT["align_cases"], ids=lambda c: c["name"])
 def test_reference_kats_on_gpu(case):
     """T/AlignerWorker_Test.java through Api.alignOnce's mirror: expectations of the reference's test + bit-identical to the oracle."""
     db = api.newDatabase(case["reference"])
@@ -159,6 +159,20 @@ def test_reads_with_ambiguous_bases_on_gpu():
         assert streams_equal(got, want), first_difference(got, want, n)
     one = db.align_batch([api.Query("ACGTACGTACGTANGTACGTACGTACGTACGTACGT")], api.AlignmentParameters())  # (the first implementation refused this read)
     assert len(one.int_off) == 2
+    db.close()
+
+
+def test_ambiguous_reference_on_gpu():
+    """Reference with N runs and IUPAC codes (multi-block index build on the host, ambiguity penalties and SkipHighAmbiguity on the device),
+    plain reads and reads with ambiguity codes of their own: bit-identical to the oracle."""
+    ref = ambiguous_reference(300_000, seed=0xA3D, n_runs=80, n_codes=900)
+    reads = synth.synthetic_single_end(ref, 8000, seed=52)[0]
+    reads[4000:] = sprinkle_ambiguity(reads[4000:], 7)
+    b = se_batch(reads)
+    db = api.ReferenceDatabase([("amb", ref)])
+    got, _ = gpu_align(db, b)
+    want = o.OracleReference([("amb", ref)]).align(b, o.make_params(), threads=os.cpu_count())
+    assert streams_equal(got, want), first_difference(got, want, len(reads))
     db.close()
 
 
