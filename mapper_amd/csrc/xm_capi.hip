@@ -711,7 +711,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // the scratch capacities are sized for ~150-300 bp mates at scale 1; batches of longer reads start at a larger scale instead of
     // sending every read through a pass that can only overflow
     int scale = idx->residentMaxLen <= 320 ? 1 : (idx->residentMaxLen <= 1280 ? 4 : 16), overflowScale = scale;
-    const int gappedScale = scale < 4 ? 4 : scale * 4;
+    const int gappedScale = scale < 4 ? (int)envInt("XM_GAPPED_SCALE", 4) : scale * 4;
     bool heavy = false, defer = false, memoFresh = false, inlineRest = false;
     int searchRounds = 0;
     unsigned long long intCap = (unsigned long long)nq * 40 + 4096, dblCap = (unsigned long long)nq * 12 + 4096;

@@ -105,7 +105,8 @@ struct HostIndex {
     return result;
   }
 
-  struct Rec { uint32_t bucket; uint64_t pos; uint32_t fromMulti; };
+  struct Rec { uint32_t bucket; uint64_t pos; };  // pos bit 63: the record comes from a possibility of a multi block
+  static constexpr uint64_t REC_MULTI = 1ull << 63;
 
   // ---- contigs with ambiguous bases: blocks over such a base are lists of conditional possibilities (M/MultiHashBlock.java,
   // M/ConditionalHashBlock.java, M/SequenceCondition.java, the multi branch of M/HashBlock_ParentRow.java:69-191 and
@@ -240,11 +241,11 @@ struct HostIndex {
         int cap = capacity[(size_t)used];
         if (primary) {  // M/PackedMap.java:107-112
           int32_t r = g.fwd % cap; if (r < 0) r += cap;
-          recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, false, g.start), fromMulti});
+          recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, false, g.start) | (fromMulti ? REC_MULTI : 0)});
         }
         if (secondary) {  // :113-118
           int32_t r = g.rev % cap; if (r < 0) r += cap;
-          recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, true, n - (g.start + g.len)), fromMulti});
+          recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, true, n - (g.start + g.len)) | (fromMulti ? REC_MULTI : 0)});
         }
       };
       bool ambiguous = false;
@@ -300,13 +301,20 @@ struct HostIndex {
       else { t.capacity = capacity[(size_t)L]; t.maxCount = maxCount[(size_t)L]; }
       t.offBase = (int64_t)bucketOff.size();
       t.posBase = (int64_t)positions.size();
-      std::sort(v.begin(), v.end(), [](const Rec& a, const Rec& b) { return a.bucket != b.bucket ? a.bucket < b.bucket : (a.pos != b.pos ? a.pos < b.pos : a.fromMulti < b.fromMulti); });
+      // (bucket, position, single before multi): the flag is the top bit of pos, so plain order on (pos << 1 | flag)
+      std::sort(v.begin(), v.end(), [](const Rec& a, const Rec& b) {
+        if (a.bucket != b.bucket) return a.bucket < b.bucket;
+        return ((a.pos << 1) | (a.pos >> 63)) < ((b.pos << 1) | (b.pos >> 63));
+      });
       {  // PackedMap.add with preventDuplicates (:124-153): a record that comes from a multi block is not added when its bucket already holds
          // that position ([approximation, see DESIGN.md] "already" is taken as: among all single-block records and the earlier multi records)
         size_t w = 0;
         for (size_t r = 0; r < v.size(); r++) {
-          if (v[r].fromMulti && w > 0 && v[w - 1].bucket == v[r].bucket && v[w - 1].pos == v[r].pos) continue;
-          v[w++] = v[r];
+          const bool multi = (v[r].pos & REC_MULTI) != 0;
+          const uint64_t pos = v[r].pos & ~REC_MULTI;
+          if (multi && w > 0 && v[w - 1].bucket == v[r].bucket && v[w - 1].pos == pos) continue;
+          v[w].bucket = v[r].bucket; v[w].pos = pos;
+          w++;
         }
         v.resize(w);
       }
