@@ -18,6 +18,11 @@
 #include <algorithm>
 #include <stdexcept>
 #include <cmath>
+#include <thread>
+#include <chrono>
+#include <cstdio>
+#include <mutex>
+#include <functional>
 
 namespace xm {
 
@@ -103,6 +108,28 @@ struct HostIndex {
     int result = uniqueCount;
     if (result % 2 == 0) result++;
     return result;
+  }
+
+  // host threads for the build (the reference's workers cooperate through helpHash/helpPack, M/HashBlock_Database.java:237-242)
+  static int buildThreads(size_t work) {
+    if (work < 200000) return 1;
+    unsigned hc = std::thread::hardware_concurrency();
+    int t = hc ? (int)hc : 1;
+    const char* e = getenv("XM_BUILD_THREADS");
+    if (e && *e) t = atoi(e);
+    return t < 1 ? 1 : (t > 64 ? 64 : t);
+  }
+  // fn(part, begin, end) over [0, n) cut into nThreads consecutive parts
+  static void parallelParts(size_t n, int nThreads, const std::function<void(int, size_t, size_t)>& fn) {
+    if (nThreads <= 1 || n < 2) { fn(0, 0, n); return; }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err((size_t)nThreads);
+    for (int t = 0; t < nThreads; t++) {
+      size_t b = n * (size_t)t / (size_t)nThreads, e = n * (size_t)(t + 1) / (size_t)nThreads;
+      th.emplace_back([&, t, b, e]() { try { fn(t, b, e); } catch (...) { err[(size_t)t] = std::current_exception(); } });
+    }
+    for (auto& x : th) x.join();
+    for (auto& x : err) if (x) std::rethrow_exception(x);
   }
 
   struct Rec { uint32_t bucket; uint64_t pos; };  // pos bit 63: the record comes from a possibility of a multi block
@@ -224,7 +251,7 @@ struct HostIndex {
       SeqView seq = contigView(c, false);
       int n = seq.len;
       // one block (a single block, or one possibility of a multi block) -> its gapmer -> records
-      auto emit = [&](const HBlock& b, uint32_t fromMulti) {
+      auto emit = [&](const HBlock& b, uint32_t fromMulti, std::vector<std::vector<Rec>>& recs) {
         QBlock g;
         int st;
         if (enableGapmers) {
@@ -267,8 +294,8 @@ struct HostIndex {
           for (const HEntry& e : cur) {
             if (e.minLength() > maxLen) continue;
             anyShort = true;
-            if (!e.multi) { if (e.single.len <= maxLen) emit(e.single, 0); }
-            else for (const HPoss& p : e.poss) if (p.hasBlock && p.block.len <= maxLen) emit(p.block, 1);
+            if (!e.multi) { if (e.single.len <= maxLen) emit(e.single, 0, recs); }
+            else for (const HPoss& p : e.poss) if (p.hasBlock && p.block.len <= maxLen) emit(p.block, 1, recs);
           }
           if (!anyShort) break;
           std::vector<HEntry> next = nextLevelMulti(cur);
@@ -276,67 +303,118 @@ struct HostIndex {
         }
         continue;
       }
+      // plain ACGT contig: every level is cut into consecutive parts, one per host thread; a part emits the records of its blocks and
+      // merges its pairs (the pair that straddles two parts belongs to the left one); parts are concatenated in order
       std::vector<HBlock> cur((size_t)n), next;
       for (int i = 0; i < n; i++) cur[(size_t)i] = hblock0(seq.base[i], i);
+      const int nT = buildThreads((size_t)n);
+      std::vector<std::vector<std::vector<Rec>>> partRecs((size_t)nT, std::vector<std::vector<Rec>>((size_t)maxLen + 1));
+      std::vector<std::vector<HBlock>> partNext((size_t)nT);
+      std::vector<char> partShort((size_t)nT);
       while (!cur.empty()) {
+        parallelParts(cur.size(), nT, [&](int t, size_t b, size_t e) {
+          bool anyShort = false;
+          std::vector<HBlock>& nx = partNext[(size_t)t];
+          nx.clear();
+          for (size_t i = b; i < e; i++) {
+            const HBlock& blk = cur[i];
+            if (blk.len <= maxLen) {  // (a longer block's gapmer uses at least blk.len bases)
+              anyShort = true;
+              emit(blk, 0, partRecs[(size_t)t]);
+            }
+            if (i + 1 < cur.size() && shouldMergeBlocks(blk, cur[i + 1])) nx.push_back(mergeBlocks(blk, cur[i + 1]));
+          }
+          partShort[(size_t)t] = anyShort ? 1 : 0;
+        });
         bool anyShort = false;
-        for (const HBlock& b : cur) {
-          if (b.len > maxLen) continue;  // its gapmer uses at least b.len bases
-          anyShort = true;
-          emit(b, 0);
-        }
-        if (!anyShort) break;
+        for (int t = 0; t < nT; t++) if (partShort[(size_t)t]) anyShort = true;
+        if (!anyShort) break;  // (the level after a level without short blocks is never looked at)
         next.clear();
-        for (size_t i = 0; i + 1 < cur.size(); i++) {
-          if (shouldMergeBlocks(cur[i], cur[i + 1])) next.push_back(mergeBlocks(cur[i], cur[i + 1]));
-        }
+        for (int t = 0; t < nT; t++) next.insert(next.end(), partNext[(size_t)t].begin(), partNext[(size_t)t].end());
         cur.swap(next);
       }
+      for (int t = 0; t < nT; t++)
+        for (int L = 0; L <= maxLen; L++) {
+          std::vector<Rec>& src = partRecs[(size_t)t][(size_t)L];
+          recs[(size_t)L].insert(recs[(size_t)L].end(), src.begin(), src.end());
+          std::vector<Rec>().swap(src);
+        }
     }
     if ((int)tables.size() < maxLen + 1) tables.resize((size_t)maxLen + 1);
-    for (int L = minLen; L <= maxLen; L++) {
-      Table t;
-      std::vector<Rec>& v = recs[(size_t)L];
-      if (v.empty()) { t.capacity = 1; t.maxCount = 1; }
-      else { t.capacity = capacity[(size_t)L]; t.maxCount = maxCount[(size_t)L]; }
+    // every table on its own (sort, duplicate suppression, CSR), tables in parallel; then concatenated in order of L
+    const int nTables = maxLen - minLen + 1;
+    std::vector<std::vector<uint32_t>> tOff((size_t)nTables);
+    std::vector<std::vector<uint64_t>> tPos((size_t)nTables);
+    std::vector<Table> tHdr((size_t)nTables);
+    size_t totalRecs = 0;
+    for (int L = minLen; L <= maxLen; L++) totalRecs += recs[(size_t)L].size();
+    const int nT2 = std::min(buildThreads(totalRecs), nTables);
+    std::vector<int> order((size_t)nTables);
+    for (int k = 0; k < nTables; k++) order[(size_t)k] = k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return recs[(size_t)(minLen + a)].size() > recs[(size_t)(minLen + b)].size(); });  // large tables first
+    std::vector<size_t> nextJob(1, 0);
+    std::mutex jobMu;
+    parallelParts((size_t)nT2, nT2, [&](int, size_t, size_t) {
+      while (true) {
+        size_t job;
+        { std::lock_guard<std::mutex> lock(jobMu); job = nextJob[0]++; }
+        if (job >= (size_t)nTables) break;
+        const int k = order[job];
+        const int L = minLen + k;
+        Table t;
+        std::vector<Rec>& v = recs[(size_t)L];
+        if (v.empty()) { t.capacity = 1; t.maxCount = 1; }
+        else { t.capacity = capacity[(size_t)L]; t.maxCount = maxCount[(size_t)L]; }
+        // (bucket, position, single before multi): the flag is the top bit of pos, so plain order on (pos << 1 | flag)
+        std::sort(v.begin(), v.end(), [](const Rec& a, const Rec& b) {
+          if (a.bucket != b.bucket) return a.bucket < b.bucket;
+          return ((a.pos << 1) | (a.pos >> 63)) < ((b.pos << 1) | (b.pos >> 63));
+        });
+        {  // PackedMap.add with preventDuplicates (:124-153): a record that comes from a multi block is not added when its bucket already holds
+           // that position ([approximation, see DESIGN.md] "already" is taken as: among all single-block records and the earlier multi records)
+          size_t w = 0;
+          for (size_t r = 0; r < v.size(); r++) {
+            const bool multi = (v[r].pos & REC_MULTI) != 0;
+            const uint64_t pos = v[r].pos & ~REC_MULTI;
+            if (multi && w > 0 && v[w - 1].bucket == v[r].bucket && v[w - 1].pos == pos) continue;
+            v[w].bucket = v[r].bucket; v[w].pos = pos;
+            w++;
+          }
+          v.resize(w);
+        }
+        std::vector<uint32_t>& off = tOff[(size_t)k];
+        std::vector<uint64_t>& pos = tPos[(size_t)k];
+        off.reserve((size_t)t.capacity + 1);
+        size_t i = 0;
+        uint64_t stored = 0;
+        for (int b = 0; b < t.capacity; b++) {
+          size_t j = i;
+          while (j < v.size() && v[j].bucket == (uint32_t)b) j++;
+          size_t cnt = j - i;
+          if (stored > 0x7FFFFFFFull) throw std::runtime_error("table too large for 31-bit bucket offsets");
+          if ((int64_t)cnt > (int64_t)t.maxCount) {
+            off.push_back((uint32_t)stored | XM_OVERFULL);
+          } else {
+            off.push_back((uint32_t)stored);
+            for (size_t x = i; x < j; x++) pos.push_back(v[x].pos);
+            stored += cnt;
+          }
+          i = j;
+        }
+        off.push_back((uint32_t)stored);
+        tHdr[(size_t)k] = t;
+        std::vector<Rec>().swap(v);
+      }
+    });
+    for (int k = 0; k < nTables; k++) {
+      Table t = tHdr[(size_t)k];
       t.offBase = (int64_t)bucketOff.size();
       t.posBase = (int64_t)positions.size();
-      // (bucket, position, single before multi): the flag is the top bit of pos, so plain order on (pos << 1 | flag)
-      std::sort(v.begin(), v.end(), [](const Rec& a, const Rec& b) {
-        if (a.bucket != b.bucket) return a.bucket < b.bucket;
-        return ((a.pos << 1) | (a.pos >> 63)) < ((b.pos << 1) | (b.pos >> 63));
-      });
-      {  // PackedMap.add with preventDuplicates (:124-153): a record that comes from a multi block is not added when its bucket already holds
-         // that position ([approximation, see DESIGN.md] "already" is taken as: among all single-block records and the earlier multi records)
-        size_t w = 0;
-        for (size_t r = 0; r < v.size(); r++) {
-          const bool multi = (v[r].pos & REC_MULTI) != 0;
-          const uint64_t pos = v[r].pos & ~REC_MULTI;
-          if (multi && w > 0 && v[w - 1].bucket == v[r].bucket && v[w - 1].pos == pos) continue;
-          v[w].bucket = v[r].bucket; v[w].pos = pos;
-          w++;
-        }
-        v.resize(w);
-      }
-      size_t i = 0;
-      uint64_t stored = 0;
-      for (int k = 0; k < t.capacity; k++) {
-        size_t j = i;
-        while (j < v.size() && v[j].bucket == (uint32_t)k) j++;
-        size_t cnt = j - i;
-        if (stored > 0x7FFFFFFFull) throw std::runtime_error("table too large for 31-bit bucket offsets");
-        if ((int64_t)cnt > (int64_t)t.maxCount) {
-          bucketOff.push_back((uint32_t)stored | XM_OVERFULL);
-        } else {
-          bucketOff.push_back((uint32_t)stored);
-          for (size_t x = i; x < j; x++) positions.push_back(v[x].pos);
-          stored += cnt;
-        }
-        i = j;
-      }
-      bucketOff.push_back((uint32_t)stored);
-      tables[(size_t)L] = t;
-      std::vector<Rec>().swap(v);
+      bucketOff.insert(bucketOff.end(), tOff[(size_t)k].begin(), tOff[(size_t)k].end());
+      positions.insert(positions.end(), tPos[(size_t)k].begin(), tPos[(size_t)k].end());
+      tables[(size_t)(minLen + k)] = t;
+      std::vector<uint32_t>().swap(tOff[(size_t)k]);
+      std::vector<uint64_t>().swap(tPos[(size_t)k]);
     }
   }
 
@@ -351,9 +429,14 @@ struct HostIndex {
     int want = maxHashed > 0 ? maxHashed : chooseMaxDuplicationLength();
     want = std::max(want, std::max(dupMaxLength, dupMinLength + 1));
     want = std::max(want, 1);
+    const bool trace = getenv("XM_TRACE_BUILD") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
     hashLengths(0, want);
     maxHashedLength = want;
+    auto t1 = std::chrono::steady_clock::now();
     detectDuplications();
+    auto t2 = std::chrono::steady_clock::now();
+    if (trace) fprintf(stderr, "[xm] index build: hashing + tables %.3f s, duplication map %.3f s\n", std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
   }
   void ensureLength(int length) {
     if (length <= maxHashedLength) return;
