@@ -84,13 +84,15 @@ typedef struct xm_result {
   int64_t* dbl_off;  /* [nq+1] */
   /* counters of this call: 0 reads, 1 bucket-header probes (PackedMap.getNumMatchesLowerBound), 2 bucket fetches (PackedMap.get),
    * 3 positions fetched, 4 candidates extended (QueryMatch_Aligner.doAlign), 5 PathAligner calls, 6 PathAligner nodes, 7 quick accepts,
-   * 8 alignments written, 9 reference-window bytes (4-bit), 10 read bytes (4-bit), 11 reads rerun with a larger scratch scale */
+   * 8 alignments written, 9 reference-window bytes (4-bit), 10 read bytes (4-bit), 11 reads rerun with a larger scratch scale,
+   * 12-15 kernel microseconds by pass: 12 light pass, 13 gapped-chain passes with deferred searches, 14 search kernels, 15 gapped / rerun
+   * passes with inline searches */
   int64_t counters[16];
-  double kernel_ms;   /* sum of the align kernel's launch durations (HIP events on the launch stream) */
-  double h2d_ms, d2h_ms;
-  int32_t kernel_launches;
+  double kernel_ms;   /* sum of the align (and search) kernels' launch durations (HIP events on the launch stream) */
+  double h2d_ms, d2h_ms;  /* batch upload; prefix sums + query-order gather + copy of the four streams to the host */
+  int32_t kernel_launches;  /* align + search kernel launches of this call */
   int32_t reserved;
-  int64_t prof[16];   /* diagnostic builds (-DXM_PROFILE) only: shader-clock ticks per phase summed over lanes; otherwise 0 */
+  int64_t prof[16];   /* diagnostic builds (-DXM_PROFILE=1: summed over lanes, =2: per wave) only: shader-clock ticks per phase; otherwise 0 */
 } xm_result;
 
 typedef struct xm_index_info_t {
@@ -117,7 +119,8 @@ int xm_index_table_dump(const xm_index* index, int32_t used_length, int32_t* cou
 int64_t xm_index_dup_keys(const xm_index* index, int32_t contig, int32_t* out, int64_t cap);
 
 /* Replaces the per-read loop of AlignerWorker.process() / Api.align (AlignerWorker.java:177-231,306-644): every query is
- * aligned on the GPU; *out is allocated by the library and released with xm_result_free. */
+ * aligned on the GPU; *out is allocated by the library (its four streams are pinned host buffers from a pool the library keeps) and
+ * released with xm_result_free.  Reads may contain IUPAC ambiguity codes (at most 128 ambiguous bases per mate). */
 int xm_align_batch(xm_index* index, const xm_params* params, const xm_query_batch* batch, xm_result** out);
 void xm_result_free(xm_result* result);
 /* The same in two steps, for callers that keep a batch in HBM (and for measuring the path without the PCIe copy):
