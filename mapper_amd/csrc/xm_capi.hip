@@ -592,7 +592,7 @@ static void uploadBatchLocked(xm_index* idx, const xm_query_batch* b) {
     if (b->mate_count[q] < 1 || b->mate_count[q] > 2) throw std::runtime_error("mate_count must be 1 or 2");
     for (int m = 0; m < b->mate_count[q]; m++) {
       int32_t len = b->mate_length[q * 2 + m];
-      if (len < 1 || len > 60000) throw std::runtime_error("mate length out of range (1..60000)");
+      if (len < 1 || len > 30000) throw std::runtime_error("mate length out of range (1..30000; longer reads are split by the caller as --split-queries-past-size does)");
       if (b->mate_offset[q * 2 + m] < 0 || b->mate_offset[q * 2 + m] + len > b->codes_length) throw std::runtime_error("mate outside of codes");
       if (len > maxLen) maxLen = len;
     }
