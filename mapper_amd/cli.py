@@ -18,7 +18,7 @@ import numpy as np
 from . import api, sam
 
 JAVA_HOST_ONLY = {"--out-vcf": 1, "--out-mutations": 1, "--out-ancestor": 1, "--out-refs-map-count": 1, "--cache-dir": 1,
-                  "--distinguish-query-ends": 1, "--split-queries-past-size": 1, "--infer-ancestors": 0, "--verify-consistent-db": 0,
+                  "--distinguish-query-ends": 1, "--infer-ancestors": 0, "--verify-consistent-db": 0,
                   "--vcf-exclude-non-mutations": 0, "--vcf-omit-support-reads": 0}
 IGNORED = {"--verbose": 0, "-v": 0, "-vv": 0, "--verbose-alignment": 0, "--verbose-reference": 0, "--verbosity-auto": 0, "--num-threads": 1,
            "--no-infer-ancestors": 0, "--allow-duplicate-contig-names": 0, "--version": 0}
@@ -67,7 +67,7 @@ def parse_args(argv):
     o = dict(references=[], queries=[], paired=[], out_sam=None, out_unaligned=None, no_output=False, enable_gapmers=True,
              mutationPenalty=-1.0, indelStart_penalty=1.5, indelExtension_penalty=0.5, additional_insertionExtension_penalty=-1.0,
              maxErrorRate=-1.0, ambiguityPenalty=-1.0, maxNumMatches=2**31 - 1, max_penaltySpan=-1.0, device=0,
-             paired_without_spacing=False, help=False)
+             paired_without_spacing=False, help=False, split=0)
     i = 0
     while i < len(argv):
         a = argv[i]
@@ -76,8 +76,14 @@ def parse_args(argv):
         elif a == "--reference":
             o["references"].append(argv[i + 1]); i += 1
         elif a == "--queries":
-            o["queries"].append(argv[i + 1]); i += 1
+            o["queries"].append((argv[i + 1], o["split"])); i += 1
+        elif a == "--split-queries-past-size":  # Mapper.java:142-148: applies to the --queries that follow
+            if o["queries"] or o["paired"]:
+                raise UsageError("Sorry, --split-queries-past-size currently is only supported before --queries")
+            o["split"] = int(argv[i + 1]); i += 1
         elif a == "--paired-queries":
+            if o["split"] > 0:
+                raise UsageError("Sorry, --paired-queries is not currently supported with --split-queries-past-size")
             left, right = argv[i + 1], argv[i + 2]
             i += 2
             expected, deviation = 100.0, 50.0  # Mapper.java:41-42
@@ -164,9 +170,15 @@ def derive_parameters(o):
 def load_queries(o):
     """-> list of (api.Query, qualities or None) in input order: --queries files first, then --paired-queries files, as Mapper.main adds them."""
     out = []
-    for path in o["queries"]:
+    for path, split in o["queries"]:
         for name, text, qual in read_sequences(path):
-            out.append((api.Query(text, name=name), [qual]))
+            if split > 0:  # SequenceSplitter.java:9-40: equal sections of at most `split` bases (the sections carry no quality; their names are [unpinned])
+                num = (len(text) - 1) // split + 1
+                for k in range(num):
+                    a, b = len(text) * k // num, len(text) * (k + 1) // num
+                    out.append((api.Query(text[a:b], name=name), [None]))
+            else:
+                out.append((api.Query(text, name=name), [qual]))
     for left, right, expected, deviation in o["paired"]:
         ls, rs = read_sequences(left), read_sequences(right)
         if len(ls) != len(rs):

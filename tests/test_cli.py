@@ -36,6 +36,16 @@ def test_paired_queries_and_spacing():
     assert o["paired"] == [("a.fq", "b.fq", 250.0, 40.0), ("c.fq", "d.fq", 100.0, 50.0)] and o["paired_without_spacing"]
 
 
+def test_split_queries(tmp_path):
+    fa = tmp_path / "long.fasta"
+    fa.write_text(">r1\n" + "ACGT" * 6 + "A\n>r2\nACGTA\n")  # 25 and 5 bases
+    o = cli.parse_args(["--reference", "r.fa", "--split-queries-past-size", "10", "--queries", str(fa), "--no-output"])
+    qs = cli.load_queries(o)
+    assert [len(q.sequences[0]) for q, _ in qs] == [8, 8, 9, 5]  # SequenceSplitter: (25-1)//10+1 = 3 sections at 25*k//3
+    with pytest.raises(cli.UsageError):
+        cli.parse_args(["--reference", "r.fa", "--queries", str(fa), "--split-queries-past-size", "10"])
+
+
 @pytest.mark.parametrize("argv,needle", [
     (["--queries", "q.fa", "--out-sam", "o"], "--reference is required"),
     (["--reference", "r.fa", "--out-sam", "o"], "--queries or --paired-queries is required"),
