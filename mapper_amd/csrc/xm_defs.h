@@ -92,6 +92,45 @@ struct SeqView {
   XM_INL uint8_t at(int i) const { XM_GLOBAL(const uint8_t)* const g = (XM_GLOBAL(const uint8_t)*)base; return rc ? bpComplement(g[len - 1 - i]) : g[i]; }
 };
 
+// Eight consecutive bases of a view, starting at view position i, as one 64-bit word (base k in byte k).  The caller guarantees
+// 0 <= i and i + 8 <= len.  A reverse-complement view reads its bytes backwards and complements them (a 4-bit code's complement is its
+// bit reversal).
+XM_INL uint64_t seqWord8(const SeqView& s, int i) {
+  uint64_t x;
+  if (!s.rc) {
+    __builtin_memcpy(&x, (const void*)(s.base + i), 8);
+    return x;
+  }
+  __builtin_memcpy(&x, (const void*)(s.base + (s.len - 8 - i)), 8);
+  x = __builtin_bswap64(x);
+  return ((x & 0x0101010101010101ull) << 3) | ((x & 0x0202020202020202ull) << 1) | ((x & 0x0404040404040404ull) >> 1) | ((x & 0x0808080808080808ull) >> 3);
+}
+// How many positions k in [0, limit) can match (Basepairs.canMatch: the two codes share a base) before the first one that cannot:
+// a.at(ai + k) against b.at(bi + k).  Eight positions per pair of loads while both views have eight left.
+XM_INL int seqMatchRun(const SeqView& a, int ai, const SeqView& b, int bi, int limit) {
+  int k = 0;
+  while (k + 8 <= limit && ai + k + 8 <= a.len && bi + k + 8 <= b.len) {
+    const uint64_t t = seqWord8(a, ai + k) & seqWord8(b, bi + k);   // per byte: the bases both codes allow (codes are < 16)
+    const uint64_t zero = ~(t + 0x7F7F7F7F7F7F7F7Full) & 0x8080808080808080ull;  // bit 7 of byte j set iff byte j of t is 0 (bytes are < 16: no carry between bytes)
+    if (zero) return k + (__builtin_ctzll(zero) >> 3);
+    k += 8;
+  }
+  while (k < limit && bpCanMatch(a.at(ai + k), b.at(bi + k))) k++;
+  return k;
+}
+// the same going down: a.at(ai - k) against b.at(bi - k), k in [0, limit)
+XM_INL int seqMatchRunBack(const SeqView& a, int ai, const SeqView& b, int bi, int limit) {
+  int k = 0;
+  while (k + 8 <= limit && ai - k - 7 >= 0 && bi - k - 7 >= 0) {
+    const uint64_t t = seqWord8(a, ai - k - 7) & seqWord8(b, bi - k - 7);  // byte j holds position (.. - 7 + j): the nearest position is byte 7
+    const uint64_t zero = ~(t + 0x7F7F7F7F7F7F7F7Full) & 0x8080808080808080ull;
+    if (zero) return k + (__builtin_clzll(zero) >> 3);
+    k += 8;
+  }
+  while (k < limit && bpCanMatch(a.at(ai - k), b.at(bi - k))) k++;
+  return k;
+}
+
 // ---------------------------------------------------------------- AlignmentParameters (M/AlignmentParameters.java:8-35)
 struct Params {
   double MutationPenalty, InsertionStart_Penalty, InsertionExtension_Penalty, DeletionStart_Penalty, DeletionExtension_Penalty,

@@ -1255,25 +1255,23 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qsIn,
       int otherStartIndex = position;
       int reverseCount = imin(blockStartIndex - maxNonmatchingBlockEnd, otherStartIndex);
       bool foundMismatch = false;
-      for (int i = 1; i <= reverseCount; i++) {
-        if (!bpCanMatch(query.at(blockStartIndex - i), reference.at(otherStartIndex - i))) {
-          numMismatches++;
-          foundMismatch = true;
-          maxNonmatchingBlockEnd = blockStartIndex + blockLength;
-          break;
-        }
+      // the two base-by-base extensions of the reference (:167-200), eight bases per pair of loads (seqMatchRun, xm_defs.h)
+      if (reverseCount > 0 && seqMatchRunBack(query, blockStartIndex - 1, reference, otherStartIndex - 1, reverseCount) < reverseCount) {
+        numMismatches++;
+        foundMismatch = true;
+        maxNonmatchingBlockEnd = blockStartIndex + blockLength;
       }
       if (!foundMismatch) {
         int forwardShift = qs.end - blockStartIndex;
-        for (int i = blockLength; i < forwardShift; i++) {
-          int indexA = blockStartIndex + i, indexB = otherStartIndex + i;
-          uint8_t ca = query.at(indexA);
-          uint8_t cb = (indexB < rs.end) ? reference.at(indexB) : (uint8_t)0;
-          if (!bpCanMatch(ca, cb)) {
+        const int limit = forwardShift - blockLength;  // positions i = blockLength .. forwardShift - 1
+        if (limit > 0) {
+          // (a reference position at or past rs.end counts as a base that matches nothing)
+          const int inside = imax(0, imin(limit, rs.end - (otherStartIndex + blockLength)));
+          const int run = seqMatchRun(query, blockStartIndex + blockLength, reference, otherStartIndex + blockLength, inside);
+          if (run < limit) {
             numMismatches++;
             foundMismatch = true;
-            maxNonmatchingBlockEnd = indexA + 1;
-            break;
+            maxNonmatchingBlockEnd = blockStartIndex + blockLength + run + 1;
           }
         }
         if (!foundMismatch) maxNonmatchingBlockEnd = qs.end;
