@@ -1,0 +1,65 @@
+"""GPU differential fuzz: random references (repeats, ambiguity codes), read lengths, single/paired mixes, ambiguity in reads and random alignment
+parameters; every batch must equal the oracle bit for bit."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib as o
+from helpers import sprinkle_ambiguity, ambiguous_reference
+from mapper_amd import api, synth
+
+
+
+def run(rounds=24, seed=2026, max_queries=4000):
+  rng = np.random.default_rng(seed)
+  bad = 0
+  for it in range(rounds):
+      n = int(rng.integers(20_000, 400_000))
+      ref = ambiguous_reference(n, seed=1000 + it, n_runs=int(rng.integers(0, 30)), n_codes=int(rng.integers(0, 200))) if it % 3 == 0 else synth.synthetic_reference(n, seed=1000 + it).copy()
+      if it % 4 == 1:  # tandem repeats
+          unit = ref[:int(rng.integers(50, 3000))].copy()
+          for k in range(int(rng.integers(3, 30))):
+              p0 = int(rng.integers(0, n - len(unit)))
+              ref[p0:p0 + len(unit)] = unit
+      L = int(rng.choice([36, 75, 100, 150, 151, 250, 301]))
+      nq = int(rng.integers(500, max_queries))
+      sub, ind = float(rng.choice([0.0, 0.005, 0.02, 0.06])), float(rng.choice([0.0, 0.05, 0.5]))
+      params = dict(MutationPenalty=float(rng.choice([1.0, 0.7, 2.0])), InsertionStart_Penalty=float(rng.choice([1.5, 1.0, 3.0])), InsertionExtension_Penalty=float(rng.choice([0.6, 0.25, 1.1])),
+                    DeletionStart_Penalty=float(rng.choice([1.5, 1.0, 3.0])), DeletionExtension_Penalty=float(rng.choice([0.5, 0.2, 1.0])), MaxErrorRate=float(rng.choice([0.1, 0.05, 0.2])),
+                    UnalignedPenalty=float(rng.choice([0.1, 0.3])), AmbiguityPenalty=float(rng.choice([0.1, 0.05, 0.2])), Max_PenaltySpan=float(rng.choice([0.5, 0.0, 1.5])),
+                    MaxNumMatches=int(rng.choice([2**31 - 1, 1, 3])))
+      queries = []
+      if it % 2 == 0:
+          reads = synth.synthetic_single_end(ref, nq, read_len=L, sub_rate=sub, indel_prob=ind, seed=5000 + it)[0]
+          if it % 5 == 0: reads = sprinkle_ambiguity(reads, it)
+          queries = [([r], 0.0, 1.0) for r in reads]
+      else:
+          m1, m2 = synth.synthetic_paired_end(ref, nq // 2, read_len=L, sub_rate=sub, indel_prob=ind, seed=5000 + it)[:2]
+          if it % 5 == 0: m1 = sprinkle_ambiguity(m1, it)
+          e, d = float(rng.choice([100.0, 0.0, 300.0])), float(rng.choice([50.0, 10.0]))
+          queries = [([m1[i], m2[i]], e, d) for i in range(len(m1))]
+          extra = synth.synthetic_single_end(ref, 200, read_len=L, seed=7000 + it)[0]
+          queries += [([r], 0.0, 1.0) for r in extra]
+      b = o.QueryBatch(queries)
+      mode = "api" if it % 7 == 3 else "mapper"
+      db = api.ReferenceDatabase([("r%d" % it, ref)], mode=mode, max_query_length=L)
+      t = time.time()
+      r = db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, api.AlignmentParameters(**params))
+      want = o.OracleReference([("r%d" % it, ref)], mode=mode).align(b, o.make_params(params), threads=os.cpu_count())
+      same = np.array_equal(want.ints, r.ints) and np.array_equal(want.dbls.view(np.int64), r.dbls.view(np.int64)) and np.array_equal(want.int_off, r.int_off)
+      aligned = int(sum(1 for q in range(len(queries)) if r.ints[r.int_off[q] + 1] > 0))
+      print("round", it, "ref", n, "len", L, "queries", len(queries), "sub", sub, "indel", ind, "mode", mode, "aligned", aligned, "kernel ms %.1f" % r.kernel_ms, "reruns", r.counters[11],
+            "IDENTICAL" if same else "DIFFERENT", flush=True)
+      if not same:
+          bad += 1
+          for q in range(len(queries)):
+              a0, a1 = want.int_off[q], want.int_off[q + 1]
+              if a1 - a0 != r.int_off[q + 1] - r.int_off[q] or not np.array_equal(want.ints[a0:a1], r.ints[r.int_off[q]:r.int_off[q + 1]]):
+                  print("  first differing query", q, "params", params); break
+      db.close()
+  print("fuzz done, differing batches:", bad)
+  return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 2026) else 0)

@@ -112,6 +112,14 @@ def test_long_reads_on_gpu():
         db.close()
 
 
+def test_random_configurations_on_gpu():
+    """Differential fuzz (scripts/gpu_fuzz.py): random references (repeats, ambiguity codes), read lengths 36-301, single / paired mixes, ambiguity in
+    reads and random alignment parameters; every batch must equal the oracle bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gpu_fuzz
+    assert gpu_fuzz.run(rounds=8, seed=77, max_queries=1500) == 0
+
+
 def test_edge_cases_on_gpu():
     rng = np.random.default_rng(3)
     c0 = synth.synthetic_reference(60_000, seed=11)
