@@ -355,7 +355,11 @@ struct PNode {  // AlignmentNode, 32 bytes = two 16-byte loads
 //    The slot is sized for the piece-wise searches BlockAligner issues (<= 960 nodes on <= 768 cells, <= 112 distinct priorities,
 //    texts <= 64 x 128);
 //    a search that outgrows it is redone in HBM mode.  One slot per wave: pathAlignAny runs the lanes of a wave through it in turn.
-constexpr int XM_PAL_HASH = 1024, XM_PAL_CELLS = 768, XM_PAL_NODES = 960, XM_PAL_BUCKETS = 112, XM_PAL_BHASH = 256, XM_PAL_TEXTA = 64, XM_PAL_TEXTB = 128;
+#ifndef XM_PAL_SMALL  // (experiment knob: a smaller slot lets more workgroups share a CU's LDS)
+constexpr int XM_PAL_HASH_BITS = 10, XM_PAL_HASH = 1024, XM_PAL_CELLS = 768, XM_PAL_NODES = 960, XM_PAL_BUCKETS = 112, XM_PAL_BHASH = 256, XM_PAL_TEXTA = 64, XM_PAL_TEXTB = 128;
+#else
+constexpr int XM_PAL_HASH_BITS = 9, XM_PAL_HASH = 512, XM_PAL_CELLS = 384, XM_PAL_NODES = 448, XM_PAL_BUCKETS = 64, XM_PAL_BHASH = 128, XM_PAL_TEXTA = 64, XM_PAL_TEXTB = 128;
+#endif
 constexpr int XM_PAL_OFF_HASH = 0;                                      // uint32[1024]: (x << 8 | y) << 16 | node index + 1; at most 768 cells
 constexpr int XM_PAL_OFF_XY = XM_PAL_OFF_HASH + XM_PAL_HASH * 4;        // uint16[960]: x << 8 | y of node i (= list entry i)
 constexpr int XM_PAL_OFF_NEXT = XM_PAL_OFF_XY + XM_PAL_NODES * 2;       // uint16[960]: next list entry, 0xFFFF = none
@@ -454,7 +458,7 @@ struct PathAlignerT {
     }
   }
   // LDS cell hash: one 32-bit word per cell, key and node index together, so a lookup is one LDS read unless it collides
-  XM_INL static uint32_t ldsCellHash(uint32_t key) { return (key * 2654435761u) >> 22; }  // top 10 bits: XM_PAL_HASH == 1024
+  XM_INL static uint32_t ldsCellHash(uint32_t key) { return (key * 2654435761u) >> (32 - XM_PAL_HASH_BITS); }  // top bits
   XM_INL void ldsResolve(uint32_t key, uint32_t& h, uint32_t& v) const {  // from the first probe (h, v) to the cell's slot or the empty slot that ends its run
     while (v != 0 && (v >> 16) != key) { h = (h + 1) & (XM_PAL_HASH - 1); v = Lhash[h]; }
   }
