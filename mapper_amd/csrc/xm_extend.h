@@ -352,27 +352,26 @@ struct PNode {  // AlignmentNode, 32 bytes = two 16-byte loads
 //  - LDS == true: the lookup structures (cell hash, bucket table, bucket heap, node lists, both texts) live in the wave's slot of the
 //    CU's local data share and only the 32-byte node payloads stay in HBM.  The gapped search is a chain of dependent lookups that
 //    only one or two lanes of a wave execute at a time, so its cost is the latency of each lookup: ~100 cycles in LDS, >1000 in HBM.
-//    The slot is sized for the piece-wise searches BlockAligner issues (<= 960 nodes on <= 768 cells, <= 112 distinct priorities,
+//    The slot is sized for the piece-wise searches BlockAligner issues (<= 1056 nodes on <= 768 cells, <= 112 distinct priorities,
 //    texts <= 64 x 128);
 //    a search that outgrows it is redone in HBM mode.  One slot per wave: pathAlignAny runs the lanes of a wave through it in turn.
 #ifndef XM_PAL_SMALL  // (experiment knob: a smaller slot lets more workgroups share a CU's LDS)
-constexpr int XM_PAL_HASH_BITS = 10, XM_PAL_HASH = 1024, XM_PAL_CELLS = 768, XM_PAL_NODES = 960, XM_PAL_BUCKETS = 112, XM_PAL_BHASH = 256, XM_PAL_TEXTA = 64, XM_PAL_TEXTB = 128;
+constexpr int XM_PAL_HASH_BITS = 10, XM_PAL_HASH = 1024, XM_PAL_CELLS = 768, XM_PAL_NODES = 1056, XM_PAL_BUCKETS = 112, XM_PAL_BHASH = 256, XM_PAL_TEXTA = 64, XM_PAL_TEXTB = 128;
 #else
 constexpr int XM_PAL_HASH_BITS = 9, XM_PAL_HASH = 512, XM_PAL_CELLS = 384, XM_PAL_NODES = 448, XM_PAL_BUCKETS = 64, XM_PAL_BHASH = 128, XM_PAL_TEXTA = 64, XM_PAL_TEXTB = 128;
 #endif
 constexpr int XM_PAL_OFF_HASH = 0;                                      // uint32[1024]: (x << 8 | y) << 16 | node index + 1; at most 768 cells
-constexpr int XM_PAL_OFF_XY = XM_PAL_OFF_HASH + XM_PAL_HASH * 4;        // uint16[960]: x << 8 | y of node i (= list entry i)
-constexpr int XM_PAL_OFF_NEXT = XM_PAL_OFF_XY + XM_PAL_NODES * 2;       // uint16[960]: next list entry, 0xFFFF = none
+constexpr int XM_PAL_OFF_XY = XM_PAL_OFF_HASH + XM_PAL_HASH * 4;        // uint16[nodes]: x << 8 | y of node i (= list entry i)
+constexpr int XM_PAL_OFF_NEXT = XM_PAL_OFF_XY + XM_PAL_NODES * 2;       // uint16[nodes]: next list entry, 0xFFFF = none
 constexpr int XM_PAL_OFF_BKEY = XM_PAL_OFF_NEXT + XM_PAL_NODES * 2;     // double[112]
 constexpr int XM_PAL_OFF_BHEAD = XM_PAL_OFF_BKEY + XM_PAL_BUCKETS * 8;  // uint16[112]
 constexpr int XM_PAL_OFF_BTAIL = XM_PAL_OFF_BHEAD + XM_PAL_BUCKETS * 2; // uint16[112]
 constexpr int XM_PAL_OFF_BHASH = XM_PAL_OFF_BTAIL + XM_PAL_BUCKETS * 2; // uint8[256]: bucket + 1
-constexpr int XM_PAL_OFF_HEAP = XM_PAL_OFF_BHASH + XM_PAL_BHASH;        // uint8[112]
-constexpr int XM_PAL_OFF_TEXTA = XM_PAL_OFF_HEAP + XM_PAL_BUCKETS;      // uint8[64]
+constexpr int XM_PAL_OFF_TEXTA = XM_PAL_OFF_BHASH + XM_PAL_BHASH;       // uint8[64]  (no heap in LDS mode: the smallest live key is found by a scan)
 constexpr int XM_PAL_OFF_TEXTB = XM_PAL_OFF_TEXTA + XM_PAL_TEXTA;       // uint8[128]
 constexpr int XM_PAL_SLOT_BYTES = (XM_PAL_OFF_TEXTB + XM_PAL_TEXTB + 63) / 64 * 64;
 static_assert(XM_PAL_OFF_BKEY % 8 == 0, "bucket keys must be 8-byte aligned");
-static_assert(XM_PAL_SLOT_BYTES * 4 <= 40 * 1024, "four waves per workgroup, four workgroups per CU, 160 KB of LDS");
+static_assert(XM_PAL_SLOT_BYTES * 4 + 432 <= 40 * 1024, "four waves per workgroup (+ the 432-byte merge-rule table), four workgroups per CU, 160 KB of LDS");
 
 #if defined(__HIP_DEVICE_COMPILE__)
 __shared__ __attribute__((aligned(16))) uint8_t xm_pal_lds[4 * XM_PAL_SLOT_BYTES];
@@ -792,7 +791,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
     uint8_t* const slot = palSlot();
     pa.Lhash = (uint32_t*)(slot + XM_PAL_OFF_HASH); pa.nCells = 0; pa.Lxy = (uint16_t*)(slot + XM_PAL_OFF_XY); pa.Lnext = (uint16_t*)(slot + XM_PAL_OFF_NEXT);
     pa.Lbkey = (double*)(slot + XM_PAL_OFF_BKEY); pa.Lbhead = (uint16_t*)(slot + XM_PAL_OFF_BHEAD); pa.Lbtail = (uint16_t*)(slot + XM_PAL_OFF_BTAIL);
-    pa.Lbhash = slot + XM_PAL_OFF_BHASH; pa.Lheap = slot + XM_PAL_OFF_HEAP; pa.LtextA = slot + XM_PAL_OFF_TEXTA; pa.LtextB = slot + XM_PAL_OFF_TEXTB;
+    pa.Lbhash = slot + XM_PAL_OFF_BHASH; pa.Lheap = nullptr; pa.LtextA = slot + XM_PAL_OFF_TEXTA; pa.LtextB = slot + XM_PAL_OFF_TEXTB;
     {
       uint64_t* const z1 = (uint64_t*)pa.Lhash;
       for (int i = 0; i < XM_PAL_HASH * 4 / 8; i++) z1[i] = 0;
@@ -865,7 +864,12 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
   auto leave = [&](bool r) -> bool {
     tmp.used = mark;
     if constexpr (LDS) {
-      if (pa.ldsOverflow) { *ldsOverflow = true; return false; }  // nothing decided, nothing counted: the HBM-mode search redoes it
+      if (pa.ldsOverflow) {
+#ifdef XM_PA_STATS
+        fprintf(stderr, "PAFALLBACK nodes %d cells %d buckets %d textA %d textB %d\n", pa.nNodes, pa.nCells, pa.nBuckets, pa.textALength, pa.textBLength);
+#endif
+        *ldsOverflow = true; return false;  // nothing decided, nothing counted: the HBM-mode search redoes it
+      }
     }
     if (pa.overflow) *status = XM_ST_OVERFLOW;
 #ifdef XM_PA_STATS
