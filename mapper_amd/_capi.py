@@ -70,7 +70,7 @@ def lib():
                 build_library()
             except Exception as e:  # noqa: BLE001
                 raise ImportError("libxmapper_hip.so is missing and could not be built with hipcc; mapper_amd has no CPU fallback: %s" % e)
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(os.environ.get("XM_LIB_PATH") or LIB_PATH)  # (XM_LIB_PATH: A/B experiments with another build of the same library)
         L.xm_last_error.restype = C.c_char_p
         L.xm_index_build.argtypes = [C.POINTER(XmRef), C.POINTER(XmBuildOpts), C.POINTER(C.c_void_p)]
         L.xm_index_ensure_length.argtypes = [C.c_void_p, C.c_int32]

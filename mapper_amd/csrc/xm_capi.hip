@@ -69,9 +69,10 @@ static long long envInt(const char* name, long long dflt) {
 // One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed, int lanesPerWave,
                                                        uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters,
-                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync, long long firstStride) {
+                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync, long long firstStride, PNode* waveNodes) {
   // lanesPerWave < 64 (gapped pass): the extension chain diverges so much that a wave runs its reads nearly one after another, so
   // spreading them over more, partly filled waves shortens the critical path; the idle lanes own no scratch arena
+  xmSetWaveNodes(waveNodes);
   xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
   const int laneInWave = (int)(threadIdx.x & 63u);
   if (laneInWave >= lanesPerWave) return;
@@ -423,6 +424,7 @@ struct xm_index {
   DevBuf<int64_t> dListHeavy, dListHeavyLate, dListScale[2], dListOut[2], dListPath[2], dFinalIntOff, dFinalDblOff;
   DevBuf<int32_t> dSlotOf;
   DevBuf<uint8_t> dMemo;
+  DevBuf<PNode> dWaveNodes;  // per wave: node payloads of its LDS-mode search
   DevBuf<PassCtl> dCtl;
   DevBuf<long long> dBlockI, dBlockD;
   DevBuf<int32_t> dFinalInts;
@@ -760,6 +762,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       int grid = (int)((nWaves * 64 + block - 1) / block);
       lanes = (long long)grid * (block / 64) * lpw;
       idx->dArenas.ensure((size_t)lanes * arenaBytes);
+      idx->dWaveNodes.ensure((size_t)grid * (block / 64) * XM_PAL_NODES);
       idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq); idx->dListPath[tp].ensure(defer ? (size_t)nTodo : 1);
       // gapped pass with an ordered list: the first read of every lane is dealt out (kernel), the counter starts behind those items
       const long long firstStride = (heavy && !defer && heavyHintThreshold > 0 && scale == gappedScale) ? (long long)grid * (block / 64) : 0;
@@ -770,7 +773,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
                          idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
                          defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
-                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, (!heavy && lightSync) ? 1 : 0, firstStride);
+                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, (!heavy && lightSync) ? 1 : 0, firstStride, idx->dWaveNodes.p);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,

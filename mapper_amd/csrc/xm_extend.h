@@ -371,13 +371,30 @@ constexpr int XM_PAL_OFF_TEXTA = XM_PAL_OFF_BHASH + XM_PAL_BHASH;       // uint8
 constexpr int XM_PAL_OFF_TEXTB = XM_PAL_OFF_TEXTA + XM_PAL_TEXTA;       // uint8[128]
 constexpr int XM_PAL_SLOT_BYTES = (XM_PAL_OFF_TEXTB + XM_PAL_TEXTB + 63) / 64 * 64;
 static_assert(XM_PAL_OFF_BKEY % 8 == 0, "bucket keys must be 8-byte aligned");
-static_assert(XM_PAL_SLOT_BYTES * 4 + 432 <= 40 * 1024, "four waves per workgroup (+ the 432-byte merge-rule table), four workgroups per CU, 160 KB of LDS");
+static_assert(XM_PAL_SLOT_BYTES * 4 + 432 + 16 <= 40 * 1024, "four waves per workgroup (+ the 432-byte merge-rule table), four workgroups per CU, 160 KB of LDS");
 
+struct PNode;
 #if defined(__HIP_DEVICE_COMPILE__)
 __shared__ __attribute__((aligned(16))) uint8_t xm_pal_lds[4 * XM_PAL_SLOT_BYTES];
 XM_INL uint8_t* palSlot() { return xm_pal_lds + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * XM_PAL_SLOT_BYTES; }
+// The node payloads of an LDS-mode search live in a buffer of the WAVE, not of the lane (one search at a time per wave): 4096 waves x 34 KB
+// stay in the Infinity Cache, where the lanes' arenas (131 072 x 1.2 MB) never do.  The kernel leaves the buffer's base here.
+__shared__ PNode* xm_pal_wave_nodes;
+XM_INL void xmSetWaveNodes(PNode* base) { if (threadIdx.x == 0) xm_pal_wave_nodes = base; }  // (before the block's first barrier)
+XM_INL PNode* palWaveNodes();
 #else
 XM_INL uint8_t* palSlot() { static thread_local double slot[XM_PAL_SLOT_BYTES / 8]; return (uint8_t*)slot; }  // host simulation (tests only)
+XM_INL void xmSetWaveNodes(PNode*) {}
+XM_INL PNode* palWaveNodes();
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+XM_INL PNode* palWaveNodes() {
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  return xm_pal_wave_nodes + wave * XM_PAL_NODES;
+}
+#else
+XM_INL PNode* palWaveNodes() { static thread_local double buf[XM_PAL_NODES * 4]; return (PNode*)buf; }
 #endif
 
 // XM_PROFILE builds: where a search step spends its time (hash lookups / node loads / arithmetic / putNode), summed into t[12..15]
@@ -786,8 +803,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
     if (pa.textALength > XM_PAL_TEXTA || pa.textBLength > XM_PAL_TEXTB || pa.textALength < 0 || pa.textBLength < 0) { *ldsOverflow = true; return false; }
     pa.maxNodes = imin(caps.maxNodes, XM_PAL_NODES);
     pa.maxBuckets = imin(caps.maxBuckets, XM_PAL_BUCKETS);
-    pa.nodes = uniP(arenaArray<PNode>(tmp, pa.maxNodes));
-    if (tmp.overflow) { *status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+    pa.nodes = palWaveNodes();
     uint8_t* const slot = palSlot();
     pa.Lhash = (uint32_t*)(slot + XM_PAL_OFF_HASH); pa.nCells = 0; pa.Lxy = (uint16_t*)(slot + XM_PAL_OFF_XY); pa.Lnext = (uint16_t*)(slot + XM_PAL_OFF_NEXT);
     pa.Lbkey = (double*)(slot + XM_PAL_OFF_BKEY); pa.Lbhead = (uint16_t*)(slot + XM_PAL_OFF_BHEAD); pa.Lbtail = (uint16_t*)(slot + XM_PAL_OFF_BTAIL);
