@@ -729,6 +729,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const long long lightWaves = envInt("XM_LIGHT_WAVES", 8), fullWaves = envInt("XM_FULL_WAVES", 4), pathWaves = envInt("XM_PATH_WAVES", 4);
     const long long fullLpw = envInt("XM_FULL_LPW", 32), lightLpw = envInt("XM_LIGHT_LPW", 64);
     const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
+    const bool fullSync = envInt("XM_FULL_SYNC", 0) != 0;  // gapped pass: the lanes of a wave take their next reads together (no taper then)
     const bool lightSync = envInt("XM_LIGHT_SYNC", 0) != 0;  // lanes of a light-pass wave take reads together (measured: no gain)
     const long long lightLevel = envInt("XM_LIGHT_LEVEL", 0);  // what the light pass still does itself (Caps::heavyAllowed)
     const long long heavyHintThreshold = envInt("XM_HEAVY_HINT", 0);  // straight-alignment penalty x 8 from which a read is put first in the gapped pass and dealt out evenly (0: no order; measured: no gain, the pass is bound by the work per wave, not by its balance)
@@ -773,7 +774,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
                          idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
                          defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
-                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, (!heavy && lightSync) ? 1 : 0, firstStride, idx->dWaveNodes.p);
+                         (heavy && !fullSync) ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, ((!heavy && lightSync) || (heavy && fullSync)) ? 1 : 0,
+                         fullSync ? 0ll : firstStride, idx->dWaveNodes.p);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,
