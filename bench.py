@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--ref-len", type=int, default=5_000_000)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--seed-probes", type=int, default=16_000_000, help="bucket-header probes of the seed-lookup micro-benchmark (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a one-GPU box)")
+    ap.add_argument("--force-device", type=int, default=-1, help="testing: every rank uses this GPU instead of its LOCAL_RANK")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads of the same workload timed on the host cores (0 = skip)")
     args = ap.parse_args()
 
@@ -40,10 +42,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    if args.force_device >= 0:
+        local_rank = args.force_device
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     else:
         dist = None
         torch.cuda.set_device(local_rank)
