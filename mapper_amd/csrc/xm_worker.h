@@ -33,6 +33,25 @@ struct QMAligner {  // QueryMatch_Aligner
   int16_t* bestIdx; int32_t nBest;  // result of getBestAlignments()
 };
 
+struct ReadResult {
+  int32_t nComponents;
+  QMAligner* aligner[2];
+  int32_t single[2];  // >= 0: the component is exactly this one alignment of aligner[c] (QueryAlignments.singleChoice)
+  int32_t empty[2];   // 1: the component is empty regardless of the aligner
+};
+
+// Where alignRead stands (AlignerWorker.alignToAncestralReference :306-484): everything its loops carry from one candidate to the next.
+// A read that stops in the light pass because a candidate needs the gapped chain (XM_ST_NEED_HEAVY) is resumed in the gapped pass at
+// that candidate, with its seeding state (pyramids, votes, candidate lists, accepted alignments) as the light pass left it.
+struct AlignReadState {
+  int32_t phase;  // 0 before the first candidate, 1 aligning the optimistic best match, 3 in the main loop at filtered[i], 4 in the partially-good loop at filtered[i], 5 after them (not resumable)
+  int32_t optimisticBestAlignment, haveOptimisticMatch, numMismatches, candidateNumMismatches, i, queryLength;
+  QMatch optimisticBestMatch;
+  double bestPenalty, estimatedPenalty, maxInterestingPenalty;
+  QMAligner* aligner;
+  ReadResult rr;
+};
+
 struct ReadCtx {
   const IndexView* ix;
   Caps caps;
@@ -49,6 +68,7 @@ struct ReadCtx {
   MemoHdr* memo;        // deferred-search gapped pass: this read's memo slot (xm_extend.h), else null
   int32_t memoCursor;
   float heavyHint;      // light pass: largest straight-alignment penalty among the candidates that needed the gapped chain
+  AlignReadState ar;
 };
 
 XM_INL SeqView queryView(const ReadCtx& cx, uint8_t seqAId) {
@@ -481,13 +501,6 @@ XM_INL void writeQAl(OutWriter& w, const QAl& q) {
 }
 
 // what alignToAncestralReference returns: up to 2 components, each a list of alignments of one aligner
-struct ReadResult {
-  int32_t nComponents;
-  QMAligner* aligner[2];
-  int32_t single[2];  // >= 0: the component is exactly this one alignment of aligner[c] (QueryAlignments.singleChoice)
-  int32_t empty[2];   // 1: the component is empty regardless of the aligner
-};
-
 XM_INL double penaltyLowerBound(const ReadCtx& cx, int numMismatchedHashblocks) {  // M/AlignerWorker.java:487-491
   double mutationPenalty = numMismatchedHashblocks * cx.params.MutationPenalty;
   double indelPenalty = cx.ix->minInterestingSize * numMismatchedHashblocks * cx.params.DeletionExtension_Penalty;
@@ -618,115 +631,145 @@ XM_NOINL void getUnpairedAlignments(ReadCtx& cx, ReadResult& rr) {
 }
 
 // alignToAncestralReference :306-484
-XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr) {
+// resume: continue a read that stopped with XM_ST_NEED_HEAVY at the candidate recorded in cx.ar (cx, its persistent arena and cx.ar.rr are
+// as that run left them; the caller has reset cx.status, re-pointed cx.tmp and raised cx.caps.heavyAllowed)
+XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr, bool resume = false) {
   const ReadIn& in = cx.in;
+  AlignReadState& st = cx.ar;
+  PathsCounter& pc = cx.pc;
+  const SeedEnv& se = cx.seed;
+  QMAligner* aligner = nullptr;
+  int al = -1;
+  if (resume) {
+    rr = st.rr;
+    aligner = st.aligner;
+    if (st.phase == 1) goto resume_optimistic;
+    if (st.phase == 3) goto resume_main;
+    if (st.phase == 4) goto resume_partial;
+    cx.status = XM_ST_INTERNAL;  // (the caller only resumes phases 1, 3 and 4)
+    return;
+  }
+  st.phase = 0;
   if (cx.dc) { cx.dc->reads++; for (int m = 0; m < in.nMates; m++) cx.dc->readBytes += (unsigned long long)((in.mateLen[m] + 1) / 2); }
   rr.nComponents = 1; rr.single[0] = -1; rr.empty[0] = 0; rr.aligner[0] = nullptr;
   for (int m = 0; m < in.nMates; m++) if (in.mateLen[m] > cx.ix->maxHashedLength) { cx.status = XM_ST_NEED_GROW; return; }
-  int queryLength = 0;
-  for (int m = 0; m < in.nMates; m++) queryLength += in.mateLen[m];
-  double maxInterestingPenalty = queryLength * cx.params.MaxErrorRate;
-  int maxInnerDistance = j2i(maxInterestingPenalty * in.deviation + in.expectedInner);
-  cx.seed.ix = cx.ix; cx.seed.caps = &cx.caps; cx.seed.dc = cx.dc; cx.seed.status = &cx.status; cx.seed.listIdCounter = &cx.listIdCounter;
-  cx.seed.mateLen = cx.in.mateLen;
-  cx.listIdCounter = 0;
-  for (int i = 0; i < in.nMates; i++) {
-    SeqView fwd = queryView(cx, (uint8_t)(i * 2)), rc = queryView(cx, (uint8_t)(i * 2 + 1));
-    if (i > 0) compInit(cx, cx.comps[i], rc, fwd); else compInit(cx, cx.comps[i], fwd, rc);  // :317-318
-    if (cx.status) return;
+  st.queryLength = 0;
+  for (int m = 0; m < in.nMates; m++) st.queryLength += in.mateLen[m];
+  st.maxInterestingPenalty = st.queryLength * cx.params.MaxErrorRate;
+  {
+    int maxInnerDistance = j2i(st.maxInterestingPenalty * in.deviation + in.expectedInner);
+    cx.seed.ix = cx.ix; cx.seed.caps = &cx.caps; cx.seed.dc = cx.dc; cx.seed.status = &cx.status; cx.seed.listIdCounter = &cx.listIdCounter;
+    cx.seed.mateLen = cx.in.mateLen;
+    cx.listIdCounter = 0;
+    for (int i = 0; i < in.nMates; i++) {
+      SeqView fwd = queryView(cx, (uint8_t)(i * 2)), rc = queryView(cx, (uint8_t)(i * 2 + 1));
+      if (i > 0) compInit(cx, cx.comps[i], rc, fwd); else compInit(cx, cx.comps[i], fwd, rc);  // :317-318
+      if (cx.status) return;
+    }
+    pc.comps = cx.comps; pc.nComps = in.nMates;
+    pc.maxOffsetBetweenComponents = jadd(maxInnerDistance, cx.comps[0].query.len);
+    pc.foundNonemptyResult = false; pc.havePrevious = false; pc.nAssembled = 0; pc.nFiltered = 0;
+    pc.assembled = arenaArray<QMatch>(cx.persist, cx.caps.maxQM);
+    pc.filtered = arenaArray<QMatch>(cx.persist, cx.caps.maxQM);
+    pc.nearby = arenaArray<int16_t>(cx.persist, cx.caps.maxCounters);
+    aligner = arenaArray<QMAligner>(cx.persist, 1);
+    if (cx.persist.overflow) { cx.status = XM_ST_OVERFLOW; return; }
   }
-  PathsCounter& pc = cx.pc;
-  pc.comps = cx.comps; pc.nComps = in.nMates;
-  pc.maxOffsetBetweenComponents = jadd(maxInnerDistance, cx.comps[0].query.len);
-  pc.foundNonemptyResult = false; pc.havePrevious = false; pc.nAssembled = 0; pc.nFiltered = 0;
-  pc.assembled = arenaArray<QMatch>(cx.persist, cx.caps.maxQM);
-  pc.filtered = arenaArray<QMatch>(cx.persist, cx.caps.maxQM);
-  pc.nearby = arenaArray<int16_t>(cx.persist, cx.caps.maxCounters);
-  QMAligner* aligner = arenaArray<QMAligner>(cx.persist, 1);
-  if (cx.persist.overflow) { cx.status = XM_ST_OVERFLOW; return; }
-  const SeedEnv& se = cx.seed;
-
-  int optimisticBestAlignment = -1;
-  bool haveOptimisticMatch = false;
-  QMatch optimisticBestMatch;
-  int numMismatches = 0;
+  st.aligner = aligner;
+  st.optimisticBestAlignment = -1;
+  st.haveOptimisticMatch = 0;
+  st.numMismatches = 0;
   pcOptimisticGetBestMatches(pc, se);
   if (cx.status) return;
-  qmaInit(cx, *aligner, in.nMates, queryLength);
+  qmaInit(cx, *aligner, in.nMates, st.queryLength);
   if (cx.status) return;
   rr.aligner[0] = aligner;
   if (pc.nFiltered == 1) {
-    optimisticBestMatch = pc.filtered[0];
-    haveOptimisticMatch = true;
-    optimisticBestAlignment = qmaAlign(cx, *aligner, optimisticBestMatch, 0);
+    st.optimisticBestMatch = pc.filtered[0];
+    st.haveOptimisticMatch = 1;
+    st.phase = 1;
+    st.rr = rr;
+resume_optimistic:
+    st.optimisticBestAlignment = qmaAlign(cx, *aligner, st.optimisticBestMatch, 0);
     if (cx.status) return;
-    if (quicklyConfidentInBestAlignment(cx, *aligner, optimisticBestAlignment, optimisticBestMatch)) {
+    if (quicklyConfidentInBestAlignment(cx, *aligner, st.optimisticBestAlignment, st.optimisticBestMatch)) {
       if (cx.dc) cx.dc->quickAccepts++;
-      rr.single[0] = optimisticBestAlignment;
+      rr.single[0] = st.optimisticBestAlignment;
       return;
     }
   }
-  if (optimisticBestAlignment >= 0) {
+  st.phase = 2;
+  if (st.optimisticBestAlignment >= 0) {
     while (true) {
-      double possiblePenalty = penaltyLowerBound(cx, numMismatches);
-      if (possiblePenalty > aligner->good[optimisticBestAlignment].totalPenalty + cx.params.Max_PenaltySpan) {
-        rr.single[0] = optimisticBestAlignment;
+      double possiblePenalty = penaltyLowerBound(cx, st.numMismatches);
+      if (possiblePenalty > aligner->good[st.optimisticBestAlignment].totalPenalty + cx.params.Max_PenaltySpan) {
+        rr.single[0] = st.optimisticBestAlignment;
         return;
       }
-      pcFindGoodPositionsHavingPriority(pc, se, numMismatches);
+      pcFindGoodPositionsHavingPriority(pc, se, st.numMismatches);
       if (cx.status) return;
-      numMismatches++;
+      st.numMismatches++;
       bool done = false;
-      for (int i = 0; i < pc.nFiltered; i++) if (!qmSamePosition(optimisticBestMatch, pc.filtered[i])) { done = true; break; }
+      for (int i = 0; i < pc.nFiltered; i++) if (!qmSamePosition(st.optimisticBestMatch, pc.filtered[i])) { done = true; break; }
       if (done) break;
     }
   }
-  double bestPenalty = (double)INT32_MAX;
-  int candidateNumMismatches = 0;
+  st.bestPenalty = (double)INT32_MAX;
+  st.candidateNumMismatches = 0;
   while (true) {
-    double estimatedPenalty = penaltyLowerBound(cx, candidateNumMismatches);
-    if (estimatedPenalty > bestPenalty + cx.params.Max_PenaltySpan) break;
-    if (candidateNumMismatches > pcGetNumBlocks(pc)) break;
-    pcFindGoodPositionsHavingPriority(pc, se, candidateNumMismatches);
+    st.estimatedPenalty = penaltyLowerBound(cx, st.candidateNumMismatches);
+    if (st.estimatedPenalty > st.bestPenalty + cx.params.Max_PenaltySpan) break;
+    if (st.candidateNumMismatches > pcGetNumBlocks(pc)) break;
+    pcFindGoodPositionsHavingPriority(pc, se, st.candidateNumMismatches);
     if (cx.status) return;
-    for (int i = 0; i < pc.nFiltered; i++) {
-      int al;
-      if (haveOptimisticMatch && qmSamePosition(pc.filtered[i], optimisticBestMatch)) al = optimisticBestAlignment;
-      else al = qmaAlign(cx, *aligner, pc.filtered[i], 0);
+    for (st.i = 0; st.i < pc.nFiltered; st.i++) {
+      if (st.haveOptimisticMatch && qmSamePosition(pc.filtered[st.i], st.optimisticBestMatch)) {
+        al = st.optimisticBestAlignment;
+      } else {
+        st.phase = 3;
+        st.rr = rr;
+resume_main:
+        al = qmaAlign(cx, *aligner, pc.filtered[st.i], 0);
+      }
       if (cx.status) return;
       if (al >= 0) {
         double penalty = aligner->good[al].totalPenalty;
-        if (bestPenalty > penalty) bestPenalty = penalty;
+        if (st.bestPenalty > penalty) st.bestPenalty = penalty;
       }
     }
-    if (estimatedPenalty >= maxInterestingPenalty) break;
-    candidateNumMismatches++;
+    if (st.estimatedPenalty >= st.maxInterestingPenalty) break;
+    st.candidateNumMismatches++;
   }
   qmaGetBestAlignments(*aligner);
   if (aligner->nBest < 1 && in.nMates > 1) {
     pcFindPartiallyGoodPositions(pc, se);
     if (cx.status) return;
-    for (int i = 0; i < pc.nFiltered; i++) {
-      int al = qmaAlign(cx, *aligner, pc.filtered[i], 0);
+    for (st.i = 0; st.i < pc.nFiltered; st.i++) {
+      st.phase = 4;
+      st.rr = rr;
+resume_partial:
+      al = qmaAlign(cx, *aligner, pc.filtered[st.i], 0);
       if (cx.status) return;
       if (al >= 0) {
         double penalty = aligner->good[al].totalPenalty;
-        if (bestPenalty > penalty) bestPenalty = penalty;
+        if (st.bestPenalty > penalty) st.bestPenalty = penalty;
       }
     }
   }
+  st.phase = 5;
   qmaGetBestAlignments(*aligner);
-  int numBest = aligner->nBest;
-  if (numBest < 1 && in.nMates > 1) {
-    getUnpairedAlignments(cx, rr);
-    if (cx.status) return;
-  }
-  if ((int64_t)numBest > (int64_t)cx.params.MaxNumMatches) {  // :476-481
-    rr.nComponents = 1; rr.single[0] = -1; rr.empty[0] = 1;
+  {
+    int numBest = aligner->nBest;
+    if (numBest < 1 && in.nMates > 1) {
+      getUnpairedAlignments(cx, rr);
+      if (cx.status) return;
+    }
+    if ((int64_t)numBest > (int64_t)cx.params.MaxNumMatches) {  // :476-481
+      rr.nComponents = 1; rr.single[0] = -1; rr.empty[0] = 1;
+    }
   }
 }
 
-// size / write the result of one read in stream format
 XM_INL void resultSize(const ReadResult& rr, int64_t& ni, int64_t& nd) {
   ni = 1; nd = 0;
   for (int c = 0; c < rr.nComponents; c++) {
