@@ -50,6 +50,7 @@ struct AlignReadState {
   double bestPenalty, estimatedPenalty, maxInterestingPenalty;
   QMAligner* aligner;
   ReadResult rr;
+  unsigned long long candidatesAtCall, refWindowBytesAtCall;  // counters when the resumable qmaAlign call started (the resumed run counts that candidate again)
 };
 
 struct ReadCtx {
@@ -689,6 +690,7 @@ XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr, bool resume = false) {
     st.haveOptimisticMatch = 1;
     st.phase = 1;
     st.rr = rr;
+    if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }
 resume_optimistic:
     st.optimisticBestAlignment = qmaAlign(cx, *aligner, st.optimisticBestMatch, 0);
     if (cx.status) return;
@@ -728,6 +730,7 @@ resume_optimistic:
       } else {
         st.phase = 3;
         st.rr = rr;
+        if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }
 resume_main:
         al = qmaAlign(cx, *aligner, pc.filtered[st.i], 0);
       }
@@ -747,6 +750,7 @@ resume_main:
     for (st.i = 0; st.i < pc.nFiltered; st.i++) {
       st.phase = 4;
       st.rr = rr;
+      if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }
 resume_partial:
       al = qmaAlign(cx, *aligner, pc.filtered[st.i], 0);
       if (cx.status) return;
@@ -787,6 +791,76 @@ XM_INL void resultWrite(const ReadResult& rr, OutWriter& w, DevCounters* dc) {
     w.ints[w.ni++] = rr.aligner[c]->nBest;
     for (int i = 0; i < rr.aligner[c]->nBest; i++) { writeQAl(w, rr.aligner[c]->good[rr.aligner[c]->bestIdx[i]]); if (dc) dc->alignmentsOut++; }
   }
+}
+
+// ---------------------------------------------------------------- light pass -> gapped pass hand-over
+// In the light pass a read's persistent arena is a region of its own (not the lane's), so when the read stops with XM_ST_NEED_HEAVY its
+// seeding state survives: the context is copied next to it (SavedRead) and the gapped pass continues from there on another lane instead
+// of seeding the read again (a quarter of the gapped pass's wave time went into that).
+struct SavedRead {
+  int32_t valid;       // 1: cx can be resumed (alignRead phases 1, 3, 4)
+  int32_t pad;
+  DevCounters partial; // what the stopped run had counted for this read
+  ReadCtx cx;
+};
+XM_INL void dcAccumulate(DevCounters& a, const DevCounters& b, bool subtract) {
+  unsigned long long* x = (unsigned long long*)&a;
+  const unsigned long long* y = (const unsigned long long*)&b;
+  for (size_t i = 0; i < sizeof(DevCounters) / sizeof(unsigned long long); i++) x[i] = subtract ? x[i] - y[i] : x[i] + y[i];
+}
+// the usable part of a read's region when its tail holds the SavedRead
+XM_INL size_t retainedPersistBytes(size_t regionBytes) { return (regionBytes - sizeof(SavedRead)) & ~(size_t)15; }
+XM_INL SavedRead* savedReadOf(void* region, size_t regionBytes) { return (SavedRead*)((uint8_t*)region + retainedPersistBytes(regionBytes)); }
+
+// light pass with hand-over: persistent arena = the read's region, temporaries = the lane's arena
+XM_INL void runReadRetaining(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* region, size_t regionBytes, void* laneArena, size_t laneArenaBytes,
+                             DevCounters* dc, ReadResult& rr, int heavyAllowed) {
+  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed; cx.caps.deferPath = 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
+  cx.memo = nullptr; cx.memoCursor = 0; cx.heavyHint = 0;
+  cx.params.StartingInsertionStartFree = 0;
+  cx.persist.init(region, retainedPersistBytes(regionBytes));
+  cx.tmp.init(laneArena, laneArenaBytes);
+  SavedRead* sv = savedReadOf(region, regionBytes);
+  sv->valid = 0;
+  DevCounters before = dc ? *dc : DevCounters();
+  XM_TIC(t0);
+  alignRead(cx, rr);
+  XM_TOC(dc, T_TOTAL, t0);
+  if (cx.status == XM_ST_NEED_HEAVY && (cx.ar.phase == 1 || cx.ar.phase == 3 || cx.ar.phase == 4)) {
+    sv->cx = cx;
+    if (dc) {
+      sv->partial = *dc;
+      dcAccumulate(sv->partial, before, true);
+      sv->partial.candidatesExtended -= dc->candidatesExtended - cx.ar.candidatesAtCall;  // the stopped candidate is counted by the run that finishes it
+      sv->partial.refWindowBytes -= dc->refWindowBytes - cx.ar.refWindowBytesAtCall;
+    }
+    sv->valid = 1;
+  }
+}
+// gapped pass, a read the light pass handed over: the context back on this lane, pointers into the context re-seated, the chain's scratch
+// capacities of the gapped pass, temporaries in this lane's arena; then on from the candidate that needed the chain
+XM_INL void runReadResumed(ReadCtx& cx, const SavedRead* sv, const IndexView* ix, int gappedScale, void* laneArena, size_t laneArenaBytes, DevCounters* dc, ReadResult& rr,
+                           MemoHdr* memo, bool deferPath) {
+  cx = sv->cx;
+  cx.ix = ix; cx.dc = dc; cx.status = XM_OK;
+  cx.seed.ix = ix; cx.seed.caps = &cx.caps; cx.seed.dc = dc; cx.seed.status = &cx.status; cx.seed.listIdCounter = &cx.listIdCounter; cx.seed.mateLen = cx.in.mateLen;
+  for (int m = 0; m < 2; m++) { cx.comps[m].pyr.status = &cx.status; cx.comps[m].pyr.dc = dc; }
+  cx.pc.comps = cx.comps;
+  cx.tmp.init(laneArena, laneArenaBytes);
+  {  // capacities: what lives in the read's persistent arena keeps the light pass's sizes (maxBlocks included: the accepted alignments are
+     // stored there); what the chain allocates in the temporaries gets the gapped pass's
+    const Caps g = makeCaps(gappedScale);
+    cx.caps.maxNodes = g.maxNodes; cx.caps.nodeHash = g.nodeHash; cx.caps.gridCap = g.gridCap; cx.caps.maxBuckets = g.maxBuckets; cx.caps.bucketHash = g.bucketHash;
+    cx.caps.matcherEntries = g.matcherEntries; cx.caps.maxSections = g.maxSections; cx.caps.maxPieces = g.maxPieces; cx.caps.maxCountMap = g.maxCountMap;
+    cx.caps.maxJoined = g.maxJoined;
+    cx.caps.heavyAllowed = 2;
+    cx.caps.deferPath = (memo && deferPath) ? 1 : 0;
+  }
+  cx.memo = memo; cx.memoCursor = 0;
+  if (dc) dcAccumulate(*dc, sv->partial, false);
+  XM_TIC(t0);
+  alignRead(cx, rr, true);
+  XM_TOC(dc, T_TOTAL, t0);
 }
 
 // Carve a lane's arena and align one read.  `arena` must be 16-byte aligned.

@@ -24,6 +24,4 @@ S2 = hs.SimReference([("amb", aref)])
 S2.align(se_batch(synth.synthetic_single_end(aref, 1500, seed=51)[0]), o.make_params()); print("ambiguous ref ok")
 long_reads = synth.synthetic_single_end(ref, 100, read_len=1000, sub_rate=0.05, indel_prob=0.9, seed=77)[0]
 S.align(se_batch(long_reads), o.make_params()); print("long ok")
-for env in ({"XMSIM_INLINE":"1"}, {"XMSIM_DEFER_ROUNDS":"100"}):
-    pass
 print("all ok")

@@ -89,26 +89,55 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       static const int deferRounds = getenv("XMSIM_DEFER_ROUNDS") ? atoi(getenv("XMSIM_DEFER_ROUNDS")) : 2;  // then searches run inline, as the product's last chain pass
       int rounds = 0;
       static const int lightLevel = getenv("XMSIM_LIGHT_LEVEL") ? atoi(getenv("XMSIM_LIGHT_LEVEL")) : 0;
+      // light pass -> gapped pass hand-over (runReadRetaining / runReadResumed): the read's region outlives the light "lane"; the gapped pass
+      // runs on another context object and another temporaries buffer, as it does on another lane of the GPU
+      static const bool handOver = !(getenv("XMSIM_NO_HANDOVER") && atoi(getenv("XMSIM_NO_HANDOVER")) != 0);
+      const size_t regionBytes = (size_t)128 * 1024;
+      std::vector<double> regionBuf(regionBytes / 8 + 2);
+      uint8_t* region = (uint8_t*)(((uintptr_t)regionBuf.data() + 15) & ~(uintptr_t)15);
+      const SavedRead* saved = nullptr;
+      static ReadCtx cx2;
+      std::vector<uint8_t> arena2;
       while (true) {
         size_t bytes = (size_t)288 * 1024 * (size_t)scale;
-        arena.resize(bytes + 64);
-        uint8_t* a = (uint8_t*)(((uintptr_t)arena.data() + 15) & ~(uintptr_t)15);
         ReadResult rr;
         DevCounters before = dc;
-        runRead(cx, &idx->view, params, in, scale, a, bytes, &dc, rr, stage != 0 ? 2 : lightLevel, stage == 1 ? memo : nullptr, rounds < deferRounds);
-        if (cx.status == XM_ST_NEED_HEAVY && stage == 0) { dc = before; stage = 1; scale = 4; memoInit(memo); continue; }
-        if (cx.status == XM_ST_NEED_PATH && stage == 1) {
-          dc = before;
-          if (!memo->hasRequest) throw std::runtime_error("NEED_PATH without a request");
-          Arena tmp;
-          tmp.init(a, bytes);
-          Caps caps = makeCaps(scale);
-          memoRunPath(memo, tmp, caps, &dc);
-          rounds++;
-          continue;
+        if (stage == 1 && saved) {
+          arena2.assign(bytes + 64, 0xAB);
+          uint8_t* a2 = (uint8_t*)(((uintptr_t)arena2.data() + 15) & ~(uintptr_t)15);
+          // a resume consumes the retained state (pyramid levels, hit lists and the aligner state advance in place), so it cannot be replayed:
+          // handed-over reads run their searches inline, as the product does (deferral only applies to reads that re-seed)
+          runReadResumed(cx2, saved, &idx->view, scale, a2, bytes, &dc, rr, nullptr, false);
+          cx.status = cx2.status;
+          saved = nullptr;
+        } else {
+          arena.resize(bytes + 64);
+          uint8_t* a = (uint8_t*)(((uintptr_t)arena.data() + 15) & ~(uintptr_t)15);
+          if (stage == 0 && handOver) {
+            runReadRetaining(cx, &idx->view, params, in, scale, region, regionBytes, a, bytes, &dc, rr, lightLevel);
+            if (cx.status == XM_ST_NEED_HEAVY) {
+              const SavedRead* sv = savedReadOf(region, regionBytes);
+              saved = sv->valid ? sv : nullptr;
+              std::vector<uint8_t>().swap(arena);  // the light lane's temporaries are gone (a stale pointer into them would be caught by the sanitizer run)
+            }
+          } else {
+            runRead(cx, &idx->view, params, in, scale, a, bytes, &dc, rr, stage != 0 ? 2 : lightLevel, stage == 1 ? memo : nullptr, rounds < deferRounds);
+          }
+          if (cx.status == XM_ST_NEED_HEAVY && stage == 0) { dc = before; stage = 1; scale = 4; memoInit(memo); continue; }
+          if (cx.status == XM_ST_NEED_PATH && stage == 1) {
+            dc = before;
+            if (!memo->hasRequest) throw std::runtime_error("NEED_PATH without a request");
+            Arena tmp;
+            tmp.init(a, bytes);
+            Caps caps = makeCaps(scale);
+            memoRunPath(memo, tmp, caps, &dc);
+            rounds++;
+            continue;
+          }
         }
         if (cx.status == XM_ST_OVERFLOW) {
           dc = before; rerun++;
+          saved = nullptr;
           if (stage == 0) { stage = 2; scale = 4; } else { stage = 2; scale *= 4; }
           if (scale > 4096) throw std::runtime_error("scratch scale limit");
           continue;
