@@ -66,10 +66,24 @@ static long long envInt(const char* name, long long dflt) {
 #define XM_WAVES_PER_SIMD 4  // 128 registers per lane: the path is latency-bound, four waves per SIMD hide more of it than the spills cost
 #endif
 
+// Light pass -> gapped pass hand-over (xm_worker.h, SavedRead).  mode 1 (light pass): a read's persistent arena is a region of the pool
+// below, the lane's arena holds the temporaries only; a read that stops in front of the gapped chain keeps its region (regionOf[q]) and the
+// lane takes a fresh one.  mode 2 (gapped pass): a read with a saved region continues from it on whatever lane picks it up; the lane's
+// arena = [one region for reads without saved state | temporaries].  mode 0: plain runRead in the lane's arena.
+struct HandOver {
+  int mode;
+  int seedScale;                   // scale the regions are sized for (the light pass's)
+  uint8_t* regions;
+  unsigned long long regionBytes;
+  long long nRegions;
+  int32_t* regionOf;               // per read: region that holds its SavedRead, -1 = none
+  unsigned long long* cursor;      // next unused region
+};
+
 // One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed, int lanesPerWave,
                                                        uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters,
-                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync, long long firstStride, PNode* waveNodes) {
+                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync, long long firstStride, PNode* waveNodes, HandOver ho) {
   // lanesPerWave < 64 (gapped pass): the extension chain diverges so much that a wave runs its reads nearly one after another, so
   // spreading them over more, partly filled waves shortens the critical path; the idle lanes own no scratch arena
   xmSetWaveNodes(waveNodes);
@@ -78,6 +92,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
   if (laneInWave >= lanesPerWave) return;
   unsigned long long lane = ((unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (unsigned)lanesPerWave + (unsigned)laneInWave;
   uint8_t* arena = arenas + lane * arenaBytes;
+  long long myRegion = (long long)lane;  // (mode 1) the pool's first regions are the lanes' initial ones, the cursor starts behind them
   DevCounters local;
   memset(&local, 0, sizeof(local));
   ReadCtx cx;
@@ -131,7 +146,22 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
     // deferred-search gapped pass (memoBase != null): the read's memo slot carries its finished calls from replay to replay
     MemoHdr* memo = memoBase ? (MemoHdr*)(memoBase + (size_t)slotOf[q] * XM_MEMO_SLOT_BYTES) : nullptr;
     if (memo && memoFresh) memoInit(memo);
-    runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed, memo, deferPath != 0);
+    if (ho.mode == 1) {
+      uint8_t* region = ho.regions + (unsigned long long)myRegion * ho.regionBytes;
+      runReadRetaining(cx, &ix, params, in, scale, region, (size_t)ho.regionBytes, arena, (size_t)arenaBytes, &local, rr, heavyAllowed);
+      if (cx.status == XM_ST_NEED_HEAVY && savedReadOf(region, (size_t)ho.regionBytes)->valid) {
+        long long fresh = (long long)atomicAdd(ho.cursor, 1ull);
+        if (fresh < ho.nRegions) { ho.regionOf[q] = (int32_t)myRegion; myRegion = fresh; }  // (pool used up: the read is seeded again by the gapped pass)
+      }
+    } else if (ho.mode == 2) {
+      const int32_t rg = ho.regionOf[q];
+      uint8_t* tmp = arena + ho.regionBytes;
+      const size_t tmpBytes = (size_t)(arenaBytes - ho.regionBytes);
+      if (rg >= 0) runReadResumed(cx, savedReadOf(ho.regions + (unsigned long long)rg * ho.regionBytes, (size_t)ho.regionBytes), &ix, scale, tmp, tmpBytes, &local, rr, nullptr, false);
+      else runReadRetaining(cx, &ix, params, in, ho.seedScale, arena, (size_t)ho.regionBytes, tmp, tmpBytes, &local, rr, 2, scale);
+    } else {
+      runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed, memo, deferPath != 0);
+    }
     int32_t st = cx.status;
     if (st != XM_OK) local = before;  // work of a read that is rerun by a later pass is counted there
     if (st == XM_OK) {
@@ -422,7 +452,7 @@ struct xm_index {
   DevBuf<double> dExpected, dDeviation, dOutDbls;
   DevBuf<unsigned long long> dCursors;  // [0],[1] result cursors, [2] next item
   DevBuf<int64_t> dListHeavy, dListHeavyLate, dListScale[2], dListOut[2], dListPath[2], dFinalIntOff, dFinalDblOff;
-  DevBuf<int32_t> dSlotOf;
+  DevBuf<int32_t> dSlotOf, dRegionOf;
   DevBuf<uint8_t> dMemo;
   DevBuf<PNode> dWaveNodes;  // per wave: node payloads of its LDS-mode search
   DevBuf<PassCtl> dCtl;
@@ -737,17 +767,33 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // a search round costs two launches whose time is the time of one read (a replay, a search) however few reads wait; once the
     // waiting reads no longer fill the GPU the rest is cheaper inline: one last chain pass, one read per wave
     const long long deferMaxRounds = envInt("XM_DEFER_ROUNDS", 3), inlineBelow = envInt("XM_INLINE_BELOW", 8192);
-    auto scratchLanes = [&](size_t arenaBytes) -> long long {  // scratch: up to 200 GiB of the 288 GiB HBM, never more than 3/4 of what is free
+    auto scratchBudget = [&]() -> unsigned long long {  // scratch: up to 200 GiB of the 288 GiB HBM, never more than 3/4 of what is free
       long long scratchGiB = scratchGiBWanted;
       size_t freeB = 0, totalB = 0;
       if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
         long long avail = (long long)(((freeB + idx->dArenas.n) / 4 * 3) >> 30);
         if (scratchGiB > avail) scratchGiB = avail < 1 ? 1 : avail;
       }
-      return (long long)(((unsigned long long)scratchGiB << 30) / arenaBytes);
+      return (unsigned long long)scratchGiB << 30;
     };
+    auto scratchLanes = [&](size_t arenaBytes) -> long long { return (long long)(scratchBudget() / arenaBytes); };
+    // light pass -> gapped pass hand-over (HandOver, SavedRead): the reads the light pass stops in front of the gapped chain keep their seeding
+    // state in HBM and the gapped pass continues from it.  Scratch layout while saved regions are alive: [region pool | lane arenas].
+    // (Deferred searches replay a read from its start, which a consumed region does not allow: no hand-over then.)
+    const bool handOver = envInt("XM_HANDOVER", 1) != 0 && !deferSearches;
+    int hoMode = handOver ? 1 : 0;   // mode of the next launch
+    const int seedScale = scale;
+    const size_t regionBytes = retainedRegionBytes(arenaUnit * (size_t)seedScale);
+    long long nRegions = 0;
+    size_t regionsTotal = 0;         // bytes at the start of the scratch that hold saved reads (0: none alive)
+    if (handOver) {
+      idx->dRegionOf.ensure((size_t)nq);
+      HIP_CHECK(hipMemsetAsync(idx->dRegionOf.p, 0xFF, sizeof(int32_t) * (size_t)nq, s));
+    }
     while (nTodo > 0) {
-      size_t arenaBytes = arenaUnit * (size_t)scale;
+      size_t arenaBytes = arenaUnit * (size_t)scale;  // bytes of scratch a lane owns in this launch
+      if (hoMode == 1) arenaBytes -= arenaPersistBytes(arenaBytes);                                // temporaries only (+ one region of the pool per lane)
+      else if (hoMode == 2) arenaBytes = regionBytes + arenaBytes - arenaPersistBytes(arenaBytes);  // a region for reads without saved state + temporaries
       // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped chain
       // diverges inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  The XM_* variables are experiment knobs.
       // a pass over few reads spreads them over all the wave slots of the GPU (the time of a launch is its longest wave)
@@ -755,14 +801,47 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       int lpw = (int)(heavy ? fullLpw : lightLpw);  // active lanes per wave
       if (heavy) lpw = (int)std::max(1ll, std::min((long long)lpw, (nTodo + waveSlots - 1) / waveSlots));
       long long lanes = waveSlots * lpw;
-      lanes = std::min(lanes, scratchLanes(arenaBytes));
+      const unsigned long long budget = scratchBudget();
+      if (hoMode == 1) lanes = std::min(lanes, (long long)(budget / (arenaBytes + regionBytes)));
+      else if (regionsTotal > 0) lanes = std::min(lanes, (long long)((idx->dArenas.n - regionsTotal) / arenaBytes));  // (sized below, before the pool was filled)
+      else lanes = std::min(lanes, (long long)(budget / arenaBytes));
       if (lanes > nTodo) lanes = nTodo;
       long long nWaves = (lanes + lpw - 1) / lpw;
       if (nWaves < 1) nWaves = 1;
+      if (hoMode != 1 && regionsTotal > 0) {  // the scratch cannot grow now: whole waves (and whole blocks of four) that fit behind the pool
+        const long long cap = (long long)((idx->dArenas.n - regionsTotal) / arenaBytes);
+        if (lpw > cap) lpw = (int)cap;
+        long long w = cap / lpw;
+        if (w >= 4) w &= ~3ll;
+        if ((nWaves >= 4 ? ((nWaves + 3) & ~3ll) : nWaves) > w) nWaves = w;
+      }
       int block = nWaves < 4 ? (int)nWaves * 64 : 256;
       int grid = (int)((nWaves * 64 + block - 1) / block);
       lanes = (long long)grid * (block / 64) * lpw;
-      idx->dArenas.ensure((size_t)lanes * arenaBytes);
+      if (hoMode == 1) {
+        // pool: one region per lane + one per read that may stop (at most 40 % of the scratch; reads beyond that are seeded again by the
+        // gapped pass).  The scratch is sized here for the gapped pass as well: it must not move while saved regions are alive.
+        long long extra = std::min((long long)nTodo, (long long)(budget * 2 / 5 / regionBytes) - lanes);
+        extra = std::min(extra, ((long long)budget - lanes * (long long)(arenaBytes + regionBytes)) / (long long)regionBytes);
+        if (extra < 0) extra = 0;
+        nRegions = lanes + extra;
+        regionsTotal = (size_t)nRegions * regionBytes;
+        const size_t gappedArena = arenaUnit * (size_t)gappedScale, gappedLane = regionBytes + gappedArena - arenaPersistBytes(gappedArena);
+        long long gappedLanes = std::min((long long)nq, (long long)idx->numCUs * 4 * fullWaves * fullLpw);
+        gappedLanes = std::min(gappedLanes, std::max(1ll, ((long long)budget - (long long)regionsTotal) / (long long)gappedLane));
+        size_t behind = std::max((size_t)lanes * arenaBytes, (size_t)gappedLanes * gappedLane);
+        behind = std::max(behind, gappedArena);  // (a rerun after a full result arena runs plain, at least one lane of it)
+        idx->dArenas.ensure(regionsTotal + behind + 1024);
+        const unsigned long long firstFree = (unsigned long long)lanes;
+        HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 3, &firstFree, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+      } else if (regionsTotal > 0) {
+        if (regionsTotal + (size_t)lanes * arenaBytes > idx->dArenas.n) throw std::runtime_error("internal error: scratch layout (hand-over)");
+      } else {
+        idx->dArenas.ensure((size_t)lanes * arenaBytes);
+      }
+      uint8_t* laneArenas = idx->dArenas.p + regionsTotal;
+      HandOver ho{hoMode, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
+      const int launchedMode = hoMode;
       idx->dWaveNodes.ensure((size_t)grid * (block / 64) * XM_PAL_NODES);
       idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq); idx->dListPath[tp].ensure(defer ? (size_t)nTodo : 1);
       // gapped pass with an ordered list: the first read of every lane is dealt out (kernel), the counter starts behind those items
@@ -772,10 +851,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
       HIP_CHECK(hipEventRecord(e0, s));
       hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
-                         idx->dArenas.p, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
+                         laneArenas, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
                          defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
                          (heavy && !fullSync) ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, ((!heavy && lightSync) || (heavy && fullSync)) ? 1 : 0,
-                         fullSync ? 0ll : firstStride, idx->dWaveNodes.p);
+                         fullSync ? 0ll : firstStride, idx->dWaveNodes.p, ho);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,
@@ -790,6 +869,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       res->counters[!heavy ? 12 : (defer ? 13 : 15)] += (int64_t)(ms * 1000.0);  // kernel microseconds: light pass / gapped chain passes / inline reruns
       launches++;
       memoFresh = false;
+      hoMode = 0;                                // (the gapped pass below switches to 2; reruns run plain)
+      if (launchedMode == 2) regionsTotal = 0;   // every saved read has been consumed
       const bool tracePasses = envInt("XM_TRACE_PASSES", 0) != 0;
       if (tracePasses) fprintf(stderr, "[xm] pass %d: %s reads %lld scale %d lpw %d waves %lld: %.3f ms -> heavy %llu path %llu scale %llu out %llu\n", launches, !heavy ? "light" : (defer ? "chain" : "inline"),
                                nTodo, scale, lpw, nWaves, ms, ctl.nHeavy, ctl.nPath[tp], ctl.nScale[ts], ctl.nOut[to]);
@@ -865,6 +946,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         heavy = true;
         defer = deferSearches;
         if (defer) { idx->dMemo.ensure((size_t)nTodo * XM_MEMO_SLOT_BYTES); memoFresh = true; }
+        if (regionsTotal > 0) hoMode = 2;
         continue;
       }
       if (pendingScale == 0) break;
@@ -872,6 +954,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       ts ^= 1;
       HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nScale[ts], 0, sizeof(unsigned long long), s));
       rerun += nTodo;
+      regionsTotal = 0;  // (no gapped pass ran: whatever the light pass saved is not wanted any more)
       overflowScale *= 4;
       scale = overflowScale;
       heavy = true;

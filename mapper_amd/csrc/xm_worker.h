@@ -811,11 +811,26 @@ XM_INL void dcAccumulate(DevCounters& a, const DevCounters& b, bool subtract) {
 // the usable part of a read's region when its tail holds the SavedRead
 XM_INL size_t retainedPersistBytes(size_t regionBytes) { return (regionBytes - sizeof(SavedRead)) & ~(size_t)15; }
 XM_INL SavedRead* savedReadOf(void* region, size_t regionBytes) { return (SavedRead*)((uint8_t*)region + retainedPersistBytes(regionBytes)); }
+// an arena of runRead splits 5 : 7 into the persistent part and the temporaries; a read's region = the persistent part + its SavedRead
+XM_INL size_t arenaPersistBytes(size_t arenaBytes) { return (arenaBytes * 5 / 12) & ~(size_t)15; }
+XM_INL size_t retainedRegionBytes(size_t arenaBytes) { return arenaPersistBytes(arenaBytes) + ((sizeof(SavedRead) + 15) & ~(size_t)15); }
 
-// light pass with hand-over: persistent arena = the read's region, temporaries = the lane's arena
+// what the extension chain allocates in the temporaries follows the scale of the pass that runs the chain; what lives in the read's
+// persistent arena (maxBlocks included: the accepted alignments are stored there) keeps the sizes of the scale the read was seeded with
+XM_INL void applyChainCaps(Caps& c, int chainScale) {
+  const Caps g = makeCaps(chainScale);
+  c.maxNodes = g.maxNodes; c.nodeHash = g.nodeHash; c.gridCap = g.gridCap; c.maxBuckets = g.maxBuckets; c.bucketHash = g.bucketHash;
+  c.matcherEntries = g.matcherEntries; c.maxSections = g.maxSections; c.maxPieces = g.maxPieces; c.maxCountMap = g.maxCountMap;
+  c.maxJoined = g.maxJoined;
+}
+
+// A read whose persistent arena is a region of its own and whose temporaries are the lane's arena.  Light pass (heavyAllowed < 2): a read
+// that stops in front of the gapped chain leaves a SavedRead at the tail of the region.  Gapped pass, read without saved state
+// (heavyAllowed 2, chainScale = the gapped scale): seeded at `scale`, chain scratch of the gapped pass.
 XM_INL void runReadRetaining(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* region, size_t regionBytes, void* laneArena, size_t laneArenaBytes,
-                             DevCounters* dc, ReadResult& rr, int heavyAllowed) {
+                             DevCounters* dc, ReadResult& rr, int heavyAllowed, int chainScale = 0) {
   cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed; cx.caps.deferPath = 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
+  if (chainScale > 0 && chainScale != scale) applyChainCaps(cx.caps, chainScale);
   cx.memo = nullptr; cx.memoCursor = 0; cx.heavyHint = 0;
   cx.params.StartingInsertionStartFree = 0;
   cx.persist.init(region, retainedPersistBytes(regionBytes));
@@ -838,7 +853,8 @@ XM_INL void runReadRetaining(ReadCtx& cx, const IndexView* ix, const Params& par
   }
 }
 // gapped pass, a read the light pass handed over: the context back on this lane, pointers into the context re-seated, the chain's scratch
-// capacities of the gapped pass, temporaries in this lane's arena; then on from the candidate that needed the chain
+// capacities of the gapped pass, temporaries in this lane's arena; then on from the candidate that needed the chain.  The saved state is
+// consumed (pyramid levels, hit lists and the aligner advance in place): a read can be resumed once.
 XM_INL void runReadResumed(ReadCtx& cx, const SavedRead* sv, const IndexView* ix, int gappedScale, void* laneArena, size_t laneArenaBytes, DevCounters* dc, ReadResult& rr,
                            MemoHdr* memo, bool deferPath) {
   cx = sv->cx;
@@ -847,15 +863,9 @@ XM_INL void runReadResumed(ReadCtx& cx, const SavedRead* sv, const IndexView* ix
   for (int m = 0; m < 2; m++) { cx.comps[m].pyr.status = &cx.status; cx.comps[m].pyr.dc = dc; }
   cx.pc.comps = cx.comps;
   cx.tmp.init(laneArena, laneArenaBytes);
-  {  // capacities: what lives in the read's persistent arena keeps the light pass's sizes (maxBlocks included: the accepted alignments are
-     // stored there); what the chain allocates in the temporaries gets the gapped pass's
-    const Caps g = makeCaps(gappedScale);
-    cx.caps.maxNodes = g.maxNodes; cx.caps.nodeHash = g.nodeHash; cx.caps.gridCap = g.gridCap; cx.caps.maxBuckets = g.maxBuckets; cx.caps.bucketHash = g.bucketHash;
-    cx.caps.matcherEntries = g.matcherEntries; cx.caps.maxSections = g.maxSections; cx.caps.maxPieces = g.maxPieces; cx.caps.maxCountMap = g.maxCountMap;
-    cx.caps.maxJoined = g.maxJoined;
-    cx.caps.heavyAllowed = 2;
-    cx.caps.deferPath = (memo && deferPath) ? 1 : 0;
-  }
+  applyChainCaps(cx.caps, gappedScale);
+  cx.caps.heavyAllowed = 2;
+  cx.caps.deferPath = (memo && deferPath) ? 1 : 0;
   cx.memo = memo; cx.memoCursor = 0;
   if (dc) dcAccumulate(*dc, sv->partial, false);
   XM_TIC(t0);
@@ -869,8 +879,7 @@ XM_INL void runRead(ReadCtx& cx, const IndexView* ix, const Params& params, cons
   cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed; cx.caps.deferPath = (memo && deferPath) ? 1 : 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
   cx.memo = memo; cx.memoCursor = 0; cx.heavyHint = 0;
   cx.params.StartingInsertionStartFree = 0;
-  size_t persistBytes = arenaBytes * 5 / 12;
-  persistBytes &= ~(size_t)15;
+  const size_t persistBytes = arenaPersistBytes(arenaBytes);
   cx.persist.init(arena, persistBytes);
   cx.tmp.init((uint8_t*)arena + persistBytes, arenaBytes - persistBytes);
   XM_TIC(t0);

@@ -92,7 +92,7 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       // light pass -> gapped pass hand-over (runReadRetaining / runReadResumed): the read's region outlives the light "lane"; the gapped pass
       // runs on another context object and another temporaries buffer, as it does on another lane of the GPU
       static const bool handOver = !(getenv("XMSIM_NO_HANDOVER") && atoi(getenv("XMSIM_NO_HANDOVER")) != 0);
-      const size_t regionBytes = (size_t)128 * 1024;
+      const size_t lightArena = (size_t)288 * 1024, regionBytes = retainedRegionBytes(lightArena);  // the product's sizes
       std::vector<double> regionBuf(regionBytes / 8 + 2);
       uint8_t* region = (uint8_t*)(((uintptr_t)regionBuf.data() + 15) & ~(uintptr_t)15);
       const SavedRead* saved = nullptr;
@@ -107,19 +107,22 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
           uint8_t* a2 = (uint8_t*)(((uintptr_t)arena2.data() + 15) & ~(uintptr_t)15);
           // a resume consumes the retained state (pyramid levels, hit lists and the aligner state advance in place), so it cannot be replayed:
           // handed-over reads run their searches inline, as the product does (deferral only applies to reads that re-seed)
-          runReadResumed(cx2, saved, &idx->view, scale, a2, bytes, &dc, rr, nullptr, false);
+          runReadResumed(cx2, saved, &idx->view, scale, a2, bytes - arenaPersistBytes(bytes), &dc, rr, nullptr, false);
           cx.status = cx2.status;
           saved = nullptr;
         } else {
           arena.resize(bytes + 64);
           uint8_t* a = (uint8_t*)(((uintptr_t)arena.data() + 15) & ~(uintptr_t)15);
           if (stage == 0 && handOver) {
-            runReadRetaining(cx, &idx->view, params, in, scale, region, regionBytes, a, bytes, &dc, rr, lightLevel);
+            runReadRetaining(cx, &idx->view, params, in, scale, region, regionBytes, a, lightArena - arenaPersistBytes(lightArena), &dc, rr, lightLevel);
             if (cx.status == XM_ST_NEED_HEAVY) {
               const SavedRead* sv = savedReadOf(region, regionBytes);
               saved = sv->valid ? sv : nullptr;
               std::vector<uint8_t>().swap(arena);  // the light lane's temporaries are gone (a stale pointer into them would be caught by the sanitizer run)
             }
+          } else if (stage == 1 && handOver) {
+            // gapped pass, read without saved state (stopped where it cannot be resumed): seeded again in a region of light-pass size
+            runReadRetaining(cx, &idx->view, params, in, 1, region, regionBytes, a, bytes - arenaPersistBytes(bytes), &dc, rr, 2, scale);
           } else {
             runRead(cx, &idx->view, params, in, scale, a, bytes, &dc, rr, stage != 0 ? 2 : lightLevel, stage == 1 ? memo : nullptr, rounds < deferRounds);
           }
