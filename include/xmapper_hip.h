@@ -108,6 +108,14 @@ int xm_device_count(void);
  * (Mapper.java:657-692, Api.java:41-69, HashBlock_Database.java:490-665, PackedMap.java:54-153, DuplicationDetector.java:97-436)
  * and uploads the result to HBM. */
 int xm_index_build(const xm_ref* ref, const xm_build_opts* opts, xm_index** out);
+/* Binary index cache, in the spirit of --cache-dir (DirCache.java:19-60, HashBlock_Database.java:106-114,477-487, PackedMap.java:249-279:
+ * the reference writes one "length-<n>" file per PackedMap under a directory keyed by its property map).  xm_index_save writes the
+ * reference, every table hashed so far and the duplication map into ONE file (beside `path`, then renamed: concurrent writers are safe).
+ * xm_index_load reads it back and uploads it; with `ref` non-null the file must hold exactly that reference and have been built with the
+ * settings `opts` asks for (the reference's cache keys: enableGapmers, minInterestingSize, maxNumShortMatches, format version; plus the
+ * duplication settings), else the call fails and the caller builds.  opts->max_hashed_length beyond the file's grows the tables. */
+int xm_index_save(xm_index* index, const char* path);
+int xm_index_load(const char* path, const xm_ref* ref, const xm_build_opts* opts, xm_index** out);
 /* Readable_HashBlock_Database.getContainingMap's lazy growth (Readable_HashBlock_Database.java:108-113): hash tables
  * through gapmers that use `length` bases.  xm_align_batch calls this itself for the longest mate of the batch. */
 int xm_index_ensure_length(xm_index* index, int32_t length);

@@ -46,7 +46,7 @@ class XmIndexInfo(C.Structure):
                 ("num_positions", C.c_int64), ("dup_granularity", C.c_double)]
 
 
-EXPORTS = ["xm_last_error", "xm_device_count", "xm_index_build", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
+EXPORTS = ["xm_last_error", "xm_device_count", "xm_index_build", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
            "xm_index_table_info", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_align_resident", "xm_seed_probe", "xm_measure_random_gather"]
 
 
@@ -73,6 +73,8 @@ def lib():
         L = C.CDLL(os.environ.get("XM_LIB_PATH") or LIB_PATH)  # (XM_LIB_PATH: A/B experiments with another build of the same library)
         L.xm_last_error.restype = C.c_char_p
         L.xm_index_build.argtypes = [C.POINTER(XmRef), C.POINTER(XmBuildOpts), C.POINTER(C.c_void_p)]
+        L.xm_index_save.argtypes = [C.c_void_p, C.c_char_p]
+        L.xm_index_load.argtypes = [C.c_char_p, C.POINTER(XmRef), C.POINTER(XmBuildOpts), C.POINTER(C.c_void_p)]
         L.xm_index_ensure_length.argtypes = [C.c_void_p, C.c_int32]
         L.xm_index_free.argtypes = [C.c_void_p]
         L.xm_index_get_info.argtypes = [C.c_void_p, C.POINTER(XmIndexInfo)]

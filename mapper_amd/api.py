@@ -5,6 +5,7 @@ Query / QueryAlignment / SequenceAlignment / AlignedBlock result types the Java 
 include/xmapper_hip.h.  Everything is aligned on the GPU by libxmapper_hip.so; there is no CPU path.
 """
 import ctypes as C
+import os
 import numpy as np
 
 from . import _capi
@@ -142,12 +143,37 @@ class BatchResult:
         return decode_streams(self.ints, self.dbls, self.int_off, self.dbl_off, q)
 
 
+def index_cache_path(cache_dir, contigs, opts):
+    """<cache_dir>/cache/<digest>/index.xmidx, the digest over the property text DirCache would hash (DirCache.java:19-60): the
+    sequence database's keys (here: names, lengths and a digest of the bases) + enableGapmers, minInterestingSize, maxNumShortMatches,
+    formatVersion, type (HashBlock_Database.java:106-114) + the duplication settings this library stores in the same file."""
+    import hashlib
+    seq = hashlib.sha256()
+    for name, codes in contigs:
+        seq.update(name.encode() + b"\0" + str(len(codes)).encode() + b"\0")
+        seq.update(np.ascontiguousarray(codes, dtype=np.uint8).tobytes())
+    props = {"sequences": seq.hexdigest(), "enableGapmers": str(bool(opts.enable_gapmers)).lower(), "minInterestingSize": str(opts.min_interesting_size),
+             "maxNumShortMatches": "5", "formatVersion": "xmidx-1", "type": "HashBlock_Database",
+             "duplications": "%d,%d,%d,%d" % (opts.dup_window, opts.dup_min_copies, opts.dup_min_length, opts.dup_max_length)}
+    text = "{\n" + "".join('%s:"%s",\n' % (k, props[k]) for k in sorted(props)) + "}"
+    d = os.path.join(os.fspath(cache_dir), "cache", hashlib.sha256(text.encode()).hexdigest()[:32])
+    os.makedirs(d, exist_ok=True)
+    meta = os.path.join(d, "metadata")
+    if not os.path.exists(meta):
+        with open(meta + ".tmp.%d" % os.getpid(), "w") as f:
+            f.write(text)
+        os.replace(meta + ".tmp.%d" % os.getpid(), meta)
+    return os.path.join(d, "index.xmidx")
+
+
 class ReferenceDatabase:
     """ReferenceDatabase.java: HashBlock_Database + DuplicationDetector of a reference, resident in HBM."""
 
-    def __init__(self, contigs, mode="mapper", enable_gapmers=True, max_query_length=0, device=-1, host_only=False, dup=None):
+    def __init__(self, contigs, mode="mapper", enable_gapmers=True, max_query_length=0, device=-1, host_only=False, dup=None, cache_dir=None):
         """contigs: list of (name, IUPAC text or code array), already in Mapper.sortAndComplementReference order
-        (use sort_reference()).  mode 'mapper' = Mapper.run assembly (duplication window 1000), 'api' = Api.newDatabase (window 1)."""
+        (use sort_reference()).  mode 'mapper' = Mapper.run assembly (duplication window 1000), 'api' = Api.newDatabase (window 1).
+        cache_dir: --cache-dir (Mapper.java:264, DirCache.java:19-60): the index is read from / written to a file under
+        <cache_dir>/cache/ that is named after the reference's cache keys (HashBlock_Database.java:106-114) and this build's settings."""
         self._L = _capi.lib()
         self.contigs = [(n, encode(s) if isinstance(s, str) else np.ascontiguousarray(s, dtype=np.uint8)) for n, s in contigs]
         ref, self._keep = _capi.make_ref(self.contigs)
@@ -163,9 +189,43 @@ class ReferenceDatabase:
         o.device = device
         o.host_only = 1 if host_only else 0
         h = C.c_void_p()
+        self.cache_file = None
+        self.cache_hit = False
+        if cache_dir is not None:
+            self.cache_file = index_cache_path(cache_dir, self.contigs, o)
+            if os.path.exists(self.cache_file) and self._L.xm_index_load(self.cache_file.encode(), C.byref(ref), C.byref(o), C.byref(h)) == 0:
+                self._h = h
+                self.cache_hit = True
+                return
+            # (a file that does not load - other settings behind the same name, truncated, older format - is rebuilt and replaced)
         if self._L.xm_index_build(C.byref(ref), C.byref(o), C.byref(h)):
             raise RuntimeError(self._L.xm_last_error().decode())
         self._h = h
+        if self.cache_file is not None:
+            self.save(self.cache_file)
+
+    def save(self, path):
+        """xm_index_save: the reference, every table hashed so far and the duplication map into one file."""
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        if self._L.xm_index_save(self._h, os.fspath(path).encode()):
+            raise RuntimeError(self._L.xm_last_error().decode())
+
+    @classmethod
+    def load(cls, path, device=-1, host_only=False, max_query_length=0):
+        """xm_index_load without a build request to check against: whatever reference and settings the file holds."""
+        self = cls.__new__(cls)
+        self._L = _capi.lib()
+        self.contigs, self._keep, self.cache_file, self.cache_hit = None, None, os.fspath(path), True
+        o = _capi.XmBuildOpts()
+        o.enable_gapmers = 1
+        o.max_hashed_length = int(max_query_length)
+        o.device = device
+        o.host_only = 1 if host_only else 0
+        h = C.c_void_p()
+        if self._L.xm_index_load(os.fspath(path).encode(), None, C.byref(o), C.byref(h)):
+            raise RuntimeError(self._L.xm_last_error().decode())
+        self._h = h
+        return self
 
     def close(self):
         if getattr(self, "_h", None):

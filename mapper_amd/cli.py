@@ -8,7 +8,8 @@ SURVEY.md section 8(f) rank 1.  What is pinned by the reference: the flag names 
 derivation of AlignmentParameters from them (:409-453), reference sorting (:1151-1172), the SAM record format
 (SamWriter_Test.java) and the statistics lines of Mapper.run (:786-796).  The SAM header, `--out-unaligned` and the other writers
 live in the un-vendored QuickVariants module: the header written here is the minimal SAM-spec one and is marked [unpinned]; the
-VCF / mutations / ancestry / refs-map-count outputs stay with the Java host and are refused here with a message saying so.
+VCF / mutations / ancestry / refs-map-count outputs stay with the Java host (`--cache-dir` is
+honoured: the index goes to one file under it, api.index_cache_path) and are refused here with a message saying so.
 """
 import gzip
 import sys
@@ -17,7 +18,7 @@ import numpy as np
 
 from . import api, sam
 
-JAVA_HOST_ONLY = {"--out-vcf": 1, "--out-mutations": 1, "--out-ancestor": 1, "--out-refs-map-count": 1, "--cache-dir": 1,
+JAVA_HOST_ONLY = {"--out-vcf": 1, "--out-mutations": 1, "--out-ancestor": 1, "--out-refs-map-count": 1,
                   "--distinguish-query-ends": 1, "--infer-ancestors": 0, "--verify-consistent-db": 0,
                   "--vcf-exclude-non-mutations": 0, "--vcf-omit-support-reads": 0}
 IGNORED = {"--verbose": 0, "-v": 0, "-vv": 0, "--verbose-alignment": 0, "--verbose-reference": 0, "--verbosity-auto": 0, "--num-threads": 1,
@@ -125,12 +126,14 @@ def parse_args(argv):
                 raise UsageError("--ambiguity-penalty must be >= 0")
         elif a == "--max-num-matches":
             o["maxNumMatches"] = int(argv[i + 1]); i += 1
+        elif a == "--cache-dir":  # Mapper.java:264: keep the hashed reference between runs
+            o["cache_dir"] = argv[i + 1]; i += 1
         elif a == "--device":  # (not a Mapper flag) which GPU
             o["device"] = int(argv[i + 1]); i += 1
         elif a == "--spacing":
             raise UsageError("--spacing is not a top-level argument: try --paired-queries <queries> <queries2> --spacing <expected> <distancePerPenalty>")
         elif a in JAVA_HOST_ONLY:
-            raise UsageError("%s is handled by the Java host (VCF / mutation / ancestry / cache subsystems are outside the accelerated path, SURVEY.md section 8)" % a)
+            raise UsageError("%s is handled by the Java host (VCF / mutation / ancestry subsystems are outside the accelerated path, SURVEY.md section 8)" % a)
         elif a in IGNORED:
             i += IGNORED[a]
         else:
@@ -218,7 +221,7 @@ def run(argv, out=sys.stdout):
     ordered = api.sort_reference(contigs)  # Mapper.sortAndComplementReference: alignment results refer to this order
     names = [n for n, _ in ordered]
     db = api.ReferenceDatabase(ordered, mode="mapper", enable_gapmers=o["enable_gapmers"], device=o["device"],
-                               max_query_length=max([len(s) for q, _ in queries for s in q.sequences] + [1]))
+                               max_query_length=max([len(s) for q, _ in queries for s in q.sequences] + [1]), cache_dir=o.get("cache_dir"))
     result = db.align_batch([q for q, _ in queries], params)
     sam_out = None
     if o["out_sam"]:

@@ -546,6 +546,50 @@ int xm_index_build(const xm_ref* ref, const xm_build_opts* optsIn, xm_index** ou
   }
 }
 
+int xm_index_save(xm_index* idx, const char* path) {
+  if (!idx || !path) return fail("xm_index_save: null argument");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    idx->host.save(path);
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_index_save: ") + e.what()); }
+}
+
+int xm_index_load(const char* path, const xm_ref* ref, const xm_build_opts* optsIn, xm_index** out) {
+  if (!path || !out) return fail("xm_index_load: null argument");
+  xm_build_opts o;
+  memset(&o, 0, sizeof(o));
+  o.enable_gapmers = 1; o.dup_window = 1000; o.dup_min_copies = 2; o.device = -1;
+  if (optsIn) o = *optsIn;
+  xm_index* idx = nullptr;
+  try {
+    idx = new xm_index();
+    idx->host.load(path);
+    if (ref) {  // the file must answer exactly this build request (the reference's cache keys, M/HashBlock_Database.java:106-114)
+      HostIndex want;
+      want.setReference(ref->num_contigs, ref->names, ref->codes, ref->lengths);
+      if (!idx->host.matchesRequest(want, o.enable_gapmers, o.min_interesting_size, o.dup_window, o.dup_min_copies, o.dup_min_length, o.dup_max_length))
+        throw std::runtime_error("the file was built from another reference or with other settings");
+    }
+    if (o.max_hashed_length > idx->host.maxHashedLength) idx->host.ensureLength(o.max_hashed_length);
+    idx->hostOnly = o.host_only != 0;
+    if (!idx->hostOnly) {
+      int n = 0;
+      if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+        throw std::runtime_error("no HIP device available: libxmapper_hip.so has no CPU path (pass host_only=1 only to inspect the index)");
+      int dev = o.device;
+      if (dev < 0) HIP_CHECK(hipGetDevice(&dev));
+      idx->device = dev;
+      idx->upload();
+    }
+    *out = idx;
+    return 0;
+  } catch (std::exception& e) {
+    delete idx;
+    return fail(std::string("xm_index_load: ") + e.what());
+  }
+}
+
 int xm_index_ensure_length(xm_index* idx, int32_t length) {
   if (!idx) return fail("null index");
   try {

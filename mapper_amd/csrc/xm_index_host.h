@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <mutex>
 #include <functional>
+#include <unistd.h>
 
 namespace xm {
 
@@ -442,6 +443,110 @@ struct HostIndex {
     if (length <= maxHashedLength) return;
     hashLengths(maxHashedLength + 1, length);
     maxHashedLength = length;
+  }
+
+  // ---- binary cache (in the spirit of --cache-dir: M/DirCache.java:19-60, M/HashBlock_Database.java:106-114,477-487, M/PackedMap.java:249-279).
+  // One file holds the reference, every table hashed so far and the duplication map; the reference's own cache keys (enableGapmers,
+  // minInterestingSize, maxNumShortMatches, formatVersion) and the duplication settings are in its header and must match on load.
+  static constexpr uint64_t CACHE_MAGIC = 0x3158444958504D58ull;  // "XMPXIDX1"
+  static constexpr uint32_t CACHE_FORMAT = 1;
+  struct CacheHeader {
+    uint64_t magic; uint32_t format; int32_t enableGapmers, minInterestingSize, maxNumShortMatches, maxHashedLength;
+    int32_t dupWindow, dupMinCopies, dupMinLength, dupMaxLength, dupDone; int64_t totalForwardSize; uint64_t referenceDigest;
+  };
+  static uint64_t fnv(const void* data, size_t n, uint64_t h = 0xCBF29CE484222325ull) {
+    const uint8_t* b = (const uint8_t*)data;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001B3ull; }
+    return h;
+  }
+  uint64_t referenceDigest() const {
+    uint64_t h = fnv(refCodes.data(), refCodes.size());
+    for (size_t c = 0; c < names.size(); c++) { h = fnv(names[c].data(), names[c].size() + 1, h); h = fnv(&contigLen[c], sizeof(int32_t), h); }
+    return h;
+  }
+  struct CacheWriter {
+    FILE* f;
+    void raw(const void* p, size_t n) { if (n && fwrite(p, 1, n, f) != n) throw std::runtime_error("index cache: write failed"); }
+    template <typename T> void vec(const std::vector<T>& v) { uint64_t n = v.size(); raw(&n, 8); raw(v.data(), v.size() * sizeof(T)); }
+  };
+  struct CacheReader {
+    FILE* f;
+    void raw(void* p, size_t n) { if (n && fread(p, 1, n, f) != n) throw std::runtime_error("index cache: file is truncated"); }
+    template <typename T> void vec(std::vector<T>& v, uint64_t limit) {
+      uint64_t n = 0; raw(&n, 8);
+      if (n > limit) throw std::runtime_error("index cache: file is corrupt");
+      v.resize((size_t)n); raw(v.data(), (size_t)n * sizeof(T));
+    }
+  };
+  void save(const std::string& path) const {
+    // written beside the target and renamed, so that ranks that build the same index at once never read a half-written file
+    const std::string tmp = path + ".tmp." + std::to_string((long long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) throw std::runtime_error("index cache: cannot create " + tmp);
+    try {
+      CacheWriter w{f};
+      CacheHeader h{CACHE_MAGIC, CACHE_FORMAT, enableGapmers, minInterestingSize, maxNumShortMatches, maxHashedLength, dupWindow, dupMinCopies, dupMinLength, dupMaxLength,
+                    dupDone ? 1 : 0, totalForwardSize, referenceDigest()};
+      w.raw(&h, sizeof(h));
+      uint64_t n = names.size(); w.raw(&n, 8);
+      for (const std::string& s : names) { uint64_t l = s.size(); w.raw(&l, 8); w.raw(s.data(), s.size()); }
+      w.vec(contigStart); w.vec(contigLen); w.vec(seqCumStart); w.vec(refCodes); w.vec(tables); w.vec(bucketOff); w.vec(positions); w.vec(dupKeyStart); w.vec(dupKeys);
+      const uint64_t tail[2] = {CACHE_MAGIC, (uint64_t)ftell(f)};
+      w.raw(tail, sizeof(tail));
+      if (fclose(f) != 0) { f = nullptr; throw std::runtime_error("index cache: write failed"); }
+      f = nullptr;
+      if (rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("index cache: cannot rename to " + path);
+    } catch (...) {
+      if (f) fclose(f);
+      remove(tmp.c_str());
+      throw;
+    }
+  }
+  void load(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("index cache: cannot open " + path);
+    try {
+      fseek(f, 0, SEEK_END);
+      const uint64_t fileBytes = (uint64_t)ftell(f);
+      fseek(f, 0, SEEK_SET);
+      CacheReader r{f};
+      CacheHeader h;
+      r.raw(&h, sizeof(h));
+      if (h.magic != CACHE_MAGIC) throw std::runtime_error("index cache: not an index file");
+      if (h.format != CACHE_FORMAT) throw std::runtime_error("index cache: format version " + std::to_string(h.format) + " (this library reads " + std::to_string(CACHE_FORMAT) + ")");
+      enableGapmers = h.enableGapmers; minInterestingSize = h.minInterestingSize; maxNumShortMatches = h.maxNumShortMatches; maxHashedLength = h.maxHashedLength;
+      dupWindow = h.dupWindow; dupMinCopies = h.dupMinCopies; dupMinLength = h.dupMinLength; dupMaxLength = h.dupMaxLength; dupDone = h.dupDone != 0; totalForwardSize = h.totalForwardSize;
+      uint64_t n = 0; r.raw(&n, 8);
+      if (n > fileBytes) throw std::runtime_error("index cache: file is corrupt");
+      names.resize((size_t)n);
+      for (std::string& s : names) { uint64_t l = 0; r.raw(&l, 8); if (l > fileBytes) throw std::runtime_error("index cache: file is corrupt"); s.resize((size_t)l); r.raw(&s[0], (size_t)l); }
+      r.vec(contigStart, fileBytes); r.vec(contigLen, fileBytes); r.vec(seqCumStart, fileBytes); r.vec(refCodes, fileBytes); r.vec(tables, fileBytes); r.vec(bucketOff, fileBytes);
+      r.vec(positions, fileBytes); r.vec(dupKeyStart, fileBytes); r.vec(dupKeys, fileBytes);
+      uint64_t tail[2] = {0, 0};
+      const uint64_t at = (uint64_t)ftell(f);
+      r.raw(tail, sizeof(tail));
+      if (tail[0] != CACHE_MAGIC || tail[1] != at) throw std::runtime_error("index cache: file is truncated");
+      fclose(f); f = nullptr;
+      if (contigLen.size() != names.size() || contigStart.size() != names.size() || seqCumStart.size() != names.size() * 2 + 1 || (int)tables.size() != maxHashedLength + 1 ||
+          h.referenceDigest != referenceDigest())
+        throw std::runtime_error("index cache: file is corrupt");
+      for (const Table& t : tables)
+        if (t.capacity < 1 || t.offBase < 0 || t.posBase < 0 || (uint64_t)t.offBase + (uint64_t)t.capacity + 1 > bucketOff.size() || (uint64_t)t.posBase > positions.size())
+          throw std::runtime_error("index cache: file is corrupt");
+    } catch (...) {
+      if (f) fclose(f);
+      throw;
+    }
+  }
+  // does this (loaded) index answer a build request for `other`'s reference with these settings?  (same resolution of defaults as build())
+  bool matchesRequest(const HostIndex& other, int enableGapmers_, int minInteresting, int dupWindow_, int dupMinCopies_, int dupMinLen, int dupMaxLen) const {
+    if (names != other.names || contigLen != other.contigLen || refCodes != other.refCodes) return false;
+    HostIndex probe;
+    probe.totalForwardSize = other.totalForwardSize;
+    const int wantMin = minInteresting > 0 ? minInteresting : j2i(std::max((std::log((double)(other.totalForwardSize + 1)) / std::log(4.0)) - 2, 1.0));
+    return enableGapmers == (enableGapmers_ ? 1 : 0) && minInterestingSize == wantMin && dupWindow == (dupWindow_ > 0 ? dupWindow_ : 1000) &&
+           dupMinCopies == (dupMinCopies_ > 0 ? dupMinCopies_ : 2) && dupMinLength == (dupMinLen > 0 ? dupMinLen : probe.chooseMinDuplicationLength()) &&
+           dupMaxLength == (dupMaxLen > 0 ? dupMaxLen : probe.chooseMaxDuplicationLength());
   }
 
   // ---- PackedMap.get on the host tables (used by the duplication pass and by the inspection API)

@@ -95,3 +95,10 @@ def test_examples_through_the_command_line(tmp_path):
     assert by_name["query5-deletion"][0][2] == "contig3" and "D" in by_name["query5-deletion"][0][5]
     assert open(un_path).read() == ">query6-too-different\nACGCGCTAAACCGAGG\n"
     assert " Alignment rate                : 83% of queries (5/6)" in log.getvalue()
+    # --cache-dir (Mapper.java:264): the second run reads the hashed reference back and writes the same SAM
+    sam2 = str(tmp_path / "again.sam")
+    for _ in range(2):
+        assert cli.run(["--reference", os.path.join(EX, "reference.fasta"), "--queries", os.path.join(EX, "queries.fasta"), "--out-sam", sam2,
+                        "--cache-dir", str(tmp_path / "cache")], out=io.StringIO()) == 0
+        assert open(sam2).read().splitlines() == lines
+    assert [f for _, _, fs in os.walk(tmp_path / "cache") for f in fs if f.endswith(".xmidx")] == ["index.xmidx"]

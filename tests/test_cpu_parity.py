@@ -67,6 +67,62 @@ def test_index_builder_matches_oracle(mode, contigs):
     P.close()
 
 
+def _same_index(A, B):
+    ia, ib = A.info(), B.info()
+    assert ia == ib
+    for L in range(0, ia["max_hashed_length"] + 1):
+        ta, tb = A.table(L), B.table(L)
+        assert ta["capacity"] == tb["capacity"] and ta["maxCount"] == tb["maxCount"], L
+        assert np.array_equal(ta["counts"], tb["counts"]) and np.array_equal(ta["positions"], tb["positions"]), L
+    for c in range(ia["num_contigs"]):
+        assert np.array_equal(A.dup_keys(c), B.dup_keys(c))
+
+
+def test_index_cache_round_trip(tmp_path):
+    """--cache-dir (DirCache.java:19-60, HashBlock_Database.java:106-114): the file written after a build gives back the same tables and
+    duplication keys; it is only used for the reference and settings it was built with; a damaged file is rebuilt, not trusted."""
+    refs = [("c0", synth.synthetic_reference(30_000, seed=5)), ("c1", ambiguous_reference(6000, seed=6))]
+    A = api.ReferenceDatabase(refs, host_only=True, cache_dir=tmp_path)
+    assert not A.cache_hit and os.path.exists(A.cache_file) and os.path.exists(os.path.join(os.path.dirname(A.cache_file), "metadata"))
+    B = api.ReferenceDatabase(refs, host_only=True, cache_dir=tmp_path)
+    assert B.cache_hit and B.cache_file == A.cache_file
+    _same_index(A, B)
+    # tables hashed on demand after the load equal those of the index that was built
+    A.ensure_length(A.info()["max_hashed_length"] + 7)
+    C2 = api.ReferenceDatabase(refs, host_only=True, cache_dir=tmp_path, max_query_length=A.info()["max_hashed_length"])
+    assert C2.cache_hit
+    _same_index(A, C2)
+    D = api.ReferenceDatabase.load(A.cache_file, host_only=True)
+    _same_index(B, D)
+    # other settings or another reference: another file
+    E = api.ReferenceDatabase(refs, host_only=True, cache_dir=tmp_path, enable_gapmers=False)
+    F = api.ReferenceDatabase([("c0", synth.synthetic_reference(30_000, seed=7))], host_only=True, cache_dir=tmp_path)
+    assert not E.cache_hit and not F.cache_hit and len({A.cache_file, E.cache_file, F.cache_file}) == 3
+    # a file behind the right name that holds something else is refused by the library (and then replaced)
+    import shutil
+    shutil.copyfile(F.cache_file, A.cache_file)
+    with pytest.raises(RuntimeError, match="another reference"):
+        L_ = api._capi.lib()
+        ref, keep = api._capi.make_ref(A.contigs)
+        h = api.C.c_void_p()
+        ob = api._capi.XmBuildOpts(); ob.enable_gapmers = 1; ob.min_interesting_size = -1; ob.dup_window = 1000; ob.dup_min_copies = 2; ob.dup_min_length = ob.dup_max_length = -1; ob.host_only = 1
+        if L_.xm_index_load(A.cache_file.encode(), api.C.byref(ref), api.C.byref(ob), api.C.byref(h)):
+            raise RuntimeError(L_.xm_last_error().decode())
+    G = api.ReferenceDatabase(refs, host_only=True, cache_dir=tmp_path)
+    assert not G.cache_hit
+    _same_index(B, G)
+    # truncated file
+    data = open(A.cache_file, "rb").read()
+    open(A.cache_file, "wb").write(data[: len(data) // 2])
+    with pytest.raises(RuntimeError, match="truncated|corrupt"):
+        api.ReferenceDatabase.load(A.cache_file, host_only=True)
+    H = api.ReferenceDatabase(refs, host_only=True, cache_dir=tmp_path)
+    assert not H.cache_hit
+    _same_index(B, H)
+    for x in (A, B, C2, D, E, F, G, H):
+        x.close()
+
+
 @pytest.mark.parametrize("mode,n", [("mapper", 60_000), ("api", 4000)])
 def test_index_builder_with_ambiguous_reference_matches_oracle(mode, n):
     """Reference with N runs and IUPAC codes: the tables the host builder makes from its multi-block restatement (possibilities of every

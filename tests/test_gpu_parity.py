@@ -184,6 +184,22 @@ def test_ambiguous_reference_on_gpu():
     db.close()
 
 
+def test_index_from_cache_aligns_the_same(tmp_path):
+    """--cache-dir: an index read back from its file (and grown for longer reads after the load) aligns exactly like the one that was built."""
+    ref = synth.synthetic_reference(200_000, seed=77)
+    built = api.ReferenceDatabase([("r", ref)], cache_dir=tmp_path)
+    cached = api.ReferenceDatabase([("r", ref)], cache_dir=tmp_path)
+    assert not built.cache_hit and cached.cache_hit
+    for read_len in (150, 260):  # 260 > the hashed lengths of the file: xm_index_ensure_length after the load
+        b = se_batch(synth.synthetic_single_end(ref, 3000, read_len=read_len, seed=78, indel_prob=0.3)[0])
+        x, _ = gpu_align(built, b)
+        y, _ = gpu_align(cached, b)
+        assert streams_equal(x, y), first_difference(x, y, 1)
+    want = o.OracleReference([("r", ref)]).align(b, o.make_params())
+    assert streams_equal(y, want), first_difference(y, want, 1)
+    built.close(); cached.close()
+
+
 def test_seed_probe_matches_host_tables():
     """xm_seed_probe (bulk PackedMap.get on the device) against the bucket contents the oracle holds."""
     ref = synth.synthetic_reference(300_000)
