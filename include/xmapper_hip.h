@@ -99,6 +99,10 @@ typedef struct xm_index_info_t {
   int32_t num_contigs, min_interesting_size, max_hashed_length, enable_gapmers, dup_window, position_bytes;
   int64_t total_forward_size, index_bytes, num_positions;
   double dup_granularity;
+  int32_t built_on_device;       /* 1: the tables were hashed on the GPU (xm_index_device.hip), 0: by the host builder (or read from a file) */
+  int32_t reserved;
+  double hash_seconds;           /* wall time of hashing the reference into tables (all calls so far), */
+  double duplication_seconds;    /* and of the duplication map */
 } xm_index_info_t;
 
 const char* xm_last_error(void);

@@ -43,7 +43,8 @@ class XmResult(C.Structure):
 class XmIndexInfo(C.Structure):
     _fields_ = [("num_contigs", C.c_int32), ("min_interesting_size", C.c_int32), ("max_hashed_length", C.c_int32), ("enable_gapmers", C.c_int32),
                 ("dup_window", C.c_int32), ("position_bytes", C.c_int32), ("total_forward_size", C.c_int64), ("index_bytes", C.c_int64),
-                ("num_positions", C.c_int64), ("dup_granularity", C.c_double)]
+                ("num_positions", C.c_int64), ("dup_granularity", C.c_double), ("built_on_device", C.c_int32), ("reserved", C.c_int32),
+                ("hash_seconds", C.c_double), ("duplication_seconds", C.c_double)]
 
 
 EXPORTS = ["xm_last_error", "xm_device_count", "xm_index_build", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",

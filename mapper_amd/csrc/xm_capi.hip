@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstdio>
 
+namespace xm { bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device); }  // xm_index_device.hip
 using namespace xm;
 
 namespace {
@@ -527,7 +528,6 @@ int xm_index_build(const xm_ref* ref, const xm_build_opts* optsIn, xm_index** ou
   try {
     idx = new xm_index();
     idx->host.setReference(ref->num_contigs, ref->names, ref->codes, ref->lengths);
-    idx->host.build(o.enable_gapmers, o.min_interesting_size, o.max_hashed_length, o.dup_window, o.dup_min_copies, o.dup_min_length, o.dup_max_length);
     idx->hostOnly = o.host_only != 0;
     if (!idx->hostOnly) {
       int n = 0;
@@ -536,8 +536,11 @@ int xm_index_build(const xm_ref* ref, const xm_build_opts* optsIn, xm_index** ou
       int dev = o.device;
       if (dev < 0) HIP_CHECK(hipGetDevice(&dev));
       idx->device = dev;
-      idx->upload();
+      idx->host.deviceHasher = &deviceHashLengths;  // the tables are hashed on this GPU (references without ambiguity codes)
+      idx->host.deviceForBuild = dev;
     }
+    idx->host.build(o.enable_gapmers, o.min_interesting_size, o.max_hashed_length, o.dup_window, o.dup_min_copies, o.dup_min_length, o.dup_max_length);
+    if (!idx->hostOnly) idx->upload();
     *out = idx;
     return 0;
   } catch (std::exception& e) {
@@ -571,7 +574,6 @@ int xm_index_load(const char* path, const xm_ref* ref, const xm_build_opts* opts
       if (!idx->host.matchesRequest(want, o.enable_gapmers, o.min_interesting_size, o.dup_window, o.dup_min_copies, o.dup_min_length, o.dup_max_length))
         throw std::runtime_error("the file was built from another reference or with other settings");
     }
-    if (o.max_hashed_length > idx->host.maxHashedLength) idx->host.ensureLength(o.max_hashed_length);
     idx->hostOnly = o.host_only != 0;
     if (!idx->hostOnly) {
       int n = 0;
@@ -580,8 +582,11 @@ int xm_index_load(const char* path, const xm_ref* ref, const xm_build_opts* opts
       int dev = o.device;
       if (dev < 0) HIP_CHECK(hipGetDevice(&dev));
       idx->device = dev;
-      idx->upload();
+      idx->host.deviceHasher = &deviceHashLengths;
+      idx->host.deviceForBuild = dev;
     }
+    if (o.max_hashed_length > idx->host.maxHashedLength) idx->host.ensureLength(o.max_hashed_length);
+    if (!idx->hostOnly) idx->upload();
     *out = idx;
     return 0;
   } catch (std::exception& e) {
@@ -612,6 +617,8 @@ int xm_index_get_info(const xm_index* idx, xm_index_info_t* info) {
   info->num_positions = (int64_t)h.positions.size();
   info->index_bytes = (int64_t)(h.bucketOff.size() * 4 + h.positions.size() * (size_t)info->position_bytes + h.refCodes.size() + h.dupKeys.size() * 4);
   info->dup_granularity = h.dupGranularity();
+  info->built_on_device = h.builtOnDevice ? 1 : 0; info->reserved = 0;
+  info->hash_seconds = h.hashSeconds; info->duplication_seconds = h.dupSeconds;
   return 0;
 }
 

@@ -20,7 +20,10 @@
 #define XM_GLOBAL(T) T
 #endif
 #define XM_INL __host__ __device__ __forceinline__
-#define XM_NOINL __host__ __device__ __noinline__
+#ifndef XM_NOINL_LINKAGE
+#define XM_NOINL_LINKAGE  // (a second translation unit of the library that includes these headers makes the out-of-line functions inline)
+#endif
+#define XM_NOINL XM_NOINL_LINKAGE __host__ __device__ __noinline__
 #else
 #define XM_HD
 #define XM_GLOBAL(T) T

@@ -1,0 +1,402 @@
+// xmapper-hip: the seed index hashed on the GPU.
+// Replaces the same reference code as xm_index_host.h's hashLengths (M/HashBlock_Database.java:490-616 hashing the reference level by
+// level, M/HashBlock.java:67-150 gapmers, M/PackedMap.java:99-153 bucket fill) and produces bit-identical tables; the duplication map
+// (M/DuplicationDetector.java) stays on the host and reads the tables this file copies back.
+//
+// Design: a pyramid level is a pure function of the level below, and every block of a level is independent of the others, so a level is
+// one launch over its blocks: a block with len <= maxLen emits the records of its gapmer, (table L, bucket, encoded position), and says
+// whether it merges with its right neighbour; a prefix sum over those flags places the merged blocks of the next level in order.  The
+// records of all contigs are sorted by (L, bucket, position) with two stable radix sorts (position first), counted per bucket, and a
+// bucket that received more than maxInterestingCountPerKey records is marked overfull and stores nothing (PackedMap.get returns null for
+// it); prefix sums over the buckets give the CSR offsets and each record's slot.  All of it is streaming HBM work (sort passes, scans).
+// Records are made in groups of consecutive tables whose record count fits the memory budget (first a counting run over all levels, then
+// one hashing run per group), which is the reference's multi-pass hashing for large genomes (M/HashBlock_Database.java:57-61,183-215).
+// Contigs with ambiguity codes need the conditional multi blocks: such references are hashed by the host builder.
+#define XM_NOINL_LINKAGE inline  // the out-of-line functions of the shared headers are defined (strongly) by xm_capi.hip
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "xm_index_host.h"
+
+namespace xm {
+
+#define XMB_CHECK(expr)                                                                                        \
+  do {                                                                                                         \
+    hipError_t e_ = (expr);                                                                                    \
+    if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP error in index build: ") + hipGetErrorString(e_) + " at " #expr); \
+  } while (0)
+
+template <typename T>
+struct BuildBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  void ensure(size_t count) {
+    if (count <= n && p) return;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = count ? count : 1;
+    XMB_CHECK(hipMalloc((void**)&p, n * sizeof(T)));
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  ~BuildBuf() { release(); }
+};
+
+#define XMB_LHIST 2048
+
+struct LevelCtl {
+  unsigned long long nRec;      // records emitted so far (all contigs of the group)
+  unsigned long long nNext;     // blocks of the next level
+  unsigned int anyShort;        // a block of this level had len <= maxLen
+  unsigned int overflow;        // more records than the counting run announced (internal error)
+};
+
+struct LevelArgs {
+  const HBlock* cur; long long n;
+  const uint8_t* contig; int32_t contigLen;
+  int enableGapmers, lo, maxLen, gLo, gHi, emit;
+  const int32_t* capacity;       // [maxLen + 1]
+  long long fwdBase, rcBase;     // encodePosition bases of this contig's two strands
+  unsigned long long* hist;      // [maxLen + 1] records per table (counting run)
+  unsigned long long* recKey; unsigned long long* recPos; unsigned long long recCap;
+  uint32_t* mergeFlag;
+  LevelCtl* ctl;
+};
+
+__global__ void xmb_level0_kernel(const uint8_t* codes, long long n, HBlock* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  PBlock b0 = level0Block(codes[i], 0);
+  HBlock h;
+  h.start = (int32_t)i; h.len = 1; h.fwd = b0.fwd; h.rev = b0.rev; h.flags = b0.flags; h.gapDir = 0; h.extraGap = 0;
+  out[i] = h;
+}
+
+// one block of a level: its records (or their count per table) and whether it merges with the block after it
+__global__ void __launch_bounds__(256) xmb_level_kernel(LevelArgs a) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long k0 = 0, p0 = 0, k1 = 0, p1 = 0;
+  int nOut = 0;
+  // counting run: most blocks of a level use the same few lengths, so the counts are gathered per workgroup in LDS first
+  __shared__ unsigned int lhist[XMB_LHIST];
+  const bool ldsHist = !a.emit && a.maxLen < XMB_LHIST;
+  if (ldsHist) {
+    for (int t = (int)threadIdx.x; t <= a.maxLen; t += (int)blockDim.x) lhist[t] = 0;
+    __syncthreads();
+  }
+  if (i < a.n) {
+    const HBlock blk = a.cur[i];
+    if (blk.len <= a.maxLen) {  // (a longer block's gapmer uses at least blk.len bases)
+      if (a.ctl->anyShort == 0) a.ctl->anyShort = 1;
+      SeqView seq;
+      seq.base = a.contig; seq.len = a.contigLen; seq.rc = 0; seq.id = 0;
+      QBlock g;
+      int st = 1;
+      if (a.enableGapmers) st = withGapAndExtension(blk, seq, g);
+      else { g.start = blk.start; g.len = blk.len; g.used = blk.len; g.fwd = blk.fwd; g.rev = blk.rev; g.flags = blk.flags; }
+      if (st != 0 && g.used >= a.lo && g.used <= a.maxLen) {
+        const bool rml = (g.flags & F_RML) != 0, rmr = (g.flags & F_RMR) != 0;
+        const bool primary = (rml != rmr) ? rml : (g.fwd >= g.rev);     // M/HashBlock.java:329-334
+        const bool secondary = (rml != rmr) ? rmr : (g.fwd <= g.rev);   // :336-340
+        if (!a.emit) {
+          const unsigned int c = (primary ? 1u : 0u) + (secondary ? 1u : 0u);
+          if (ldsHist) atomicAdd(&lhist[g.used], c); else atomicAdd(&a.hist[g.used], (unsigned long long)c);
+        } else if (g.used >= a.gLo && g.used <= a.gHi) {
+          const int cap = a.capacity[g.used];
+          const unsigned long long table = (unsigned long long)(unsigned)(g.used - a.gLo) << 32;
+          if (primary) {  // M/PackedMap.java:107-112
+            int32_t r = g.fwd % cap; if (r < 0) r += cap;
+            k0 = table | (unsigned)r; p0 = (unsigned long long)(a.fwdBase + g.start);
+            nOut = 1;
+          }
+          if (secondary) {  // :113-118
+            int32_t r = g.rev % cap; if (r < 0) r += cap;
+            const unsigned long long k = table | (unsigned)r, p = (unsigned long long)(a.rcBase + (a.contigLen - (g.start + g.len)));
+            if (nOut == 0) { k0 = k; p0 = p; } else { k1 = k; p1 = p; }
+            nOut++;
+          }
+        }
+      }
+    }
+    a.mergeFlag[i] = (i + 1 < a.n && shouldMergeBlocks(blk, a.cur[i + 1])) ? 1u : 0u;
+  }
+  if (ldsHist) {
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t <= a.maxLen; t += (int)blockDim.x) { const unsigned int c = lhist[t]; if (c) atomicAdd(&a.hist[t], (unsigned long long)c); }
+  }
+  // one atomic per wave for the record slots
+  if (a.emit) {
+    const unsigned long long active = __ballot(1);
+    unsigned long long base = 0;
+    // inclusive prefix of nOut over the wave (64 lanes): shuffle scan
+    int incl = nOut;
+    for (int d = 1; d < 64; d <<= 1) { int v = __shfl_up(incl, d); if ((int)__lane_id() >= d) incl += v; }
+    const int total = __shfl(incl, 63 - __builtin_clzll(active));
+    if (total > 0) {
+      const int leader = __ffsll((long long)active) - 1;
+      if ((int)__lane_id() == leader) base = atomicAdd(&a.ctl->nRec, (unsigned long long)total);
+      base = (unsigned long long)__shfl((long long)base, leader);
+      const unsigned long long at = base + (unsigned long long)(incl - nOut);
+      if (nOut > 0) {
+        if (at + (unsigned long long)nOut > a.recCap) { a.ctl->overflow = 1; }
+        else {
+          a.recKey[at] = k0; a.recPos[at] = p0;
+          if (nOut > 1) { a.recKey[at + 1] = k1; a.recPos[at + 1] = p1; }
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) xmb_merge_kernel(const HBlock* cur, long long n, const uint32_t* flag, const uint32_t* offset, HBlock* next, LevelCtl* ctl) {
+  xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (flag[i]) next[offset[i]] = mergeBlocks(cur[i], cur[i + 1]);
+  if (i == n - 1) ctl->nNext = (unsigned long long)offset[i] + flag[i];
+}
+
+struct TableDesc { unsigned long long bucketBase; int32_t capacity, maxCount; };  // bucketBase: first of the table's capacity + 1 offset entries in the group
+
+XM_INL int xmbTableOf(const TableDesc* t, int nTables, unsigned long long j) {  // table whose offset entries contain j
+  int lo = 0, hi = nTables - 1;
+  while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (t[mid].bucketBase <= j) lo = mid; else hi = mid - 1; }
+  return lo;
+}
+
+__global__ void xmb_count_kernel(const unsigned long long* key, unsigned long long n, const TableDesc* tables, unsigned long long* rawCount) {
+  unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const unsigned long long k = key[r];
+  atomicAdd(&rawCount[tables[k >> 32].bucketBase + (k & 0xFFFFFFFFull)], 1ull);
+}
+
+// per offset entry: what the bucket stores (nothing when it is overfull; the extra last entry of a table is no bucket)
+__global__ void xmb_stored_kernel(const unsigned long long* rawCount, unsigned long long nEntries, const TableDesc* tables, int nTables, unsigned long long* stored) {
+  unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nEntries) return;
+  const TableDesc t = tables[xmbTableOf(tables, nTables, j)];
+  const unsigned long long c = rawCount[j];
+  stored[j] = (j - t.bucketBase >= (unsigned long long)t.capacity || c > (unsigned long long)t.maxCount) ? 0ull : c;
+}
+
+__global__ void xmb_offsets_kernel(const unsigned long long* rawCount, const unsigned long long* storedOff, unsigned long long nEntries, const TableDesc* tables, int nTables,
+                                   uint32_t* bucketOff, unsigned long long* tableStored) {
+  unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nEntries) return;
+  const int ti = xmbTableOf(tables, nTables, j);
+  const TableDesc t = tables[ti];
+  const unsigned long long rel = storedOff[j] - storedOff[t.bucketBase];
+  const bool last = j - t.bucketBase >= (unsigned long long)t.capacity;
+  const bool overfull = !last && rawCount[j] > (unsigned long long)t.maxCount;
+  bucketOff[j] = (uint32_t)rel | (overfull ? XM_OVERFULL : 0u);
+  if (last) tableStored[ti] = rel;  // (64-bit: the host refuses a table that does not fit 31-bit offsets)
+}
+
+__global__ void xmb_place_kernel(const unsigned long long* key, const unsigned long long* pos, unsigned long long n, const TableDesc* tables, const unsigned long long* rawCount,
+                                 const unsigned long long* rawOff, const unsigned long long* storedOff, unsigned long long* outPos) {
+  unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const unsigned long long k = key[r];
+  const TableDesc t = tables[k >> 32];
+  const unsigned long long j = t.bucketBase + (k & 0xFFFFFFFFull);
+  if (rawCount[j] > (unsigned long long)t.maxCount) return;
+  outPos[storedOff[j] + (r - rawOff[j])] = pos[r];
+}
+
+static inline unsigned gridFor(unsigned long long n, int block = 256) { return (unsigned)((n + (unsigned long long)block - 1) / (unsigned long long)block); }
+
+static void scanU64(BuildBuf<uint8_t>& temp, const unsigned long long* in, unsigned long long* out, size_t n, hipStream_t s) {
+  size_t bytes = 0;
+  XMB_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, 0ull, n, rocprim::plus<unsigned long long>(), s));
+  temp.ensure(bytes);
+  XMB_CHECK(rocprim::exclusive_scan(temp.p, bytes, in, out, 0ull, n, rocprim::plus<unsigned long long>(), s));
+}
+
+// hashLengths(minLen, maxLen) of xm_index_host.h on the GPU.  false: not done (the caller hashes on the host).
+bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
+  const bool trace = getenv("XM_TRACE_BUILD") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  XMB_CHECK(hipSetDevice(device));
+  hipStream_t s = nullptr;
+  XMB_CHECK(hipStreamCreate(&s));
+  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
+
+  // capacities and per-key limits exactly as the host builder chooses them
+  std::vector<int32_t> capacity((size_t)maxLen + 1, 0), maxCount((size_t)maxLen + 1, 0);
+  const int lo = std::max(minLen, h.minInterestingSize);
+  for (int L = lo; L <= maxLen; L++) {
+    int cap = h.estimateRequiredCapacity(L);
+    if (cap < 1) cap = 1;
+    if (cap > INT32_MAX / 2) cap = INT32_MAX / 2;  // M/PackedMap.java:22-25
+    capacity[(size_t)L] = cap;
+    int mx = L * L;  // M/HashBlock_Database.java:569-576
+    if (mx < h.maxNumShortMatches) mx = h.maxNumShortMatches;
+    if (mx > 32766) mx = 32766;
+    if (mx < 1) mx = 1;
+    maxCount[(size_t)L] = mx;
+  }
+
+  BuildBuf<uint8_t> dCodes, dTemp;
+  BuildBuf<int32_t> dCapacity;
+  BuildBuf<HBlock> dCur, dNext;
+  BuildBuf<uint32_t> dFlag, dOffset;
+  BuildBuf<unsigned long long> dHist;
+  BuildBuf<LevelCtl> dCtl;
+  dCodes.ensure(h.refCodes.size());
+  XMB_CHECK(hipMemcpyAsync(dCodes.p, h.refCodes.data(), h.refCodes.size(), hipMemcpyHostToDevice, s));
+  dCapacity.ensure(capacity.size());
+  XMB_CHECK(hipMemcpyAsync(dCapacity.p, capacity.data(), capacity.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  dHist.ensure((size_t)maxLen + 1);
+  XMB_CHECK(hipMemsetAsync(dHist.p, 0, ((size_t)maxLen + 1) * sizeof(unsigned long long), s));
+  dCtl.ensure(1);
+  XMB_CHECK(hipMemsetAsync(dCtl.p, 0, sizeof(LevelCtl), s));
+  int32_t longest = 0;
+  for (int c = 0; c < h.numContigs(); c++) longest = std::max(longest, h.contigLen[(size_t)c]);
+  dCur.ensure((size_t)longest); dNext.ensure((size_t)longest); dFlag.ensure((size_t)longest); dOffset.ensure((size_t)longest);
+
+  BuildBuf<unsigned long long> dKeyA, dPosA, dKeyB, dPosB;
+  unsigned long long recCap = 0;
+
+  // every level of every contig: counting run (emit = 0) or the records of the tables [gLo, gHi]
+  auto hashAll = [&](int emit, int gLo, int gHi) {
+    for (int c = 0; c < h.numContigs(); c++) {
+      long long n = h.contigLen[(size_t)c];
+      const uint8_t* contig = dCodes.p + h.contigStart[(size_t)c];
+      hipLaunchKernelGGL(xmb_level0_kernel, dim3(gridFor((unsigned long long)n)), dim3(256), 0, s, contig, n, dCur.p);
+      HBlock* cur = dCur.p;
+      HBlock* next = dNext.p;
+      while (n > 0) {
+        XMB_CHECK(hipMemsetAsync(&dCtl.p->nNext, 0, sizeof(unsigned long long) + sizeof(unsigned int), s));  // nNext, anyShort
+        LevelArgs a;
+        a.cur = cur; a.n = n; a.contig = contig; a.contigLen = h.contigLen[(size_t)c]; a.enableGapmers = h.enableGapmers; a.lo = lo; a.maxLen = maxLen;
+        a.gLo = gLo; a.gHi = gHi; a.emit = emit; a.capacity = dCapacity.p;
+        a.fwdBase = h.encodePosition(c, false, 0); a.rcBase = h.encodePosition(c, true, 0);
+        a.hist = dHist.p; a.recKey = dKeyA.p; a.recPos = dPosA.p; a.recCap = recCap; a.mergeFlag = dFlag.p; a.ctl = dCtl.p;
+        hipLaunchKernelGGL(xmb_level_kernel, dim3(gridFor((unsigned long long)n)), dim3(256), 0, s, a);
+        size_t bytes = 0;
+        XMB_CHECK(rocprim::exclusive_scan(nullptr, bytes, dFlag.p, dOffset.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+        dTemp.ensure(bytes);
+        XMB_CHECK(rocprim::exclusive_scan(dTemp.p, bytes, dFlag.p, dOffset.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+        hipLaunchKernelGGL(xmb_merge_kernel, dim3(gridFor((unsigned long long)n)), dim3(256), 0, s, cur, n, dFlag.p, dOffset.p, next, dCtl.p);
+        XMB_CHECK(hipGetLastError());
+        LevelCtl ctl;
+        XMB_CHECK(hipMemcpyAsync(&ctl, dCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, s));
+        XMB_CHECK(hipStreamSynchronize(s));
+        if (ctl.overflow) throw std::runtime_error("internal error: index build emitted more records than it counted");
+        if (!ctl.anyShort) break;  // (the level after a level without short blocks is never looked at)
+        n = (long long)ctl.nNext;
+        std::swap(cur, next);
+      }
+    }
+  };
+
+  hashAll(0, 0, 0);
+  std::vector<unsigned long long> hist((size_t)maxLen + 1);
+  XMB_CHECK(hipMemcpy(hist.data(), dHist.p, hist.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  auto t1 = std::chrono::steady_clock::now();
+
+  // groups of consecutive tables whose records fit the budget (a sort needs both record arrays twice + its own scratch)
+  size_t freeB = 0, totalB = 0;
+  XMB_CHECK(hipMemGetInfo(&freeB, &totalB));
+  unsigned long long budgetRecs = (unsigned long long)(freeB / 2) / 40;
+  if (const char* e = getenv("XM_BUILD_GROUP_RECORDS")) { if (*e) budgetRecs = strtoull(e, nullptr, 10); }  // (testing: force several groups)
+  if (budgetRecs < 1) budgetRecs = 1;
+
+  if ((int)h.tables.size() < maxLen + 1) h.tables.resize((size_t)maxLen + 1);
+  BuildBuf<TableDesc> dTables;
+  BuildBuf<unsigned long long> dRaw, dRawOff, dStored, dStoredOff, dTableStored, dOutPos;
+  BuildBuf<uint32_t> dBucketOff;
+  int groups = 0;
+  unsigned long long totalRecs = 0;
+  for (int gLo = minLen; gLo <= maxLen;) {
+    int gHi = gLo;
+    unsigned long long nRecs = hist[(size_t)gLo];
+    while (gHi + 1 <= maxLen && nRecs + hist[(size_t)(gHi + 1)] <= budgetRecs) { gHi++; nRecs += hist[(size_t)gHi]; }
+    groups++;
+    totalRecs += nRecs;
+    const int nTables = gHi - gLo + 1;
+    std::vector<TableDesc> tdesc((size_t)nTables);
+    unsigned long long nEntries = 0;
+    for (int k = 0; k < nTables; k++) {
+      const int L = gLo + k;
+      const bool empty = hist[(size_t)L] == 0;
+      tdesc[(size_t)k].bucketBase = nEntries;
+      tdesc[(size_t)k].capacity = empty ? 1 : capacity[(size_t)L];  // PackedMap(1, 1) placeholder (M/HashBlock_Database.java:387-393)
+      tdesc[(size_t)k].maxCount = empty ? 1 : maxCount[(size_t)L];
+      nEntries += (unsigned long long)tdesc[(size_t)k].capacity + 1;
+    }
+    dTables.ensure((size_t)nTables);
+    XMB_CHECK(hipMemcpyAsync(dTables.p, tdesc.data(), sizeof(TableDesc) * (size_t)nTables, hipMemcpyHostToDevice, s));
+    unsigned long long* sortedKey = nullptr;
+    unsigned long long* sortedPos = nullptr;
+    if (nRecs > 0) {
+      recCap = nRecs;
+      dKeyA.ensure((size_t)nRecs); dPosA.ensure((size_t)nRecs); dKeyB.ensure((size_t)nRecs); dPosB.ensure((size_t)nRecs);
+      XMB_CHECK(hipMemsetAsync(dCtl.p, 0, sizeof(LevelCtl), s));
+      hashAll(1, gLo, gHi);
+      LevelCtl ctl;
+      XMB_CHECK(hipMemcpy(&ctl, dCtl.p, sizeof(ctl), hipMemcpyDeviceToHost));
+      if (ctl.nRec != nRecs) throw std::runtime_error("internal error: index build counted " + std::to_string(nRecs) + " records and emitted " + std::to_string(ctl.nRec));
+      // (L, bucket, position): stable sort by position, then by (L, bucket)
+      unsigned posBits = 1;
+      while (posBits < 64 && ((unsigned long long)h.seqCumStart.back() >> posBits) != 0) posBits++;
+      unsigned tableBits = 1;
+      while ((1 << tableBits) < nTables) tableBits++;
+      size_t bytes = 0;
+      XMB_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, dPosA.p, dPosB.p, dKeyA.p, dKeyB.p, (size_t)nRecs, 0, posBits, s));
+      dTemp.ensure(bytes);
+      XMB_CHECK(rocprim::radix_sort_pairs(dTemp.p, bytes, dPosA.p, dPosB.p, dKeyA.p, dKeyB.p, (size_t)nRecs, 0, posBits, s));
+      XMB_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, dKeyB.p, dKeyA.p, dPosB.p, dPosA.p, (size_t)nRecs, 0, 32 + tableBits, s));
+      dTemp.ensure(bytes);
+      XMB_CHECK(rocprim::radix_sort_pairs(dTemp.p, bytes, dKeyB.p, dKeyA.p, dPosB.p, dPosA.p, (size_t)nRecs, 0, 32 + tableBits, s));
+      sortedKey = dKeyA.p; sortedPos = dPosA.p;
+    }
+    // CSR: records per bucket, what each bucket stores, offsets, slots
+    dRaw.ensure((size_t)nEntries); dRawOff.ensure((size_t)nEntries); dStored.ensure((size_t)nEntries); dStoredOff.ensure((size_t)nEntries + 1); dBucketOff.ensure((size_t)nEntries);
+    dTableStored.ensure((size_t)nTables);
+    XMB_CHECK(hipMemsetAsync(dRaw.p, 0, sizeof(unsigned long long) * (size_t)nEntries, s));
+    if (nRecs > 0) hipLaunchKernelGGL(xmb_count_kernel, dim3(gridFor(nRecs)), dim3(256), 0, s, sortedKey, nRecs, dTables.p, dRaw.p);
+    hipLaunchKernelGGL(xmb_stored_kernel, dim3(gridFor(nEntries)), dim3(256), 0, s, dRaw.p, nEntries, dTables.p, nTables, dStored.p);
+    scanU64(dTemp, dRaw.p, dRawOff.p, (size_t)nEntries, s);
+    scanU64(dTemp, dStored.p, dStoredOff.p, (size_t)nEntries, s);
+    hipLaunchKernelGGL(xmb_offsets_kernel, dim3(gridFor(nEntries)), dim3(256), 0, s, dRaw.p, dStoredOff.p, nEntries, dTables.p, nTables, dBucketOff.p, dTableStored.p);
+    XMB_CHECK(hipGetLastError());
+    std::vector<unsigned long long> tableStored((size_t)nTables);
+    XMB_CHECK(hipMemcpyAsync(tableStored.data(), dTableStored.p, sizeof(unsigned long long) * (size_t)nTables, hipMemcpyDeviceToHost, s));
+    XMB_CHECK(hipStreamSynchronize(s));
+    unsigned long long groupStored = 0;
+    for (int k = 0; k < nTables; k++) {
+      if (tableStored[(size_t)k] > 0x7FFFFFFFull) throw std::runtime_error("table too large for 31-bit bucket offsets");
+      groupStored += tableStored[(size_t)k];
+    }
+    dOutPos.ensure((size_t)groupStored);
+    if (nRecs > 0) hipLaunchKernelGGL(xmb_place_kernel, dim3(gridFor(nRecs)), dim3(256), 0, s, sortedKey, sortedPos, nRecs, dTables.p, dRaw.p, dRawOff.p, dStoredOff.p, dOutPos.p);
+    XMB_CHECK(hipGetLastError());
+    // append to the host index (the duplication pass, the inspection API and the cache read the tables there)
+    const size_t offBase = h.bucketOff.size(), posBase = h.positions.size();
+    h.bucketOff.resize(offBase + (size_t)nEntries);
+    h.positions.resize(posBase + (size_t)groupStored);
+    XMB_CHECK(hipMemcpyAsync(h.bucketOff.data() + offBase, dBucketOff.p, sizeof(uint32_t) * (size_t)nEntries, hipMemcpyDeviceToHost, s));
+    if (groupStored) XMB_CHECK(hipMemcpyAsync(h.positions.data() + posBase, dOutPos.p, sizeof(uint64_t) * (size_t)groupStored, hipMemcpyDeviceToHost, s));
+    XMB_CHECK(hipStreamSynchronize(s));
+    unsigned long long posAt = 0;
+    for (int k = 0; k < nTables; k++) {
+      Table t;
+      t.capacity = tdesc[(size_t)k].capacity; t.maxCount = tdesc[(size_t)k].maxCount;
+      t.offBase = (int64_t)(offBase + (size_t)tdesc[(size_t)k].bucketBase);
+      t.posBase = (int64_t)(posBase + (size_t)posAt);
+      posAt += tableStored[(size_t)k];
+      h.tables[(size_t)(gLo + k)] = t;
+    }
+    gLo = gHi + 1;
+  }
+  if (trace) {
+    auto t2 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[xm] index build on the GPU: tables %d..%d, %llu records in %d group(s): counting run %.3f s, hashing + sort + CSR + copy back %.3f s\n", minLen, maxLen,
+            totalRecs, groups, std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
+  }
+  return true;
+}
+
+}  // namespace xm

@@ -2,7 +2,8 @@
 // Replaces M/HashBlock_Database.java:41-91,490-665 (hashing the reference), M/PackedMap.java:54-153 (bucket fill),
 // M/HashBlock_Buffer.java, M/DuplicationDetector.java:97-436 (reference-only precompute).  In the reference this is
 // CPU work done once per run (threads cooperate through helpHash/helpPack); here it is plain host C++ that emits the
-// flat CSR layout the GPU probes.  A device-side build is a later row of SURVEY.md §8(f).
+// flat CSR layout the GPU probes.  With a GPU present, references without ambiguity codes are hashed there instead
+// (xm_index_device.hip, same tables); this file is the builder for the rest and the oracle-checked statement of the layout.
 //
 // Design (differs from the reference's lazy, garbage-collected row objects): a pyramid level is a pure function of the
 // level below, so each contig is hashed level by level over flat arrays; every gapmer becomes a (table, bucket,
@@ -233,7 +234,24 @@ struct HostIndex {
 
   // Hash every gapmer with minLen <= used <= maxLen and append tables [minLen..maxLen].  Tables below minInterestingSize and
   // tables that receive no record are the reference's PackedMap(1, 1) placeholders (M/HashBlock_Database.java:387-393).
+  // set by the library when a GPU is there (xm_index_device.hip): the same tables, hashed, sorted and cut into CSR form on the device
+  bool (*deviceHasher)(HostIndex&, int, int, int) = nullptr;
+  int deviceForBuild = -1;
+  int hasAmbiguity = -1;  // (cached) a contig holds a base code other than A C G T
+  bool builtOnDevice = false;
+  double hashSeconds = 0, dupSeconds = 0;
+  bool referenceIsAmbiguous() {
+    if (hasAmbiguity < 0) {
+      hasAmbiguity = 0;
+      for (uint8_t c : refCodes) if (bpIsAmbiguous(c)) { hasAmbiguity = 1; break; }
+    }
+    return hasAmbiguity != 0;
+  }
   void hashLengths(int minLen, int maxLen) {
+    if (deviceHasher && deviceForBuild >= 0 && !referenceIsAmbiguous()) {
+      const char* e = getenv("XM_DEVICE_BUILD");  // 0: hash on the host even though a GPU is there
+      if (!(e && *e && atoi(e) == 0) && deviceHasher(*this, minLen, maxLen, deviceForBuild)) { builtOnDevice = true; return; }
+    }
     std::vector<int> capacity((size_t)maxLen + 1, 0), maxCount((size_t)maxLen + 1, 0);
     for (int L = std::max(minLen, minInterestingSize); L <= maxLen; L++) {
       int cap = estimateRequiredCapacity(L);
@@ -437,12 +455,16 @@ struct HostIndex {
     auto t1 = std::chrono::steady_clock::now();
     detectDuplications();
     auto t2 = std::chrono::steady_clock::now();
+    hashSeconds += std::chrono::duration<double>(t1 - t0).count();
+    dupSeconds += std::chrono::duration<double>(t2 - t1).count();
     if (trace) fprintf(stderr, "[xm] index build: hashing + tables %.3f s, duplication map %.3f s\n", std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
   }
   void ensureLength(int length) {
     if (length <= maxHashedLength) return;
+    auto t0 = std::chrono::steady_clock::now();
     hashLengths(maxHashedLength + 1, length);
     maxHashedLength = length;
+    hashSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
 
   // ---- binary cache (in the spirit of --cache-dir: M/DirCache.java:19-60, M/HashBlock_Database.java:106-114,477-487, M/PackedMap.java:249-279).
@@ -592,40 +614,71 @@ struct HostIndex {
       const Table& t = tables[(size_t)L];
       std::map<size_t, KeyMap> pending;                       // `blocks` of process(): flushed every 10000 hashcodes
       int prefixLength = (L + 3) / 4;
-      for (int hashcode = 0; hashcode < t.capacity; hashcode++) {
-        int64_t first = 0;
-        int cnt = bucketGet(L, (uint32_t)hashcode, first);   // lookupByForwardHash: packed key of `hashcode` is itself
-        if (cnt >= dupMinCopies) {                            // numForwardMatches = matches.length / 2
+      // the reference walks every hashcode of the table in order; nearly all of them hold fewer than dupMinCopies positions, so the walk
+      // itself is done by all host threads (each over a slice, slices concatenated in order) and only the hashcodes that can hold a
+      // duplication go through the ordered part below.  saveDuplications runs after every 10000th hashcode and after the last one: with
+      // nothing pending it does nothing, so it is enough to run it whenever the next candidate lies past such a boundary.
+      std::vector<int> candidates;
+      {
+        const int nT = buildThreads((size_t)t.capacity);
+        std::vector<std::vector<int>> part((size_t)nT);
+        parallelParts((size_t)t.capacity, nT, [&](int ti, size_t b, size_t e) {
+          for (size_t hc = b; hc < e; hc++) {
+            int64_t first = 0;
+            if (bucketGet(L, (uint32_t)hc, first) >= dupMinCopies) part[(size_t)ti].push_back((int)hc);
+          }
+        });
+        for (auto& v : part) candidates.insert(candidates.end(), v.begin(), v.end());
+      }
+      // what a candidate hashcode contributes (its positions grouped by text) does not depend on the others: computed by all threads;
+      // the contributions are then applied in hashcode order
+      struct Found { size_t ci; size_t seq; int start; Dup d; };
+      std::vector<Found> found;
+      {
+        const int nT = buildThreads(candidates.size() * 16);
+        std::vector<std::vector<Found>> part((size_t)nT);
+        parallelParts(candidates.size(), nT, [&](int ti, size_t cb, size_t ce) {
           struct P { int contig; bool rc; int start; };
           std::vector<P> matches;
-          for (int i = 0; i < cnt; i++) { P p; decode((int64_t)positions[(size_t)(first + i)], p.contig, p.rc, p.start); matches.push_back(p); }
-          for (int i = 0; i < cnt; i++) {                     // + reverseComplement(position, blockLength)  (sic: used length, not span)
-            P p = matches[(size_t)i];
-            p.start = contigLen[(size_t)p.contig] - p.start - L;
-            p.rc = !p.rc;
-            matches.push_back(p);
+          for (size_t ci = cb; ci < ce; ci++) {
+            int64_t first = 0;
+            const int cnt = bucketGet(L, (uint32_t)candidates[ci], first);  // lookupByForwardHash: packed key of `hashcode` is itself; numForwardMatches = matches.length / 2
+            matches.clear();
+            for (int i = 0; i < cnt; i++) { P p; decode((int64_t)positions[(size_t)(first + i)], p.contig, p.rc, p.start); matches.push_back(p); }
+            for (int i = 0; i < cnt; i++) {                     // + reverseComplement(position, blockLength)  (sic: used length, not span)
+              P p = matches[(size_t)i];
+              p.start = contigLen[(size_t)p.contig] - p.start - L;
+              p.rc = !p.rc;
+              matches.push_back(p);
+            }
+            std::map<std::string, std::vector<P>> byText;       // group by prefix + suffix text to skip hash collisions
+            for (const P& p : matches) {
+              SeqView v = contigView(p.contig, p.rc);
+              std::string text;
+              for (int i = 0; i < prefixLength; i++) text.push_back((char)v.at(p.start + i));
+              for (int i = 0; i < prefixLength; i++) text.push_back((char)v.at(p.start + L - prefixLength + i));
+              bool ambiguousText = false;  // :75 isAmbiguousText: positions whose prefix or suffix has a non-ACGT base are left out
+              for (char ch : text) if (bpIsAmbiguous((uint8_t)ch)) ambiguousText = true;
+              if (ambiguousText) continue;
+              std::vector<P>& g = byText[text];
+              bool dupPos = false;                               // removeDuplicatePositions
+              for (const P& q : g) if (q.contig == p.contig && q.rc == p.rc && q.start == p.start) { dupPos = true; break; }
+              if (!dupPos) g.push_back(p);
+            }
+            for (auto& e : byText) {
+              if ((int)e.second.size() < dupMinCopies) continue;
+              Dup d{L, (int)e.second.size()};
+              for (const P& p : e.second) part[(size_t)ti].push_back(Found{ci, (size_t)p.contig * 2 + (p.rc ? 1 : 0), p.start, d});
+            }
           }
-          std::map<std::string, std::vector<P>> byText;       // group by prefix + suffix text to skip hash collisions
-          for (const P& p : matches) {
-            SeqView v = contigView(p.contig, p.rc);
-            std::string text;
-            for (int i = 0; i < prefixLength; i++) text.push_back((char)v.at(p.start + i));
-            for (int i = 0; i < prefixLength; i++) text.push_back((char)v.at(p.start + L - prefixLength + i));
-            bool ambiguousText = false;  // :75 isAmbiguousText: positions whose prefix or suffix has a non-ACGT base are left out
-            for (char ch : text) if (bpIsAmbiguous((uint8_t)ch)) ambiguousText = true;
-            if (ambiguousText) continue;
-            std::vector<P>& g = byText[text];
-            bool dupPos = false;                               // removeDuplicatePositions
-            for (const P& q : g) if (q.contig == p.contig && q.rc == p.rc && q.start == p.start) { dupPos = true; break; }
-            if (!dupPos) g.push_back(p);
-          }
-          for (auto& e : byText) {
-            if ((int)e.second.size() < dupMinCopies) continue;
-            Dup d{L, (int)e.second.size()};
-            for (const P& p : e.second) pending[(size_t)p.contig * 2 + (p.rc ? 1 : 0)][p.start] = d;
-          }
-        }
-        if (hashcode % 10000 == 9999 || hashcode == t.capacity - 1) {  // saveDuplications :332-400
+        });
+        for (auto& v : part) found.insert(found.end(), v.begin(), v.end());
+      }
+      size_t fi = 0;
+      for (size_t ci = 0; ci < candidates.size(); ci++) {
+        const int hashcode = candidates[ci];
+        for (; fi < found.size() && found[fi].ci == ci; fi++) pending[found[fi].seq][found[fi].start] = found[fi].d;
+        if (ci + 1 == candidates.size() || candidates[ci + 1] / 10000 != hashcode / 10000) {  // saveDuplications :332-400 (every 10000 hashcodes, and at the end)
           for (auto& seqEntry : pending) {
             KeyMap& m = all[seqEntry.first];
             for (auto& kv : seqEntry.second) {

@@ -184,6 +184,59 @@ def test_ambiguous_reference_on_gpu():
     db.close()
 
 
+def _layout(info):  # what describes the index itself (not where or how fast it was built)
+    return {k: v for k, v in info.items() if k not in ("built_on_device", "reserved", "hash_seconds", "duplication_seconds")}
+
+
+def _tables_equal(A, B, what):
+    ia, ib = (_layout(x.info()) for x in (A, B))
+    assert ia == ib, what
+    for L in range(0, ia["max_hashed_length"] + 1):
+        ta, tb = A.table(L), B.table(L)
+        assert ta["capacity"] == tb["capacity"] and ta["maxCount"] == tb["maxCount"], (what, L)
+        assert np.array_equal(ta["counts"], tb["counts"]), (what, L)
+        assert np.array_equal(ta["positions"], tb["positions"]), (what, L)
+    for c in range(ia["num_contigs"]):
+        assert np.array_equal(A.dup_keys(c), B.dup_keys(c)), what
+
+
+@pytest.mark.parametrize("mode,contigs,gapmers,group", [("mapper", [300_000], True, None), ("mapper", [50_000, 31_000, 700, 1], True, "20000"),
+                                                         ("api", [4000], True, "1"), ("mapper", [120_000], False, None)])
+def test_index_hashed_on_the_gpu_equals_host_builder(mode, contigs, gapmers, group, monkeypatch):
+    """the tables hashed, sorted and cut into CSR form on the GPU (xm_index_device.hip) are the host builder's
+    (which the CPU tier checks against the oracle's literal HashBlock_Database), bucket by bucket, for every hashed length - also when the
+    records are made in several groups of tables, and for the tables added later by xm_index_ensure_length."""
+    refs = [("c%d" % i, synth.synthetic_reference(n, seed=0xEC011 + i)) for i, n in enumerate(contigs)]
+    refs[0] = (refs[0][0], np.concatenate([refs[0][1], refs[0][1][:900]]))  # a repeat: overfull buckets and duplication keys
+    if group:
+        monkeypatch.setenv("XM_BUILD_GROUP_RECORDS", group)
+    monkeypatch.setenv("XM_DEVICE_BUILD", "1")
+    D = api.ReferenceDatabase(refs, mode=mode, enable_gapmers=gapmers)
+    monkeypatch.setenv("XM_DEVICE_BUILD", "0")
+    H = api.ReferenceDatabase(refs, mode=mode, enable_gapmers=gapmers)
+    assert D.info()["built_on_device"] == 1 and H.info()["built_on_device"] == 0
+    _tables_equal(D, H, "build")
+    grow = D.info()["max_hashed_length"] + 23
+    monkeypatch.setenv("XM_DEVICE_BUILD", "1")
+    D.ensure_length(grow)
+    monkeypatch.setenv("XM_DEVICE_BUILD", "0")
+    H.ensure_length(grow)
+    _tables_equal(D, H, "grown")
+    if mode == "mapper" and gapmers and len(contigs) == 1:
+        R = o.OracleReference(refs, mode=mode)
+        b = se_batch(synth.synthetic_single_end(refs[0][1], 2000, seed=9, indel_prob=0.3)[0])
+        got, _ = gpu_align(D, b)
+        want = R.align(b, o.make_params())
+        assert streams_equal(got, want), first_difference(got, want, 1)
+    D.close(); H.close()
+
+
+def test_ambiguous_reference_is_hashed_on_the_host():
+    db = api.ReferenceDatabase([("amb", ambiguous_reference(20_000, seed=3))])
+    assert db.info()["built_on_device"] == 0
+    db.close()
+
+
 def test_index_from_cache_aligns_the_same(tmp_path):
     """--cache-dir: an index read back from its file (and grown for longer reads after the load) aligns exactly like the one that was built."""
     ref = synth.synthetic_reference(200_000, seed=77)
