@@ -2,10 +2,11 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mapper_amd import api, synth
-sizes = [int(x) for x in (sys.argv[1:] or ["5000000", "50000000"])]
-for n in sizes:
+sizes = sys.argv[1:] or ["5000000", "50000000"]  # "N" = GPU, host, GPU;  "N:gpu" = GPU only
+for spec in sizes:
+    n = int(spec.split(":")[0])
     ref = synth.synthetic_reference(n, seed=0xEC011)
-    for dev in ("1", "0", "1"):
+    for dev in (("1", "1") if spec.endswith(":gpu") else ("1", "0", "1")):
         os.environ["XM_DEVICE_BUILD"] = dev
         t = time.time()
         db = api.ReferenceDatabase([("r", ref)], max_query_length=150)
