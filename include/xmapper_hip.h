@@ -139,6 +139,12 @@ void xm_result_free(xm_result* result);
  * xm_batch_upload validates and copies the batch to the device, xm_align_resident aligns the resident batch. */
 int xm_batch_upload(xm_index* index, const xm_query_batch* batch);
 int xm_align_resident(xm_index* index, const xm_params* params, xm_result** out);
+/* The reference's workers take the next batch of queries while the previous one is being aligned (AlignerWorker.run / requestMoreWork,
+ * AlignerWorker.java:92-175).  Here: xm_batch_stage copies the NEXT batch into a second set of device buffers on its own stream and may
+ * run (from another host thread) while xm_align_resident is aligning the resident batch; xm_batch_commit then makes the staged batch
+ * the resident one (it waits for a running xm_align_resident).  xm_batch_upload = stage + commit without the overlap. */
+int xm_batch_stage(xm_index* index, const xm_query_batch* batch);
+int xm_batch_commit(xm_index* index);
 
 /* Bulk form of Readable_HashBlock_Database.getNumMatchesLowerBound + matchBlock / PackedMap.get (PackedMap.java:160-172,
  * 228-236) for n (used_length, lookup key) pairs: counts[i] = number of stored positions, -1 when the bucket is overfull or

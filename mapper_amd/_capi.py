@@ -48,7 +48,7 @@ class XmIndexInfo(C.Structure):
 
 
 EXPORTS = ["xm_last_error", "xm_device_count", "xm_index_build", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
-           "xm_index_table_info", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_align_resident", "xm_seed_probe", "xm_measure_random_gather"]
+           "xm_index_table_info", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe", "xm_measure_random_gather"]
 
 
 def build_library(force=False):
@@ -86,6 +86,8 @@ def lib():
         L.xm_align_batch.argtypes = [C.c_void_p, C.POINTER(XmParams), C.POINTER(XmQueryBatch), C.POINTER(C.POINTER(XmResult))]
         L.xm_result_free.argtypes = [C.POINTER(XmResult)]
         L.xm_batch_upload.argtypes = [C.c_void_p, C.POINTER(XmQueryBatch)]
+        L.xm_batch_stage.argtypes = [C.c_void_p, C.POINTER(XmQueryBatch)]
+        L.xm_batch_commit.argtypes = [C.c_void_p]
         L.xm_align_resident.argtypes = [C.c_void_p, C.POINTER(XmParams), C.POINTER(C.POINTER(XmResult))]
         L.xm_seed_probe.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.xm_measure_random_gather.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_double)]

@@ -279,6 +279,62 @@ class ReferenceDatabase:
         if self._L.xm_batch_upload(self._h, C.byref(b)):
             raise RuntimeError(self._L.xm_last_error().decode())
 
+    def stage_arrays(self, mate_count, mate_offset, mate_length, codes, expected_inner, deviation):
+        """xm_batch_stage: copy the NEXT batch to HBM on its own stream (may run while align_resident() works on the resident batch)."""
+        b, keep = _capi.make_batch(mate_count, mate_offset, mate_length, codes, expected_inner, deviation)
+        if self._L.xm_batch_stage(self._h, C.byref(b)):
+            raise RuntimeError(self._L.xm_last_error().decode())
+
+    def commit_staged(self):
+        """xm_batch_commit: the staged batch becomes the resident one."""
+        if self._L.xm_batch_commit(self._h):
+            raise RuntimeError(self._L.xm_last_error().decode())
+
+    def align_stream(self, batches, parameters):
+        """Aligns a sequence of batches (each a tuple of upload_arrays' six arrays) and yields their BatchResults in order.  The copy of
+        batch k+1 to HBM runs on a second host thread and a second stream while batch k is being aligned (the
+        reference's workers fetch their next batch the same way, AlignerWorker.java:92-175)."""
+        import queue
+        import threading
+        ready = queue.Queue()
+        aligned = threading.Semaphore(0)
+        stop = threading.Event()
+
+        def uploader():
+            try:
+                first = True
+                for arrays in batches:
+                    if stop.is_set():
+                        break
+                    self.stage_arrays(*arrays)
+                    if not first:
+                        aligned.acquire()  # the previous batch has been aligned: its buffers may be swapped away
+                        if stop.is_set():
+                            break
+                    self.commit_staged()
+                    first = False
+                    ready.put(True)
+                ready.put(None)
+            except BaseException as e:  # noqa: BLE001  (handed to the consumer)
+                ready.put(e)
+
+        t = threading.Thread(target=uploader, daemon=True)
+        t.start()
+        try:
+            while True:
+                token = ready.get()
+                if token is None:
+                    break
+                if isinstance(token, BaseException):
+                    raise token
+                r = self.align_resident(parameters)
+                aligned.release()
+                yield r
+        finally:
+            stop.set()
+            aligned.release()
+            t.join(timeout=60)
+
     def align_resident(self, parameters):
         p = parameters._c() if isinstance(parameters, AlignmentParameters) else parameters
         res = C.POINTER(_capi.XmResult)()

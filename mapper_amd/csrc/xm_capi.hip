@@ -373,6 +373,7 @@ struct DevBuf {
     p = np; n = count;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void swapWith(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
   ~DevBuf() { release(); }
 };
 
@@ -465,6 +466,17 @@ struct xm_index {
   int64_t residentNq = -1;   // batch kept in HBM by xm_batch_upload
   int residentMaxLen = 0;    // longest mate of that batch
   double residentH2dMs = 0;
+  // second set of batch buffers: xm_batch_stage copies the next batch on its own stream while xm_align_resident works on the resident one
+  std::mutex stageMu;
+  hipStream_t copyStream = nullptr;
+  hipEvent_t cev0 = nullptr, cev1 = nullptr;
+  DevBuf<uint8_t> sCodes;
+  DevBuf<int32_t> sMateCount, sMateLength;
+  DevBuf<int64_t> sMateOffset;
+  DevBuf<double> sExpected, sDeviation;
+  int64_t stagedNq = -1;
+  int stagedMaxLen = 0;
+  double stagedH2dMs = 0;
 
   void upload() {
     HIP_CHECK(hipSetDevice(device));
@@ -504,7 +516,10 @@ struct xm_index {
     dCursors.release(); dCounters.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (cev0) (void)hipEventDestroy(cev0);
+    if (cev1) (void)hipEventDestroy(cev1);
     if (stream) (void)hipStreamDestroy(stream);
+    if (copyStream) (void)hipStreamDestroy(copyStream);
   }
 };
 
@@ -668,7 +683,7 @@ void xm_result_free(xm_result* r) {
 }
 
 // validation + Readable_HashBlock_Database growth + host-to-device copy of one batch; the batch stays resident in HBM
-static void uploadBatchLocked(xm_index* idx, const xm_query_batch* b) {
+static int validateBatch(const xm_query_batch* b) {  // -> longest mate
   const int64_t nq = b->num_queries;
   int maxLen = 1;
   for (int64_t q = 0; q < nq; q++) {
@@ -680,6 +695,12 @@ static void uploadBatchLocked(xm_index* idx, const xm_query_batch* b) {
       if (len > maxLen) maxLen = len;
     }
   }
+  return maxLen;
+}
+
+static void uploadBatchLocked(xm_index* idx, const xm_query_batch* b) {
+  const int64_t nq = b->num_queries;
+  const int maxLen = validateBatch(b);
   if (maxLen > idx->host.maxHashedLength) {  // Readable_HashBlock_Database.getContainingMap growth, done before the launch
     idx->host.ensureLength(maxLen);
     idx->upload();
@@ -718,6 +739,59 @@ int xm_batch_upload(xm_index* idx, const xm_query_batch* b) {
     uploadBatchLocked(idx, b);
     return 0;
   } catch (std::exception& e) { return fail(std::string("xm_batch_upload: ") + e.what()); }
+}
+
+int xm_batch_stage(xm_index* idx, const xm_query_batch* b) {
+  if (!idx || !b) return fail("xm_batch_stage: null argument");
+  if (idx->hostOnly) return fail("xm_batch_stage: index was built with host_only=1");
+  try {
+    std::lock_guard<std::mutex> stageLock(idx->stageMu);
+    const int64_t nq = b->num_queries;
+    const int maxLen = validateBatch(b);
+    if (maxLen > idx->host.maxHashedLength) {  // the tables grow: that touches what a running xm_align_resident reads, so wait for it
+      std::lock_guard<std::mutex> lock(idx->mu);
+      idx->host.ensureLength(maxLen);
+      idx->upload();
+    }
+    HIP_CHECK(hipSetDevice(idx->device));
+    if (!idx->copyStream) { HIP_CHECK(hipStreamCreateWithFlags(&idx->copyStream, hipStreamNonBlocking)); HIP_CHECK(hipEventCreate(&idx->cev0)); HIP_CHECK(hipEventCreate(&idx->cev1)); }
+    hipStream_t s = idx->copyStream;
+    idx->stagedNq = -1;
+    idx->stagedH2dMs = 0;
+    if (nq > 0) {
+      HIP_CHECK(hipEventRecord(idx->cev0, s));
+      idx->sMateCount.ensure((size_t)nq); idx->sMateOffset.ensure((size_t)nq * 2); idx->sMateLength.ensure((size_t)nq * 2);
+      idx->sCodes.ensure((size_t)b->codes_length); idx->sExpected.ensure((size_t)nq); idx->sDeviation.ensure((size_t)nq);
+      HIP_CHECK(hipMemcpyAsync(idx->sMateCount.p, b->mate_count, sizeof(int32_t) * (size_t)nq, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(idx->sMateOffset.p, b->mate_offset, sizeof(int64_t) * (size_t)nq * 2, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(idx->sMateLength.p, b->mate_length, sizeof(int32_t) * (size_t)nq * 2, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(idx->sCodes.p, b->codes, (size_t)b->codes_length, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(idx->sExpected.p, b->expected_inner, sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(idx->sDeviation.p, b->deviation, sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipEventRecord(idx->cev1, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, idx->cev0, idx->cev1));
+      idx->stagedH2dMs = ms;
+    }
+    idx->stagedNq = nq;
+    idx->stagedMaxLen = maxLen;
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_batch_stage: ") + e.what()); }
+}
+
+int xm_batch_commit(xm_index* idx) {
+  if (!idx) return fail("xm_batch_commit: null argument");
+  try {
+    std::lock_guard<std::mutex> stageLock(idx->stageMu);
+    if (idx->stagedNq < 0) return fail("xm_batch_commit: no staged batch (call xm_batch_stage first)");
+    std::lock_guard<std::mutex> lock(idx->mu);  // (waits for a running xm_align_resident)
+    idx->dMateCount.swapWith(idx->sMateCount); idx->dMateOffset.swapWith(idx->sMateOffset); idx->dMateLength.swapWith(idx->sMateLength);
+    idx->dCodes.swapWith(idx->sCodes); idx->dExpected.swapWith(idx->sExpected); idx->dDeviation.swapWith(idx->sDeviation);
+    idx->residentNq = idx->stagedNq; idx->residentMaxLen = idx->stagedMaxLen; idx->residentH2dMs = idx->stagedH2dMs;
+    idx->stagedNq = -1;
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_batch_commit: ") + e.what()); }
 }
 
 int xm_align_resident(xm_index* idx, const xm_params* p, xm_result** out) {

@@ -253,6 +253,34 @@ def test_index_from_cache_aligns_the_same(tmp_path):
     built.close(); cached.close()
 
 
+def test_streamed_batches_overlap_upload_and_alignment():
+    """xm_batch_stage / xm_batch_commit (align_stream): batches of different shapes streamed through the two buffer sets give exactly the
+    results of one xm_align_batch call each, in order; stopping early leaves the database usable."""
+    ref = synth.synthetic_reference(300_000, seed=31)
+    db = api.ReferenceDatabase([("r", ref)])
+    batches = []
+    for k, (n, read_len) in enumerate([(4000, 150), (100, 150), (3000, 250), (1, 36), (5000, 150)]):
+        batches.append(se_batch(synth.synthetic_single_end(ref, n, read_len=read_len, seed=100 + k, indel_prob=0.3)[0]))
+    m1, m2 = synth.synthetic_paired_end(ref, 1500, seed=200)[:2]
+    batches.append(pe_batch(m1, m2, 100.0, 50.0))
+    arrays = [(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation) for b in batches]
+    with pytest.raises(RuntimeError, match="no staged batch"):
+        db.commit_staged()
+    want = [gpu_align(db, b)[0] for b in batches]
+    got = list(db.align_stream(iter(arrays), api.AlignmentParameters()))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        x = o.Streams(g.ints, g.dbls, g.int_off, g.dbl_off, g.counters)
+        assert streams_equal(x, w), first_difference(x, w, 1)
+    gen = db.align_stream(iter(arrays), api.AlignmentParameters())
+    first = next(gen)
+    gen.close()
+    assert np.array_equal(first.ints, want[0].ints)
+    again, _ = gpu_align(db, batches[1])
+    assert streams_equal(again, want[1])
+    db.close()
+
+
 def test_seed_probe_matches_host_tables():
     """xm_seed_probe (bulk PackedMap.get on the device) against the bucket contents the oracle holds."""
     ref = synth.synthetic_reference(300_000)
