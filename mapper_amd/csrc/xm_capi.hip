@@ -84,12 +84,17 @@ struct HandOver {
 // One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed, int lanesPerWave,
                                                        uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters,
-                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync, long long firstStride, PNode* waveNodes, HandOver ho) {
+                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync, long long firstStride, PNode* waveNodes, HandOver ho, int pairLanes) {
   // lanesPerWave < 64 (gapped pass): the extension chain diverges so much that a wave runs its reads nearly one after another, so
   // spreading them over more, partly filled waves shortens the critical path; the idle lanes own no scratch arena
   xmSetWaveNodes(waveNodes);
+  xmSetPairMode(pairLanes);
   xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
-  const int laneInWave = (int)(threadIdx.x & 63u);
+  // pairLanes (gapped pass, lanesPerWave <= 32): a read is run by two adjacent lanes doing the same work (xm_extend.h, xmSetPairMode);
+  // `laneInWave` below is the read's slot in the wave, `second` marks the lane that leaves atomics and result writes to its partner
+  const int physLane = (int)(threadIdx.x & 63u);
+  const int laneInWave = pairLanes ? (physLane >> 1) : physLane;
+  const bool second = pairLanes && (physLane & 1);
   if (laneInWave >= lanesPerWave) return;
   unsigned long long lane = ((unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (unsigned)lanesPerWave + (unsigned)laneInWave;
   uint8_t* arena = arenas + lane * arenaBytes;
@@ -128,7 +133,9 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
         item = first + (unsigned)laneInWave;
         if ((long long)item >= nTodo) continue;  // (the next batch is past the end for everybody)
       } else {
-        item = atomicAdd(nextItem, 1ull);
+        item = 0;
+        if (!second) item = atomicAdd(nextItem, 1ull);
+        if (pairLanes) item = (unsigned long long)__shfl((long long)item, physLane & ~1);
         if ((long long)item >= nTodo) break;
       }
     }
@@ -165,6 +172,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
     }
     int32_t st = cx.status;
     if (st != XM_OK) local = before;  // work of a read that is rerun by a later pass is counted there
+    if (second) continue;             // (pair mode: the first lane of the read publishes)
     if (st == XM_OK) {
       int64_t ni, nd;
       resultSize(rr, ni, nd);
@@ -186,7 +194,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
     }
     out.status[q] = st;
   }
-  addCounters(counters, local);
+  if (!second) addCounters(counters, local);
 }
 
 // Every PathAligner search the gapped pass left waiting (MemoHdr, xm_extend.h): one request per lane, every lane in the same code.
@@ -905,6 +913,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // light pass -> gapped pass hand-over (HandOver, SavedRead): the reads the light pass stops in front of the gapped chain keep their seeding
     // state in HBM and the gapped pass continues from it.  Scratch layout while saved regions are alive: [region pool | lane arenas].
     // (Deferred searches replay a read from its start, which a consumed region does not allow: no hand-over then.)
+    const bool pairMode = envInt("XM_PAIR_LANES", 1) != 0;
     const bool handOver = envInt("XM_HANDOVER", 1) != 0 && !deferSearches;
     int hoMode = handOver ? 1 : 0;   // mode of the next launch
     const int seedScale = scale;
@@ -964,6 +973,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       } else {
         idx->dArenas.ensure((size_t)lanes * arenaBytes);
       }
+      const int pairLanes = (heavy && lpw <= 32 && !defer && !fullSync && pairMode) ? 1 : 0;  // two lanes per read (xm_extend.h, xmSetPairMode)
       uint8_t* laneArenas = idx->dArenas.p + regionsTotal;
       HandOver ho{hoMode, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
       const int launchedMode = hoMode;
@@ -979,7 +989,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
                          laneArenas, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
                          defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
                          (heavy && !fullSync) ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, ((!heavy && lightSync) || (heavy && fullSync)) ? 1 : 0,
-                         fullSync ? 0ll : firstStride, idx->dWaveNodes.p, ho);
+                         fullSync ? 0ll : firstStride, idx->dWaveNodes.p, ho, pairLanes);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,

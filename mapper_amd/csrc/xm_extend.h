@@ -382,10 +382,19 @@ XM_INL uint8_t* palSlot() { return xm_pal_lds + __builtin_amdgcn_readfirstlane((
 __shared__ PNode* xm_pal_wave_nodes;
 XM_INL void xmSetWaveNodes(PNode* base) { if (threadIdx.x == 0) xm_pal_wave_nodes = base; }  // (before the block's first barrier)
 XM_INL PNode* palWaveNodes();
+// Pair mode (gapped pass): every read is run by TWO adjacent lanes that execute the same instructions on the same data (a wave of the
+// gapped pass holds at most 32 reads, so the other 32 lanes would idle anyway).  The second lane costs nothing while both do the same,
+// and wherever a step of the read has two independent halves, each lane takes one and they swap results (PathAligner: the first two
+// updates of an explored node).  Atomics and result writes are the first lane's.
+__shared__ int xm_pair_mode;
+XM_INL void xmSetPairMode(int on) { if (threadIdx.x == 0) xm_pair_mode = on; }  // (before the block's first barrier)
+XM_INL bool xmPairMode() { return __builtin_amdgcn_readfirstlane(xm_pair_mode) != 0; }
 #else
 XM_INL uint8_t* palSlot() { static thread_local double slot[XM_PAL_SLOT_BYTES / 8]; return (uint8_t*)slot; }  // host simulation (tests only)
 XM_INL void xmSetWaveNodes(PNode*) {}
 XM_INL PNode* palWaveNodes();
+XM_INL void xmSetPairMode(int) {}
+XM_INL bool xmPairMode() { return false; }
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -620,7 +629,20 @@ struct PathAlignerT {
     saveNode(idx, x, y, cellSlot, cellTaken);
     nodesPut++;
   }
+  // What an update decided: the node to put (putNode's arguments), or nothing.  Computing it reads the search structures only, so the
+  // first two updates of an explored node, which look at disjoint cells, can be computed side by side (pair mode, pathSearchT).
+  struct UpdateOut { int32_t put, x, y, fl, cellSlot, existing; double pen, insX, insY; };
   XM_INL void update(int x, int y) {  // :555-571 + computeUpdated :573-719
+    UpdateOut o;
+    computeUpdate(x, y, o);
+    if (o.put) {
+      XM_PA_TIC(t1);
+      putNode(o.x, o.y, o.pen, o.insX, o.insY, (uint8_t)o.fl, o.cellSlot, o.existing != 0);
+      XM_PA_TOC(tPut, t1);
+    }
+  }
+  XM_INL void computeUpdate(int x, int y, UpdateOut& out) {
+    out.put = 0;
     if (x <= 0 || x > textALength) return;
     if (y <= 0 || y > textBLength) return;
     // the four lookups first (independent loads), then the four nodes (index 0 stands in for "null": node 0 always exists)
@@ -705,8 +727,8 @@ struct PathAlignerT {
         if (iabs(signedDist(x, y)) == 0) fl |= 1; else fl |= 2;
       }
       XM_PA_TOC(tCompute, t0);
-      putNode(x, y, bestPenalty, insertXPenalty, insertYPenalty, fl, cellSlot, existing >= 0);
-      XM_PA_TOC(tPut, t0);
+      out.put = 1; out.x = x; out.y = y; out.pen = bestPenalty; out.insX = insertXPenalty; out.insY = insertYPenalty; out.fl = fl; out.cellSlot = cellSlot;
+      out.existing = existing >= 0 ? 1 : 0;
     } else {
       XM_PA_TOC(tCompute, t0);
     }
@@ -761,7 +783,7 @@ struct PaProblem {
 // PathAligner.align :55-293 up to and including justify: the search, the traceback and the final block list (outBlocks[0..nbOut)).
 // false = null (or *status set).  LDS mode: *ldsOverflow = true means "does not fit the slot, nothing decided".
 template <bool LDS>
-XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, int32_t* status, DevCounters* dc, ABlock* const outBlocksIn, int32_t& nbOut, bool* ldsOverflow) {
+XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, int32_t* status, DevCounters* dc, ABlock* const outBlocksIn, int32_t& nbOut, bool* ldsOverflow, bool pair = false) {
   XM_TIC(tPath);
   // by-value copies: anything read through a reference inside a loop that also stores would be re-loaded (and waited for) on
   // every iteration, because the compiler cannot prove the store does not alias it
@@ -918,6 +940,29 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
       int x = pa.listX(li), y = pa.listY(li);
       if (pa.activePenalty > pa.maxInterestingPenalty + 0.000001) return leave(false);
       if (x == pa.goalX) { haveLast = true; lastX = x; lastY = y; break; }
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (LDS && pair) {
+        // explore :722-729 with two lanes: (x+d, y) and (x, y+d) read disjoint cells and neither reads what the other puts, so the two
+        // lanes of the pair compute one each, swap what they decided, and then both put the two nodes in the reference's order (every
+        // lane keeps the whole search state).  (x+d, y+d) looks at both new nodes: computed by both lanes after the puts.
+        const bool second = ((int)__lane_id() & 1) != 0;
+        typename PathAlignerT<LDS>::UpdateOut mine, other, a, b;
+        pa.computeUpdate(second ? x : x + pa.stepDelta, second ? y + pa.stepDelta : y, mine);
+        other.put = __shfl_xor(mine.put, 1); other.x = __shfl_xor(mine.x, 1); other.y = __shfl_xor(mine.y, 1); other.fl = __shfl_xor(mine.fl, 1);
+        other.cellSlot = __shfl_xor(mine.cellSlot, 1); other.existing = __shfl_xor(mine.existing, 1);
+        other.pen = __shfl_xor(mine.pen, 1); other.insX = __shfl_xor(mine.insX, 1); other.insY = __shfl_xor(mine.insY, 1);
+        a = second ? other : mine; b = second ? mine : other;
+        // (both lanes hold the same a and b now: scalar again)
+        a.put = uniI(a.put); a.x = uniI(a.x); a.y = uniI(a.y); a.fl = uniI(a.fl); a.cellSlot = uniI(a.cellSlot); a.existing = uniI(a.existing);
+        a.pen = uniD(a.pen); a.insX = uniD(a.insX); a.insY = uniD(a.insY);
+        b.put = uniI(b.put); b.x = uniI(b.x); b.y = uniI(b.y); b.fl = uniI(b.fl); b.cellSlot = uniI(b.cellSlot); b.existing = uniI(b.existing);
+        b.pen = uniD(b.pen); b.insX = uniD(b.insX); b.insY = uniD(b.insY);
+        if (a.put) pa.putNode(a.x, a.y, a.pen, a.insX, a.insY, (uint8_t)a.fl, a.cellSlot, a.existing != 0);
+        // the first put may have taken the empty slot the second one's lookup ended at: look the cell up again then
+        if (b.put) pa.putNode(b.x, b.y, b.pen, b.insX, b.insY, (uint8_t)b.fl, (a.put && !a.existing && !b.existing) ? -1 : b.cellSlot, b.existing != 0);
+        pa.update(x + pa.stepDelta, y + pa.stepDelta);
+      } else
+#endif
 #pragma unroll 1  // one copy of update() in the loop: the code of this search has to stay in the instruction cache
       for (int mv = 0; mv < 3; mv++) {  // explore :722-729: (x+d, y), (x, y+d), (x+d, y+d)
         int ux = (mv == 1) ? x : x + pa.stepDelta;
@@ -1037,8 +1082,8 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
 XM_NOINL bool pathSearchHbm(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb) {
   return pathSearchT<false>(pr, tmp, caps, status, dc, outBlocks, nb, nullptr);
 }
-XM_NOINL bool pathSearchLds(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool* ldsOverflow) {
-  return pathSearchT<true>(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow);
+XM_NOINL bool pathSearchLds(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool* ldsOverflow, bool pair) {
+  return pathSearchT<true>(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow, pair);
 }
 
 // The search of a request left in a memo slot (xm_path_kernel: one request per lane).  The request carries the two texts, so the
@@ -1109,13 +1154,21 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long pending = __ballot(1);
     const int lane = (int)__lane_id();
-    while (pending) {
-      const int leader = __ffsll((long long)pending) - 1;
-      if (lane == leader) found = pathSearchLds(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow);
-      pending &= pending - 1;
+    if (xmPairMode()) {  // the two lanes of a read take the slot together
+      while (pending) {
+        const int leader = (__ffsll((long long)pending) - 1) & ~1;
+        if ((lane & ~1) == leader) found = pathSearchLds(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, true);
+        pending &= ~(3ull << leader);
+      }
+    } else {
+      while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        if (lane == leader) found = pathSearchLds(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, false);
+        pending &= pending - 1;
+      }
     }
 #else
-    found = pathSearchLds(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow);
+    found = pathSearchLds(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, false);
 #endif
     if (ldsOverflow) found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb);
   }
