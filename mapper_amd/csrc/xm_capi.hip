@@ -1082,6 +1082,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         defer = deferSearches;
         if (defer) { idx->dMemo.ensure((size_t)nTodo * XM_MEMO_SLOT_BYTES); memoFresh = true; }
         if (regionsTotal > 0) hoMode = 2;
+        if (envInt("XM_PROF_GAPPED_ONLY", 0) != 0)  // XM_PROFILE builds: the in-kernel timers of the gapped pass alone
+          HIP_CHECK(hipMemsetAsync((char*)idx->dCounters.p + offsetof(DevCounters, t), 0, sizeof(((DevCounters*)nullptr)->t), s));
         continue;
       }
       if (pendingScale == 0) break;
