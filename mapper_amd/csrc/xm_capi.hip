@@ -1006,6 +1006,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       memoFresh = false;
       hoMode = 0;                                // (the gapped pass below switches to 2; reruns run plain)
       if (launchedMode == 2) regionsTotal = 0;   // every saved read has been consumed
+#ifdef XM_LIGHT_ONLY
+      fprintf(stderr, "[xm] light-only experiment build: pass %d %.3f ms\n", launches, ms);
+      break;  // (experiment build, scripts/gpu_light_only.sh: only the first pass is meaningful)
+#endif
       const bool tracePasses = envInt("XM_TRACE_PASSES", 0) != 0;
       if (tracePasses) fprintf(stderr, "[xm] pass %d: %s reads %lld scale %d lpw %d waves %lld: %.3f ms -> heavy %llu path %llu scale %llu out %llu\n", launches, !heavy ? "light" : (defer ? "chain" : "inline"),
                                nTodo, scale, lpw, nWaves, ms, ctl.nHeavy, ctl.nPath[tp], ctl.nScale[ts], ctl.nOut[to]);

@@ -1622,9 +1622,16 @@ XM_NOINL bool blockAlign(const ExtEnv& e, const Section& qsIn, const Section& rs
 }
 
 // ---------------------------------------------------------------- the outer chain (M/QueryMatch_Aligner.java:18-29)
+// XM_LIGHT_ONLY: a translation unit that only ever runs the light pass (its kernel never enters the gapped chain, so the chain's code and
+// registers are not compiled into it)
+#ifdef XM_LIGHT_ONLY
+#define XM_LIGHT_ONLY_FLAG true
+#else
+#define XM_LIGHT_ONLY_FLAG false
+#endif
 struct NextBlock {
   XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const {
-    if (e.caps->heavyAllowed < 2) { *e.status = XM_ST_NEED_HEAVY; return false; }
+    if (XM_LIGHT_ONLY_FLAG || e.caps->heavyAllowed < 2) { *e.status = XM_ST_NEED_HEAVY; return false; }
     XM_TIC(t0);
     bool r = blockAlign(e, qs, rs, p, an, out);
     XM_TOC(e.dc, T_BLOCK, t0);
@@ -1633,7 +1640,7 @@ struct NextBlock {
 };
 struct NextHashBlock1 {
   XM_INL bool operator()(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) const {
-    if (e.caps->heavyAllowed < 1) {
+    if (XM_LIGHT_ONLY_FLAG || e.caps->heavyAllowed < 1) {
       // cost hint for the gapped pass: the penalty of the straight alignment that was not good enough (p.MaxErrorRate is that
       // alignment's error rate here, StraightAligner :59-61).  A read with an indel mismatches on one whole side of it.
       if (e.heavyHint) *e.heavyHint = (float)(p.MaxErrorRate * secLen(qs));
