@@ -173,7 +173,11 @@ def main():
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                          "algorithmic_bytes_per_step": int(alg_bytes), "bytes_per_read": round(alg_bytes / nq, 1),
                          "kernel_ms_per_step": round(kernel_ms / args.steps, 3), "launches_per_step": launches / args.steps,
-                         "result_d2h_ms_per_step": round(d2h_ms / args.steps, 3)},
+                         "result_d2h_ms_per_step": round(d2h_ms / args.steps, 3),
+                         "traffic_rate": None if traffic is None else round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1),
+                         "note": "achieved/peak/frac: algorithmic bytes against the 8 TB/s stream peak.  traffic (PMC) is per-lane scratch in HBM, touched in "
+                                 "scattered 32-64 B pieces: traffic_rate (GB/s, traffic / average launch duration) is to be read against this GPU's measured "
+                                 "random-64-B-sector ceiling (seed_probe.random_64B_gather_ceiling_sectors_per_s x 64 B), not against the stream peak"},
             "cpu_baseline": cpu,
             "seed_probe": seed,
         }
