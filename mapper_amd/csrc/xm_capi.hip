@@ -158,8 +158,15 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
       uint8_t* region = ho.regions + (unsigned long long)myRegion * ho.regionBytes;
       runReadRetaining(cx, &ix, params, in, scale, region, (size_t)ho.regionBytes, arena, (size_t)arenaBytes, &local, rr, heavyAllowed);
       if (cx.status == XM_ST_NEED_HEAVY && savedReadOf(region, (size_t)ho.regionBytes)->valid) {
-        long long fresh = (long long)atomicAdd(ho.cursor, 1ull);
-        if (fresh < ho.nRegions) { ho.regionOf[q] = (int32_t)myRegion; myRegion = fresh; }  // (pool used up: the read is seeded again by the gapped pass)
+        // the read keeps this region; the lane needs a fresh one only if it will take another read (the list counter only grows, so a
+        // lane that sees the list drained here finds it drained at its next fetch and leaves)
+        const bool drained = (long long)__hip_atomic_load(nextItem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nTodo;
+        if (drained) {
+          ho.regionOf[q] = (int32_t)myRegion;
+        } else {
+          long long fresh = (long long)atomicAdd(ho.cursor, 1ull);
+          if (fresh < ho.nRegions) { ho.regionOf[q] = (int32_t)myRegion; myRegion = fresh; }  // (pool used up: the read is seeded again by the gapped pass)
+        }
       }
     } else if (ho.mode == 2) {
       const int32_t rg = ho.regionOf[q];
@@ -876,7 +883,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // the scratch capacities are sized for ~150-300 bp mates at scale 1; batches of longer reads start at a larger scale instead of
     // sending every read through a pass that can only overflow
     int scale = idx->residentMaxLen <= 320 ? 1 : (idx->residentMaxLen <= 1280 ? 4 : 16), overflowScale = scale;
-    const int gappedScale = scale < 4 ? (int)envInt("XM_GAPPED_SCALE", 4) : scale * 4;
+    const int gappedScale = scale < 4 ? (int)envInt("XM_GAPPED_SCALE", 4) : scale * (int)envInt("XM_GAPPED_FACTOR", 4);
     bool heavy = false, defer = false, memoFresh = false, inlineRest = false;
     int searchRounds = 0;
     unsigned long long intCap = (unsigned long long)nq * 40 + 4096, dblCap = (unsigned long long)nq * 12 + 4096;
@@ -955,7 +962,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       if (hoMode == 1) {
         // pool: one region per lane + one per read that may stop (at most 40 % of the scratch; reads beyond that are seeded again by the
         // gapped pass).  The scratch is sized here for the gapped pass as well: it must not move while saved regions are alive.
-        long long extra = std::min((long long)nTodo, (long long)(budget * 2 / 5 / regionBytes) - lanes);
+        // (a lane takes a fresh region only before it fetches another read, and only nTodo - lanes reads are fetched by lanes that already had one)
+        // (+ some slack: lanes that see a few reads left all take a region, but only some of them get a read)
+        long long extra = nTodo > lanes ? (long long)nTodo - lanes + std::min(lanes, 4096ll) : 0;
+        extra = std::min(extra, (long long)(budget * 2 / 5 / regionBytes) - lanes);
         extra = std::min(extra, ((long long)budget - lanes * (long long)(arenaBytes + regionBytes)) / (long long)regionBytes);
         if (extra < 0) extra = 0;
         nRegions = lanes + extra;
