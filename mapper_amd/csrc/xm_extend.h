@@ -429,7 +429,7 @@ struct PathAlignerT {
   // buckets are never recycled (a removed key cannot reappear: new estimates are clamped to the active key); lookup by exact
   // key bits through an open-addressing hash, priorities.poll() through a binary min-heap of bucket ids
   double* bkey; int32_t* bhead; int32_t* btail; int32_t nBuckets, maxBuckets;
-  int32_t* bhash; int32_t bhashMask; int32_t* heap; int32_t heapSize;
+  int32_t* bhash; int32_t bhashMask, bhashCap; int32_t* heap; int32_t heapSize;
   int16_t* lx; int16_t* ly; int32_t* lnext;
   // LDS mode
   uint32_t* Lhash; int32_t nCells; uint16_t* Lxy; uint16_t* Lnext; double* Lbkey; uint16_t* Lbhead; uint16_t* Lbtail; uint8_t* Lbhash; uint8_t* Lheap;
@@ -534,6 +534,11 @@ struct PathAlignerT {
       }
     }
   }
+  XM_INL static uint32_t mixKey(double key) {
+    uint64_t kb;
+    __builtin_memcpy(&kb, &key, 8);
+    return (uint32_t)((kb ^ (kb >> 29)) * 0x9E3779B97F4A7C15ull >> 40);
+  }
   XM_INL double estimateOverallPenalty(int x, int y, double pen, double insX, double insY, uint8_t fl) const {  // :475-521
     if (!confident) return pen;
     int sd = signedDist(x, y);
@@ -574,9 +579,7 @@ struct PathAlignerT {
     // registers, which saves the three dependent lookups below for them
     if (lastBucket >= 0 && est == lastKey) { b = lastBucket; tail = lastTail; }
     else {
-    uint64_t kb;
-    __builtin_memcpy(&kb, &est, 8);
-    const uint32_t mixed = (uint32_t)((kb ^ (kb >> 29)) * 0x9E3779B97F4A7C15ull >> 40);
+    const uint32_t mixed = mixKey(est);
     uint32_t h;
     if constexpr (LDS) {
       h = mixed & (XM_PAL_BHASH - 1);
@@ -599,7 +602,20 @@ struct PathAlignerT {
       if (nBuckets >= maxBuckets) { if constexpr (LDS) ldsOverflow = true; overflow = true; return; }
       b = nBuckets++;
       if constexpr (LDS) { Lbkey[b] = est; Lbhead[b] = 0xFFFF; Lbtail[b] = 0xFFFF; Lbhash[h] = (uint8_t)(b + 1); }
-      else { bkey[b] = est; bhead[b] = -1; btail[b] = -1; bhash[h] = b + 1; }
+      else {
+        bkey[b] = est; bhead[b] = -1; btail[b] = -1; bhash[h] = b + 1;
+        // the key table starts small (a search clears it before it starts, and most searches use a few dozen keys) and grows with the keys
+        if (nBuckets * 4 > bhashMask + 1 && bhashMask + 1 < bhashCap) {
+          const int newSize = imin(bhashCap, (bhashMask + 1) * 4);
+          for (int i = 0; i < newSize; i++) bhash[i] = 0;
+          bhashMask = newSize - 1;
+          for (int k = 0; k < nBuckets; k++) {
+            uint32_t hh = mixKey(bkey[k]) & (uint32_t)bhashMask;
+            while (bhash[hh] != 0) hh = (hh + 1) & (uint32_t)bhashMask;
+            bhash[hh] = k + 1;
+          }
+        }
+      }
       if constexpr (LDS) {
         heapSize++;  // LDS mode keeps no heap (the search loop scans the <= 112 keys): heapSize counts the live buckets
       } else {
@@ -816,7 +832,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
   const int referenceLen = pr.referenceLen;
   pa.gridW = secLen(qs) + 2; pa.gridH = secLen(rs) + 2;
   pa.grid = nullptr; pa.hash = nullptr; pa.hashMask = 0; pa.useGrid = false;
-  pa.bkey = nullptr; pa.bhead = nullptr; pa.btail = nullptr; pa.bhash = nullptr; pa.bhashMask = 0; pa.heap = nullptr; pa.lx = nullptr; pa.ly = nullptr; pa.lnext = nullptr;
+  pa.bkey = nullptr; pa.bhead = nullptr; pa.btail = nullptr; pa.bhash = nullptr; pa.bhashMask = 0; pa.bhashCap = 0; pa.heap = nullptr; pa.lx = nullptr; pa.ly = nullptr; pa.lnext = nullptr;
   pa.Lhash = nullptr; pa.Lxy = nullptr; pa.Lnext = nullptr; pa.Lbkey = nullptr; pa.Lbhead = nullptr; pa.Lbtail = nullptr; pa.Lbhash = nullptr; pa.Lheap = nullptr;
   pa.LtextA = nullptr; pa.LtextB = nullptr;
   pa.startIndexA = qs.start; pa.endIndexA = qs.end; pa.startIndexB = rs.start; pa.endIndexB = rs.end;
@@ -858,13 +874,13 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
     else { pa.hash = arenaArray<int32_t>(tmp, caps.nodeHash); pa.hashMask = caps.nodeHash - 1; }
     pa.maxBuckets = caps.maxBuckets;
     pa.bkey = arenaArray<double>(tmp, caps.maxBuckets); pa.bhead = arenaArray<int32_t>(tmp, caps.maxBuckets); pa.btail = arenaArray<int32_t>(tmp, caps.maxBuckets);
-    pa.bhash = arenaArray<int32_t>(tmp, caps.bucketHash); pa.bhashMask = caps.bucketHash - 1;
+    pa.bhash = arenaArray<int32_t>(tmp, caps.bucketHash); pa.bhashCap = caps.bucketHash; pa.bhashMask = imin(caps.bucketHash, 2048) - 1;
     pa.heap = arenaArray<int32_t>(tmp, caps.maxBuckets);
     pa.lx = arenaArray<int16_t>(tmp, caps.maxNodes); pa.ly = arenaArray<int16_t>(tmp, caps.maxNodes); pa.lnext = arenaArray<int32_t>(tmp, caps.maxNodes);
     if (tmp.overflow) { *status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
     int32_t* const h1 = pa.useGrid ? pa.grid : pa.hash; const int n1 = pa.useGrid ? pa.gridW * pa.gridH : caps.nodeHash;
     for (int i = 0; i < n1; i++) h1[i] = 0;
-    int32_t* const h2 = pa.bhash; const int n2 = caps.bucketHash;
+    int32_t* const h2 = pa.bhash; const int n2 = pa.bhashMask + 1;
     for (int i = 0; i < n2; i++) h2[i] = 0;
   }
   XM_TOC(dc, T_PATH_INIT, tPath);
