@@ -957,7 +957,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
       if (pa.activePenalty > pa.maxInterestingPenalty + 0.000001) return leave(false);
       if (x == pa.goalX) { haveLast = true; lastX = x; lastY = y; break; }
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (LDS && pair) {
+      if (pair) {
         // explore :722-729 with two lanes: (x+d, y) and (x, y+d) read disjoint cells and neither reads what the other puts, so the two
         // lanes of the pair compute one each, swap what they decided, and then both put the two nodes in the reference's order (every
         // lane keeps the whole search state).  (x+d, y+d) looks at both new nodes: computed by both lanes after the puts.
@@ -968,11 +968,14 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
         other.cellSlot = __shfl_xor(mine.cellSlot, 1); other.existing = __shfl_xor(mine.existing, 1);
         other.pen = __shfl_xor(mine.pen, 1); other.insX = __shfl_xor(mine.insX, 1); other.insY = __shfl_xor(mine.insY, 1);
         a = second ? other : mine; b = second ? mine : other;
-        // (both lanes hold the same a and b now: scalar again)
+        // (LDS mode: one search at a time per wave, both lanes hold the same a and b now: scalar again.  HBM mode: several pairs of the
+        // wave may be searching at once, every pair with its own values)
+        if constexpr (LDS) {
         a.put = uniI(a.put); a.x = uniI(a.x); a.y = uniI(a.y); a.fl = uniI(a.fl); a.cellSlot = uniI(a.cellSlot); a.existing = uniI(a.existing);
         a.pen = uniD(a.pen); a.insX = uniD(a.insX); a.insY = uniD(a.insY);
         b.put = uniI(b.put); b.x = uniI(b.x); b.y = uniI(b.y); b.fl = uniI(b.fl); b.cellSlot = uniI(b.cellSlot); b.existing = uniI(b.existing);
         b.pen = uniD(b.pen); b.insX = uniD(b.insX); b.insY = uniD(b.insY);
+        }
         if (a.put) pa.putNode(a.x, a.y, a.pen, a.insX, a.insY, (uint8_t)a.fl, a.cellSlot, a.existing != 0);
         // the first put may have taken the empty slot the second one's lookup ended at: look the cell up again then
         if (b.put) pa.putNode(b.x, b.y, b.pen, b.insX, b.insY, (uint8_t)b.fl, (a.put && !a.existing && !b.existing) ? -1 : b.cellSlot, b.existing != 0);
@@ -1095,8 +1098,8 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
   return true;
 }
 
-XM_NOINL bool pathSearchHbm(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb) {
-  return pathSearchT<false>(pr, tmp, caps, status, dc, outBlocks, nb, nullptr);
+XM_NOINL bool pathSearchHbm(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair = false) {
+  return pathSearchT<false>(pr, tmp, caps, status, dc, outBlocks, nb, nullptr, pair);
 }
 XM_NOINL bool pathSearchLds(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool* ldsOverflow, bool pair) {
   return pathSearchT<true>(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow, pair);
@@ -1186,7 +1189,7 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
 #else
     found = pathSearchLds(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, false);
 #endif
-    if (ldsOverflow) found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb);
+    if (ldsOverflow) found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, xmPairMode());
   }
   if (!found || *e.status) return false;
   out.nb = nb;
