@@ -343,6 +343,32 @@ class ReferenceDatabase:
         d = _capi.view_result(self._L, res)
         return BatchResult(d)
 
+    @staticmethod
+    def batch_arrays(queries):
+        """The six arrays of upload_arrays / align_arrays for a list of Query objects."""
+        nq = len(queries)
+        mc = np.zeros(nq, np.int32); mo = np.zeros(2 * nq, np.int64); ml = np.zeros(2 * nq, np.int32)
+        ei = np.zeros(nq); dv = np.ones(nq)
+        chunks, off = [], 0
+        for i, q in enumerate(queries):
+            mc[i] = len(q.sequences)
+            ei[i], dv[i] = q.expected_inner_distance, q.spacing_deviation_per_unit_penalty
+            for m, s in enumerate(q.sequences):
+                mo[2 * i + m], ml[2 * i + m] = off, len(s)
+                chunks.append(s)
+                off += len(s)
+        codes = np.concatenate(chunks) if chunks else np.zeros(1, np.uint8)
+        return mc, mo, ml, codes, ei, dv
+
+    def align_batches(self, queries, parameters, batch_size):
+        """Aligns `queries` in batches of `batch_size` (AlignerWorker takes its queries batch by batch too, AlignerWorker.java:92-231) and
+        yields (first query index, BatchResult) per batch; the next batch is packed and copied to HBM while the current one is aligned
+        (align_stream)."""
+        starts = list(range(0, len(queries), max(1, int(batch_size))))
+        arrays = (self.batch_arrays(queries[s:s + batch_size]) for s in starts)
+        for s, r in zip(starts, self.align_stream(arrays, parameters)):
+            yield s, r
+
     def align_batch(self, queries, parameters):
         nq = len(queries)
         mc = np.zeros(nq, np.int32); mo = np.zeros(2 * nq, np.int64); ml = np.zeros(2 * nq, np.int32)

@@ -128,6 +128,10 @@ def parse_args(argv):
             o["maxNumMatches"] = int(argv[i + 1]); i += 1
         elif a == "--cache-dir":  # Mapper.java:264: keep the hashed reference between runs
             o["cache_dir"] = argv[i + 1]; i += 1
+        elif a == "--batch-size":  # (not a Mapper flag) queries per GPU batch; batches are streamed (upload of the next one during the alignment of the current one)
+            o["batch_size"] = int(argv[i + 1]); i += 1
+            if o["batch_size"] < 1:
+                raise UsageError("--batch-size must be >= 1")
         elif a == "--device":  # (not a Mapper flag) which GPU
             o["device"] = int(argv[i + 1]); i += 1
         elif a == "--spacing":
@@ -222,7 +226,7 @@ def run(argv, out=sys.stdout):
     names = [n for n, _ in ordered]
     db = api.ReferenceDatabase(ordered, mode="mapper", enable_gapmers=o["enable_gapmers"], device=o["device"],
                                max_query_length=max([len(s) for q, _ in queries for s in q.sequences] + [1]), cache_dir=o.get("cache_dir"))
-    result = db.align_batch([q for q, _ in queries], params)
+    batch_size = o.get("batch_size") or 1_000_000
     sam_out = None
     if o["out_sam"]:
         sam_out = sys.stdout if o["out_sam"] == "-" else open(o["out_sam"], "w")
@@ -230,8 +234,13 @@ def run(argv, out=sys.stdout):
     un_out = open(o["out_unaligned"], "w") if o["out_unaligned"] else None
     num_aligned = total_len = num_indels = 0
     total_penalty = 0.0
+    results = db.align_batches([q for q, _ in queries], params, batch_size)
+    first, result, nxt = 0, None, 0
     for qi, (q, quals) in enumerate(queries):
-        comps = result.query_alignments(qi)
+        if qi >= nxt:  # the next batch's results (queries are written in input order)
+            first, result = next(results)
+            nxt = first + len(result)
+        comps = result.query_alignments(qi - first)
         aligned = any(len(c) > 0 for c in comps)
         if aligned:
             num_aligned += 1

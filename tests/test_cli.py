@@ -54,6 +54,7 @@ def test_split_queries(tmp_path):
     (["--reference", "r.fa", "--queries", "q.fa", "--out-sam", "o", "--frobnicate"], "Unrecognized argument: --frobnicate"),
     (["--reference", "r.fa", "--queries", "q.fa", "--out-vcf", "o.vcf"], "handled by the Java host"),
     (["--reference", "r.fa", "--queries", "q.fa", "--out-sam", "o", "--extend-indel-penalty", "0"], "--extend-indel-penalty must be > 0"),
+    (["--reference", "r.fa", "--queries", "q.fa", "--out-sam", "o", "--batch-size", "0"], "--batch-size must be >= 1"),
     (["--reference", "r.fa", "--paired-queries", "a", "b", "--out-sam", "o", "--snp-penalty", "2", "--max-penalty", "0.3"], "specify --spacing explicitly"),
 ])
 def test_usage_errors(argv, needle):
@@ -102,3 +103,8 @@ def test_examples_through_the_command_line(tmp_path):
                         "--cache-dir", str(tmp_path / "cache")], out=io.StringIO()) == 0
         assert open(sam2).read().splitlines() == lines
     assert [f for _, _, fs in os.walk(tmp_path / "cache") for f in fs if f.endswith(".xmidx")] == ["index.xmidx"]
+    # --batch-size: the queries in batches of two, streamed (upload of the next batch during the alignment of the current one): same output
+    sam3, un3 = str(tmp_path / "batched.sam"), str(tmp_path / "batched_unaligned.fasta")
+    assert cli.run(["--reference", os.path.join(EX, "reference.fasta"), "--queries", os.path.join(EX, "queries.fasta"), "--out-sam", sam3,
+                    "--out-unaligned", un3, "--batch-size", "2"], out=io.StringIO()) == 0
+    assert open(sam3).read().splitlines() == lines and open(un3).read() == open(un_path).read()
