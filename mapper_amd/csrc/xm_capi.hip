@@ -894,7 +894,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     double kernelMs = 0;
     int launches = 0;
     int64_t rerun = 0;
-    const size_t arenaUnit = 288 * 1024;
+    const size_t arenaUnit = (size_t)envInt("XM_ARENA_KB", 288) * 1024;  // scratch of a lane at scale 1 (experiment knob: the capacities do not follow it, a smaller arena only overflows earlier)
     const long long scratchGiBWanted = envInt("XM_SCRATCH_GIB", 200);
     const long long lightWaves = envInt("XM_LIGHT_WAVES", 8), fullWaves = envInt("XM_FULL_WAVES", 4), pathWaves = envInt("XM_PATH_WAVES", 4);
     const long long fullLpw = envInt("XM_FULL_LPW", 32), lightLpw = envInt("XM_LIGHT_LPW", 64);
@@ -921,6 +921,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // state in HBM and the gapped pass continues from it.  Scratch layout while saved regions are alive: [region pool | lane arenas].
     // (Deferred searches replay a read from its start, which a consumed region does not allow: no hand-over then.)
     const bool pairMode = envInt("XM_PAIR_LANES", 1) != 0;
+    // temporaries of a gapped-pass lane (reads that resume from a saved region): 7/12 of the arena of that scale by default (experiment knob: percent of it)
+    const long long gappedTmpPct = envInt("XM_GAPPED_TMP_PCT", 100);
+    auto gappedTmpBytes = [&](size_t arena) -> size_t { return (size_t)((arena - arenaPersistBytes(arena)) * (size_t)gappedTmpPct / 100) & ~(size_t)15; };
     const bool handOver = envInt("XM_HANDOVER", 1) != 0 && !deferSearches;
     int hoMode = handOver ? 1 : 0;   // mode of the next launch
     const int seedScale = scale;
@@ -934,7 +937,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     while (nTodo > 0) {
       size_t arenaBytes = arenaUnit * (size_t)scale;  // bytes of scratch a lane owns in this launch
       if (hoMode == 1) arenaBytes -= arenaPersistBytes(arenaBytes);                                // temporaries only (+ one region of the pool per lane)
-      else if (hoMode == 2) arenaBytes = regionBytes + arenaBytes - arenaPersistBytes(arenaBytes);  // a region for reads without saved state + temporaries
+      else if (hoMode == 2) arenaBytes = regionBytes + gappedTmpBytes(arenaBytes);  // a region for reads without saved state + temporaries
       // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped chain
       // diverges inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  The XM_* variables are experiment knobs.
       // a pass over few reads spreads them over all the wave slots of the GPU (the time of a launch is its longest wave)
@@ -970,7 +973,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         if (extra < 0) extra = 0;
         nRegions = lanes + extra;
         regionsTotal = (size_t)nRegions * regionBytes;
-        const size_t gappedArena = arenaUnit * (size_t)gappedScale, gappedLane = regionBytes + gappedArena - arenaPersistBytes(gappedArena);
+        const size_t gappedArena = arenaUnit * (size_t)gappedScale, gappedLane = regionBytes + gappedTmpBytes(gappedArena);
         long long gappedLanes = std::min((long long)nq, (long long)idx->numCUs * 4 * fullWaves * fullLpw);
         gappedLanes = std::min(gappedLanes, std::max(1ll, ((long long)budget - (long long)regionsTotal) / (long long)gappedLane));
         size_t behind = std::max((size_t)lanes * arenaBytes, (size_t)gappedLanes * gappedLane);
