@@ -796,10 +796,16 @@ struct PaProblem {
   bool confident; double maxInsExt, maxDelExt; int32_t predictedBestOffset;
 };
 
+// An LDS-mode search that is about to outgrow the wave's slot does not start over in HBM mode: it stops in front of the list entry it
+// was going to explore (nothing of that entry done yet) and the HBM-mode search takes the whole state over from the slot and the wave's
+// node buffer - nodes, cells, lists, buckets - and continues at that entry.  (The searches that do not fit are only a little larger than
+// the slot: ~990 nodes when they stop, ~1060 when they finish.)
+struct PaResume { int32_t valid, li, bucket, nNodes, nBuckets; unsigned long long nodesPut; };
+
 // PathAligner.align :55-293 up to and including justify: the search, the traceback and the final block list (outBlocks[0..nbOut)).
 // false = null (or *status set).  LDS mode: *ldsOverflow = true means "does not fit the slot, nothing decided".
 template <bool LDS>
-XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, int32_t* status, DevCounters* dc, ABlock* const outBlocksIn, int32_t& nbOut, bool* ldsOverflow, bool pair = false) {
+XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, int32_t* status, DevCounters* dc, ABlock* const outBlocksIn, int32_t& nbOut, bool* ldsOverflow, bool pair = false, PaResume* resume = nullptr) {
   XM_TIC(tPath);
   // by-value copies: anything read through a reference inside a loop that also stores would be re-loaded (and waited for) on
   // every iteration, because the compiler cannot prove the store does not alias it
@@ -899,6 +905,56 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
   if (pa.searchReverse) { pa.startX = width - 1; pa.startY = height - 1; pa.goalX = 1; pa.goalY = 1; }
   else { pa.startX = 0; pa.startY = 0; pa.goalX = width - 2; pa.goalY = height - 2; }
   const double disallowed = PathAlignerT<LDS>::disallowed;
+  int resumeLi = -2;  // (HBM mode taking over an LDS-mode search: the list entry to go on with)
+  bool importing = false;
+  if constexpr (!LDS) importing = resume && resume->valid;
+  if (importing) {
+    if constexpr (!LDS) {
+      const uint8_t* const slot = palSlot();
+      const uint32_t* const Lh = (const uint32_t*)(slot + XM_PAL_OFF_HASH);
+      const uint16_t* const Lxy = (const uint16_t*)(slot + XM_PAL_OFF_XY);
+      const uint16_t* const Lnx = (const uint16_t*)(slot + XM_PAL_OFF_NEXT);
+      const double* const Lbk = (const double*)(slot + XM_PAL_OFF_BKEY);
+      const uint16_t* const Lbh = (const uint16_t*)(slot + XM_PAL_OFF_BHEAD);
+      const uint16_t* const Lbt = (const uint16_t*)(slot + XM_PAL_OFF_BTAIL);
+      const PNode* const waveNodes = palWaveNodes();
+      const int nN = resume->nNodes, nB = resume->nBuckets;
+      if (nN > pa.maxNodes || nB > pa.maxBuckets) { *status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+      for (int i = 0; i < nN; i++) {
+        pa.nodes[i] = waveNodes[i];
+        const uint16_t xy = Lxy[i], nx = Lnx[i];
+        pa.lx[i] = (int16_t)(xy >> 8); pa.ly[i] = (int16_t)(xy & 0xFF); pa.lnext[i] = nx == 0xFFFF ? -1 : (int32_t)nx;
+      }
+      pa.nNodes = nN;
+      for (int h = 0; h < XM_PAL_HASH; h++) {  // cells: (x, y) -> latest node
+        const uint32_t v = Lh[h];
+        if (v) pa.saveNode((int)(v & 0xFFFFu) - 1, (int)(v >> 24), (int)((v >> 16) & 0xFFu));
+      }
+      pa.nBuckets = nB;
+      for (int k = 0; k < nB; k++) {
+        const double key = Lbk[k];
+        const uint16_t hd = Lbh[k], tl = Lbt[k];
+        pa.bkey[k] = key; pa.bhead[k] = hd == 0xFFFF ? -1 : (int32_t)hd; pa.btail[k] = tl == 0xFFFF ? -1 : (int32_t)tl;
+        if (key != HUGE_VAL) {  // a live bucket: into the key table and the heap (a removed key cannot come back)
+          uint32_t hh = pa.mixKey(key) & (uint32_t)pa.bhashMask;
+          while (pa.bhash[hh] != 0) hh = (hh + 1) & (uint32_t)pa.bhashMask;
+          pa.bhash[hh] = k + 1;
+          int i = pa.heapSize++;
+          while (i > 0) {
+            const int parent = (i - 1) >> 1;
+            const int pb = pa.heapAt(parent);
+            if (pa.bucketKey(pb) <= key) break;
+            pa.setHeap(i, pb);
+            i = parent;
+          }
+          pa.setHeap(i, k);
+        }
+      }
+      pa.nodesPut = resume->nodesPut;
+      resumeLi = resume->li;
+      if (pa.heapSize < 1 || pa.heapAt(0) != resume->bucket) { *status = XM_ST_INTERNAL; tmp.used = mark; return false; }
+    }
+  } else
   if (pa.textBLength >= pa.textALength) {
     double startingInsertionStartPenalty = params.getStartingInsertionStartPenalty();
     if (!pa.mayQueryExtendPastEndOfReference) startingInsertionStartPenalty = disallowed;
@@ -908,7 +964,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
     int initialInsertionCount = imax(0, pa.textALength - pa.textBLength) + 1;
     for (int i = 0; i < initialInsertionCount && !pa.overflow; i++) pa.putNode(pa.startX + i * pa.stepDelta, pa.startY, 0, disallowed, disallowed, 0);
   }
-  if (pa.mayQueryExtendPastEndOfReference) {
+  if (!importing && pa.mayQueryExtendPastEndOfReference) {
     int initialInsertionCount = j2i(pr.maxInsExt / params.DeletionExtension_Penalty);
     for (int i = 1; i < initialInsertionCount && !pa.overflow; i++) pa.putNode(pa.startX + i * pa.stepDelta, pa.startY, i * params.UnalignedPenalty, disallowed, disallowed, 0);
   }
@@ -951,11 +1007,21 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
       b = pa.heapAt(0);
     }
     pa.activePenalty = pa.bucketKey(b);
-    int li = pa.bucketHead(b);
+    int li = resumeLi != -2 ? resumeLi : pa.bucketHead(b);
+    resumeLi = -2;
     while (li >= 0) {
       int x = pa.listX(li), y = pa.listY(li);
       if (pa.activePenalty > pa.maxInterestingPenalty + 0.000001) return leave(false);
       if (x == pa.goalX) { haveLast = true; lastX = x; lastY = y; break; }
+      if constexpr (LDS) {
+        // exploring an entry puts at most three nodes (cells, priorities): if that may not fit the slot any more, the HBM-mode search goes on from here
+        if (resume && (pa.nNodes + 3 > pa.maxNodes || pa.nCells + 3 > XM_PAL_CELLS || pa.nBuckets + 3 > pa.maxBuckets)) {
+          resume->valid = 1; resume->li = li; resume->bucket = b; resume->nNodes = pa.nNodes; resume->nBuckets = pa.nBuckets; resume->nodesPut = pa.nodesPut;
+          tmp.used = mark;
+          *ldsOverflow = true;
+          return false;
+        }
+      }
 #if defined(__HIP_DEVICE_COMPILE__)
       if (pair) {
         // explore :722-729 with two lanes: (x+d, y) and (x, y+d) read disjoint cells and neither reads what the other puts, so the two
@@ -1098,11 +1164,11 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
   return true;
 }
 
-XM_NOINL bool pathSearchHbm(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair = false) {
-  return pathSearchT<false>(pr, tmp, caps, status, dc, outBlocks, nb, nullptr, pair);
+XM_NOINL bool pathSearchHbm(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair = false, PaResume* resume = nullptr) {
+  return pathSearchT<false>(pr, tmp, caps, status, dc, outBlocks, nb, nullptr, pair, resume);
 }
-XM_NOINL bool pathSearchLds(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool* ldsOverflow, bool pair) {
-  return pathSearchT<true>(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow, pair);
+XM_NOINL bool pathSearchLds(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool* ldsOverflow, bool pair, PaResume* resume = nullptr) {
+  return pathSearchT<true>(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow, pair, resume);
 }
 
 // The search of a request left in a memo slot (xm_path_kernel: one request per lane).  The request carries the two texts, so the
@@ -1133,6 +1199,20 @@ XM_INL void memoRunPath(MemoHdr* m, Arena& tmp, const Caps& caps, DevCounters* d
   }
   m->hasRequest = 0;
   tmp.used = mark;
+}
+
+// One turn at the wave's slot: the LDS-mode search, and when it stops in front of an entry it has no room for, the HBM-mode search that
+// takes its state over (while the slot and the wave's node buffer still hold it).  ldsOverflow stays set for the searches that could not
+// even start in the slot (texts too long, too many start nodes): those are done in HBM mode from the beginning, after the turns.
+XM_INL bool pathSearchSlot(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool* ldsOverflow, bool pair) {
+  PaResume rs;
+  rs.valid = 0; rs.li = -1; rs.bucket = -1; rs.nNodes = 0; rs.nBuckets = 0; rs.nodesPut = 0;
+  bool found = pathSearchLds(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow, pair, &rs);
+  if (*ldsOverflow && rs.valid) {
+    *ldsOverflow = false;
+    found = pathSearchHbm(pr, tmp, caps, status, dc, outBlocks, nb, pair, &rs);
+  }
+  return found;
 }
 
 // PathAligner.align.  Inline mode: LDS-mode search first (the lanes of the wave that arrive here together take the wave's slot
@@ -1176,18 +1256,18 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
     if (xmPairMode()) {  // the two lanes of a read take the slot together
       while (pending) {
         const int leader = (__ffsll((long long)pending) - 1) & ~1;
-        if ((lane & ~1) == leader) found = pathSearchLds(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, true);
+        if ((lane & ~1) == leader) found = pathSearchSlot(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, true);
         pending &= ~(3ull << leader);
       }
     } else {
       while (pending) {
         const int leader = __ffsll((long long)pending) - 1;
-        if (lane == leader) found = pathSearchLds(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, false);
+        if (lane == leader) found = pathSearchSlot(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, false);
         pending &= pending - 1;
       }
     }
 #else
-    found = pathSearchLds(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, false);
+    found = pathSearchSlot(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, false);
 #endif
     if (ldsOverflow) found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, xmPairMode());
   }
