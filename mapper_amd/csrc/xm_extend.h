@@ -352,11 +352,11 @@ struct PNode {  // AlignmentNode, 32 bytes = two 16-byte loads
 //  - LDS == true: the lookup structures (cell hash, bucket table, bucket heap, node lists, both texts) live in the wave's slot of the
 //    CU's local data share and only the 32-byte node payloads stay in HBM.  The gapped search is a chain of dependent lookups that
 //    only one or two lanes of a wave execute at a time, so its cost is the latency of each lookup: ~100 cycles in LDS, >1000 in HBM.
-//    The slot is sized for the piece-wise searches BlockAligner issues (<= 1056 nodes on <= 768 cells, <= 112 distinct priorities,
-//    texts <= 64 x 128);
-//    a search that outgrows it is redone in HBM mode.  One slot per wave: pathAlignAny runs the lanes of a wave through it in turn.
+//    The slot is sized for the piece-wise searches BlockAligner issues (<= 1008 nodes on <= 768 cells, <= 112 distinct priorities,
+//    texts <= 128 x 253: the windows of paired reads are up to ~190 bases);
+//    a search that outgrows it goes on in HBM mode (PaResume).  One slot per wave: pathAlignAny runs the lanes of a wave through it in turn.
 #ifndef XM_PAL_SMALL  // (experiment knob: a smaller slot lets more workgroups share a CU's LDS)
-constexpr int XM_PAL_HASH_BITS = 10, XM_PAL_HASH = 1024, XM_PAL_CELLS = 768, XM_PAL_NODES = 1056, XM_PAL_BUCKETS = 112, XM_PAL_BHASH = 256, XM_PAL_TEXTA = 64, XM_PAL_TEXTB = 128;
+constexpr int XM_PAL_HASH_BITS = 10, XM_PAL_HASH = 1024, XM_PAL_CELLS = 768, XM_PAL_NODES = 1008, XM_PAL_BUCKETS = 112, XM_PAL_BHASH = 256, XM_PAL_TEXTA = 128, XM_PAL_TEXTB = 256;
 #else
 constexpr int XM_PAL_HASH_BITS = 9, XM_PAL_HASH = 512, XM_PAL_CELLS = 384, XM_PAL_NODES = 448, XM_PAL_BUCKETS = 64, XM_PAL_BHASH = 128, XM_PAL_TEXTA = 64, XM_PAL_TEXTB = 128;
 #endif
@@ -367,8 +367,8 @@ constexpr int XM_PAL_OFF_BKEY = XM_PAL_OFF_NEXT + XM_PAL_NODES * 2;     // doubl
 constexpr int XM_PAL_OFF_BHEAD = XM_PAL_OFF_BKEY + XM_PAL_BUCKETS * 8;  // uint16[112]
 constexpr int XM_PAL_OFF_BTAIL = XM_PAL_OFF_BHEAD + XM_PAL_BUCKETS * 2; // uint16[112]
 constexpr int XM_PAL_OFF_BHASH = XM_PAL_OFF_BTAIL + XM_PAL_BUCKETS * 2; // uint8[256]: bucket + 1
-constexpr int XM_PAL_OFF_TEXTA = XM_PAL_OFF_BHASH + XM_PAL_BHASH;       // uint8[64]  (no heap in LDS mode: the smallest live key is found by a scan)
-constexpr int XM_PAL_OFF_TEXTB = XM_PAL_OFF_TEXTA + XM_PAL_TEXTA;       // uint8[128]
+constexpr int XM_PAL_OFF_TEXTA = XM_PAL_OFF_BHASH + XM_PAL_BHASH;       // uint8[128]  (no heap in LDS mode: the smallest live key is found by a scan)
+constexpr int XM_PAL_OFF_TEXTB = XM_PAL_OFF_TEXTA + XM_PAL_TEXTA;       // uint8[256]
 constexpr int XM_PAL_SLOT_BYTES = (XM_PAL_OFF_TEXTB + XM_PAL_TEXTB + 63) / 64 * 64;
 static_assert(XM_PAL_OFF_BKEY % 8 == 0, "bucket keys must be 8-byte aligned");
 static_assert(XM_PAL_SLOT_BYTES * 4 + 432 + 16 <= 40 * 1024, "four waves per workgroup (+ the 432-byte merge-rule table), four workgroups per CU, 160 KB of LDS");
@@ -844,7 +844,8 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
   pa.startIndexA = qs.start; pa.endIndexA = qs.end; pa.startIndexB = rs.start; pa.endIndexB = rs.end;
   pa.textALength = secLen(qs); pa.textBLength = secLen(rs);
   if constexpr (LDS) {
-    if (pa.textALength > XM_PAL_TEXTA || pa.textBLength > XM_PAL_TEXTB || pa.textALength < 0 || pa.textBLength < 0) { *ldsOverflow = true; return false; }
+    // (a list entry packs x and y into a byte each: y runs to textB + 1)
+    if (pa.textALength > XM_PAL_TEXTA || pa.textBLength > XM_PAL_TEXTB - 3 || pa.textALength < 0 || pa.textBLength < 0) { *ldsOverflow = true; return false; }
     pa.maxNodes = imin(caps.maxNodes, XM_PAL_NODES);
     pa.maxBuckets = imin(caps.maxBuckets, XM_PAL_BUCKETS);
     pa.nodes = palWaveNodes();
