@@ -204,6 +204,59 @@ __global__ void xmb_place_kernel(const unsigned long long* key, const unsigned l
   outPos[storedOff[j] + (r - rawOff[j])] = pos[r];
 }
 
+// Duplication map, first step (M/DuplicationDetector.java:97-330): a hashcode holds a duplication only if two different positions among
+// its matches and their reverse complements show the same unambiguous text (prefix + suffix of the block).  Nearly every bucket with two
+// or more positions holds hash collisions only; this kernel tells the host which buckets are worth its ordered pass (buckets with more
+// than eight positions are passed on unseen).  One lane per bucket of the tables in the duplication range.
+struct DupArgs {
+  const unsigned long long* stored; const unsigned long long* storedOff; const unsigned long long* positions;
+  const TableDesc* tables; int nTables, gLo, dupMinLength, dupMaxLength, dupMinCopies;
+  const uint8_t* codes; const long long* contigStart; const int32_t* contigLen; const long long* seqCumStart; int nSeq;  // nSeq = 2 * contigs
+  unsigned long long* out; unsigned long long outCap; unsigned long long* outCount;
+};
+__global__ void __launch_bounds__(256) xmb_dup_candidates_kernel(DupArgs a, unsigned long long nEntries) {
+  const unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nEntries) return;
+  const int ti = xmbTableOf(a.tables, a.nTables, j);
+  const int L = a.gLo + ti;
+  if (L < a.dupMinLength || L > a.dupMaxLength) return;
+  const TableDesc t = a.tables[ti];
+  if (j - t.bucketBase >= (unsigned long long)t.capacity) return;
+  const int cnt = (int)a.stored[j];
+  if (cnt < a.dupMinCopies) return;  // (dupMinCopies >= 2 here: the host only asks then)
+  bool flag = cnt > 8;
+  if (!flag) {
+    int contig[16], start[16]; bool rc[16];
+    for (int i = 0; i < cnt; i++) {
+      const long long enc = (long long)a.positions[a.storedOff[j] + (unsigned long long)i];
+      int lo = 0, hi = a.nSeq - 1;  // last sequence whose cumulative start is <= enc
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.seqCumStart[mid] <= enc) lo = mid; else hi = mid - 1; }
+      contig[i] = lo >> 1; rc[i] = (lo & 1) != 0; start[i] = (int)(enc - a.seqCumStart[lo]);
+      contig[cnt + i] = contig[i]; rc[cnt + i] = !rc[i]; start[cnt + i] = a.contigLen[contig[i]] - start[i] - L;  // reverseComplement(position, used length)
+    }
+    const int n = 2 * cnt, prefixLength = (L + 3) / 4;
+    for (int x = 0; x < n && !flag; x++) {
+      for (int y = x + 1; y < n && !flag; y++) {
+        if (contig[x] == contig[y] && rc[x] == rc[y] && start[x] == start[y]) continue;  // (the same position twice is one position)
+        SeqView vx, vy;
+        vx.base = a.codes + a.contigStart[contig[x]]; vx.len = a.contigLen[contig[x]]; vx.rc = rc[x] ? 1 : 0; vx.id = 0;
+        vy.base = a.codes + a.contigStart[contig[y]]; vy.len = a.contigLen[contig[y]]; vy.rc = rc[y] ? 1 : 0; vy.id = 0;
+        if (start[x] < 0 || start[y] < 0 || start[x] + L > vx.len || start[y] + L > vy.len) { flag = true; break; }  // (never expected: the host decides)
+        bool same = true;
+        for (int i = 0; i < prefixLength && same; i++) {
+          const uint8_t p = vx.at(start[x] + i), q = vy.at(start[y] + i), r = vx.at(start[x] + L - prefixLength + i), u = vy.at(start[y] + L - prefixLength + i);
+          if (p != q || r != u || bpIsAmbiguous(p) || bpIsAmbiguous(r)) same = false;
+        }
+        if (same) flag = true;
+      }
+    }
+  }
+  if (flag) {
+    const unsigned long long at = atomicAdd(a.outCount, 1ull);
+    if (at < a.outCap) a.out[at] = ((unsigned long long)(unsigned)ti << 32) | (unsigned long long)(j - t.bucketBase);
+  }
+}
+
 static inline unsigned gridFor(unsigned long long n, int block = 256) { return (unsigned)((n + (unsigned long long)block - 1) / (unsigned long long)block); }
 
 static void scanU64(BuildBuf<uint8_t>& temp, const unsigned long long* in, unsigned long long* out, size_t n, hipStream_t s) {
@@ -373,6 +426,40 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
     dOutPos.ensure((size_t)groupStored);
     if (nRecs > 0) hipLaunchKernelGGL(xmb_place_kernel, dim3(gridFor(nRecs)), dim3(256), 0, s, sortedKey, sortedPos, nRecs, dTables.p, dRaw.p, dRawOff.p, dStoredOff.p, dOutPos.p);
     XMB_CHECK(hipGetLastError());
+    // duplication map: the buckets of this group's tables that are worth the host's ordered pass (first build only)
+    if (!h.dupDone && h.dupMinCopies >= 2 && gHi >= h.dupMinLength && gLo <= h.dupMaxLength && groupStored > 0) {
+      std::vector<long long> cs(h.contigStart.begin(), h.contigStart.end()), sc(h.seqCumStart.begin(), h.seqCumStart.end());
+      BuildBuf<long long> dContigStart, dSeqCum;
+      BuildBuf<int32_t> dContigLen;
+      BuildBuf<unsigned long long> dFlagged, dFlagCount;
+      dContigStart.ensure(cs.size()); dSeqCum.ensure(sc.size()); dContigLen.ensure(h.contigLen.size()); dFlagCount.ensure(1);
+      XMB_CHECK(hipMemcpyAsync(dContigStart.p, cs.data(), cs.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+      XMB_CHECK(hipMemcpyAsync(dSeqCum.p, sc.data(), sc.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+      XMB_CHECK(hipMemcpyAsync(dContigLen.p, h.contigLen.data(), h.contigLen.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      XMB_CHECK(hipMemsetAsync(dFlagCount.p, 0, sizeof(unsigned long long), s));
+      const unsigned long long cap = std::min<unsigned long long>(nEntries, 1ull << 26);
+      dFlagged.ensure((size_t)cap);
+      DupArgs da;
+      da.stored = dStored.p; da.storedOff = dStoredOff.p; da.positions = dOutPos.p; da.tables = dTables.p; da.nTables = nTables; da.gLo = gLo;
+      da.dupMinLength = h.dupMinLength; da.dupMaxLength = h.dupMaxLength; da.dupMinCopies = h.dupMinCopies;
+      da.codes = dCodes.p; da.contigStart = dContigStart.p; da.contigLen = dContigLen.p; da.seqCumStart = dSeqCum.p; da.nSeq = h.numContigs() * 2;
+      da.out = dFlagged.p; da.outCap = cap; da.outCount = dFlagCount.p;
+      hipLaunchKernelGGL(xmb_dup_candidates_kernel, dim3(gridFor(nEntries)), dim3(256), 0, s, da, nEntries);
+      XMB_CHECK(hipGetLastError());
+      unsigned long long nFlagged = 0;
+      XMB_CHECK(hipMemcpyAsync(&nFlagged, dFlagCount.p, sizeof(nFlagged), hipMemcpyDeviceToHost, s));
+      XMB_CHECK(hipStreamSynchronize(s));
+      if (nFlagged <= cap) {  // (more than the list holds: the host walks these tables itself)
+        std::vector<unsigned long long> flagged((size_t)nFlagged);
+        if (nFlagged) XMB_CHECK(hipMemcpy(flagged.data(), dFlagged.p, sizeof(unsigned long long) * (size_t)nFlagged, hipMemcpyDeviceToHost));
+        std::sort(flagged.begin(), flagged.end());
+        for (int k = 0; k < nTables; k++) {
+          const int L = gLo + k;
+          if (L >= h.dupMinLength && L <= h.dupMaxLength) h.dupCandidates[L];  // (an empty list is an answer too)
+        }
+        for (unsigned long long v : flagged) h.dupCandidates[gLo + (int)(v >> 32)].push_back((int)(v & 0xFFFFFFFFull));
+      }
+    }
     // append to the host index (the duplication pass, the inspection API and the cache read the tables there)
     const size_t offBase = h.bucketOff.size(), posBase = h.positions.size();
     h.bucketOff.resize(offBase + (size_t)nEntries);

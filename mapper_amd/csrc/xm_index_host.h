@@ -239,6 +239,7 @@ struct HostIndex {
   int deviceForBuild = -1;
   int hasAmbiguity = -1;  // (cached) a contig holds a base code other than A C G T
   bool builtOnDevice = false;
+  std::map<int, std::vector<int>> dupCandidates;  // (GPU build) per table: the hashcodes that can hold a duplication, ascending
   double hashSeconds = 0, dupSeconds = 0;
   bool referenceIsAmbiguous() {
     if (hasAmbiguity < 0) {
@@ -619,7 +620,10 @@ struct HostIndex {
       // duplication go through the ordered part below.  saveDuplications runs after every 10000th hashcode and after the last one: with
       // nothing pending it does nothing, so it is enough to run it whenever the next candidate lies past such a boundary.
       std::vector<int> candidates;
-      {
+      auto given = dupCandidates.find(L);
+      if (given != dupCandidates.end()) {
+        candidates.swap(given->second);  // the GPU build has looked at every bucket of this table already (xmb_dup_candidates_kernel)
+      } else {
         const int nT = buildThreads((size_t)t.capacity);
         std::vector<std::vector<int>> part((size_t)nT);
         parallelParts((size_t)t.capacity, nT, [&](int ti, size_t b, size_t e) {
@@ -711,6 +715,7 @@ struct HostIndex {
         }
       }
     }
+    dupCandidates.clear();
     dupKeyStart.assign(1, 0);
     dupKeys.clear();
     for (int c = 0; c < numContigs(); c++) {
