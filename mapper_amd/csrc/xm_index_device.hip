@@ -362,6 +362,14 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
   BuildBuf<uint32_t> dBucketOff;
   int groups = 0;
   unsigned long long totalRecs = 0;
+  double tHash = 0, tSort = 0, tCsr = 0, tDup = 0, tCopy = 0;  // (XM_TRACE_BUILD) seconds per stage; the stream is synchronised at the marks then
+  auto mark = [&](double& acc, std::chrono::steady_clock::time_point& from) {
+    if (!trace) return;
+    (void)hipStreamSynchronize(s);
+    auto now = std::chrono::steady_clock::now();
+    acc += std::chrono::duration<double>(now - from).count();
+    from = now;
+  };
   for (int gLo = minLen; gLo <= maxLen;) {
     int gHi = gLo;
     unsigned long long nRecs = hist[(size_t)gLo];
@@ -384,6 +392,7 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
     unsigned long long* sortedKey = nullptr;
     unsigned long long* sortedPos = nullptr;
     if (nRecs > 0) {
+      auto tm = std::chrono::steady_clock::now();
       recCap = nRecs;
       dKeyA.ensure((size_t)nRecs); dPosA.ensure((size_t)nRecs); dKeyB.ensure((size_t)nRecs); dPosB.ensure((size_t)nRecs);
       XMB_CHECK(hipMemsetAsync(dCtl.p, 0, sizeof(LevelCtl), s));
@@ -391,6 +400,7 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
       LevelCtl ctl;
       XMB_CHECK(hipMemcpy(&ctl, dCtl.p, sizeof(ctl), hipMemcpyDeviceToHost));
       if (ctl.nRec != nRecs) throw std::runtime_error("internal error: index build counted " + std::to_string(nRecs) + " records and emitted " + std::to_string(ctl.nRec));
+      mark(tHash, tm);
       // (L, bucket, position): stable sort by position, then by (L, bucket)
       unsigned posBits = 1;
       while (posBits < 64 && ((unsigned long long)h.seqCumStart.back() >> posBits) != 0) posBits++;
@@ -404,7 +414,9 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
       dTemp.ensure(bytes);
       XMB_CHECK(rocprim::radix_sort_pairs(dTemp.p, bytes, dKeyB.p, dKeyA.p, dPosB.p, dPosA.p, (size_t)nRecs, 0, 32 + tableBits, s));
       sortedKey = dKeyA.p; sortedPos = dPosA.p;
+      mark(tSort, tm);
     }
+    auto tm2 = std::chrono::steady_clock::now();
     // CSR: records per bucket, what each bucket stores, offsets, slots
     dRaw.ensure((size_t)nEntries); dRawOff.ensure((size_t)nEntries); dStored.ensure((size_t)nEntries); dStoredOff.ensure((size_t)nEntries + 1); dBucketOff.ensure((size_t)nEntries);
     dTableStored.ensure((size_t)nTables);
@@ -426,6 +438,7 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
     dOutPos.ensure((size_t)groupStored);
     if (nRecs > 0) hipLaunchKernelGGL(xmb_place_kernel, dim3(gridFor(nRecs)), dim3(256), 0, s, sortedKey, sortedPos, nRecs, dTables.p, dRaw.p, dRawOff.p, dStoredOff.p, dOutPos.p);
     XMB_CHECK(hipGetLastError());
+    mark(tCsr, tm2);
     // duplication map: the buckets of this group's tables that are worth the host's ordered pass (first build only)
     if (!h.dupDone && h.dupMinCopies >= 2 && gHi >= h.dupMinLength && gLo <= h.dupMaxLength && groupStored > 0) {
       std::vector<long long> cs(h.contigStart.begin(), h.contigStart.end()), sc(h.seqCumStart.begin(), h.seqCumStart.end());
@@ -460,6 +473,7 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
         for (unsigned long long v : flagged) h.dupCandidates[gLo + (int)(v >> 32)].push_back((int)(v & 0xFFFFFFFFull));
       }
     }
+    mark(tDup, tm2);
     // append to the host index (the duplication pass, the inspection API and the cache read the tables there)
     const size_t offBase = h.bucketOff.size(), posBase = h.positions.size();
     h.bucketOff.resize(offBase + (size_t)nEntries);
@@ -467,6 +481,7 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
     XMB_CHECK(hipMemcpyAsync(h.bucketOff.data() + offBase, dBucketOff.p, sizeof(uint32_t) * (size_t)nEntries, hipMemcpyDeviceToHost, s));
     if (groupStored) XMB_CHECK(hipMemcpyAsync(h.positions.data() + posBase, dOutPos.p, sizeof(uint64_t) * (size_t)groupStored, hipMemcpyDeviceToHost, s));
     XMB_CHECK(hipStreamSynchronize(s));
+    mark(tCopy, tm2);
     unsigned long long posAt = 0;
     for (int k = 0; k < nTables; k++) {
       Table t;
@@ -480,8 +495,9 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
   }
   if (trace) {
     auto t2 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[xm] index build on the GPU: tables %d..%d, %llu records in %d group(s): counting run %.3f s, hashing + sort + CSR + copy back %.3f s\n", minLen, maxLen,
-            totalRecs, groups, std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
+    fprintf(stderr, "[xm] index build on the GPU: tables %d..%d, %llu records in %d group(s): counting run %.3f s, then %.3f s (hashing %.3f, sorts %.3f, CSR %.3f, "
+            "duplication candidates %.3f, copy to the host %.3f)\n", minLen, maxLen, totalRecs, groups, std::chrono::duration<double>(t1 - t0).count(),
+            std::chrono::duration<double>(t2 - t1).count(), tHash, tSort, tCsr, tDup, tCopy);
   }
   return true;
 }
