@@ -73,6 +73,10 @@ PASS_SHAPES = [
     {"XM_TAPER_PCT": "0", "XM_FULL_LPW": "64"},                                 # no end-of-list taper, full waves in the gapped pass
     {"XM_LIGHT_WAVES": "2", "XM_FULL_WAVES": "1", "XM_SCRATCH_GIB": "2"},       # few lanes: every lane aligns many reads in turn
     {"XM_HEAVY_HINT": "64", "XM_LIGHT_SYNC": "1"},                              # gapped pass ordered by the cost hint and dealt out; wave-synchronous light batches
+    {"XM_HANDOVER": "0"},                                                       # gapped pass seeds its reads again (no saved regions)
+    {"XM_PAIR_LANES": "0"},                                                     # one lane per read in the gapped pass
+    {"XM_HANDOVER": "0", "XM_PAIR_LANES": "0", "XM_FULL_LPW": "64"},            # both off, full waves
+    {"XM_GAPPED_TMP_PCT": "25", "XM_SCRATCH_GIB": "1"},                         # small temporaries (HBM-mode searches overflow into the rerun passes), tiny region pool
 ]
 
 
