@@ -6,8 +6,10 @@
 // or loaded by libxmapper_hip.so / the mapper_amd package, which has no CPU path.
 #include "../../include/xmapper_hip.h"
 #include "../../mapper_amd/csrc/xm_worker.h"
+#include "../../mapper_amd/csrc/xm_wave.h"
 #include "../../mapper_amd/csrc/xm_index_host.h"
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -15,6 +17,10 @@
 using namespace xm;
 
 static thread_local std::string g_err;
+static long long g_waveStatus[16];
+static long long g_waveWhy[64];
+static long long g_markHist[6][128];  // high-water marks of the wave form per read: chunks, counters, history, pending, query matches, alignments
+static void markDump() { const char* names[6] = {"chunks", "counters", "history", "pending", "qmatches", "alignments"}; for (int k = 0; k < 6; k++) { fprintf(stderr, "[wave marks] %s:", names[k]); for (int i = 0; i < 128; i++) if (g_markHist[k][i]) fprintf(stderr, " %d:%lld", i, g_markHist[k][i]); fprintf(stderr, "\n"); } }
 
 struct SimIndex {
   HostIndex host;
@@ -78,6 +84,57 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       for (int m = 0; m < 2; m++) { in.mate[m] = b->codes + b->mate_offset[q * 2 + m]; in.mateLen[m] = m < in.nMates ? b->mate_length[q * 2 + m] : 0; }
       in.expectedInner = in.nMates > 1 ? b->expected_inner[q] : 0.0;
       in.deviation = in.nMates > 1 ? b->deviation[q] : 1.0;
+      // the wave-per-read form first (XMSIM_WAVE: 1 = its light tier, 2 = light then heavy tier), exactly as the product's passes 0 / 0b run
+      // it (mapper_amd/csrc/xm_wave.h; a WV_PAR region is a loop over the 64 lanes here); reads it does not finish go through the
+      // lane-per-read sequence below
+      static const int waveMode = getenv("XMSIM_WAVE") ? atoi(getenv("XMSIM_WAVE")) : 0;
+      if (waveMode > 0) {
+        typedef WaveLdsT<WCfgLightPE> LightLds;
+        typedef WaveLdsT<WCfgHeavy> HeavyLds;
+        static LightLds ldsLight;
+        static HeavyLds ldsHeavy;
+        static std::vector<uint8_t> waveArena((size_t)(288 * 1024 * 4 * 7 / 12 + 4096));
+        bool finished = false;
+        for (int tier = 0; tier < waveMode && tier < 2 && !finished; tier++) {
+          DevCounters before = dc;
+          WEnv e;
+          e.ix = &idx->view; e.params = params; e.dc = &dc; e.mateBase[0] = in.mate[0]; e.mateBase[1] = in.mate[1]; e.tier = tier;
+          Caps caps = makeCaps(4);
+          caps.heavyAllowed = 2;
+          Arena tmp;
+          tmp.init((void*)(((uintptr_t)waveArena.data() + 15) & ~(uintptr_t)15), waveArena.size() - 64);
+          e.caps = &caps; e.tmp = &tmp;
+          WResult wr;
+          int32_t st;
+          int64_t ni = 0, nd = 0;
+          if (tier == 0) { wAlignRead(&ldsLight, e, in, wr); st = ldsLight.status; if (st == XM_OK) wResultSize(&ldsLight, wr, ni, nd); }
+          else { wAlignRead(&ldsHeavy, e, in, wr); st = ldsHeavy.status; if (st == XM_OK) wResultSize(&ldsHeavy, wr, ni, nd); }
+          g_waveStatus[st < 16 ? st : 15]++;
+          if (getenv("XMSIM_WAVE_STATS")) {
+            static bool reg = false; if (!reg) { reg = true; atexit(markDump); }
+            auto mark = [&](auto& Ld) {
+              auto clip = [](int v) { return v < 0 ? 0 : (v > 127 ? 127 : v); };
+              g_markHist[0][clip(Ld.nChunksUsed)]++;
+              for (int m = 0; m < in.nMates; m++) { g_markHist[1][clip(Ld.m[m].nCounters)]++; g_markHist[2][clip(Ld.m[m].nHistory)]++; g_markHist[3][clip(Ld.m[m].pendTail)]++; }
+              g_markHist[4][clip(Ld.nAssembled)]++; g_markHist[5][clip(Ld.al[0].nGood)]++;
+            };
+            if (tier == 0) mark(ldsLight); else mark(ldsHeavy);
+          }
+          if (st == XM_ST_WAVE_FALLBACK) g_waveWhy[(tier == 0 ? ldsLight.why : ldsHeavy.why) & 63]++;
+          if (st == XM_OK) {
+            res->int_off[q] = (int64_t)ints.size(); res->dbl_off[q] = (int64_t)dbls.size();
+            ints.resize(ints.size() + (size_t)ni); dbls.resize(dbls.size() + (size_t)nd);
+            if (tier == 0) wResultWrite(&ldsLight, wr, ints.data() + res->int_off[q], dbls.data() + res->dbl_off[q], &dc);
+            else wResultWrite(&ldsHeavy, wr, ints.data() + res->int_off[q], dbls.data() + res->dbl_off[q], &dc);
+            finished = true;
+          } else {
+            dc = before;
+            if (st != XM_ST_WAVE_FALLBACK && st != XM_ST_WAVE_GAPPED) throw std::runtime_error("Failed to align query " + std::to_string(q) + " (wave status " + std::to_string(st) + ")");
+            if (st == XM_ST_WAVE_FALLBACK) break;  // (ambiguity codes, long or overlapping mates: the heavy tier does not take them either)
+          }
+        }
+        if (finished) continue;
+      }
       // the product's pass sequence for one read: light pass at scale 1; reads that need the gapped chain rerun at scale 4 with
       // deferred PathAligner searches (chain pass -> search "kernel" -> replay ...); scratch overflow -> inline reruns at 16x, 64x...
       // XMSIM_INLINE=1: plain inline run at scale 1, 4, 16... (the first implementation's sequence)
@@ -170,6 +227,10 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
     return 0;
   } catch (std::exception& e) { g_err = e.what(); return 1; }
 }
+
+// how the wave form left the reads of all calls so far, by status (0 = finished there)
+void xmsim_wave_status_counts(long long* out) { for (int i = 0; i < 16; i++) out[i] = g_waveStatus[i]; }
+void xmsim_wave_why_counts(long long* out) { for (int i = 0; i < 64; i++) out[i] = g_waveWhy[i]; }
 
 void xmsim_result_free(xm_result* r) {
   if (!r) return;
