@@ -9,6 +9,7 @@
 #include "../../include/xmapper_hip.h"
 #include "xm_worker.h"
 #include "xm_index_host.h"
+#include "xm_kernel_args.h"
 #include <hip/hip_runtime.h>
 #include <string>
 #include <vector>
@@ -30,25 +31,6 @@ int fail(const std::string& msg) { g_error = msg; return 1; }
     hipError_t _e = (expr);                                                                                 \
     if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e));      \
   } while (0)
-
-struct BatchView {
-  int64_t nq;
-  const int32_t* mateCount;
-  const int64_t* mateOffset;
-  const int32_t* mateLength;
-  const uint8_t* codes;
-  const double* expectedInner;
-  const double* deviation;
-};
-
-struct OutView {
-  int32_t* ints; double* dbls;          // result arenas
-  unsigned long long intCap, dblCap;
-  unsigned long long* cursor;           // [0] ints used, [1] dbls used
-  int32_t* status;                      // [nq]
-  int64_t* intOff; int64_t* dblOff;     // [nq] offsets into the arenas
-  int32_t* intLen; int32_t* dblLen;     // [nq]
-};
 
 __device__ __forceinline__ void addCounters(DevCounters* g, const DevCounters& l) {
   atomicAdd(&g->reads, l.reads); atomicAdd(&g->headerProbes, l.headerProbes); atomicAdd(&g->bucketFetches, l.bucketFetches);
@@ -248,6 +230,19 @@ __global__ void __launch_bounds__(256) xm_classify_kernel(const int64_t* todo, l
   } else if (st == XM_ST_NEED_PATH) listPath[atomicAdd(&ctl->nPath[tp], 1ull)] = q;
   else if (st == XM_ST_OVERFLOW) listScale[atomicAdd(&ctl->nScale[ts], 1ull)] = q;
   else if (st == XM_ST_OUT_OVERFLOW) listOut[atomicAdd(&ctl->nOut[to], 1ull)] = q;
+  else atomicMin(&ctl->errQuery, (unsigned long long)q);
+}
+
+// after a pass of the wave-per-read form (xm_wave_kernel.hip): reads for its heavy tier, reads it leaves to the lane-per-read passes
+struct WaveCtl { unsigned long long nHeavy, nFallback, errQuery; };
+__global__ void __launch_bounds__(256) xm_wave_classify_kernel(const int64_t* todo, long long nTodo, const int32_t* status, int64_t* listHeavy, int64_t* listFallback, WaveCtl* ctl) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nTodo) return;
+  const int64_t q = todo ? todo[i] : (int64_t)i;
+  const int32_t st = status[q] & 0xFF;
+  if (st == XM_OK) return;
+  if (st == 9 /* XM_ST_WAVE_GAPPED */ && listHeavy) listHeavy[atomicAdd(&ctl->nHeavy, 1ull)] = q;
+  else if (st == 8 /* XM_ST_WAVE_FALLBACK */ || st == 9) listFallback[atomicAdd(&ctl->nFallback, 1ull)] = q;
   else atomicMin(&ctl->errQuery, (unsigned long long)q);
 }
 
@@ -472,6 +467,12 @@ struct xm_index {
   DevBuf<int32_t> dSlotOf, dRegionOf;
   DevBuf<uint8_t> dMemo;
   DevBuf<PNode> dWaveNodes;  // per wave: node payloads of its LDS-mode search
+  // wave-per-read passes
+  DevBuf<int64_t> dListWaveHeavy, dListFallback;
+  DevBuf<WaveCtl> dWaveCtl;
+  DevBuf<uint8_t> dWaveArenas;
+  DevBuf<PNode> dWaveNodes2;
+  bool residentAnyPaired = false, stagedAnyPaired = false;
   DevBuf<PassCtl> dCtl;
   DevBuf<long long> dBlockI, dBlockD;
   DevBuf<int32_t> dFinalInts;
@@ -698,11 +699,13 @@ void xm_result_free(xm_result* r) {
 }
 
 // validation + Readable_HashBlock_Database growth + host-to-device copy of one batch; the batch stays resident in HBM
-static int validateBatch(const xm_query_batch* b) {  // -> longest mate
+static int validateBatch(const xm_query_batch* b, bool* anyPaired = nullptr) {  // -> longest mate
   const int64_t nq = b->num_queries;
   int maxLen = 1;
+  if (anyPaired) *anyPaired = false;
   for (int64_t q = 0; q < nq; q++) {
     if (b->mate_count[q] < 1 || b->mate_count[q] > 2) throw std::runtime_error("mate_count must be 1 or 2");
+    if (anyPaired && b->mate_count[q] == 2) *anyPaired = true;
     for (int m = 0; m < b->mate_count[q]; m++) {
       int32_t len = b->mate_length[q * 2 + m];
       if (len < 1 || len > 30000) throw std::runtime_error("mate length out of range (1..30000; longer reads are split by the caller as --split-queries-past-size does)");
@@ -715,7 +718,9 @@ static int validateBatch(const xm_query_batch* b) {  // -> longest mate
 
 static void uploadBatchLocked(xm_index* idx, const xm_query_batch* b) {
   const int64_t nq = b->num_queries;
-  const int maxLen = validateBatch(b);
+  bool anyPaired = false;
+  const int maxLen = validateBatch(b, &anyPaired);
+  idx->residentAnyPaired = anyPaired;
   if (maxLen > idx->host.maxHashedLength) {  // Readable_HashBlock_Database.getContainingMap growth, done before the launch
     idx->host.ensureLength(maxLen);
     idx->upload();
@@ -762,7 +767,9 @@ int xm_batch_stage(xm_index* idx, const xm_query_batch* b) {
   try {
     std::lock_guard<std::mutex> stageLock(idx->stageMu);
     const int64_t nq = b->num_queries;
-    const int maxLen = validateBatch(b);
+    bool anyPaired = false;
+    const int maxLen = validateBatch(b, &anyPaired);
+    idx->stagedAnyPaired = anyPaired;
     if (maxLen > idx->host.maxHashedLength) {  // the tables grow: that touches what a running xm_align_resident reads, so wait for it
       std::lock_guard<std::mutex> lock(idx->mu);
       idx->host.ensureLength(maxLen);
@@ -803,7 +810,7 @@ int xm_batch_commit(xm_index* idx) {
     std::lock_guard<std::mutex> lock(idx->mu);  // (waits for a running xm_align_resident)
     idx->dMateCount.swapWith(idx->sMateCount); idx->dMateOffset.swapWith(idx->sMateOffset); idx->dMateLength.swapWith(idx->sMateLength);
     idx->dCodes.swapWith(idx->sCodes); idx->dExpected.swapWith(idx->sExpected); idx->dDeviation.swapWith(idx->sDeviation);
-    idx->residentNq = idx->stagedNq; idx->residentMaxLen = idx->stagedMaxLen; idx->residentH2dMs = idx->stagedH2dMs;
+    idx->residentNq = idx->stagedNq; idx->residentMaxLen = idx->stagedMaxLen; idx->residentH2dMs = idx->stagedH2dMs; idx->residentAnyPaired = idx->stagedAnyPaired;
     idx->stagedNq = -1;
     return 0;
   } catch (std::exception& e) { return fail(std::string("xm_batch_commit: ") + e.what()); }
@@ -933,6 +940,69 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     if (handOver) {
       idx->dRegionOf.ensure((size_t)nq);
       HIP_CHECK(hipMemsetAsync(idx->dRegionOf.p, 0xFF, sizeof(int32_t) * (size_t)nq, s));
+    }
+    // ---- passes 0 / 0b: the wave-per-read form (xm_wave_kernel.hip).  Light tier over every read (seed, vote, ungapped alignment, accept),
+    // then its heavy tier over the reads that need the gapped chain or more LDS.  What neither takes (ambiguity codes in the read,
+    // mates longer than 256 bases, overlapping mates, a structure that outgrows LDS) goes through the lane-per-read passes below.
+    if (envInt("XM_WAVE", 1) != 0 && idx->residentMaxLen <= 256) {
+      const bool tracePasses = envInt("XM_TRACE_PASSES", 0) != 0;
+      idx->dListWaveHeavy.ensure((size_t)nq); idx->dListFallback.ensure((size_t)nq); idx->dWaveCtl.ensure(1);
+      WaveCtl wctl0{0, 0, ~0ull};
+      HIP_CHECK(hipMemcpyAsync(idx->dWaveCtl.p, &wctl0, sizeof(wctl0), hipMemcpyHostToDevice, s));
+      OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
+      const int heavyTier = (int)envInt("XM_WAVE_HEAVY", 1);
+      const int64_t* wTodo = nullptr;
+      long long wN = nq;
+      for (int tier = 0; tier < 2 && wN > 0; tier++) {
+        if (tier == 1 && !heavyTier) break;
+        WaveLaunch wl;
+        wl.config = tier == 0 ? (idx->residentAnyPaired ? 1 : 0) : 2;
+        int wavesPerBlock = 1, ldsPerBlock = 1, wavesPerSimd = 1;
+        xmWaveGeometry(wl.config, &wavesPerBlock, &ldsPerBlock, &wavesPerSimd);
+        long long blocksPerCU = std::min<long long>((160 * 1024) / ldsPerBlock, (long long)(wavesPerSimd * 4) / wavesPerBlock);
+        if (blocksPerCU < 1) blocksPerCU = 1;
+        wl.itemsPerFetch = (int)envInt(tier == 0 ? "XM_WAVE_FETCH" : "XM_WAVE_HEAVY_FETCH", tier == 0 ? 8 : 1);
+        long long blocks = std::min<long long>((long long)idx->numCUs * blocksPerCU, (wN + (long long)wavesPerBlock * wl.itemsPerFetch - 1) / ((long long)wavesPerBlock * wl.itemsPerFetch));
+        if (blocks < 1) blocks = 1;
+        wl.grid = (int)blocks; wl.block = wavesPerBlock * 64;
+        wl.ix = idx->view; wl.params = params; wl.batch = bv; wl.todo = wTodo; wl.nTodo = wN; wl.out = ov; wl.nextItem = idx->dCursors.p + 2; wl.counters = idx->dCounters.p;
+        wl.arenas = nullptr; wl.arenaBytes = 0; wl.chainScale = gappedScale; wl.waveNodes = nullptr;
+        if (tier == 1) {
+          const size_t chainArena = arenaUnit * (size_t)gappedScale;
+          wl.arenaBytes = (unsigned long long)((chainArena - arenaPersistBytes(chainArena)) & ~(size_t)15);
+          idx->dWaveArenas.ensure((size_t)blocks * wavesPerBlock * (size_t)wl.arenaBytes);
+          idx->dWaveNodes2.ensure((size_t)blocks * wavesPerBlock * XM_PAL_NODES);
+          wl.arenas = idx->dWaveArenas.p; wl.waveNodes = idx->dWaveNodes2.p;
+        }
+        HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
+        HIP_CHECK(hipEventRecord(e0, s));
+        const int rc = xmWaveLaunch(wl, (void*)s);
+        if (rc != 0) throw std::runtime_error(std::string("wave kernel launch: ") + hipGetErrorString((hipError_t)rc));
+        HIP_CHECK(hipEventRecord(e1, s));
+        hipLaunchKernelGGL(xm_wave_classify_kernel, dim3((unsigned)((wN + 255) / 256)), dim3(256), 0, s, wTodo, wN, idx->dStatus.p, tier == 0 && heavyTier ? idx->dListWaveHeavy.p : (int64_t*)nullptr,
+                           idx->dListFallback.p, idx->dWaveCtl.p);
+        HIP_CHECK(hipGetLastError());
+        WaveCtl wctl;
+        HIP_CHECK(hipMemcpyAsync(&wctl, idx->dWaveCtl.p, sizeof(wctl), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(cursors, idx->dCursors.p, sizeof(cursors), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        kernelMs += ms;
+        res->counters[tier == 0 ? 12 : 13] += (int64_t)(ms * 1000.0);
+        launches++;
+        if (tracePasses) fprintf(stderr, "[xm] wave pass tier %d config %d: reads %lld, %d x %d threads, %d per fetch: %.3f ms -> heavy %llu fallback %llu\n", tier, wl.config, wN, wl.grid, wl.block,
+                                 wl.itemsPerFetch, ms, wctl.nHeavy, wctl.nFallback);
+        if (wctl.errQuery != ~0ull) {
+          int32_t code = 0;
+          HIP_CHECK(hipMemcpy(&code, idx->dStatus.p + wctl.errQuery, sizeof(code), hipMemcpyDeviceToHost));
+          throw std::runtime_error("Failed to align query " + std::to_string(wctl.errQuery) + ": the reference implementation would have thrown here (status " + std::to_string(code & 0xFF) + ")");
+        }
+        if (tier == 0) { wTodo = idx->dListWaveHeavy.p; wN = (long long)wctl.nHeavy; }
+        else wN = 0;
+        todo = idx->dListFallback.p;
+        nTodo = (long long)wctl.nFallback;
+      }
+      HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
     }
     while (nTodo > 0) {
       size_t arenaBytes = arenaUnit * (size_t)scale;  // bytes of scratch a lane owns in this launch

@@ -375,7 +375,10 @@ static_assert(XM_PAL_SLOT_BYTES * 4 + 432 + 16 <= 40 * 1024, "four waves per wor
 
 struct PNode;
 #if defined(__HIP_DEVICE_COMPILE__)
-__shared__ __attribute__((aligned(16))) uint8_t xm_pal_lds[4 * XM_PAL_SLOT_BYTES];
+#ifndef XM_PAL_WAVES
+#define XM_PAL_WAVES 4  // waves per workgroup of the kernel this is compiled into (one slot each)
+#endif
+__shared__ __attribute__((aligned(16))) uint8_t xm_pal_lds[XM_PAL_WAVES * XM_PAL_SLOT_BYTES];
 XM_INL uint8_t* palSlot() { return xm_pal_lds + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * XM_PAL_SLOT_BYTES; }
 // The node payloads of an LDS-mode search live in a buffer of the WAVE, not of the lane (one search at a time per wave): 4096 waves x 34 KB
 // stay in the Infinity Cache, where the lanes' arenas (131 072 x 1.2 MB) never do.  The kernel leaves the buffer's base here.
@@ -1251,7 +1254,11 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
     pr.confident = an.confidentAboutBestOffset; pr.maxInsExt = an.maxInsertionExtensionPenalty; pr.maxDelExt = an.maxDeletionExtensionPenalty;
     pr.predictedBestOffset = an.predictedBestOffset;
     bool ldsOverflow = false;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(XM_WAVE_UNIFORM)
+    // wave-per-read kernels (xm_wave_kernel.hip): every lane of the wave is on the same search with the same values, so the wave's slot
+    // is simply used (all lanes write the same words)
+    found = pathSearchSlot(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, false);
+#elif defined(__HIP_DEVICE_COMPILE__)
     unsigned long long pending = __ballot(1);
     const int lane = (int)__lane_id();
     if (xmPairMode()) {  // the two lanes of a read take the slot together

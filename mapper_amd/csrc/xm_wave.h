@@ -46,11 +46,11 @@ XM_INL void wvFence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 #define WV_ENDPAR }
 #define WV_LANE0
 template <typename T>
-inline unsigned long long wvBallotHost(const T* v) { unsigned long long m = 0; for (int i = 0; i < 64; i++) if (v[i] != 0) m |= 1ull << i; return m; }
+XM_INL unsigned long long wvBallotHost(const T* v) { unsigned long long m = 0; for (int i = 0; i < 64; i++) if (v[i] != 0) m |= 1ull << i; return m; }
 #define WV_BALLOT(name) wvBallotHost(name)
 #define WV_BCAST_I(name, lane) ((int)(name)[lane])
-inline int wvUni(int v) { return v; }
-inline void wvFence() {}
+XM_INL int wvUni(int v) { return v; }
+XM_INL void wvFence() {}
 #endif
 
 // ---------------------------------------------------------------- capacities of one wave's LDS share
@@ -61,9 +61,9 @@ constexpr int WV_MAXBLOCKS = 8;              // AlignedBlocks per SequenceAlignm
 constexpr int WV_MAXHITS = 64;               // staged hits per round
 // A configuration fixes the capacities of one kernel instance.  The light tiers are sized for what nearly every read needs
 // (measured high-water marks: profiles/r02/NOTES.md); a read that outgrows one leaves with XM_ST_WAVE_FALLBACK.
-struct WCfgLightSE { static constexpr int kMates = 1, kChunks = 6, kCounters = 8, kHistory = 12, kPending = 24, kQM = 4, kGood = 3, kPool = 12; };
-struct WCfgLightPE { static constexpr int kMates = 2, kChunks = 12, kCounters = 8, kHistory = 12, kPending = 24, kQM = 4, kGood = 3, kPool = 16; };
-struct WCfgHeavy { static constexpr int kMates = 2, kChunks = 40, kCounters = 24, kHistory = 128, kPending = 96, kQM = 12, kGood = 6, kPool = 40; };
+struct WCfgLightSE { static constexpr int kTier = 0, kMates = 1, kChunks = 6, kCounters = 8, kHistory = 12, kPending = 24, kQM = 4, kGood = 3, kPool = 12; };
+struct WCfgLightPE { static constexpr int kTier = 0, kMates = 2, kChunks = 12, kCounters = 8, kHistory = 12, kPending = 24, kQM = 4, kGood = 3, kPool = 16; };
+struct WCfgHeavy { static constexpr int kTier = 1, kMates = 2, kChunks = 40, kCounters = 24, kHistory = 128, kPending = 96, kQM = 12, kGood = 6, kPool = 40; };
 
 struct WCounter {  // M/HashBlockMatch_Counter.java + its SequenceMatch
   int32_t offset, contig, numMatches, numDistinctMismatches, lastMismatchedPosition, lastMatchedBlockId, historyProcessedIndex, priority;
@@ -119,7 +119,7 @@ struct WAlignerT {  // QueryMatch_Aligner
 
 template <class CFG>
 struct WaveLdsT {
-  static constexpr int kMates = CFG::kMates, kChunks = CFG::kChunks, kCounters = CFG::kCounters, kHistory = CFG::kHistory, kPending = CFG::kPending, kQM = CFG::kQM,
+  static constexpr int kTier = CFG::kTier, kMates = CFG::kMates, kChunks = CFG::kChunks, kCounters = CFG::kCounters, kHistory = CFG::kHistory, kPending = CFG::kPending, kQM = CFG::kQM,
                        kGood = CFG::kGood, kPool = CFG::kPool;
   int32_t status, nMates, listIdCounter, nChunksUsed;
   int32_t why, tier;  // where a read left the wave form (diagnostics); 0 light tier, 1 heavy tier
@@ -139,7 +139,7 @@ struct WaveLdsT {
 };
 
 struct WEnv {  // what a wave carries in registers
-  const IndexView* ix;
+  IndexView ix;                 // by value: with the wave functions inlined these stay in scalar registers (kernel arguments)
   Params params;
   DevCounters* dc;
   const uint8_t* mateBase[2];   // the mates as given in the batch (HBM), for the gapped chain
@@ -149,9 +149,23 @@ struct WEnv {  // what a wave carries in registers
 };
 
 #define WL_T XM_LDSP(LDS)*
+// wave functions are inlined into their kernel: a call sends the callee-saved registers through scratch memory, and that per read
+#define WV_FN XM_INL
+// XM_WAVE_PROFILE builds: shader-clock ticks of a scope, summed into DevCounters::t[slot] (every lane keeps its own copy; lane 0's is published)
+#if defined(XM_WAVE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+struct WTimer {
+  DevCounters* dc; int slot; unsigned long long t0;
+  XM_INL WTimer(DevCounters* d, int s) : dc(d), slot(s), t0(clock64()) {}
+  XM_INL ~WTimer() { if (dc) dc->t[slot] += clock64() - t0; }
+};
+#define WV_TIMER(e, slot) WTimer wtimer_##slot((e).dc, slot)
+#else
+#define WV_TIMER(e, slot) do { } while (0)
+#endif
+enum { WT_TOTAL = 0, WT_WALK = 2, WT_STEP = 3, WT_UNGAPPED = 4, WT_HITS = 5, WT_CHAIN = 6, WT_CONFIDENT = 10, WT_ALIGNMATCH = 11, WT_MATEINIT = 12, WT_WRITE = 13, WT_OPTIMISTIC = 14 };
 // a structure outgrew its capacity: the light tier hands the read to the heavy tier, the heavy tier to the lane-per-read kernel
 template <class LDS>
-XM_INL int32_t wOverflowStatus(WL_T L) { return L->tier == 0 ? XM_ST_WAVE_GAPPED : XM_ST_WAVE_FALLBACK; }
+XM_INL int32_t wOverflowStatus(WL_T L) { return LDS::kTier == 0 ? XM_ST_WAVE_GAPPED : XM_ST_WAVE_FALLBACK; }
 
 // ---------------------------------------------------------------- sequences
 template <class LDS>
@@ -223,19 +237,18 @@ XM_INL WBlock wMergeBlocks(const WBlock& Lb, const WBlock& Rb) {
 // for the merge (M/HashBlock_ParentRow.java:69-127,200-208); a block of level k-1 is at most 2^(k-1) long, which bounds how
 // much of the level below a window needs.
 template <class LDS>
-XM_NOINL void wPyrEnsure(WL_T L, int mi, int level, int upTo) {
+WV_FN void wPyrEnsure(WL_T L, int mi, int level, int upTo) {
   const int len = L->m[mi].len;
   if (level <= 0) return;
   if (level >= WV_MAXLEVELS) { { L->status = wOverflowStatus(L); L->why = 1; } return; }
   // how far each level below must be known: a block of level k at p reaches into level k-1 as far as p + 2^(k-1)
-  int need[WV_MAXLEVELS];
-  need[level] = imin(len, upTo);
-  for (int k = level - 1; k >= 1; k--) need[k] = imin(len, need[k + 1] + (1 << (k < 10 ? k : 10)));
+  // (need of level k = upTo + 2^k + 2^(k+1) + ... + 2^(level-1), clipped to the mate)
   for (int k = 1; k <= level; k++) {
-    while ((int)L->m[mi].frontier[k] < need[k]) {
+    const int needK = imin(len, upTo + (1 << level) - (1 << k));
+    while ((int)L->m[mi].frontier[k] < needK) {
       const int a = L->m[mi].frontier[k];
       const int w = a >> 6;
-      const int b = imin(need[k], imin((w + 1) << 6, len));  // one window at a time
+      const int b = imin(needK, imin((w + 1) << 6, len));  // one window at a time
       if (L->m[mi].chunkOf[k][w] == 0xFF) {
         if (L->nChunksUsed >= LDS::kChunks) { { L->status = wOverflowStatus(L); L->why = 2; } return; }
         L->m[mi].chunkOf[k][w] = (uint8_t)L->nChunksUsed;
@@ -354,15 +367,37 @@ XM_INL bool wqPrimaryPolarity(const WQBlock& b) {  // M/HashBlock.java:329-334
 }
 XM_INL int32_t wqLookupKey(const WQBlock& b) { return wqPrimaryPolarity(b) ? b.fwd : b.rev; }
 
+// The table descriptors (one per gapmer length) are read on every probe: the kernel keeps a copy of the first WV_TABLECACHE in LDS.
+constexpr int WV_TABLECACHE = 160;
+#if defined(__HIP_DEVICE_COMPILE__)
+__shared__ Table xm_wave_tables[WV_TABLECACHE];
+XM_INL void xmWaveLoadTables(const IndexView& ix) {  // every thread of the block, before the block's first barrier
+  const int n = imin(ix.maxHashedLength + 1, WV_TABLECACHE);
+  for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+    xm_wave_tables[i].capacity = ix.tables[i].capacity; xm_wave_tables[i].maxCount = ix.tables[i].maxCount;
+    xm_wave_tables[i].offBase = ix.tables[i].offBase; xm_wave_tables[i].posBase = ix.tables[i].posBase;
+  }
+}
+XM_INL Table wTable(const IndexView& ix, int used) {
+  Table t;
+  if (used < WV_TABLECACHE) { t.capacity = xm_wave_tables[used].capacity; t.maxCount = xm_wave_tables[used].maxCount; t.offBase = xm_wave_tables[used].offBase; t.posBase = xm_wave_tables[used].posBase; }
+  else t = ix.tables[used];
+  return t;
+}
+#else
+XM_INL void xmWaveLoadTables(const IndexView&) {}
+XM_INL Table wTable(const IndexView& ix, int used) { return ix.tables[used]; }
+#endif
+
 // M/Readable_HashBlock_Database.java:72-80 + M/PackedMap.java:228-236: one 8-byte header probe
 template <class LDS>
 XM_INL int wNumMatchesLowerBound(WL_T L, const WEnv& e, const WQBlock& b) {
-  const IndexView& ix = *e.ix;
+  const IndexView& ix = e.ix;
   if (b.used < ix.minInterestingSize) return INT32_MAX;
   if (b.used > ix.maxHashedLength) { L->status = XM_ST_NEED_GROW; return INT32_MAX; }
-  const Table* t = &ix.tables[b.used];
-  const uint32_t k = packedKey(t, wqLookupKey(b));
-  const uint32_t* off = ix.bucketOff + t->offBase + k;
+  const Table t = wTable(ix, b.used);
+  const uint32_t k = packedKey(&t, wqLookupKey(b));
+  const uint32_t* off = ix.bucketOff + t.offBase + k;
   const uint32_t o0 = off[0], o1 = off[1];
   if (e.dc) e.dc->headerProbes++;
   if (o0 & XM_OVERFULL) return INT32_MAX;
@@ -371,7 +406,7 @@ XM_INL int wNumMatchesLowerBound(WL_T L, const WEnv& e, const WQBlock& b) {
 XM_INL int wDbMaxNumMatchesAllowed(const IndexView& ix, const WQBlock& b) {  // :82-90 (the table of a hashed length always exists here)
   if (b.used < ix.minInterestingSize) return -1;
   if (b.used > ix.maxHashedLength) return 0;
-  return ix.tables[b.used].maxCount;
+  return wTable(ix, b.used).maxCount;
 }
 
 // ---------------------------------------------------------------- HashBlockPath (M/HashBlockPath.java)
@@ -415,7 +450,7 @@ XM_INL void wPathMoveUpOrRight(WL_T L, int mi) {  // :111-122
 template <class LDS>
 XM_INL bool wPathWithGap(WL_T L, const WEnv& e, int mi, WQBlock& out) {  // :197-203
   XM_LDSP(WPathState)* p = &L->m[mi].path;
-  if (!e.ix->enableGapmers) {
+  if (!e.ix.enableGapmers) {
     out.start = p->curStart; out.len = p->curLen; out.used = p->curLen; out.fwd = p->curFwd; out.rev = p->curRev; out.flags = p->curFlags; out.id = -1;
     return true;
   }
@@ -433,16 +468,16 @@ XM_INL bool wPathWithGap(WL_T L, const WEnv& e, int mi, WQBlock& out) {  // :197
 }
 template <class LDS>
 XM_INL int wPathMaxNumMatchesAllowed(WL_T L, const WEnv& e, int mi, const WQBlock& b) {  // :205-219
-  if (b.len >= L->m[mi].len / 6) return wDbMaxNumMatchesAllowed(*e.ix, b);
+  if (b.len >= L->m[mi].len / 6) return wDbMaxNumMatchesAllowed(e.ix, b);
   if (b.flags & F_RMR) return 5;
   return b.used + 1;
 }
 // advanceToNextPosition :143-195 (mates with ambiguity codes never come here, so there are no multi blocks to skip)
 template <class LDS>
-XM_NOINL bool wPathAdvance(WL_T L, const WEnv& e, int mi) {
+WV_FN bool wPathAdvance(WL_T L, const WEnv& e, int mi) {
   const int singleLen = L->m[mi].path.curLen;
-  const bool gapmers = e.ix->enableGapmers != 0;
-  if (maxGapmerNumBasepairsUsed(singleLen) < e.ix->minInterestingSize && gapmers) {
+  const bool gapmers = e.ix.enableGapmers != 0;
+  if (maxGapmerNumBasepairsUsed(singleLen) < e.ix.minInterestingSize && gapmers) {
     wPathMoveUpOrRight(L, mi);
   } else {
     WQBlock ext;
@@ -457,7 +492,7 @@ XM_NOINL bool wPathAdvance(WL_T L, const WEnv& e, int mi) {
       }
     } else {
       const int typical = singleLen * 3 / 2;
-      if (typical <= e.ix->minInterestingSize && gapmers) wPathMoveUpOrRight(L, mi);
+      if (typical <= e.ix.minInterestingSize && gapmers) wPathMoveUpOrRight(L, mi);
       else { if (L->m[mi].path.batchIndex > 0) wPathMoveDown(L, mi); else wPathMoveRight(L, mi); }
     }
   }
@@ -465,7 +500,8 @@ XM_NOINL bool wPathAdvance(WL_T L, const WEnv& e, int mi) {
 }
 // getNextInterestingBlock :27-50 (+ getNextBlockWithGoodNumberOfMatches :68-96, recentlySeen :52-65)
 template <class LDS>
-XM_NOINL bool wPathNextInterestingBlock(WL_T L, const WEnv& e, int mi, WQBlock& out) {
+WV_FN bool wPathNextInterestingBlock(WL_T L, const WEnv& e, int mi, WQBlock& out) {
+  WV_TIMER(e, WT_WALK);
   if (!L->m[mi].path.curExists) return false;
   while (true) {
     if (!wPathAdvance(L, e, mi)) return false;
@@ -498,7 +534,7 @@ XM_INL void wCounterUpdate(WL_T L, const WEnv& e, int mi, int ci) {  // :41-46,7
   int idx = k->historyProcessedIndex;
   if (idx >= nHistory) return;
   int nd = k->numDistinctMismatches, lastPos = k->lastMismatchedPosition;
-  const int lastId = k->lastMatchedBlockId, off = k->offset, refLen = e.ix->contigLen[k->contig];
+  const int lastId = k->lastMatchedBlockId, off = k->offset, refLen = e.ix.contigLen[k->contig];
   for (; idx < nHistory; idx++) {
     const int bStart = L->m[mi].history[idx].start, bEnd = L->m[mi].history[idx].end, bId = L->m[mi].history[idx].id;
     if (bId != lastId && bStart >= lastPos && off + bEnd <= refLen) { nd++; lastPos = bEnd; }
@@ -530,13 +566,13 @@ XM_INL void wCompAddMatch(WL_T L, const WEnv& e, int mi, int ci, const WQBlock& 
       wDeclareGood(L, e, mi, ci);
     } else if (queryBlockNumMatches <= qb.len) {
       const int distanceFromStart = fm.offset;
-      const int distanceFromEnd = e.ix->contigLen[fm.contig] - (fm.offset + L->mateLen[fm.seqAId >> 1]);
+      const int distanceFromEnd = e.ix.contigLen[fm.contig] - (fm.offset + L->mateLen[fm.seqAId >> 1]);
       if (imin(distanceFromStart, distanceFromEnd) < 0) wDeclareGood(L, e, mi, ci);
     }
   }
 }
 template <class LDS>
-XM_NOINL void wCompUpdateMatches(WL_T L, const WEnv& e, int mi, const WSeqMatch& m, const WQBlock& qb, int queryBlockNumMatches) {  // :193-252
+WV_FN void wCompUpdateMatches(WL_T L, const WEnv& e, int mi, const WSeqMatch& m, const WQBlock& qb, int queryBlockNumMatches) {  // :193-252
   const uint8_t mapSel = (m.seqAId & 1) ? 0 : 1;  // (sic) reversed matches are filed under "forward", M/Counting_HashBlockPath.java:197-200
   int cur = -1, lower = -1, higher = -1, lowerOff = 0, higherOff = 0;
   const int nC = L->m[mi].nCounters;
@@ -590,7 +626,7 @@ XM_INL int wNextCounterInOrder(WL_T L, int mi, int mapSel, int lastContig, int l
   return best;
 }
 template <class LDS>
-XM_NOINL void wTryEnsureGoodMatchCounter(WL_T L, const WEnv& e, int mi) {  // :291-308
+WV_FN void wTryEnsureGoodMatchCounter(WL_T L, const WEnv& e, int mi) {  // :291-308
   if (!L->m[mi].foundGood && L->m[mi].nCounters <= L->m[mi].len) {
     for (int mapSel = 0; mapSel < 2; mapSel++) {
       int lc = 0, lo = 0;
@@ -608,7 +644,7 @@ XM_NOINL void wTryEnsureGoodMatchCounter(WL_T L, const WEnv& e, int mi) {  // :2
 
 // getNextInterestingBlock :344-368
 template <class LDS>
-XM_NOINL bool wCompNextInterestingBlock(WL_T L, const WEnv& e, int mi, WQBlock& out) {
+WV_FN bool wCompNextInterestingBlock(WL_T L, const WEnv& e, int mi, WQBlock& out) {
   L->m[mi].all.id = 0;  // previousAllPositions = null
   while (true) {
     WQBlock b;
@@ -637,9 +673,10 @@ XM_NOINL bool wCompNextInterestingBlock(WL_T L, const WEnv& e, int mi, WQBlock& 
 // step() :40-179.  The bucket's positions are decoded and flank-voted one per lane and staged in LDS (WaveLds::hits); the
 // counters then take the staged hits in bucket order.
 template <class LDS>
-XM_NOINL bool wCompStep(WL_T L, const WEnv& e, int mi) {
+WV_FN bool wCompStep(WL_T L, const WEnv& e, int mi) {
+  WV_TIMER(e, WT_STEP);
   if (L->m[mi].done) return false;
-  const IndexView& ix = *e.ix;
+  const IndexView& ix = e.ix;
   WQBlock qb;
   int64_t first = 0;
   bool invert = false;
@@ -653,15 +690,15 @@ XM_NOINL bool wCompStep(WL_T L, const WEnv& e, int mi) {
     }
     if (qb.used < ix.minInterestingSize) continue;
     if (qb.used > ix.maxHashedLength) { L->status = XM_ST_NEED_GROW; return false; }
-    const Table* t = &ix.tables[qb.used];
-    const uint32_t k = packedKey(t, wqLookupKey(qb));
-    const uint32_t* off = ix.bucketOff + t->offBase + k;
+    const Table t = wTable(ix, qb.used);
+    const uint32_t k = packedKey(&t, wqLookupKey(qb));
+    const uint32_t* off = ix.bucketOff + t.offBase + k;
     const uint32_t o0 = off[0], o1 = off[1];
     if (e.dc) { e.dc->headerProbes++; e.dc->bucketFetches++; }
     if (o0 & XM_OVERFULL) continue;
     nHits = (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
-    if (nHits > t->maxCount) continue;
-    first = t->posBase + (int64_t)(o0 & ~XM_OVERFULL);
+    if (nHits > t.maxCount) continue;
+    first = t.posBase + (int64_t)(o0 & ~XM_OVERFULL);
     invert = !wqPrimaryPolarity(qb);
     if (e.dc) e.dc->hitsFetched += (unsigned long long)nHits;
     break;
@@ -674,6 +711,7 @@ XM_NOINL bool wCompStep(WL_T L, const WEnv& e, int mi) {
   }
   const int qLen = L->m[mi].len;
   const int queryId = L->m[mi].queryId, rcId = L->m[mi].rcId;
+  WV_TIMER(e, WT_HITS);
   for (int h0 = 0; h0 < nHits; h0 += WV_MAXHITS) {
     const int nRound = imin(WV_MAXHITS, nHits - h0);
     wvFence();
@@ -740,7 +778,7 @@ template <class LDS>
 XM_INL auto wList(WL_T L, int mi, int which) { return which == WLIST_HP ? &L->m[mi].hp : (which == WLIST_BEST ? &L->m[mi].best : &L->m[mi].all); }
 
 template <class LDS>
-XM_NOINL int wCompFindGoodPositionsHavingPriorityUpTo(WL_T L, const WEnv& e, int mi, int priority) {  // :406-433 -> WLIST_HP
+WV_FN int wCompFindGoodPositionsHavingPriorityUpTo(WL_T L, const WEnv& e, int mi, int priority) {  // :406-433 -> WLIST_HP
   while (true) {
     if (L->m[mi].numNonoverlappingBlocksVisited >= jadd(priority, 1)) break;
     if (!wCompStep(L, e, mi)) break;
@@ -759,7 +797,7 @@ XM_NOINL int wCompFindGoodPositionsHavingPriorityUpTo(WL_T L, const WEnv& e, int
   return WLIST_HP;
 }
 template <class LDS>
-XM_NOINL int wCompGetAllPositions(WL_T L, const WEnv& e, int mi) {  // :435-451 -> WLIST_ALL
+WV_FN int wCompGetAllPositions(WL_T L, const WEnv& e, int mi) {  // :435-451 -> WLIST_ALL
   if (L->m[mi].all.id == 0) {
     int n = 0;
     for (int mapSel = 0; mapSel < 2; mapSel++) {
@@ -779,7 +817,7 @@ XM_NOINL int wCompGetAllPositions(WL_T L, const WEnv& e, int mi) {  // :435-451 
   return WLIST_ALL;
 }
 template <class LDS>
-XM_NOINL int wCompGetBestMatches(WL_T L, const WEnv& e, int mi) {  // :471-493 (+ getNumGoodDistinctMismatches :457-469) -> WLIST_BEST
+WV_FN int wCompGetBestMatches(WL_T L, const WEnv& e, int mi) {  // :471-493 (+ getNumGoodDistinctMismatches :457-469) -> WLIST_BEST
   L->listIdCounter = L->listIdCounter + 1;
   L->m[mi].best.id = L->listIdCounter;
   L->m[mi].best.n = 0;
@@ -813,7 +851,7 @@ XM_INL WSeqMatch wCounterMatch(WL_T L, int mi, int ci) {
 }
 XM_INL int wSmStartB(const WSeqMatch& m) { return imax(0, m.offset); }
 template <class LDS>
-XM_INL int wSmEndB(WL_T L, const WEnv& e, const WSeqMatch& m) { return imin(m.offset + L->mateLen[m.seqAId >> 1], e.ix->contigLen[m.contig]); }
+XM_INL int wSmEndB(WL_T L, const WEnv& e, const WSeqMatch& m) { return imin(m.offset + L->mateLen[m.seqAId >> 1], e.ix.contigLen[m.contig]); }
 XM_INL bool wSmEquals(const WSeqMatch& a, const WSeqMatch& b) { return a.offset == b.offset && a.seqAId == b.seqAId && a.contig == b.contig; }
 
 template <class LDS>
@@ -830,7 +868,7 @@ XM_INL WQMatch wLoadQMatch(XM_LDSP(const WQMatch)* s) {
 }
 
 template <class LDS>
-XM_NOINL void wPcMatchWithoutCache(WL_T L, const WEnv& e, const int* which) {  // :136-247 + assembleQueryMatches :249-265
+WV_FN void wPcMatchWithoutCache(WL_T L, const WEnv& e, const int* which) {  // :136-247 + assembleQueryMatches :249-265
   L->nAssembled = 0;
   if (L->nMates == 1) {
     auto l0 = wList(L, 0, which[0]);
@@ -919,7 +957,7 @@ XM_INL void wPcFilterPriority(WL_T L, int priority) {  // :267-294
   L->nFiltered = n;
 }
 template <class LDS>
-XM_NOINL void wPcFindGoodPositionsHavingPriority(WL_T L, const WEnv& e, int numMismatches) {  // :21-24, :51-81
+WV_FN void wPcFindGoodPositionsHavingPriority(WL_T L, const WEnv& e, int numMismatches) {  // :21-24, :51-81
   int which[2] = {WLIST_HP, WLIST_HP};
   for (int i = 0; i < L->nMates; i++) {
     which[i] = wCompFindGoodPositionsHavingPriorityUpTo(L, e, i, numMismatches);
@@ -931,9 +969,10 @@ XM_NOINL void wPcFindGoodPositionsHavingPriority(WL_T L, const WEnv& e, int numM
   wPcFilterPriority(L, numMismatches);
 }
 template <class LDS>
-XM_NOINL void wPcOptimisticGetBestMatches(WL_T L, const WEnv& e) {  // :84-98 (+ filterMatchesHavingMinPriority :296-304, sic: max)
+WV_FN void wPcOptimisticGetBestMatches(WL_T L, const WEnv& e) {  // :84-98 (+ filterMatchesHavingMinPriority :296-304, sic: max)
   int which[2] = {WLIST_BEST, WLIST_BEST};
   for (int i = 0; i < L->nMates; i++) {
+  WV_TIMER(e, WT_OPTIMISTIC);
     while (true) {
       which[i] = wCompGetBestMatches(L, e, i);
       if (wList(L, i, which[i])->n == 1 || !wCompStep(L, e, i)) break;
@@ -948,7 +987,7 @@ XM_NOINL void wPcOptimisticGetBestMatches(WL_T L, const WEnv& e) {  // :84-98 (+
   wPcFilterPriority(L, mn);
 }
 template <class LDS>
-XM_NOINL void wPcFindPartiallyGoodPositions(WL_T L, const WEnv& e) {  // :26-49
+WV_FN void wPcFindPartiallyGoodPositions(WL_T L, const WEnv& e) {  // :26-49
   L->nFiltered = 0;
   if (L->nMates != 2) return;
   if constexpr (LDS::kMates < 2) return;
@@ -1009,8 +1048,9 @@ struct WSa {  // SequenceAlignment header in registers; its blocks are WaveLds::
 // sum of AlignmentParameters.getPenalty(query[qStart+i], reference[rStart+i]) over i in [0, n), added in index order (:106-126):
 // 64 bases per round, one per lane; the terms that are not zero are then added one by one in position order
 template <class LDS>
-XM_NOINL double wUngappedPenalty(WL_T L, const WEnv& e, int seqAId, int contig, int qStart, int rStart, int n) {
-  const IndexView& ix = *e.ix;
+WV_FN double wUngappedPenalty(WL_T L, const WEnv& e, int seqAId, int contig, int qStart, int rStart, int n) {
+  WV_TIMER(e, WT_UNGAPPED);
+  const IndexView& ix = e.ix;
   double total = 0;
   for (int r0 = 0; r0 < n; r0 += 64) {
     WV_VAR(int, isMis);
@@ -1042,7 +1082,8 @@ XM_NOINL double wUngappedPenalty(WL_T L, const WEnv& e, int seqAId, int contig, 
 
 // the gapped chain of xm_extend.h for one candidate (heavy tier): SkipHighAmbiguity -> HashBlock_Aligner -> BlockAligner -> ...
 template <class LDS>
-XM_NOINL bool wGappedChain(WL_T L, const WEnv& e, int seqAId, int contig, const Section& qs, const Section& rs, const Params& sub, Analysis& an, WSa& out, int slot) {
+WV_FN bool wGappedChain(WL_T L, const WEnv& e, int seqAId, int contig, const Section& qs, const Section& rs, const Params& sub, Analysis& an, WSa& out, int slot) {
+  WV_TIMER(e, WT_CHAIN);
   Arena& tmp = *e.tmp;
   const size_t mark = tmp.used;
   int32_t status = 0;
@@ -1050,7 +1091,7 @@ XM_NOINL bool wGappedChain(WL_T L, const WEnv& e, int seqAId, int contig, const 
   x.caps = e.caps; x.dc = e.dc; x.status = &status; x.tmp = e.tmp;
   const int mi = seqAId >> 1;
   x.query.base = e.mateBase[mi]; x.query.len = L->mateLen[mi]; x.query.rc = (uint8_t)(seqAId & 1); x.query.id = (uint8_t)seqAId;
-  x.reference = refView(*e.ix, contig, false);
+  x.reference = refView(e.ix, contig, false);
   x.contig = contig;
   x.memo = nullptr; x.memoCursor = nullptr; x.heavyHint = nullptr;
   Matcher* slots = arenaArray<Matcher>(tmp, 3);
@@ -1087,8 +1128,9 @@ XM_NOINL bool wGappedChain(WL_T L, const WEnv& e, int seqAId, int contig, const 
 
 // alignMatch :412-462 with the outermost StraightAligner (:13-71) done here; fromHashblockMatch is always true
 template <class LDS>
-XM_NOINL bool wAlignMatch(WL_T L, const WEnv& e, int seqAId, int contig, int offset, const Params& params, WSa& out, int slot) {
-  const IndexView& ix = *e.ix;
+WV_FN bool wAlignMatch(WL_T L, const WEnv& e, int seqAId, int contig, int offset, const Params& params, WSa& out, int slot) {
+  WV_TIMER(e, WT_ALIGNMATCH);
+  const IndexView& ix = e.ix;
   const int refLen = ix.contigLen[contig], qLen = L->mateLen[seqAId >> 1];
   const int startB = imax(0, offset), endB = imin(offset + qLen, refLen);
   const Section qs{startB - offset, endB - offset};
@@ -1124,15 +1166,19 @@ XM_NOINL bool wAlignMatch(WL_T L, const WEnv& e, int seqAId, int contig, int off
     } else if (indelPenalty > maxInterestingPenalty) decided = true;
   }
   if (!decided) {
-    if (e.tier == 0) { L->status = XM_ST_WAVE_GAPPED; return false; }
-    const double rate = simpleTotal / secLen(qs);
-    Params sub = params;
-    sub.MaxErrorRate = dmin(rate, params.MaxErrorRate);
-    const bool have = wGappedChain(L, e, seqAId, contig, qs, rs, sub, an, out, slot);
-    if (L->status) return false;
-    result = have;
-    if (!have || out.alignedPenalty >= simpleTotal) {
-      if (simpleTotal <= maxInterestingPenalty) { useSimple = true; result = true; }
+    if constexpr (LDS::kTier == 0) {  // (the light kernels do not contain the gapped chain)
+      L->status = XM_ST_WAVE_GAPPED;
+      return false;
+    } else {
+      const double rate = simpleTotal / secLen(qs);
+      Params sub = params;
+      sub.MaxErrorRate = dmin(rate, params.MaxErrorRate);
+      const bool have = wGappedChain(L, e, seqAId, contig, qs, rs, sub, an, out, slot);
+      if (L->status) return false;
+      result = have;
+      if (!have || out.alignedPenalty >= simpleTotal) {
+        if (simpleTotal <= maxInterestingPenalty) { useSimple = true; result = true; }
+      }
     }
   }
   if (useSimple) {
@@ -1156,7 +1202,7 @@ struct WCand { int32_t nSeq, innerDistance; WSa seq[2]; double spacingPenalty, o
 
 // doAlign :94-272 (mates that overlap on the reference, innerDistance < 0, are left to the lane-per-read kernel)
 template <class LDS>
-XM_NOINL bool wQmaDoAlign(WL_T L, const WEnv& e, int ai, const WQMatch& match, double extraSpacing, WCand& res) {
+WV_FN bool wQmaDoAlign(WL_T L, const WEnv& e, int ai, const WQMatch& match, double extraSpacing, WCand& res) {
   if (e.dc) e.dc->candidatesExtended++;
   if (L->al[ai].nGood >= LDS::kGood) { { L->status = wOverflowStatus(L); L->why = 14; } return false; }
   Params parameters = e.params;
@@ -1218,7 +1264,7 @@ XM_NOINL bool wQmaDoAlign(WL_T L, const WEnv& e, int ai, const WQMatch& match, d
 
 // align :35-54: returns the index of the alignment in the aligner's list, or -1 for null
 template <class LDS>
-XM_NOINL int wQmaAlign(WL_T L, const WEnv& e, int ai, const WQMatch& match, double extraSpacing) {
+WV_FN int wQmaAlign(WL_T L, const WEnv& e, int ai, const WQMatch& match, double extraSpacing) {
   WCand cand;
   if (!wQmaDoAlign(L, e, ai, match, extraSpacing, cand) || L->status) return -1;
   auto a = &L->al[ai];
@@ -1268,7 +1314,7 @@ XM_INL bool wSaSame(WL_T L, int ai, int i, int j, int k) {  // [inferred] Sequen
 }
 // getBestAlignments :71-92 (withoutDuplicates keeps first occurrences)
 template <class LDS>
-XM_NOINL void wQmaGetBestAlignments(WL_T L, const WEnv& e, int ai) {
+WV_FN void wQmaGetBestAlignments(WL_T L, const WEnv& e, int ai) {
   auto a = &L->al[ai];
   const double maxInterestingPenaltyAnywhere = a->queryLength * a->maxErrorRate;
   double cutoffPenalty = a->bestPenalty + e.params.Max_PenaltySpan;
@@ -1294,13 +1340,13 @@ XM_NOINL void wQmaGetBestAlignments(WL_T L, const WEnv& e, int ai) {
 // ---------------------------------------------------------------- per-read driver (M/AlignerWorker.java:306-644)
 XM_INL double wPenaltyLowerBound(const WEnv& e, int numMismatchedHashblocks) {  // :487-491
   const double mutationPenalty = numMismatchedHashblocks * e.params.MutationPenalty;
-  const double indelPenalty = e.ix->minInterestingSize * numMismatchedHashblocks * e.params.DeletionExtension_Penalty;
+  const double indelPenalty = e.ix.minInterestingSize * numMismatchedHashblocks * e.params.DeletionExtension_Penalty;
   return dmin(mutationPenalty, indelPenalty);
 }
 // does any aligned base pair of the alignment involve an ambiguity code (SequenceAlignment.hasAmbiguousBasepairs, [inferred])
 template <class LDS>
-XM_NOINL bool wAlHasAmbiguous(WL_T L, const WEnv& e, int ai, int alIdx) {
-  const IndexView& ix = *e.ix;
+WV_FN bool wAlHasAmbiguous(WL_T L, const WEnv& e, int ai, int alIdx) {
+  const IndexView& ix = e.ix;
   auto a = &L->al[ai];
   unsigned long long any = 0;
   const int nSeq = a->good[alIdx].nSeq;
@@ -1324,23 +1370,24 @@ XM_NOINL bool wAlHasAmbiguous(WL_T L, const WEnv& e, int ai, int alIdx) {
   return any != 0;
 }
 template <class LDS>
-XM_NOINL bool wQuicklyConfidentInBestAlignment(WL_T L, const WEnv& e, int ai, int alIdx, const WQMatch& m) {  // :494-587
+WV_FN bool wQuicklyConfidentInBestAlignment(WL_T L, const WEnv& e, int ai, int alIdx, const WQMatch& m) {  // :494-587
   if (alIdx < 0) return false;
   auto a = &L->al[ai];
   const int nSeq = a->good[alIdx].nSeq;
   for (int k = 0; k < nSeq; k++) {
+  WV_TIMER(e, WT_CONFIDENT);
     const int nb = a->good[alIdx].seq[k].nb, fb = a->good[alIdx].seq[k].firstBlock;
     for (int b = 0; b < nb; b++) if (a->pool[fb + b].lenA != a->pool[fb + b].lenB) return false;  // hasIndel
   }
   const int contig = m.c[0].contig;
   const int matchStart = wQmStartIndexB(m), matchEnd = wQmEndIndexB(m);
-  const double granularity = e.ix->dupGranularity;
+  const double granularity = e.ix.dupGranularity;
   const double penalty = a->good[alIdx].totalPenalty;
   const double numberOfMutations = (penalty + e.params.Max_PenaltySpan) / e.params.MutationPenalty;
   const double existingMutationRate = numberOfMutations / wQmQueryTotalLength(L, m);
   if (penalty <= 0 && e.params.Max_PenaltySpan < e.params.getMinPossibleNonzeroPenalty()) return true;
   const double probabilityMutationInSection = 1 - pow(1 - existingMutationRate, granularity);
-  const double acceptableProbability = 1.0 / (double)e.ix->totalForwardAndReverseSize;
+  const double acceptableProbability = 1.0 / (double)e.ix.totalForwardAndReverseSize;
   const double numberOfUnmatchedBlocksForHighConfidence = log(acceptableProbability) / log(probabilityMutationInSection);
   const double totalLengthForHighConfidence = numberOfUnmatchedBlocksForHighConfidence * granularity;
   const double matchMiddle = (double)((matchStart + matchEnd) / 2);
@@ -1348,9 +1395,9 @@ XM_NOINL bool wQuicklyConfidentInBestAlignment(WL_T L, const WEnv& e, int ai, in
   const int windowStart = j2i(matchMiddle - interestingWindow);
   const int windowEnd = j2i(matchMiddle + interestingWindow);
   bool hasNearbyDuplication = false;
-  if (mayContainDuplicationInRange(*e.ix, contig, windowStart, windowEnd)) hasNearbyDuplication = true;
+  if (mayContainDuplicationInRange(e.ix, contig, windowStart, windowEnd)) hasNearbyDuplication = true;
   else if (matchStart <= interestingWindow) hasNearbyDuplication = true;
-  else if (matchEnd >= e.ix->contigLen[contig] - interestingWindow) hasNearbyDuplication = true;
+  else if (matchEnd >= e.ix.contigLen[contig] - interestingWindow) hasNearbyDuplication = true;
   if (hasNearbyDuplication) return false;
   if (wAlHasAmbiguous(L, e, ai, alIdx)) return false;
   return true;
@@ -1365,7 +1412,7 @@ struct WResult {  // what alignToAncestralReference returns: up to 2 components,
 
 // getUnpairedAlignments :602-644 (the two sub-aligners take over both aligner slots: the paired aligner has no alignment by then)
 template <class LDS>
-XM_NOINL void wGetUnpairedAlignments(WL_T L, const WEnv& e, WResult& rr) {
+WV_FN void wGetUnpairedAlignments(WL_T L, const WEnv& e, WResult& rr) {
   if constexpr (LDS::kMates < 2) { L->status = XM_ST_INTERNAL; return; }
   rr.nComponents = 2;
   const double expectedInnerDistance = L->expectedInner;
@@ -1386,7 +1433,7 @@ XM_NOINL void wGetUnpairedAlignments(WL_T L, const WEnv& e, WResult& rr) {
       const WSeqMatch sm = wCounterMatch(L, sequenceIndex, ci);
       int minInnerDistance;
       if (sequenceIndex % 2 == 1) minInnerDistance = imax(0, sm.offset);
-      else minInnerDistance = e.ix->contigLen[sm.contig] - wSmEndB(L, e, sm);
+      else minInnerDistance = e.ix.contigLen[sm.contig] - wSmEndB(L, e, sm);
       double innerDistance = minInnerDistance;
       if (innerDistance < expectedInnerDistance) innerDistance = expectedInnerDistance;
       const double spacingPenalty = innerDistance / L->deviation;
@@ -1402,7 +1449,8 @@ XM_NOINL void wGetUnpairedAlignments(WL_T L, const WEnv& e, WResult& rr) {
 
 // one mate into LDS and its Counting_HashBlockPath reset (M/Counting_HashBlockPath.java:20-37); false: the mate has an ambiguity code
 template <class LDS>
-XM_NOINL bool wMateInit(WL_T L, const WEnv& e, int mi, const uint8_t* codes, int len, bool reverseComplement) {
+WV_FN bool wMateInit(WL_T L, const WEnv& e, int mi, const uint8_t* codes, int len, bool reverseComplement) {
+  WV_TIMER(e, WT_MATEINIT);
   auto M = &L->m[mi];
   XM_GLOBAL(const uint8_t)* const g = (XM_GLOBAL(const uint8_t)*)codes;
   unsigned long long bad = 0;
@@ -1441,7 +1489,8 @@ XM_NOINL bool wMateInit(WL_T L, const WEnv& e, int mi, const uint8_t* codes, int
 
 // alignToAncestralReference :306-484
 template <class LDS>
-XM_NOINL void wAlignRead(WL_T L, const WEnv& e, const ReadIn& in, WResult& rr) {
+WV_FN void wAlignRead(WL_T L, const WEnv& e, const ReadIn& in, WResult& rr) {
+  WV_TIMER(e, WT_TOTAL);
   rr.nComponents = 1; rr.single[0] = -1; rr.empty[0] = 0; rr.aligner[0] = -1; rr.single[1] = -1; rr.empty[1] = 0; rr.aligner[1] = -1;
   L->status = 0;
   L->why = 0;
@@ -1456,7 +1505,7 @@ XM_NOINL void wAlignRead(WL_T L, const WEnv& e, const ReadIn& in, WResult& rr) {
   if (in.nMates > LDS::kMates) { L->status = XM_ST_WAVE_FALLBACK; return; }
   for (int m = 0; m < in.nMates; m++) {
     if (in.mateLen[m] > WV_MAXLEN || in.mateLen[m] < 1) { { L->status = XM_ST_WAVE_FALLBACK; L->why = 17; } return; }
-    if (in.mateLen[m] > e.ix->maxHashedLength) { L->status = XM_ST_NEED_GROW; return; }
+    if (in.mateLen[m] > e.ix.maxHashedLength) { L->status = XM_ST_NEED_GROW; return; }
   }
   if (e.dc) { e.dc->reads++; for (int m = 0; m < in.nMates; m++) e.dc->readBytes += (unsigned long long)((in.mateLen[m] + 1) / 2); }
   int queryLength = 0;

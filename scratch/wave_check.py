@@ -18,7 +18,7 @@ else:
     batch = pe_batch(m1, m2)
 t=time.time(); R = o.OracleReference([("ecoli_syn", ref)], mode="mapper"); want = R.align(batch, o.make_params()); print("oracle %.1fs" % (time.time()-t))
 t=time.time(); S = hs.SimReference([("ecoli_syn", ref)], mode="mapper"); got = S.align(batch, o.make_params()); print("sim %.1fs" % (time.time()-t))
-cnt = (C.c_longlong*16)(); hs.lib().xmsim_wave_status_counts(cnt); print("wave status counts", list(cnt)); w=(C.c_longlong*64)(); hs.lib().xmsim_wave_why_counts(w); print("why", {i:w[i] for i in range(64) if w[i]})
+print("wave status counts", list(hs.wave_status_counts())); w=(C.c_longlong*64)(); hs.lib().xmsim_wave_why_counts(w); print("why", {i:w[i] for i in range(64) if w[i]})
 print("equal:", streams_equal(got, want))
 if not streams_equal(got, want): print(first_difference(got, want, nq))
 print("counters sim   ", list(got.counters[:11])); print("counters oracle", list(want.counters[:11]) if hasattr(want,'counters') and want.counters is not None else None)

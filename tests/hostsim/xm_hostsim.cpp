@@ -17,6 +17,7 @@
 using namespace xm;
 
 static thread_local std::string g_err;
+static int g_waveMode = -1;  // -1: from XMSIM_WAVE (default 0)
 static long long g_waveStatus[16];
 static long long g_waveWhy[64];
 static long long g_markHist[6][128];  // high-water marks of the wave form per read: chunks, counters, history, pending, query matches, alignments
@@ -87,7 +88,7 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       // the wave-per-read form first (XMSIM_WAVE: 1 = its light tier, 2 = light then heavy tier), exactly as the product's passes 0 / 0b run
       // it (mapper_amd/csrc/xm_wave.h; a WV_PAR region is a loop over the 64 lanes here); reads it does not finish go through the
       // lane-per-read sequence below
-      static const int waveMode = getenv("XMSIM_WAVE") ? atoi(getenv("XMSIM_WAVE")) : 0;
+      const int waveMode = g_waveMode >= 0 ? g_waveMode : (getenv("XMSIM_WAVE") ? atoi(getenv("XMSIM_WAVE")) : 0);
       if (waveMode > 0) {
         typedef WaveLdsT<WCfgLightPE> LightLds;
         typedef WaveLdsT<WCfgHeavy> HeavyLds;
@@ -98,7 +99,7 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
         for (int tier = 0; tier < waveMode && tier < 2 && !finished; tier++) {
           DevCounters before = dc;
           WEnv e;
-          e.ix = &idx->view; e.params = params; e.dc = &dc; e.mateBase[0] = in.mate[0]; e.mateBase[1] = in.mate[1]; e.tier = tier;
+          e.ix = idx->view; e.params = params; e.dc = &dc; e.mateBase[0] = in.mate[0]; e.mateBase[1] = in.mate[1]; e.tier = tier;
           Caps caps = makeCaps(4);
           caps.heavyAllowed = 2;
           Arena tmp;
@@ -228,8 +229,10 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
   } catch (std::exception& e) { g_err = e.what(); return 1; }
 }
 
+// 0: lane-per-read sequence only, 1: the wave form's light tier first, 2: light then heavy tier first (the product's sequence)
+void xmsim_set_wave_mode(int mode) { g_waveMode = mode; }
 // how the wave form left the reads of all calls so far, by status (0 = finished there)
-void xmsim_wave_status_counts(long long* out) { for (int i = 0; i < 16; i++) out[i] = g_waveStatus[i]; }
+void xmsim_wave_status_counts(long long* out, int reset) { for (int i = 0; i < 16; i++) { out[i] = g_waveStatus[i]; if (reset) g_waveStatus[i] = 0; } }
 void xmsim_wave_why_counts(long long* out) { for (int i = 0; i < 64; i++) out[i] = g_waveWhy[i]; }
 
 void xmsim_result_free(xm_result* r) {

@@ -42,6 +42,8 @@ def lib():
         L.xmsim_dup_keys.restype = C.c_int64
         L.xmsim_pyramid_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
         L.xmsim_pyramid_dump.restype = C.c_int64
+        L.xmsim_set_wave_mode.argtypes = [C.c_int]
+        L.xmsim_wave_status_counts.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -126,3 +128,15 @@ def pyramid_dump(codes):
     n = L.xmsim_pyramid_dump(codes.ctypes.data, len(codes), out.ctypes.data, cap)
     assert 0 <= n <= cap
     return out[:n]
+
+
+def set_wave_mode(mode):
+    """0: lane-per-read pass sequence only; 1: the wave-per-read form's light tier first; 2: light then heavy tier first (what the product runs)."""
+    lib().xmsim_set_wave_mode(mode)
+
+
+def wave_status_counts(reset=True):
+    """How the wave form left the reads since the last reset: index = status (0 finished there, 8 left to the lane-per-read passes, 9 handed to the heavy tier)."""
+    out = np.zeros(16, dtype=np.int64)
+    lib().xmsim_wave_status_counts(out.ctypes.data, 1 if reset else 0)
+    return out
