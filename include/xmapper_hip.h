@@ -85,8 +85,8 @@ typedef struct xm_result {
   /* counters of this call: 0 reads, 1 bucket-header probes (PackedMap.getNumMatchesLowerBound), 2 bucket fetches (PackedMap.get),
    * 3 positions fetched, 4 candidates extended (QueryMatch_Aligner.doAlign), 5 PathAligner calls, 6 PathAligner nodes, 7 quick accepts,
    * 8 alignments written, 9 reference-window bytes (4-bit), 10 read bytes (4-bit), 11 reads rerun with a larger scratch scale,
-   * 12-15 kernel microseconds by pass: 12 light pass, 13 gapped-chain passes with deferred searches, 14 search kernels, 15 gapped / rerun
-   * passes with inline searches */
+   * 12-15 kernel microseconds by pass: 12 wave-per-read light tier (+ lane-per-read light pass of what the wave form left), 13 wave-per-read
+   * chain tier, 14 wave-per-read search tier, 15 lane-per-read gapped / rerun passes */
   int64_t counters[16];
   double kernel_ms;   /* sum of the align (and search) kernels' launch durations (HIP events on the launch stream) */
   double h2d_ms, d2h_ms;  /* batch upload; prefix sums + query-order gather + copy of the four streams to the host */

@@ -233,16 +233,22 @@ __global__ void __launch_bounds__(256) xm_classify_kernel(const int64_t* todo, l
   else atomicMin(&ctl->errQuery, (unsigned long long)q);
 }
 
-// after a pass of the wave-per-read form (xm_wave_kernel.hip): reads for its heavy tier, reads it leaves to the lane-per-read passes
-struct WaveCtl { unsigned long long nHeavy, nFallback, errQuery; };
-__global__ void __launch_bounds__(256) xm_wave_classify_kernel(const int64_t* todo, long long nTodo, const int32_t* status, int64_t* listHeavy, int64_t* listFallback, WaveCtl* ctl) {
+// after a pass of the wave-per-read form (xm_wave_kernel.hip): reads for the next tier, reads with a waiting search request, reads left
+// to the lane-per-read passes
+struct WaveCtl { unsigned long long nNext, nSearch, nFallback, errQuery; };
+__global__ void __launch_bounds__(256) xm_wave_classify_kernel(const int64_t* todo, long long nTodo, const int32_t* status, int64_t* listNext, int32_t* slotOfOut, int64_t* listSearch,
+                                                               int64_t* listFallback, WaveCtl* ctl) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nTodo) return;
   const int64_t q = todo ? todo[i] : (int64_t)i;
   const int32_t st = status[q] & 0xFF;
   if (st == XM_OK) return;
-  if (st == 9 /* XM_ST_WAVE_GAPPED */ && listHeavy) listHeavy[atomicAdd(&ctl->nHeavy, 1ull)] = q;
-  else if (st == 8 /* XM_ST_WAVE_FALLBACK */ || st == 9) listFallback[atomicAdd(&ctl->nFallback, 1ull)] = q;
+  if (st == 9 /* XM_ST_WAVE_GAPPED */ && listNext) {
+    const unsigned long long pos = atomicAdd(&ctl->nNext, 1ull);
+    listNext[pos] = q;
+    if (slotOfOut) slotOfOut[q] = (int32_t)pos;  // the read's memo (it keeps it through the later tiers)
+  } else if (st == 10 /* XM_ST_WAVE_SEARCH */ && listSearch) listSearch[atomicAdd(&ctl->nSearch, 1ull)] = q;
+  else if (st == 8 /* XM_ST_WAVE_FALLBACK */ || st == 9 || st == 10) listFallback[atomicAdd(&ctl->nFallback, 1ull)] = q;
   else atomicMin(&ctl->errQuery, (unsigned long long)q);
 }
 
@@ -468,7 +474,9 @@ struct xm_index {
   DevBuf<uint8_t> dMemo;
   DevBuf<PNode> dWaveNodes;  // per wave: node payloads of its LDS-mode search
   // wave-per-read passes
-  DevBuf<int64_t> dListWaveHeavy, dListFallback;
+  DevBuf<int64_t> dListWaveHeavy, dListWaveNext, dListWaveSearch[2], dListFallback;
+  DevBuf<uint8_t> dWaveMemo;
+  DevBuf<int32_t> dWaveSlotOf;
   DevBuf<WaveCtl> dWaveCtl;
   DevBuf<uint8_t> dWaveArenas;
   DevBuf<PNode> dWaveNodes2;
@@ -941,67 +949,113 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       idx->dRegionOf.ensure((size_t)nq);
       HIP_CHECK(hipMemsetAsync(idx->dRegionOf.p, 0xFF, sizeof(int32_t) * (size_t)nq, s));
     }
-    // ---- passes 0 / 0b: the wave-per-read form (xm_wave_kernel.hip).  Light tier over every read (seed, vote, ungapped alignment, accept),
-    // then its heavy tier over the reads that need the gapped chain or more LDS.  What neither takes (ambiguity codes in the read,
-    // mates longer than 256 bases, overlapping mates, a structure that outgrows LDS) goes through the lane-per-read passes below.
+    // ---- passes 0: the wave-per-read form (xm_wave_kernel.hip).  Light tier over every read (seed, vote, ungapped alignment, accept); chain
+    // tier over the reads that need the gapped chain (or more LDS): a read that meets a PathAligner search leaves the request in its memo, the
+    // search kernel runs all waiting searches (one wavefront each), and those reads run again with the results, until none waits; then the
+    // same with the largest capacities for the reads that outgrew the chain tier's.  What the wave form does not take (ambiguity codes in the
+    // read or its reference window, mates longer than 256 bases, overlapping mates, a structure that outgrows LDS) goes through the
+    // lane-per-read passes below.
     if (envInt("XM_WAVE", 1) != 0 && idx->residentMaxLen <= 256) {
       const bool tracePasses = envInt("XM_TRACE_PASSES", 0) != 0;
-      idx->dListWaveHeavy.ensure((size_t)nq); idx->dListFallback.ensure((size_t)nq); idx->dWaveCtl.ensure(1);
-      WaveCtl wctl0{0, 0, ~0ull};
-      HIP_CHECK(hipMemcpyAsync(idx->dWaveCtl.p, &wctl0, sizeof(wctl0), hipMemcpyHostToDevice, s));
+      idx->dListWaveHeavy.ensure((size_t)nq); idx->dListWaveNext.ensure((size_t)nq); idx->dListFallback.ensure((size_t)nq); idx->dWaveCtl.ensure(1);
+      idx->dWaveSlotOf.ensure((size_t)nq);
+      WaveCtl wctl{0, 0, 0, ~0ull};
+      HIP_CHECK(hipMemcpyAsync(idx->dWaveCtl.p, &wctl, sizeof(wctl), hipMemcpyHostToDevice, s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
-      const int heavyTier = (int)envInt("XM_WAVE_HEAVY", 1);
-      const int64_t* wTodo = nullptr;
-      long long wN = nq;
-      for (int tier = 0; tier < 2 && wN > 0; tier++) {
-        if (tier == 1 && !heavyTier) break;
+      const int lastTier = (int)envInt("XM_WAVE_TIERS", 3) - 1;  // (experiment knob: 1 = light tier only, 2 = light + chain tier)
+      int sWaves = 4, sLds = 1, sPerSimd = 4, memoBytes = 1, nodesPerWave = 1;
+      xmSearchGeometry(&sWaves, &sLds, &sPerSimd, &memoBytes, &nodesPerWave);
+      unsigned long long fallbackSoFar = 0;
+      // one launch of a tier over `list` (null = all reads) + classification; returns the counts of the lists it filled
+      auto launchTier = [&](int tier, const int64_t* list, long long n, int64_t* listNext, int32_t* slotOfOut, int64_t* listSearch) {
         WaveLaunch wl;
-        wl.config = tier == 0 ? (idx->residentAnyPaired ? 1 : 0) : 2;
+        wl.config = tier == 0 ? (idx->residentAnyPaired ? 1 : 0) : (tier == 1 ? (idx->residentAnyPaired ? 3 : 2) : 4);
         int wavesPerBlock = 1, ldsPerBlock = 1, wavesPerSimd = 1;
         xmWaveGeometry(wl.config, &wavesPerBlock, &ldsPerBlock, &wavesPerSimd);
         long long blocksPerCU = std::min<long long>((160 * 1024) / ldsPerBlock, (long long)(wavesPerSimd * 4) / wavesPerBlock);
         if (blocksPerCU < 1) blocksPerCU = 1;
-        wl.itemsPerFetch = (int)envInt(tier == 0 ? "XM_WAVE_FETCH" : "XM_WAVE_HEAVY_FETCH", tier == 0 ? 8 : 1);
-        long long blocks = std::min<long long>((long long)idx->numCUs * blocksPerCU, (wN + (long long)wavesPerBlock * wl.itemsPerFetch - 1) / ((long long)wavesPerBlock * wl.itemsPerFetch));
+        wl.itemsPerFetch = (int)envInt(tier == 0 ? "XM_WAVE_FETCH" : "XM_WAVE_CHAIN_FETCH", tier == 0 ? 8 : 1);
+        long long blocks = std::min<long long>((long long)idx->numCUs * blocksPerCU, (n + (long long)wavesPerBlock * wl.itemsPerFetch - 1) / ((long long)wavesPerBlock * wl.itemsPerFetch));
         if (blocks < 1) blocks = 1;
         wl.grid = (int)blocks; wl.block = wavesPerBlock * 64;
-        wl.ix = idx->view; wl.params = params; wl.batch = bv; wl.todo = wTodo; wl.nTodo = wN; wl.out = ov; wl.nextItem = idx->dCursors.p + 2; wl.counters = idx->dCounters.p;
-        wl.arenas = nullptr; wl.arenaBytes = 0; wl.chainScale = gappedScale; wl.waveNodes = nullptr;
-        if (tier == 1) {
-          const size_t chainArena = arenaUnit * (size_t)gappedScale;
-          wl.arenaBytes = (unsigned long long)((chainArena - arenaPersistBytes(chainArena)) & ~(size_t)15);
-          idx->dWaveArenas.ensure((size_t)blocks * wavesPerBlock * (size_t)wl.arenaBytes);
-          idx->dWaveNodes2.ensure((size_t)blocks * wavesPerBlock * XM_PAL_NODES);
-          wl.arenas = idx->dWaveArenas.p; wl.waveNodes = idx->dWaveNodes2.p;
+        wl.ix = idx->view; wl.params = params; wl.batch = bv; wl.todo = list; wl.nTodo = n; wl.out = ov; wl.nextItem = idx->dCursors.p + 2; wl.counters = idx->dCounters.p;
+        wl.memoBase = (WMemo*)idx->dWaveMemo.p; wl.slotOf = idx->dWaveSlotOf.p;
+        wl.waveNodes = nullptr;
+        if (tier >= 1 && envInt("XM_WAVE_INLINE_SEARCH", 1) != 0) {  // (0: every search through the memo and the search kernel)
+          idx->dWaveNodes2.ensure(((size_t)blocks * wavesPerBlock * (size_t)xmWaveInlineNodeBytes() + sizeof(PNode) - 1) / sizeof(PNode));
+          wl.waveNodes = idx->dWaveNodes2.p;
         }
         HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
+        HIP_CHECK(hipMemsetAsync(idx->dWaveCtl.p, 0, 2 * sizeof(unsigned long long), s));  // nNext, nSearch
         HIP_CHECK(hipEventRecord(e0, s));
         const int rc = xmWaveLaunch(wl, (void*)s);
         if (rc != 0) throw std::runtime_error(std::string("wave kernel launch: ") + hipGetErrorString((hipError_t)rc));
         HIP_CHECK(hipEventRecord(e1, s));
-        hipLaunchKernelGGL(xm_wave_classify_kernel, dim3((unsigned)((wN + 255) / 256)), dim3(256), 0, s, wTodo, wN, idx->dStatus.p, tier == 0 && heavyTier ? idx->dListWaveHeavy.p : (int64_t*)nullptr,
-                           idx->dListFallback.p, idx->dWaveCtl.p);
+        hipLaunchKernelGGL(xm_wave_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, list, n, idx->dStatus.p, listNext, slotOfOut, listSearch, idx->dListFallback.p, idx->dWaveCtl.p);
         HIP_CHECK(hipGetLastError());
-        WaveCtl wctl;
         HIP_CHECK(hipMemcpyAsync(&wctl, idx->dWaveCtl.p, sizeof(wctl), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(cursors, idx->dCursors.p, sizeof(cursors), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
         kernelMs += ms;
-        res->counters[tier == 0 ? 12 : 13] += (int64_t)(ms * 1000.0);
+        res->counters[tier == 0 ? 12 : 13] += (int64_t)(ms * 1000.0);  // kernel microseconds: light tier / chain tiers
         launches++;
-        if (tracePasses) fprintf(stderr, "[xm] wave pass tier %d config %d: reads %lld, %d x %d threads, %d per fetch: %.3f ms -> heavy %llu fallback %llu\n", tier, wl.config, wN, wl.grid, wl.block,
-                                 wl.itemsPerFetch, ms, wctl.nHeavy, wctl.nFallback);
+        if (tracePasses) fprintf(stderr, "[xm] wave tier %d config %d: reads %lld, %d x %d threads: %.3f ms -> next tier %llu, searches %llu, lane-per-read %llu (so far)\n", tier, wl.config, n, wl.grid,
+                                 wl.block, ms, listNext ? wctl.nNext : 0ull, wctl.nSearch, wctl.nFallback);
         if (wctl.errQuery != ~0ull) {
           int32_t code = 0;
           HIP_CHECK(hipMemcpy(&code, idx->dStatus.p + wctl.errQuery, sizeof(code), hipMemcpyDeviceToHost));
           throw std::runtime_error("Failed to align query " + std::to_string(wctl.errQuery) + ": the reference implementation would have thrown here (status " + std::to_string(code & 0xFF) + ")");
         }
-        if (tier == 0) { wTodo = idx->dListWaveHeavy.p; wN = (long long)wctl.nHeavy; }
-        else wN = 0;
-        todo = idx->dListFallback.p;
-        nTodo = (long long)wctl.nFallback;
+        fallbackSoFar = wctl.nFallback;
+      };
+      auto launchSearches = [&](const int64_t* list, long long n) {
+        SearchLaunch sl;
+        long long blocks = std::min<long long>((long long)idx->numCUs * std::min<long long>((160 * 1024) / sLds, (long long)(sPerSimd * 4) / sWaves), (n + sWaves - 1) / sWaves);
+        if (blocks < 1) blocks = 1;
+        sl.grid = (int)blocks; sl.block = sWaves * 64;
+        sl.ix = idx->view; sl.params = params; sl.batch = bv; sl.list = list; sl.n = n; sl.memoBase = (WMemo*)idx->dWaveMemo.p; sl.slotOf = idx->dWaveSlotOf.p; sl.nextItem = idx->dCursors.p + 2;
+        idx->dWaveArenas.ensure((size_t)blocks * sWaves * (size_t)nodesPerWave);  // (node payloads: bytes per wave)
+        sl.waveNodes = idx->dWaveArenas.p;
+        HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
+        HIP_CHECK(hipEventRecord(e0, s));
+        const int rc = xmSearchLaunch(sl, (void*)s);
+        if (rc != 0) throw std::runtime_error(std::string("search kernel launch: ") + hipGetErrorString((hipError_t)rc));
+        HIP_CHECK(hipEventRecord(e1, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        kernelMs += ms;
+        res->counters[14] += (int64_t)(ms * 1000.0);  // search kernel microseconds
+        launches++;
+        if (tracePasses) fprintf(stderr, "[xm] search kernel: %lld searches, %d x %d threads: %.3f ms\n", n, sl.grid, sl.block, ms);
+      };
+      // light tier
+      launchTier(0, nullptr, nq, lastTier >= 1 ? idx->dListWaveHeavy.p : (int64_t*)nullptr, idx->dWaveSlotOf.p, nullptr);
+      long long nChain = lastTier >= 1 ? (long long)wctl.nNext : 0;
+      if (nChain > 0) {
+        idx->dWaveMemo.ensure((size_t)nChain * (size_t)memoBytes);
+        if (xmMemoInitLaunch((WMemo*)idx->dWaveMemo.p, nChain, (void*)s) != 0) throw std::runtime_error("memo init launch failed");
+        idx->dListWaveSearch[0].ensure((size_t)nChain); idx->dListWaveSearch[1].ensure((size_t)nChain);
+        long long nBig = 0;  // reads for the chain tier with the largest capacities (dListWaveNext, filled behind what is already there)
+        for (int tier = 1; tier <= 2 && tier <= lastTier; tier++) {
+          const int64_t* list = tier == 1 ? idx->dListWaveHeavy.p : idx->dListWaveNext.p;
+          long long n = tier == 1 ? nChain : nBig;
+          int which = 0, rounds = 0;
+          while (n > 0) {
+            // (tier 1 appends its hand-overs to dListWaveNext behind those of its earlier rounds)
+            launchTier(tier, list, n, tier == 1 && lastTier >= 2 ? idx->dListWaveNext.p + nBig : (int64_t*)nullptr, nullptr, idx->dListWaveSearch[which].p);
+            if (tier == 1 && lastTier >= 2) nBig += (long long)wctl.nNext;
+            const long long nSearch = (long long)wctl.nSearch;
+            if (nSearch == 0) break;
+            if (++rounds > 4 * 16) throw std::runtime_error("internal error: search rounds do not end");
+            launchSearches(idx->dListWaveSearch[which].p, nSearch);
+            list = idx->dListWaveSearch[which].p; n = nSearch;
+            which ^= 1;
+          }
+        }
       }
+      todo = idx->dListFallback.p;
+      nTodo = (long long)fallbackSoFar;
       HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
     }
     while (nTodo > 0) {

@@ -24,7 +24,9 @@ struct OutView {
   int32_t* intLen; int32_t* dblLen;     // [nq]
 };
 
-// One launch of the wave-per-read form (xm_wave_kernel.hip).  config: 0 single-end light tier, 1 paired light tier, 2 heavy tier.
+// One launch of the wave-per-read form (xm_wave_kernel.hip).  config: 0 / 1 light tier (single-end / with pairs), 2 / 3 chain tier,
+// 4 chain tier with the largest capacities.
+struct WMemo;
 struct WaveLaunch {
   int config;
   int grid, block;
@@ -36,14 +38,30 @@ struct WaveLaunch {
   OutView out;
   unsigned long long* nextItem;
   DevCounters* counters;
-  uint8_t* arenas;           // heavy tier: one scratch arena per wave (the gapped chain's temporaries)
-  unsigned long long arenaBytes;
-  int chainScale;            // heavy tier: capacities of the gapped chain (makeCaps)
-  void* waveNodes;           // heavy tier: per-wave node payloads of PathAligner's LDS-mode search (PNode[waves * XM_PAL_NODES])
+  WMemo* memoBase;           // chain tiers: the reads' memos (search requests and results), memo of read q = memoBase[slotOf[q]]
+  const int32_t* slotOf;
+  void* waveNodes;           // chain tiers: per wave, the node payloads of its inline searches (xmWaveInlineNodeBytes() each)
   int itemsPerFetch;         // reads a wave takes from the work counter at a time
 };
-// waves per workgroup and LDS bytes per workgroup of a configuration, and the launch itself (returns hipError_t as int)
+// The search kernel: one wavefront per waiting search request (PathAligner's best-first emulation of xm_extend.h).
+struct SearchLaunch {
+  int grid, block;
+  IndexView ix;
+  Params params;
+  BatchView batch;
+  const int64_t* list;       // reads with a waiting request
+  long long n;
+  WMemo* memoBase;
+  const int32_t* slotOf;
+  unsigned long long* nextItem;
+  void* waveNodes;           // per wave: the node payloads of its search (WSNode[waves * WS_NODES])
+};
+// waves per workgroup, LDS bytes per workgroup and waves per SIMD a configuration is compiled for; the launches (return hipError_t as int)
+int xmWaveInlineNodeBytes();
 void xmWaveGeometry(int config, int* wavesPerBlock, int* ldsBytesPerBlock, int* wavesPerSimd);
 int xmWaveLaunch(const WaveLaunch& a, void* stream);
+void xmSearchGeometry(int* wavesPerBlock, int* ldsBytesPerBlock, int* wavesPerSimd, int* memoBytes, int* nodeBytesPerWave);
+int xmSearchLaunch(const SearchLaunch& a, void* stream);
+int xmMemoInitLaunch(WMemo* memoBase, long long n, void* stream);
 
 }  // namespace xm

@@ -23,6 +23,7 @@
 namespace xm {
 
 constexpr int32_t XM_ST_WAVE_FALLBACK = 8;  // the wave form does not take this read: the lane-per-read passes align it
+constexpr int32_t XM_ST_WAVE_SEARCH = 10;   // chain tier: a PathAligner search request is waiting in the read's memo (search kernel, then the read runs again)
 constexpr int32_t XM_ST_WAVE_GAPPED = 9;    // light tier: the read needs the heavy tier of the wave form (gapped chain, or a structure outgrew the light capacities)
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -61,9 +62,12 @@ constexpr int WV_MAXBLOCKS = 8;              // AlignedBlocks per SequenceAlignm
 constexpr int WV_MAXHITS = 64;               // staged hits per round
 // A configuration fixes the capacities of one kernel instance.  The light tiers are sized for what nearly every read needs
 // (measured high-water marks: profiles/r02/NOTES.md); a read that outgrows one leaves with XM_ST_WAVE_FALLBACK.
-struct WCfgLightSE { static constexpr int kTier = 0, kMates = 1, kChunks = 6, kCounters = 8, kHistory = 12, kPending = 24, kQM = 4, kGood = 3, kPool = 12; };
-struct WCfgLightPE { static constexpr int kTier = 0, kMates = 2, kChunks = 12, kCounters = 8, kHistory = 12, kPending = 24, kQM = 4, kGood = 3, kPool = 16; };
-struct WCfgHeavy { static constexpr int kTier = 1, kMates = 2, kChunks = 40, kCounters = 24, kHistory = 128, kPending = 96, kQM = 12, kGood = 6, kPool = 40; };
+struct WCfgLightSE { static constexpr bool kLast = false; static constexpr int kTier = 0, kMates = 1, kChunks = 6, kCounters = 8, kHistory = 12, kPending = 24, kQM = 4, kGood = 3, kPool = 12, kMRef = 1, kMQ = 1, kCountMap = 1, kPieces = 1, kPiecePool = 1; };
+struct WCfgLightPE { static constexpr bool kLast = false; static constexpr int kTier = 0, kMates = 2, kChunks = 12, kCounters = 8, kHistory = 12, kPending = 24, kQM = 4, kGood = 3, kPool = 16, kMRef = 1, kMQ = 1, kCountMap = 1, kPieces = 1, kPiecePool = 1; };
+// tier 1: + the gapped chain (PathAligner's searches go through the read's memo to the search kernel); WCfgHeavy: the same with the largest capacities
+struct WCfgMidSE { static constexpr bool kLast = false; static constexpr int kTier = 1, kMates = 1, kChunks = 24, kCounters = 8, kHistory = 24, kPending = 48, kQM = 4, kGood = 3, kPool = 16, kMRef = 384, kMQ = WV_MAXLEN, kCountMap = 32, kPieces = 16, kPiecePool = 48; };
+struct WCfgMidPE { static constexpr bool kLast = false; static constexpr int kTier = 1, kMates = 2, kChunks = 28, kCounters = 8, kHistory = 24, kPending = 48, kQM = 4, kGood = 3, kPool = 24, kMRef = 384, kMQ = WV_MAXLEN, kCountMap = 32, kPieces = 16, kPiecePool = 48; };
+struct WCfgHeavy { static constexpr bool kLast = true; static constexpr int kTier = 1, kMates = 2, kChunks = 40, kCounters = 24, kHistory = 128, kPending = 96, kQM = 12, kGood = 6, kPool = 40, kMRef = 384, kMQ = WV_MAXLEN, kCountMap = 32, kPieces = 16, kPiecePool = 64; };
 
 struct WCounter {  // M/HashBlockMatch_Counter.java + its SequenceMatch
   int32_t offset, contig, numMatches, numDistinctMismatches, lastMismatchedPosition, lastMatchedBlockId, historyProcessedIndex, priority;
@@ -118,11 +122,22 @@ struct WAlignerT {  // QueryMatch_Aligner
 };
 
 template <class CFG>
+struct WMatcherT {  // HashBlock_Matcher: the k-mer codes of the reference window and of the query instead of per-section tables (xm_wave_chain.h)
+  int32_t referenceStart, referenceLength, blockLength, sectionLength, maxSectionIndex, nSections;
+  unsigned long long presentLo, presentHi;   // locations[i] != null
+  int16_t rCode[CFG::kMRef];
+  int16_t qCode[CFG::kMQ];
+};
+struct WPiece { int32_t nb, firstBlock, referenceReversed, pad; double totalPenalty, alignedPenalty; };
+
+template <class CFG>
 struct WaveLdsT {
+  static constexpr bool kLast = CFG::kLast;
   static constexpr int kTier = CFG::kTier, kMates = CFG::kMates, kChunks = CFG::kChunks, kCounters = CFG::kCounters, kHistory = CFG::kHistory, kPending = CFG::kPending, kQM = CFG::kQM,
-                       kGood = CFG::kGood, kPool = CFG::kPool;
+                       kGood = CFG::kGood, kPool = CFG::kPool, kMRef = CFG::kMRef, kMQ = CFG::kMQ, kCountMap = CFG::kCountMap, kPieces = CFG::kPieces, kPiecePool = CFG::kPiecePool;
   int32_t status, nMates, listIdCounter, nChunksUsed;
-  int32_t why, tier;  // where a read left the wave form (diagnostics); 0 light tier, 1 heavy tier
+  int32_t why, tier;  // where a read left the wave form (diagnostics); tier of the kernel
+  int32_t searchCursor, padSearch;  // how many pathAlign calls this run of the read has made
   int32_t mateLen[2];
   double expectedInner, deviation;
   WMateT<CFG> m[CFG::kMates];
@@ -136,7 +151,19 @@ struct WaveLdsT {
   WQMatch filtered[CFG::kQM]; int32_t nFiltered;
   WAlignerT<CFG> al[CFG::kMates];
   ABlock candBlocks[2][WV_MAXBLOCKS];
+  // the gapped chain (xm_wave_chain.h; tiers 1 and 2)
+  WMatcherT<CFG> mt[3];                       // HashBlock_Matchers: slot A (outer HashBlock_Aligner), B (inner), T (temporaries)
+  int32_t cmKeys[CFG::kCountMap], cmVals[CFG::kCountMap], cmN, padCm;  // CountMap of the running analyzePenalty
+  WPiece pieces[2][CFG::kPieces];             // BlockAligner: the two piece lists
+  ABlock piecePool[2][CFG::kPiecePool];
+  ABlock scratchBlocks[WV_MAXBLOCKS];
 };
+
+// ---------------------------------------------------------------- search requests and results of a read (HBM), see wPathAlign in xm_wave_chain.h
+constexpr int WV_MEMO_MAX = 16;  // searches of one read the memo holds (a read that needs more is left to the lane-per-read passes)
+struct WSearchResult { int32_t ok, nb, status, nodesPut; double totalPenalty, alignedPenalty; ABlock blocks[WV_MAXBLOCKS]; };  // ok: 1 alignment, 0 null, -1 failed (status)
+struct WSearchReq { int32_t seqAId, contig, qsStart, qsEnd, rsStart, rsEnd, predictedBestOffset, confident, startingInsertionStartFree, pad; double maxIns, maxDel, maxErrorRate; };
+struct WMemo { int32_t count, pending, pad0, pad1; WSearchReq req; WSearchResult res[WV_MEMO_MAX]; };
 
 struct WEnv {  // what a wave carries in registers
   IndexView ix;                 // by value: with the wave functions inlined these stay in scalar registers (kernel arguments)
@@ -145,7 +172,9 @@ struct WEnv {  // what a wave carries in registers
   const uint8_t* mateBase[2];   // the mates as given in the batch (HBM), for the gapped chain
   int32_t tier;                 // 0 light (no gapped chain), 1 heavy
   const Caps* caps;             // heavy tier: scratch capacities of the gapped chain
-  Arena* tmp;                   // heavy tier: the wave's scratch arena in HBM
+  Arena* tmp;                   // (unused by the wave tiers)
+  WMemo* memo;                  // chain tiers: the read's memo (searches that outgrow the inline capacities)
+  struct WSNode* searchNodes;   // chain tiers: the wave's node payload buffer in HBM (WSearchLdsInline::kNodes entries)
 };
 
 #define WL_T XM_LDSP(LDS)*
@@ -165,7 +194,7 @@ struct WTimer {
 enum { WT_TOTAL = 0, WT_WALK = 2, WT_STEP = 3, WT_UNGAPPED = 4, WT_HITS = 5, WT_CHAIN = 6, WT_CONFIDENT = 10, WT_ALIGNMATCH = 11, WT_MATEINIT = 12, WT_WRITE = 13, WT_OPTIMISTIC = 14 };
 // a structure outgrew its capacity: the light tier hands the read to the heavy tier, the heavy tier to the lane-per-read kernel
 template <class LDS>
-XM_INL int32_t wOverflowStatus(WL_T L) { return LDS::kTier == 0 ? XM_ST_WAVE_GAPPED : XM_ST_WAVE_FALLBACK; }
+XM_INL int32_t wOverflowStatus(WL_T L) { return LDS::kLast ? XM_ST_WAVE_FALLBACK : XM_ST_WAVE_GAPPED; }
 
 // ---------------------------------------------------------------- sequences
 template <class LDS>
@@ -1080,51 +1109,10 @@ WV_FN double wUngappedPenalty(WL_T L, const WEnv& e, int seqAId, int contig, int
   return total;
 }
 
-// the gapped chain of xm_extend.h for one candidate (heavy tier): SkipHighAmbiguity -> HashBlock_Aligner -> BlockAligner -> ...
-template <class LDS>
-WV_FN bool wGappedChain(WL_T L, const WEnv& e, int seqAId, int contig, const Section& qs, const Section& rs, const Params& sub, Analysis& an, WSa& out, int slot) {
-  WV_TIMER(e, WT_CHAIN);
-  Arena& tmp = *e.tmp;
-  const size_t mark = tmp.used;
-  int32_t status = 0;
-  ExtEnv x;
-  x.caps = e.caps; x.dc = e.dc; x.status = &status; x.tmp = e.tmp;
-  const int mi = seqAId >> 1;
-  x.query.base = e.mateBase[mi]; x.query.len = L->mateLen[mi]; x.query.rc = (uint8_t)(seqAId & 1); x.query.id = (uint8_t)seqAId;
-  x.reference = refView(e.ix, contig, false);
-  x.contig = contig;
-  x.memo = nullptr; x.memoCursor = nullptr; x.heavyHint = nullptr;
-  Matcher* slots = arenaArray<Matcher>(tmp, 3);
-  ABlock* blocks = arenaArray<ABlock>(tmp, (size_t)e.caps->maxBlocks);
-  if (tmp.overflow) { { L->status = XM_ST_WAVE_FALLBACK; L->why = 11; } tmp.overflow = false; tmp.used = mark; return false; }
-  for (int i = 0; i < 3; i++) {
-    slots[i].present = arenaArray<uint8_t>(tmp, e.caps->maxSections);
-    slots[i].tables = arenaArray<int16_t>(tmp, e.caps->matcherEntries);
-    slots[i].tableCap = e.caps->matcherEntries;
-    slots[i].maxSections = e.caps->maxSections;
-    slots[i].nSections = 0;
-    slots[i].sectionLength = 0;
-  }
-  if (tmp.overflow) { { L->status = XM_ST_WAVE_FALLBACK; L->why = 12; } tmp.overflow = false; tmp.used = mark; return false; }
-  x.slotA = &slots[0]; x.slotB = &slots[1]; x.slotT = &slots[2];
-  SeqAl sa;
-  sa.blocks = blocks;
-  sa.nb = 0;
-  const bool have = NextHashBlock1()(x, qs, rs, sub, an, sa);
-  bool ok = have && status == 0;
-  if (status != 0) L->status = (status == XM_ST_OVERFLOW) ? XM_ST_WAVE_FALLBACK : status;
-  if (ok) {
-    if (sa.nb > WV_MAXBLOCKS) { { L->status = wOverflowStatus(L); L->why = 13; } ok = false; }
-    else {
-      for (int i = 0; i < sa.nb; i++) { L->candBlocks[slot][i].startA = sa.blocks[i].startA; L->candBlocks[slot][i].startB = sa.blocks[i].startB; L->candBlocks[slot][i].lenA = sa.blocks[i].lenA; L->candBlocks[slot][i].lenB = sa.blocks[i].lenB; }
-      out.nb = sa.nb; out.contig = sa.contig; out.referenceReversed = sa.referenceReversed; out.seqAId = sa.seqAId;
-      out.totalPenalty = sa.totalPenalty; out.alignedPenalty = sa.alignedPenalty;
-    }
-  }
-  tmp.used = mark;
-  wvFence();
-  return ok;
-}
+}  // namespace xm
+#include "xm_wave_search.h"
+#include "xm_wave_chain.h"
+namespace xm {
 
 // alignMatch :412-462 with the outermost StraightAligner (:13-71) done here; fromHashblockMatch is always true
 template <class LDS>
@@ -1173,7 +1161,11 @@ WV_FN bool wAlignMatch(WL_T L, const WEnv& e, int seqAId, int contig, int offset
       const double rate = simpleTotal / secLen(qs);
       Params sub = params;
       sub.MaxErrorRate = dmin(rate, params.MaxErrorRate);
-      const bool have = wGappedChain(L, e, seqAId, contig, qs, rs, sub, an, out, slot);
+      WChainCtx cx{seqAId, contig, qLen, refLen};
+      WAn wan;
+      wan.mslot = -1; wan.predictedBestOffset = an.predictedBestOffset; wan.lastCheckedOffset = an.lastCheckedOffset; wan.confident = 1;
+      wan.maxIns = an.maxInsertionExtensionPenalty; wan.maxDel = an.maxDeletionExtensionPenalty;
+      const bool have = wChainBehindStraight(L, e, cx, qs, rs, sub, wan, out, &L->candBlocks[slot][0]);
       if (L->status) return false;
       result = have;
       if (!have || out.alignedPenalty >= simpleTotal) {
@@ -1495,6 +1487,7 @@ WV_FN void wAlignRead(WL_T L, const WEnv& e, const ReadIn& in, WResult& rr) {
   L->status = 0;
   L->why = 0;
   L->tier = e.tier;
+  L->searchCursor = 0;
   L->nMates = in.nMates;
   L->listIdCounter = 0;
   L->nChunksUsed = 0;

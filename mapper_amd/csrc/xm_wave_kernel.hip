@@ -1,12 +1,11 @@
 // xmapper-hip: the wave-per-read kernels (xm_wave.h): one wavefront aligns one read, its state lives in the wave's share of LDS.
-//   config 0: light tier, single-end batches   (seed, vote, ungapped alignment, accept; 4 waves per workgroup)
-//   config 1: light tier, batches with pairs
-//   config 2: heavy tier: everything the light tier hands on (reads that need the gapped chain HashBlock_Aligner -> BlockAligner ->
-//             PathAligner of xm_extend.h, reads that outgrow the light capacities); one wave per workgroup, scratch arena per wave in HBM
+//   config 0 / 1: light tier, single-end batches / batches with pairs (seed, vote, ungapped alignment, accept)
+//   config 2 / 3: chain tier: + the gapped chain of xm_wave_chain.h (HashBlock_Aligner, BlockAligner, the StraightAligners) up to PathAligner's search
+//   config 4:     the chain tier with the largest capacities
+// A tier hands a read it cannot finish to the next one (XM_ST_WAVE_GAPPED).  PathAligner's searches are requests in the reads' memos
+// (XM_ST_WAVE_SEARCH): xm_wave_search_kernel runs them, one wavefront per search, and the chain tier runs those reads again.
 // A read the wave form does not take leaves with XM_ST_WAVE_FALLBACK and is aligned by the lane-per-read kernel of xm_capi.hip.
 #define XM_NOINL_LINKAGE inline  // the out-of-line functions of the shared headers are defined (strongly) by xm_capi.hip
-#define XM_PAL_WAVES 1           // PathAligner's LDS slot: one per wave of a workgroup; the heavy tier runs one wave per workgroup
-#define XM_WAVE_UNIFORM 1        // all lanes of a wave work on the same read (pathAlign: no turns at the slot)
 #include <hip/hip_runtime.h>
 #ifndef WV_SE_MINWAVES
 #define WV_SE_MINWAVES 4  // waves per SIMD the single-end light kernel is compiled for (register budget 512 / that)
@@ -39,25 +38,19 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
 
 template <class CFG, int TIER, int WAVES, int MINWAVES>
 __global__ void __launch_bounds__(WAVES * 64, MINWAVES) xm_wave_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, OutView out,
-                                                                       unsigned long long* nextItem, DevCounters* counters, uint8_t* arenas, unsigned long long arenaBytes,
-                                                                       int chainScale, PNode* waveNodes, int itemsPerFetch) {
+                                                                       unsigned long long* nextItem, DevCounters* counters, WMemo* memoBase, const int32_t* slotOf, WSNode* waveNodes, int itemsPerFetch) {
   typedef WaveLdsT<CFG> LDS;
   __shared__ LDS lds[WAVES];
-  if (TIER == 1) { xmSetWaveNodes(waveNodes); xmSetPairMode(0); }
   xmWaveLoadTables(ix);
   xmLoadMergeRule();  // (ends with a barrier)
   const int waveInBlock = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63u);
   XM_LDSP(LDS)* L = (XM_LDSP(LDS)*)&lds[waveInBlock];
-  const unsigned long long waveIndex = (unsigned long long)blockIdx.x * WAVES + (unsigned)waveInBlock;
   DevCounters local;
   memset(&local, 0, sizeof(local));
-  Caps caps = makeCaps(TIER == 1 ? chainScale : 1);
-  caps.heavyAllowed = 2; caps.deferPath = 0;
-  Arena tmp;
-  tmp.init(arenas ? arenas + waveIndex * arenaBytes : nullptr, arenas ? (size_t)arenaBytes : 0);
   WEnv e;
-  e.ix = ix; e.params = params; e.params.StartingInsertionStartFree = 0; e.dc = &local; e.tier = TIER; e.caps = &caps; e.tmp = &tmp;
+  e.ix = ix; e.params = params; e.params.StartingInsertionStartFree = 0; e.dc = &local; e.tier = TIER; e.caps = nullptr; e.tmp = nullptr; e.memo = nullptr;
+  e.searchNodes = TIER >= 1 && waveNodes ? waveNodes + ((unsigned long long)blockIdx.x * WAVES + (unsigned)waveInBlock) * WSearchLdsInline::kNodes : nullptr;
   while (true) {
     unsigned long long first = 0;
     if (lane == 0) first = atomicAdd(nextItem, (unsigned long long)itemsPerFetch);
@@ -77,6 +70,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINWAVES) xm_wave_kernel(IndexView
       // single-end Query: expectedInnerDistance 0, deviation 1 (spacing penalty is always 0, T/SamWriter_Test.java:26)
       in.expectedInner = in.nMates > 1 ? batch.expectedInner[q] : 0.0;
       in.deviation = in.nMates > 1 ? batch.deviation[q] : 1.0;
+      if (TIER >= 1) e.memo = memoBase + slotOf[q];
       unsigned long long before[11];
       saveCounters(local, before);
       WResult rr;
@@ -103,27 +97,77 @@ __global__ void __launch_bounds__(WAVES * 64, MINWAVES) xm_wave_kernel(IndexView
   if (lane == 0) waveAddCounters(counters, local);
 }
 
+// One wavefront per waiting search (wPathSearch, xm_wave_search.h): lookup structures in the wave's LDS, node payloads in the wave's buffer
+// in HBM; the result goes into the read's memo.
+#ifndef WV_SEARCH_WAVES
+#define WV_SEARCH_WAVES 1  // waves per workgroup (the search kernel only sees the searches that outgrow the chain tiers' inline capacities)
+#endif
+__global__ void __launch_bounds__(WV_SEARCH_WAVES * 64, 1) xm_wave_search_kernel(IndexView ix, Params params, BatchView batch, const int64_t* list, long long n, WMemo* memoBase, const int32_t* slotOf,
+                                                                                  unsigned long long* nextItem, WSNode* waveNodes) {
+  __shared__ WSearchLdsKernel lds[WV_SEARCH_WAVES];
+  const int waveInBlock = (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63u);
+  const unsigned long long waveIndex = (unsigned long long)blockIdx.x * WV_SEARCH_WAVES + (unsigned)waveInBlock;
+  XM_LDSP(WSearchLdsKernel)* S = (XM_LDSP(WSearchLdsKernel)*)&lds[waveInBlock];
+  WSNode* nodes = waveNodes + waveIndex * WSearchLdsKernel::kNodes;
+  params.StartingInsertionStartFree = 0;
+  while (true) {
+    unsigned long long item = 0;
+    if (lane == 0) item = atomicAdd(nextItem, 1ull);
+    item = uni64(item);
+    if ((long long)item >= n) break;
+    const int64_t q = list[item];
+    WMemo* M = memoBase + slotOf[q];
+    const int mi = M->req.seqAId >> 1;
+    wRunSearch(S, nodes, ix, params, batch.codes + batch.mateOffset[q * 2 + mi], batch.mateLength[q * 2 + mi], M);
+  }
+}
+__global__ void __launch_bounds__(256) xm_wave_memo_init_kernel(WMemo* memoBase, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { memoBase[i].count = 0; memoBase[i].pending = 0; }
+}
+
 template <class CFG, int TIER, int WAVES, int MINWAVES>
 hipError_t launchOne(const WaveLaunch& a, hipStream_t s) {
   hipLaunchKernelGGL((xm_wave_kernel<CFG, TIER, WAVES, MINWAVES>), dim3(a.grid), dim3(WAVES * 64), 0, s, a.ix, a.params, a.batch, a.todo, a.nTodo, a.out, a.nextItem, a.counters,
-                     a.arenas, a.arenaBytes, a.chainScale, (PNode*)a.waveNodes, a.itemsPerFetch);
+                     a.memoBase, a.slotOf, (WSNode*)a.waveNodes, a.itemsPerFetch);
   return hipGetLastError();
 }
 
 }  // namespace
 
+int xmWaveInlineNodeBytes() { return WSearchLdsInline::kNodes * (int)sizeof(WSNode); }
 void xmWaveGeometry(int config, int* wavesPerBlock, int* ldsBytesPerBlock, int* wavesPerSimd) {
-  const int mergeRule = (int)sizeof(MergeRuleTable);
-  if (config == 0) { *wavesPerBlock = 4; *wavesPerSimd = WV_SE_MINWAVES; *ldsBytesPerBlock = 4 * (int)sizeof(WaveLdsT<WCfgLightSE>) + mergeRule; }
-  else if (config == 1) { *wavesPerBlock = 2; *wavesPerSimd = 3; *ldsBytesPerBlock = 2 * (int)sizeof(WaveLdsT<WCfgLightPE>) + mergeRule; }
-  else { *wavesPerBlock = 1; *wavesPerSimd = 1; *ldsBytesPerBlock = (int)sizeof(WaveLdsT<WCfgHeavy>) + XM_PAL_SLOT_BYTES + mergeRule + 16; }
+  const int shared = (int)sizeof(MergeRuleTable) + WV_TABLECACHE * (int)sizeof(Table);
+  if (config == 0) { *wavesPerBlock = 4; *wavesPerSimd = WV_SE_MINWAVES; *ldsBytesPerBlock = 4 * (int)sizeof(WaveLdsT<WCfgLightSE>) + shared; }
+  else if (config == 1) { *wavesPerBlock = 2; *wavesPerSimd = 3; *ldsBytesPerBlock = 2 * (int)sizeof(WaveLdsT<WCfgLightPE>) + shared; }
+  else if (config == 2) { *wavesPerBlock = 1; *wavesPerSimd = 2; *ldsBytesPerBlock = (int)sizeof(WaveLdsT<WCfgMidSE>) + shared; }
+  else if (config == 3) { *wavesPerBlock = 1; *wavesPerSimd = 2; *ldsBytesPerBlock = (int)sizeof(WaveLdsT<WCfgMidPE>) + shared; }
+  else { *wavesPerBlock = 1; *wavesPerSimd = 1; *ldsBytesPerBlock = (int)sizeof(WaveLdsT<WCfgHeavy>) + shared; }
 }
 
 int xmWaveLaunch(const WaveLaunch& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a.config == 0) return (int)launchOne<WCfgLightSE, 0, 4, WV_SE_MINWAVES>(a, s);
   if (a.config == 1) return (int)launchOne<WCfgLightPE, 0, 2, 3>(a, s);
+  if (a.config == 2) return (int)launchOne<WCfgMidSE, 1, 1, 2>(a, s);
+  if (a.config == 3) return (int)launchOne<WCfgMidPE, 1, 1, 2>(a, s);
   return (int)launchOne<WCfgHeavy, 1, 1, 1>(a, s);
+}
+
+void xmSearchGeometry(int* wavesPerBlock, int* ldsBytesPerBlock, int* wavesPerSimd, int* memoBytes, int* nodeBytesPerWave) {
+  *wavesPerBlock = WV_SEARCH_WAVES; *wavesPerSimd = 1; *ldsBytesPerBlock = WV_SEARCH_WAVES * (int)sizeof(WSearchLdsKernel);
+  *memoBytes = (int)sizeof(WMemo); *nodeBytesPerWave = WSearchLdsKernel::kNodes * (int)sizeof(WSNode);
+}
+int xmSearchLaunch(const SearchLaunch& a, void* stream) {
+  hipLaunchKernelGGL(xm_wave_search_kernel, dim3(a.grid), dim3(WV_SEARCH_WAVES * 64), 0, (hipStream_t)stream, a.ix, a.params, a.batch, a.list, a.n, a.memoBase, a.slotOf, a.nextItem,
+                     (WSNode*)a.waveNodes);
+  return (int)hipGetLastError();
+}
+int xmMemoInitLaunch(WMemo* memoBase, long long n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(xm_wave_memo_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, memoBase, n);
+  return (int)hipGetLastError();
 }
 
 }  // namespace xm

@@ -21,7 +21,7 @@ P = api.AlignmentParameters()
 for rep in range(3):
     t = time.time()
     r = db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, P)
-    print(kind, "rep", rep, "nq", nq, "wall %.1f ms" % ((time.time() - t) * 1e3), "kernel ms %.2f" % r.kernel_ms, "launches", r.kernel_launches, "us wave-light/wave-heavy/search/lane-passes",
+    print(kind, "rep", rep, "nq", nq, "wall %.1f ms" % ((time.time() - t) * 1e3), "kernel ms %.2f" % r.kernel_ms, "launches", r.kernel_launches, "us wave light tier / chain tiers / search kernel / lane passes",
           list(r.counters[12:16]), "reruns", r.counters[11], "probes/fetches/hits/cands", list(r.counters[1:5]), "PA calls/nodes", list(r.counters[5:7]), "quick", r.counters[7], flush=True)
 if nCheck > 0:
     n = min(nq, nCheck)

@@ -13,9 +13,9 @@ if kind == "se":
 else:
     m1, m2 = synth.synthetic_paired_end(ref, nq)[:2]; b = pe_batch(m1, m2, 100.0, 50.0)
 names = {0: "TOTAL", 2: "WALK", 3: "STEP", 4: "UNGAPPED", 5: "HITS", 6: "CHAIN", 10: "CONFIDENT", 11: "ALIGNMATCH", 12: "MATEINIT", 13: "WRITE", 14: "OPTIMISTIC"}
-for heavy in ("0", "1"):
-    os.environ["XM_WAVE_HEAVY"] = heavy
+for heavy in ("3",):
+    os.environ["XM_WAVE_TIERS"] = heavy
     for rep in range(2):
         r = db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, api.AlignmentParameters())
-    print("heavy tier", heavy, "kernel ms %.2f" % r.kernel_ms, "us by pass", list(r.counters[12:16]), flush=True)
+    print("tiers", heavy, "kernel ms %.2f" % r.kernel_ms, "us by pass", list(r.counters[12:16]), flush=True)
     print("   Mticks (all slots)", {names.get(i, str(i)): round(x / 1e6, 1) for i, x in enumerate(r.prof) if x}, flush=True)

@@ -91,12 +91,18 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       const int waveMode = g_waveMode >= 0 ? g_waveMode : (getenv("XMSIM_WAVE") ? atoi(getenv("XMSIM_WAVE")) : 0);
       if (waveMode > 0) {
         typedef WaveLdsT<WCfgLightPE> LightLds;
+        typedef WaveLdsT<WCfgMidPE> MidLds;
         typedef WaveLdsT<WCfgHeavy> HeavyLds;
         static LightLds ldsLight;
+        static MidLds ldsMid;
         static HeavyLds ldsHeavy;
         static std::vector<uint8_t> waveArena((size_t)(288 * 1024 * 4 * 7 / 12 + 4096));
+        static WMemo memo;
+        memo.count = 0; memo.pending = 0;
         bool finished = false;
-        for (int tier = 0; tier < waveMode && tier < 2 && !finished; tier++) {
+        int searchRounds = 0;
+        // waveMode 1: light tier only; 2: + chain tier (with its search rounds); 3: + the chain tier with the largest capacities
+        for (int tier = 0; tier < waveMode && tier < 3 && !finished; ) {
           DevCounters before = dc;
           WEnv e;
           e.ix = idx->view; e.params = params; e.dc = &dc; e.mateBase[0] = in.mate[0]; e.mateBase[1] = in.mate[1]; e.tier = tier;
@@ -105,33 +111,47 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
           Arena tmp;
           tmp.init((void*)(((uintptr_t)waveArena.data() + 15) & ~(uintptr_t)15), waveArena.size() - 64);
           e.caps = &caps; e.tmp = &tmp;
+          e.memo = tier == 0 ? nullptr : &memo;
+          static std::vector<WSNode> inlineNodes(WSearchLdsInline::kNodes);
+          static const bool inlineSearch = !(getenv("XMSIM_NO_INLINE_SEARCH") && atoi(getenv("XMSIM_NO_INLINE_SEARCH")) != 0);  // (0: every search through the memo and the search "kernel")
+          e.searchNodes = tier == 0 || !inlineSearch ? nullptr : inlineNodes.data();
           WResult wr;
-          int32_t st;
+          int32_t st = 0, why = 0;
           int64_t ni = 0, nd = 0;
-          if (tier == 0) { wAlignRead(&ldsLight, e, in, wr); st = ldsLight.status; if (st == XM_OK) wResultSize(&ldsLight, wr, ni, nd); }
-          else { wAlignRead(&ldsHeavy, e, in, wr); st = ldsHeavy.status; if (st == XM_OK) wResultSize(&ldsHeavy, wr, ni, nd); }
-          g_waveStatus[st < 16 ? st : 15]++;
-          if (getenv("XMSIM_WAVE_STATS")) {
-            static bool reg = false; if (!reg) { reg = true; atexit(markDump); }
-            auto mark = [&](auto& Ld) {
+          auto run = [&](auto& Ld) {
+            wAlignRead(&Ld, e, in, wr);
+            st = Ld.status; why = Ld.why;
+            if (st == XM_OK) wResultSize(&Ld, wr, ni, nd);
+            if (getenv("XMSIM_WAVE_STATS")) {
+              static bool reg = false; if (!reg) { reg = true; atexit(markDump); }
               auto clip = [](int v) { return v < 0 ? 0 : (v > 127 ? 127 : v); };
               g_markHist[0][clip(Ld.nChunksUsed)]++;
               for (int m = 0; m < in.nMates; m++) { g_markHist[1][clip(Ld.m[m].nCounters)]++; g_markHist[2][clip(Ld.m[m].nHistory)]++; g_markHist[3][clip(Ld.m[m].pendTail)]++; }
               g_markHist[4][clip(Ld.nAssembled)]++; g_markHist[5][clip(Ld.al[0].nGood)]++;
-            };
-            if (tier == 0) mark(ldsLight); else mark(ldsHeavy);
-          }
-          if (st == XM_ST_WAVE_FALLBACK) g_waveWhy[(tier == 0 ? ldsLight.why : ldsHeavy.why) & 63]++;
+            }
+          };
+          auto write = [&](auto& Ld) { wResultWrite(&Ld, wr, ints.data() + res->int_off[q], dbls.data() + res->dbl_off[q], &dc); };
+          if (tier == 0) run(ldsLight); else if (tier == 1) run(ldsMid); else run(ldsHeavy);
+          g_waveStatus[st < 16 ? st : 15]++;
+          if (st == XM_ST_WAVE_FALLBACK || (st == XM_ST_WAVE_GAPPED && tier >= 1)) g_waveWhy[why & 63]++;
           if (st == XM_OK) {
             res->int_off[q] = (int64_t)ints.size(); res->dbl_off[q] = (int64_t)dbls.size();
             ints.resize(ints.size() + (size_t)ni); dbls.resize(dbls.size() + (size_t)nd);
-            if (tier == 0) wResultWrite(&ldsLight, wr, ints.data() + res->int_off[q], dbls.data() + res->dbl_off[q], &dc);
-            else wResultWrite(&ldsHeavy, wr, ints.data() + res->int_off[q], dbls.data() + res->dbl_off[q], &dc);
+            if (tier == 0) write(ldsLight); else if (tier == 1) write(ldsMid); else write(ldsHeavy);
             finished = true;
           } else {
             dc = before;
+            if (st == XM_ST_WAVE_SEARCH) {  // the search "kernel", then the same tier again
+              const int mi = memo.req.seqAId >> 1;
+              static WSearchLdsKernel searchLds;
+              static std::vector<WSNode> searchNodes(WSearchLdsKernel::kNodes);
+              wRunSearch(&searchLds, searchNodes.data(), idx->view, params, in.mate[mi], in.mateLen[mi], &memo);
+              if (++searchRounds > 4 * WV_MEMO_MAX) throw std::runtime_error("search rounds do not end");
+              continue;
+            }
             if (st != XM_ST_WAVE_FALLBACK && st != XM_ST_WAVE_GAPPED) throw std::runtime_error("Failed to align query " + std::to_string(q) + " (wave status " + std::to_string(st) + ")");
-            if (st == XM_ST_WAVE_FALLBACK) break;  // (ambiguity codes, long or overlapping mates: the heavy tier does not take them either)
+            if (st == XM_ST_WAVE_FALLBACK) break;  // (ambiguity codes, long or overlapping mates: no tier of the wave form takes them)
+            tier++;
           }
         }
         if (finished) continue;

@@ -131,7 +131,7 @@ def pyramid_dump(codes):
 
 
 def set_wave_mode(mode):
-    """0: lane-per-read pass sequence only; 1: the wave-per-read form's light tier first; 2: light then heavy tier first (what the product runs)."""
+    """0: lane-per-read pass sequence only; 1: the wave-per-read form's light tier first; 2: + its chain tier; 3: + its search tier (what the product runs)."""
     lib().xmsim_set_wave_mode(mode)
 
 

@@ -13,13 +13,13 @@ from mapper_amd import api, synth
 
 @pytest.fixture(autouse=True)
 def _wave_mode():
-    hs.set_wave_mode(2)
+    hs.set_wave_mode(3)
     hs.wave_status_counts()
     yield
     hs.set_wave_mode(-1)
 
 
-@pytest.mark.parametrize("tiers", [1, 2])
+@pytest.mark.parametrize("tiers", [1, 2, 3])
 def test_wave_form_single_end(tiers):
     """configs[1] shape: every read is taken by the wave form (nothing left to the lane-per-read passes), results bit-equal to the oracle."""
     hs.set_wave_mode(tiers)
@@ -30,9 +30,9 @@ def test_wave_form_single_end(tiers):
     got = hs.SimReference([("ecoli_syn", ref)]).align(b, o.make_params())
     assert streams_equal(got, want), first_difference(got, want, len(reads))
     st = hs.wave_status_counts()
-    assert st[0] + (st[9] if tiers == 1 else 0) == len(reads) or st[8] == 0
-    if tiers == 2:
-        assert st[8] == 0 and st[0] == len(reads)
+    assert st[8] == 0
+    if tiers == 3:
+        assert st[0] == len(reads)
 
 
 @pytest.mark.parametrize("read_len", [36, 75, 100, 250, 256])
@@ -72,7 +72,7 @@ def test_wave_form_leaves_what_it_does_not_take():
         got = S.align(b, o.make_params())
         assert streams_equal(got, want), first_difference(got, want, n)
     st = hs.wave_status_counts()
-    assert st[8] >= 60 and st[0] >= 600
+    assert st[8] >= 860 and st[0] >= 400   # (reads next to an ambiguity code of the reference leave the chain tier too)
 
 
 @pytest.mark.parametrize("case", KAT["align_cases"], ids=lambda c: c["name"])
