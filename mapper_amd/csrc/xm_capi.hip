@@ -516,7 +516,8 @@ struct xm_index {
     up(dTables, host.tables); up(dBucketOff, host.bucketOff); up(dDupKeyStart, host.dupKeyStart);
     dDupKeys.ensure(host.dupKeys.size());
     if (!host.dupKeys.empty()) HIP_CHECK(hipMemcpy(dDupKeys.p, host.dupKeys.data(), host.dupKeys.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    posIs64 = host.seqCumStart.back() > 0xFFFFFFFFll;
+    // (XM_FORCE_POS64=1: test hook, the 64-bit position arrays of references beyond 2^32 encoded positions on a small reference)
+    posIs64 = host.seqCumStart.back() > 0xFFFFFFFFll || envInt("XM_FORCE_POS64", 0) != 0;
     if (posIs64) {
       up(dPositions64, host.positions);
     } else {
@@ -651,7 +652,7 @@ int xm_index_get_info(const xm_index* idx, xm_index_info_t* info) {
   if (!idx || !info) return fail("null argument");
   const HostIndex& h = idx->host;
   info->num_contigs = h.numContigs(); info->min_interesting_size = h.minInterestingSize; info->max_hashed_length = h.maxHashedLength;
-  info->enable_gapmers = h.enableGapmers; info->dup_window = h.dupWindow; info->position_bytes = h.seqCumStart.back() > 0xFFFFFFFFll ? 8 : 4;
+  info->enable_gapmers = h.enableGapmers; info->dup_window = h.dupWindow; info->position_bytes = (idx->hostOnly ? h.seqCumStart.back() > 0xFFFFFFFFll : idx->posIs64) ? 8 : 4;
   info->total_forward_size = h.totalForwardSize;
   info->num_positions = (int64_t)h.positions.size();
   info->index_bytes = (int64_t)(h.bucketOff.size() * 4 + h.positions.size() * (size_t)info->position_bytes + h.refCodes.size() + h.dupKeys.size() * 4);
@@ -949,13 +950,14 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       idx->dRegionOf.ensure((size_t)nq);
       HIP_CHECK(hipMemsetAsync(idx->dRegionOf.p, 0xFF, sizeof(int32_t) * (size_t)nq, s));
     }
-    // ---- passes 0: the wave-per-read form (xm_wave_kernel.hip).  Light tier over every read (seed, vote, ungapped alignment, accept); chain
+    // ---- passes 0 (XM_WAVE=1; off by default: measured slower than the lane-per-read passes on MI355X this round, profiles/r02/NOTES.md):
+    // the wave-per-read form (xm_wave_kernel.hip).  Light tier over every read (seed, vote, ungapped alignment, accept); chain
     // tier over the reads that need the gapped chain (or more LDS): a read that meets a PathAligner search leaves the request in its memo, the
     // search kernel runs all waiting searches (one wavefront each), and those reads run again with the results, until none waits; then the
     // same with the largest capacities for the reads that outgrew the chain tier's.  What the wave form does not take (ambiguity codes in the
     // read or its reference window, mates longer than 256 bases, overlapping mates, a structure that outgrows LDS) goes through the
     // lane-per-read passes below.
-    if (envInt("XM_WAVE", 1) != 0 && idx->residentMaxLen <= 256) {
+    if (envInt("XM_WAVE", 0) != 0 && idx->residentMaxLen <= 256) {
       const bool tracePasses = envInt("XM_TRACE_PASSES", 0) != 0;
       idx->dListWaveHeavy.ensure((size_t)nq); idx->dListWaveNext.ensure((size_t)nq); idx->dListFallback.ensure((size_t)nq); idx->dWaveCtl.ensure(1);
       idx->dWaveSlotOf.ensure((size_t)nq);
@@ -1016,7 +1018,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         sl.grid = (int)blocks; sl.block = sWaves * 64;
         sl.ix = idx->view; sl.params = params; sl.batch = bv; sl.list = list; sl.n = n; sl.memoBase = (WMemo*)idx->dWaveMemo.p; sl.slotOf = idx->dWaveSlotOf.p; sl.nextItem = idx->dCursors.p + 2;
         idx->dWaveArenas.ensure((size_t)blocks * sWaves * (size_t)nodesPerWave);  // (node payloads: bytes per wave)
-        sl.waveNodes = idx->dWaveArenas.p;
+        sl.waveNodes = idx->dWaveArenas.p; sl.counters = idx->dCounters.p;
         HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
         HIP_CHECK(hipEventRecord(e0, s));
         const int rc = xmSearchLaunch(sl, (void*)s);

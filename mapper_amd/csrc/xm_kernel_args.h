@@ -54,7 +54,8 @@ struct SearchLaunch {
   WMemo* memoBase;
   const int32_t* slotOf;
   unsigned long long* nextItem;
-  void* waveNodes;           // per wave: the node payloads of its search (WSNode[waves * WS_NODES])
+  void* waveNodes;           // per wave: the node payloads of its search
+  DevCounters* counters;     // (profile builds: phase timers)
 };
 // waves per workgroup, LDS bytes per workgroup and waves per SIMD a configuration is compiled for; the launches (return hipError_t as int)
 int xmWaveInlineNodeBytes();

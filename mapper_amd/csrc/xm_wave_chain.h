@@ -341,7 +341,7 @@ WV_FN bool wPathAlign(WL_T L, const WEnv& e, const WChainCtx& cx, const Section&
   if (e.searchNodes) {
     wPyramidsForget(L);
     XM_LDSP(WSearchLdsInline)* S = (XM_LDSP(WSearchLdsInline)*)&L->chunkFwd[0][0];
-    wPathSearch(S, e.searchNodes, e.ix, e.params, e.mateBase[cx.seqAId >> 1], cx.qLen, q, res);
+    wPathSearch(S, e.searchNodes, e.ix, e.params, e.mateBase[cx.seqAId >> 1], cx.qLen, q, res, e.dc);
     wvFence();
   }
   if (res.ok < 0 && res.status == XM_ST_OVERFLOW) {

@@ -7,6 +7,9 @@
 // A read the wave form does not take leaves with XM_ST_WAVE_FALLBACK and is aligned by the lane-per-read kernel of xm_capi.hip.
 #define XM_NOINL_LINKAGE inline  // the out-of-line functions of the shared headers are defined (strongly) by xm_capi.hip
 #include <hip/hip_runtime.h>
+#ifndef WV_CONFIG
+#error "compile with -DWV_CONFIG=0..4 (one wave-per-read kernel configuration), 5 (search kernel) or 100 (geometry, dispatch)"
+#endif
 #ifndef WV_SE_MINWAVES
 #define WV_SE_MINWAVES 4  // waves per SIMD the single-end light kernel is compiled for (register budget 512 / that)
 #endif
@@ -17,6 +20,7 @@ namespace xm {
 
 namespace {
 
+#if WV_CONFIG <= 4
 __device__ __forceinline__ void waveAddCounters(DevCounters* g, const DevCounters& l) {
   atomicAdd(&g->reads, l.reads); atomicAdd(&g->headerProbes, l.headerProbes); atomicAdd(&g->bucketFetches, l.bucketFetches);
   atomicAdd(&g->hitsFetched, l.hitsFetched); atomicAdd(&g->candidatesExtended, l.candidatesExtended); atomicAdd(&g->pathAlignerCalls, l.pathAlignerCalls);
@@ -24,6 +28,7 @@ __device__ __forceinline__ void waveAddCounters(DevCounters* g, const DevCounter
   atomicAdd(&g->refWindowBytes, l.refWindowBytes); atomicAdd(&g->readBytes, l.readBytes);
   for (int i = 0; i < 16; i++) if (l.t[i]) atomicAdd(&g->t[i], l.t[i]);
 }
+#endif
 __device__ __forceinline__ void saveCounters(const DevCounters& l, unsigned long long* b) {
   b[0] = l.reads; b[1] = l.headerProbes; b[2] = l.bucketFetches; b[3] = l.hitsFetched; b[4] = l.candidatesExtended; b[5] = l.pathAlignerCalls; b[6] = l.pathAlignerNodes;
   b[7] = l.quickAccepts; b[8] = l.alignmentsOut; b[9] = l.refWindowBytes; b[10] = l.readBytes;
@@ -36,6 +41,7 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
   return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
 }
 
+#if WV_CONFIG <= 4
 template <class CFG, int TIER, int WAVES, int MINWAVES>
 __global__ void __launch_bounds__(WAVES * 64, MINWAVES) xm_wave_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, OutView out,
                                                                        unsigned long long* nextItem, DevCounters* counters, WMemo* memoBase, const int32_t* slotOf, WSNode* waveNodes, int itemsPerFetch) {
@@ -97,19 +103,36 @@ __global__ void __launch_bounds__(WAVES * 64, MINWAVES) xm_wave_kernel(IndexView
   if (lane == 0) waveAddCounters(counters, local);
 }
 
+template <class CFG, int TIER, int WAVES, int MINWAVES>
+hipError_t launchOne(const WaveLaunch& a, hipStream_t s) {
+  hipLaunchKernelGGL((xm_wave_kernel<CFG, TIER, WAVES, MINWAVES>), dim3(a.grid), dim3(WAVES * 64), 0, s, a.ix, a.params, a.batch, a.todo, a.nTodo, a.out, a.nextItem, a.counters,
+                     a.memoBase, a.slotOf, (WSNode*)a.waveNodes, a.itemsPerFetch);
+  return hipGetLastError();
+}
+
+#endif
+#if WV_CONFIG == 5
 // One wavefront per waiting search (wPathSearch, xm_wave_search.h): lookup structures in the wave's LDS, node payloads in the wave's buffer
 // in HBM; the result goes into the read's memo.
 #ifndef WV_SEARCH_WAVES
 #define WV_SEARCH_WAVES 1  // waves per workgroup (the search kernel only sees the searches that outgrow the chain tiers' inline capacities)
 #endif
-__global__ void __launch_bounds__(WV_SEARCH_WAVES * 64, 1) xm_wave_search_kernel(IndexView ix, Params params, BatchView batch, const int64_t* list, long long n, WMemo* memoBase, const int32_t* slotOf,
-                                                                                  unsigned long long* nextItem, WSNode* waveNodes) {
-  __shared__ WSearchLdsKernel lds[WV_SEARCH_WAVES];
+#ifndef WV_SEARCH_MINWAVES
+#define WV_SEARCH_MINWAVES 1
+#endif
+#ifndef WV_SEARCH_LDS
+#define WV_SEARCH_LDS WSearchLdsKernel  // (experiments: WSearchLdsInline = the capacities of the chain tiers' inline searches)
+#endif
+__global__ void __launch_bounds__(WV_SEARCH_WAVES * 64, WV_SEARCH_MINWAVES) xm_wave_search_kernel(IndexView ix, Params params, BatchView batch, const int64_t* list, long long n, WMemo* memoBase, const int32_t* slotOf,
+                                                                                  unsigned long long* nextItem, WSNode* waveNodes, DevCounters* counters) {
+  __shared__ WV_SEARCH_LDS lds[WV_SEARCH_WAVES];
+  DevCounters local;
+  memset(&local, 0, sizeof(local));
   const int waveInBlock = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63u);
   const unsigned long long waveIndex = (unsigned long long)blockIdx.x * WV_SEARCH_WAVES + (unsigned)waveInBlock;
-  XM_LDSP(WSearchLdsKernel)* S = (XM_LDSP(WSearchLdsKernel)*)&lds[waveInBlock];
-  WSNode* nodes = waveNodes + waveIndex * WSearchLdsKernel::kNodes;
+  XM_LDSP(WV_SEARCH_LDS)* S = (XM_LDSP(WV_SEARCH_LDS)*)&lds[waveInBlock];
+  WSNode* nodes = waveNodes + waveIndex * WV_SEARCH_LDS::kNodes;
   params.StartingInsertionStartFree = 0;
   while (true) {
     unsigned long long item = 0;
@@ -119,23 +142,43 @@ __global__ void __launch_bounds__(WV_SEARCH_WAVES * 64, 1) xm_wave_search_kernel
     const int64_t q = list[item];
     WMemo* M = memoBase + slotOf[q];
     const int mi = M->req.seqAId >> 1;
-    wRunSearch(S, nodes, ix, params, batch.codes + batch.mateOffset[q * 2 + mi], batch.mateLength[q * 2 + mi], M);
+    wRunSearch(S, nodes, ix, params, batch.codes + batch.mateOffset[q * 2 + mi], batch.mateLength[q * 2 + mi], M, &local);
   }
+  if (lane == 0) for (int i = 0; i < 16; i++) if (local.t[i]) atomicAdd(&counters->t[i], local.t[i]);
 }
+#endif
+#if WV_CONFIG == 100
 __global__ void __launch_bounds__(256) xm_wave_memo_init_kernel(WMemo* memoBase, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { memoBase[i].count = 0; memoBase[i].pending = 0; }
 }
 
-template <class CFG, int TIER, int WAVES, int MINWAVES>
-hipError_t launchOne(const WaveLaunch& a, hipStream_t s) {
-  hipLaunchKernelGGL((xm_wave_kernel<CFG, TIER, WAVES, MINWAVES>), dim3(a.grid), dim3(WAVES * 64), 0, s, a.ix, a.params, a.batch, a.todo, a.nTodo, a.out, a.nextItem, a.counters,
-                     a.memoBase, a.slotOf, (WSNode*)a.waveNodes, a.itemsPerFetch);
-  return hipGetLastError();
-}
-
+#endif
 }  // namespace
 
+#if WV_CONFIG == 0
+int xmWaveLaunch0(const WaveLaunch& a, void* s) { return (int)launchOne<WCfgLightSE, 0, 4, WV_SE_MINWAVES>(a, (hipStream_t)s); }
+#elif WV_CONFIG == 1
+int xmWaveLaunch1(const WaveLaunch& a, void* s) { return (int)launchOne<WCfgLightPE, 0, 2, 3>(a, (hipStream_t)s); }
+#elif WV_CONFIG == 2
+int xmWaveLaunch2(const WaveLaunch& a, void* s) { return (int)launchOne<WCfgMidSE, 1, 1, 2>(a, (hipStream_t)s); }
+#elif WV_CONFIG == 3
+int xmWaveLaunch3(const WaveLaunch& a, void* s) { return (int)launchOne<WCfgMidPE, 1, 1, 2>(a, (hipStream_t)s); }
+#elif WV_CONFIG == 4
+int xmWaveLaunch4(const WaveLaunch& a, void* s) { return (int)launchOne<WCfgHeavy, 1, 1, 1>(a, (hipStream_t)s); }
+#elif WV_CONFIG == 5
+int xmSearchLaunch(const SearchLaunch& a, void* stream) {
+  hipLaunchKernelGGL(xm_wave_search_kernel, dim3(a.grid), dim3(WV_SEARCH_WAVES * 64), 0, (hipStream_t)stream, a.ix, a.params, a.batch, a.list, a.n, a.memoBase, a.slotOf, a.nextItem,
+                     (WSNode*)a.waveNodes, a.counters);
+  return (int)hipGetLastError();
+}
+void xmSearchGeometry(int* wavesPerBlock, int* ldsBytesPerBlock, int* wavesPerSimd, int* memoBytes, int* nodeBytesPerWave) {
+  *wavesPerBlock = WV_SEARCH_WAVES; *wavesPerSimd = WV_SEARCH_MINWAVES; *ldsBytesPerBlock = WV_SEARCH_WAVES * (int)sizeof(WV_SEARCH_LDS);
+  *memoBytes = (int)sizeof(WMemo); *nodeBytesPerWave = WV_SEARCH_LDS::kNodes * (int)sizeof(WSNode);
+}
+#elif WV_CONFIG == 100
+int xmWaveLaunch0(const WaveLaunch&, void*); int xmWaveLaunch1(const WaveLaunch&, void*); int xmWaveLaunch2(const WaveLaunch&, void*);
+int xmWaveLaunch3(const WaveLaunch&, void*); int xmWaveLaunch4(const WaveLaunch&, void*);
 int xmWaveInlineNodeBytes() { return WSearchLdsInline::kNodes * (int)sizeof(WSNode); }
 void xmWaveGeometry(int config, int* wavesPerBlock, int* ldsBytesPerBlock, int* wavesPerSimd) {
   const int shared = (int)sizeof(MergeRuleTable) + WV_TABLECACHE * (int)sizeof(Table);
@@ -145,29 +188,18 @@ void xmWaveGeometry(int config, int* wavesPerBlock, int* ldsBytesPerBlock, int* 
   else if (config == 3) { *wavesPerBlock = 1; *wavesPerSimd = 2; *ldsBytesPerBlock = (int)sizeof(WaveLdsT<WCfgMidPE>) + shared; }
   else { *wavesPerBlock = 1; *wavesPerSimd = 1; *ldsBytesPerBlock = (int)sizeof(WaveLdsT<WCfgHeavy>) + shared; }
 }
-
 int xmWaveLaunch(const WaveLaunch& a, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  if (a.config == 0) return (int)launchOne<WCfgLightSE, 0, 4, WV_SE_MINWAVES>(a, s);
-  if (a.config == 1) return (int)launchOne<WCfgLightPE, 0, 2, 3>(a, s);
-  if (a.config == 2) return (int)launchOne<WCfgMidSE, 1, 1, 2>(a, s);
-  if (a.config == 3) return (int)launchOne<WCfgMidPE, 1, 1, 2>(a, s);
-  return (int)launchOne<WCfgHeavy, 1, 1, 1>(a, s);
-}
-
-void xmSearchGeometry(int* wavesPerBlock, int* ldsBytesPerBlock, int* wavesPerSimd, int* memoBytes, int* nodeBytesPerWave) {
-  *wavesPerBlock = WV_SEARCH_WAVES; *wavesPerSimd = 1; *ldsBytesPerBlock = WV_SEARCH_WAVES * (int)sizeof(WSearchLdsKernel);
-  *memoBytes = (int)sizeof(WMemo); *nodeBytesPerWave = WSearchLdsKernel::kNodes * (int)sizeof(WSNode);
-}
-int xmSearchLaunch(const SearchLaunch& a, void* stream) {
-  hipLaunchKernelGGL(xm_wave_search_kernel, dim3(a.grid), dim3(WV_SEARCH_WAVES * 64), 0, (hipStream_t)stream, a.ix, a.params, a.batch, a.list, a.n, a.memoBase, a.slotOf, a.nextItem,
-                     (WSNode*)a.waveNodes);
-  return (int)hipGetLastError();
+  if (a.config == 0) return xmWaveLaunch0(a, stream);
+  if (a.config == 1) return xmWaveLaunch1(a, stream);
+  if (a.config == 2) return xmWaveLaunch2(a, stream);
+  if (a.config == 3) return xmWaveLaunch3(a, stream);
+  return xmWaveLaunch4(a, stream);
 }
 int xmMemoInitLaunch(WMemo* memoBase, long long n, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(xm_wave_memo_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, memoBase, n);
   return (int)hipGetLastError();
 }
+#endif
 
 }  // namespace xm

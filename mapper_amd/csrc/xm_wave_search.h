@@ -52,6 +52,22 @@ struct WSState {  // wave-uniform scalars of a running search
 
 XM_INL uint32_t wsCellKey(int x, int y) { return ((uint32_t)x << 9) | (uint32_t)y; }
 #define WSL_T XM_LDSP(SL)*
+// XM_WAVE_PROFILE builds: shader-clock ticks of the phases of a search into DevCounters::t[1] (whole search), [7] set-up and first nodes,
+// [8] smallest-key scans, [9] the lane-parallel part of explore, [15] puts and the third update
+#if defined(XM_WAVE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+struct WSTimer {
+  DevCounters* dc; int slot; unsigned long long t0;
+  XM_INL WSTimer(DevCounters* d, int s) : dc(d), slot(s), t0(clock64()) {}
+  XM_INL ~WSTimer() { if (dc) dc->t[slot] += clock64() - t0; }
+};
+#define WS_TIMER(dc, slot) WSTimer wstimer_##slot(dc, slot)
+#define WS_TIC(var) const unsigned long long var = clock64()
+#define WS_TOC(dc, slot, var) do { if (dc) (dc)->t[slot] += clock64() - var; } while (0)
+#else
+#define WS_TIMER(dc, slot) do { } while (0)
+#define WS_TIC(var) do { } while (0)
+#define WS_TOC(dc, slot, var) do { } while (0)
+#endif
 
 // cell (x, y) -> slot of the cell in the hash (its own, or the empty one that ends its run) and the node index stored there (-1 = none)
 template <class SL>
@@ -247,16 +263,24 @@ XM_INL double wvBcastD(double v, int lane) {
   return v;
 }
 #define WV_BCAST_D(name, lane) wvBcastD(name, lane)
+XM_INL int wvShflI(int v, int lane) { return __shfl(v, lane); }
+XM_INL double wvShflD(double v, int lane) { return __shfl(v, lane); }
+XM_INL int wvOf(int v, int lane) { return wvShflI(v, lane); }
+XM_INL double wvOf(double v, int lane) { return wvShflD(v, lane); }
+#define WV_OF(name, lane) wvOf(name, lane)
 #else
 #define WV_BCAST_D(name, lane) ((name)[lane])
+#define WV_OF(name, lane) ((name)[lane])
 #endif
 
 // PathAligner.align :55-293 up to and including justify and the penalties of the result.  ok: 1 alignment (blocks, penalties), 0 null,
 // -1 failed (status).  Texts: the query section [qsStart, qsEnd) of the mate view (reverse complement when qRc) and the reference section.
 template <class SL>
-XM_INL void wPathSearch(WSL_T S, WSNode* nodes, const IndexView& ix, const Params& paramsIn, const uint8_t* mateBase, int mateLen, const WSearchReq& r, WSearchResult& res) {
+XM_INL void wPathSearch(WSL_T S, WSNode* nodes, const IndexView& ix, const Params& paramsIn, const uint8_t* mateBase, int mateLen, const WSearchReq& r, WSearchResult& res, DevCounters* dc = nullptr) {
+  WS_TIMER(dc, 1);
   const double disallowed = 1000000.0;
   res.ok = 0; res.nb = 0; res.status = 0; res.nodesPut = 0; res.totalPenalty = 0; res.alignedPenalty = 0;
+  WS_TIC(tSetup);
   WSState st;
   st.p = paramsIn;
   st.p.MaxErrorRate = r.maxErrorRate;
@@ -338,6 +362,7 @@ XM_INL void wPathSearch(WSL_T S, WSNode* nodes, const IndexView& ix, const Param
       wsPutNode(S, nodes, st, x, y, pen, disallowed, disallowed, 0, wsEstimate(st, x, y, pen, disallowed, disallowed, 0), -1);
     }
   }
+  WS_TOC(dc, 7, tSetup);
   bool haveLast = false, failed = false;
   int lastX = 0, lastY = 0;
   while (!haveLast && !failed) {
@@ -345,6 +370,7 @@ XM_INL void wPathSearch(WSL_T S, WSNode* nodes, const IndexView& ix, const Param
     if (st.liveBuckets < 1) { res.ok = -1; res.status = XM_ST_INTERNAL; return; }  // Java: NullPointerException
     // priorities.poll(): the live bucket with the smallest key, one or two keys per lane
     int b;
+    WS_TIC(tPop);
     {
       WV_VAR(double, myKey);
       WV_VAR(int, myB);
@@ -357,6 +383,7 @@ XM_INL void wPathSearch(WSL_T S, WSNode* nodes, const IndexView& ix, const Param
       const int nl = st.nBuckets < 64 ? st.nBuckets : 64;
       for (int l = 0; l < nl; l++) { const double key = WV_BCAST_D(myKey, l); if (key < best) { best = key; b = WV_BCAST_I(myB, l); } }
     }
+    WS_TOC(dc, 8, tPop);
     st.activePenalty = S->bkey[b];
     int li = S->bhead[b] == 0xFFFF ? -1 : (int)S->bhead[b];
     while (li >= 0) {
@@ -364,69 +391,84 @@ XM_INL void wPathSearch(WSL_T S, WSNode* nodes, const IndexView& ix, const Param
       const int x = xyv >> 9, y = xyv & 511;
       if (st.activePenalty > st.maxInterestingPenalty + 0.000001) { failed = true; break; }
       if (x == st.goalX) { haveLast = true; lastX = x; lastY = y; break; }
-      // explore :722-729
+      // explore :722-729.  The eight cells the three updates look at, one per lane: the explored cell N, the three targets A = (x+d, y),
+      // B = (x, y+d), C = (x+d, y+d), and A's upper / diagonal and B's left / diagonal neighbours
       const int ax = x + d, ay = y, bx = x, by = y + d, cx2 = x + d, cy2 = y + d;
       const bool inA = !(ax <= 0 || ax > st.textALength || ay <= 0 || ay > st.textBLength);
       const bool inB = !(bx <= 0 || bx > st.textALength || by <= 0 || by > st.textBLength);
       const bool inC = !(cx2 <= 0 || cx2 > st.textALength || cy2 <= 0 || cy2 > st.textBLength);
-      WV_VAR(int, uPut); WV_VAR(int, uFl); WV_VAR(int, uSlot); WV_VAR(int, uExisting);
+      WS_TIC(tRegion);
+      WV_VAR(int, cHas); WV_VAR(int, cSlotV); WV_VAR(int, cFlV);
+      WV_VAR(double, cPenV); WV_VAR(double, cInsXV); WV_VAR(double, cInsYV);
+      WV_PAR
+        WV(cHas) = 0; WV(cSlotV) = -1; WV(cFlV) = 0; WV(cPenV) = 0; WV(cInsXV) = 0; WV(cInsYV) = 0;
+        if (wl > 7) continue;
+        // lane k: 0 N, 1 A, 2 B, 3 C, 4 A.up (x+d, y-d), 5 A.diag (x, y-d), 6 B.left (x-d, y+d), 7 B.diag (x-d, y)
+        const int kx = (wl == 1 || wl == 3 || wl == 4) ? x + d : ((wl == 6 || wl == 7) ? x - d : x);
+        const int ky = (wl == 2 || wl == 3 || wl == 6) ? y + d : ((wl == 4 || wl == 5) ? y - d : y);
+        // (the cells of A and B are also the upper and left neighbours of C)
+        const bool need = wl == 0 ? true : (wl == 1 ? (inA || inC) : (wl == 2 ? (inB || inC) : ((wl == 4 || wl == 5) ? inA : ((wl == 6 || wl == 7) ? inB : inC))));
+        if (!need || kx < 0 || ky < 0 || kx > 127 || ky > 511) continue;
+        int slot;
+        const int idx = wsFind(S, kx, ky, slot);
+        WV(cSlotV) = slot;
+        if (idx >= 0) { const WSNode n = wsLoadNode(S, nodes, idx); WV(cHas) = 1; WV(cPenV) = n.pen; WV(cInsXV) = n.insX; WV(cInsYV) = n.insY; WV(cFlV) = n.fl; }
+      WV_ENDPAR
+      // lanes 0 and 1 compute the updates of A and B side by side, each taking its four neighbours from the lanes that looked them up
+      WV_VAR(int, uPut); WV_VAR(int, uFl);
       WV_VAR(double, uPen); WV_VAR(double, uInsX); WV_VAR(double, uInsY); WV_VAR(double, uEst);
       WV_PAR
-        WV(uPut) = 0; WV(uFl) = 0; WV(uSlot) = -1; WV(uExisting) = 0; WV(uPen) = 0; WV(uInsX) = 0; WV(uInsY) = 0; WV(uEst) = 0;
-        if (wl > 2) continue;
-        const int tx = wl == 1 ? bx : ax, ty = wl == 0 ? ay : (wl == 1 ? by : cy2);
-        const bool in = wl == 0 ? inA : (wl == 1 ? inB : inC);
-        if (!in) continue;
-        int sE, sL, sU, sD;
-        const int iE = wsFind(S, tx, ty, sE);
-        WV(uSlot) = sE;
-        if (wl == 2) {  // lane 2: the third cell's current node only (its update needs the other two outcomes)
-          WV(uExisting) = iE >= 0 ? 1 : 0;
-          if (iE >= 0) { const WSNode n = wsLoadNode(S, nodes, iE); WV(uPen) = n.pen; WV(uInsX) = n.insX; WV(uInsY) = n.insY; WV(uFl) = n.fl; }
-          continue;
-        }
-        const int iL = wsFind(S, tx - d, ty, sL), iU = wsFind(S, tx, ty - d, sU), iD = wsFind(S, tx - d, ty - d, sD);
-        WSNode zero; zero.pen = zero.insX = zero.insY = 0; zero.fl = 0; zero.pad = 0;
-        const WSNode nE = iE >= 0 ? wsLoadNode(S, nodes, iE) : zero, nL = iL >= 0 ? wsLoadNode(S, nodes, iL) : zero, nU = iU >= 0 ? wsLoadNode(S, nodes, iU) : zero, nD = iD >= 0 ? wsLoadNode(S, nodes, iD) : zero;
+        // (A: existing = lane 1, left = N (lane 0), up = lane 4, diag = lane 5;  B: existing = lane 2, left = lane 6, up = N (lane 0), diag = lane 7)
+        const int sE = wl == 0 ? 1 : 2, sL = wl == 0 ? 0 : 6, sU = wl == 0 ? 4 : 0, sD = wl == 0 ? 5 : 7;
+        WSNode nE, nL, nU, nD;
+        const int hasE = WV_OF(cHas, sE), hasL = WV_OF(cHas, sL), hasU = WV_OF(cHas, sU), hasD = WV_OF(cHas, sD);
+        nE.pen = WV_OF(cPenV, sE); nE.insX = WV_OF(cInsXV, sE); nE.insY = WV_OF(cInsYV, sE); nE.fl = WV_OF(cFlV, sE); nE.pad = 0;
+        nL.pen = WV_OF(cPenV, sL); nL.insX = WV_OF(cInsXV, sL); nL.insY = WV_OF(cInsYV, sL); nL.fl = WV_OF(cFlV, sL); nL.pad = 0;
+        nU.pen = WV_OF(cPenV, sU); nU.insX = WV_OF(cInsXV, sU); nU.insY = WV_OF(cInsYV, sU); nU.fl = WV_OF(cFlV, sU); nU.pad = 0;
+        nD.pen = WV_OF(cPenV, sD); nD.insX = WV_OF(cInsXV, sD); nD.insY = WV_OF(cInsYV, sD); nD.fl = WV_OF(cFlV, sD); nD.pad = 0;
+        WV(uPut) = 0; WV(uFl) = 0; WV(uPen) = 0; WV(uInsX) = 0; WV(uInsY) = 0; WV(uEst) = 0;
+        if (wl > 1) continue;
+        const int tx = wl == 0 ? ax : bx, ty = wl == 0 ? ay : by;
+        if (!(wl == 0 ? inA : inB)) continue;
         const int ia = tx - 1, ib = ty - 1;
         WSUpdate o;
-        wsCompute(st, tx, ty, iE >= 0, nE, iL >= 0, nL, iU >= 0, nU, iD >= 0, nD, wsCharA(S, st, ia), wsCharB(S, st, ib), wsCharA(S, st, ia - d), wsCharA(S, st, ia + d),
+        wsCompute(st, tx, ty, hasE != 0, nE, hasL != 0, nL, hasU != 0, nU, hasD != 0, nD, wsCharA(S, st, ia), wsCharB(S, st, ib), wsCharA(S, st, ia - d), wsCharA(S, st, ia + d),
                   wsCharB(S, st, ib - d), wsCharB(S, st, ib + d), o);
-        WV(uExisting) = iE >= 0 ? 1 : 0;
         if (o.put) { WV(uPut) = 1; WV(uFl) = o.fl; WV(uPen) = o.pen; WV(uInsX) = o.insX; WV(uInsY) = o.insY; WV(uEst) = o.est; }
       WV_ENDPAR
-      // the two outcomes and the third cell, wave-uniform
+      WS_TOC(dc, 9, tRegion);
+      WS_TIC(tPuts);
+      // the two outcomes, wave-uniform; the nodes are put in the reference's order
       const int aPut = WV_BCAST_I(uPut, 0), bPut = WV_BCAST_I(uPut, 1);
-      const int aFl = WV_BCAST_I(uFl, 0), bFl = WV_BCAST_I(uFl, 1), cFlOld = WV_BCAST_I(uFl, 2);
-      const int aSlot = WV_BCAST_I(uSlot, 0), bSlot = WV_BCAST_I(uSlot, 1), cSlot = WV_BCAST_I(uSlot, 2);
-      const int aExisting = WV_BCAST_I(uExisting, 0), bExisting = WV_BCAST_I(uExisting, 1), cExisting = WV_BCAST_I(uExisting, 2);
+      const int aFl = WV_BCAST_I(uFl, 0), bFl = WV_BCAST_I(uFl, 1);
+      const int aSlot = WV_BCAST_I(cSlotV, 1), bSlot = WV_BCAST_I(cSlotV, 2), cSlot = WV_BCAST_I(cSlotV, 3);
+      const int aHad = WV_BCAST_I(cHas, 1), bHad = WV_BCAST_I(cHas, 2), cHad = WV_BCAST_I(cHas, 3), nHad = WV_BCAST_I(cHas, 0);
       const double aPen = WV_BCAST_D(uPen, 0), aInsX = WV_BCAST_D(uInsX, 0), aInsY = WV_BCAST_D(uInsY, 0), aEst = WV_BCAST_D(uEst, 0);
       const double bPen = WV_BCAST_D(uPen, 1), bInsX = WV_BCAST_D(uInsX, 1), bInsY = WV_BCAST_D(uInsY, 1), bEst = WV_BCAST_D(uEst, 1);
-      const double cPenOld = WV_BCAST_D(uPen, 2), cInsXOld = WV_BCAST_D(uInsX, 2), cInsYOld = WV_BCAST_D(uInsY, 2);
       if (aPut) wsPutNode(S, nodes, st, ax, ay, aPen, aInsX, aInsY, aFl, aEst, aSlot);
       if (st.overflow) break;
       if (bPut) wsPutNode(S, nodes, st, bx, by, bPen, bInsX, bInsY, bFl, bEst, bSlot);
       if (st.overflow) break;
       if (inC) {
-        // (x+d, y+d): left = the cell of the second update, up = the cell of the first, diag = the explored node itself (lane-0 work, wave-uniform values)
-        int sTmp;
-        const int iL = wsFind(S, bx, by, sTmp), iU = wsFind(S, ax, ay, sTmp), iD = wsFind(S, x, y, sTmp);
-        WSNode zero; zero.pen = zero.insX = zero.insY = 0; zero.fl = 0; zero.pad = 0;
-        WSNode nE = zero, nL = zero, nU = zero, nD = zero;
-        nE.pen = cPenOld; nE.insX = cInsXOld; nE.insY = cInsYOld; nE.fl = cFlOld;
-        // the node a cell holds after the two puts: the new one when its update put, else the one it had
-        if (iL >= 0) { if (bPut) { nL.pen = bPen; nL.insX = bInsX; nL.insY = bInsY; nL.fl = bFl; } else nL = wsLoadNode(S, nodes, iL); }
-        if (iU >= 0) { if (aPut) { nU.pen = aPen; nU.insX = aInsX; nU.insY = aInsY; nU.fl = aFl; } else nU = wsLoadNode(S, nodes, iU); }
-        if (iD >= 0) nD = wsLoadNode(S, nodes, iD);
+        // (x+d, y+d): left = what cell B holds after the two puts, up = what cell A holds, diag = the explored cell N (wave-uniform values)
+        WSNode nE, nL, nU, nD;
+        nE.pen = WV_BCAST_D(cPenV, 3); nE.insX = WV_BCAST_D(cInsXV, 3); nE.insY = WV_BCAST_D(cInsYV, 3); nE.fl = WV_BCAST_I(cFlV, 3); nE.pad = 0;
+        nD.pen = WV_BCAST_D(cPenV, 0); nD.insX = WV_BCAST_D(cInsXV, 0); nD.insY = WV_BCAST_D(cInsYV, 0); nD.fl = WV_BCAST_I(cFlV, 0); nD.pad = 0;
+        bool hasL = bHad != 0, hasU = aHad != 0;
+        if (bPut) { nL.pen = bPen; nL.insX = bInsX; nL.insY = bInsY; nL.fl = bFl; hasL = true; }
+        else { nL.pen = WV_BCAST_D(cPenV, 2); nL.insX = WV_BCAST_D(cInsXV, 2); nL.insY = WV_BCAST_D(cInsYV, 2); nL.fl = WV_BCAST_I(cFlV, 2); }
+        if (aPut) { nU.pen = aPen; nU.insX = aInsX; nU.insY = aInsY; nU.fl = aFl; hasU = true; }
+        else { nU.pen = WV_BCAST_D(cPenV, 1); nU.insX = WV_BCAST_D(cInsXV, 1); nU.insY = WV_BCAST_D(cInsYV, 1); nU.fl = WV_BCAST_I(cFlV, 1); }
+        nL.pad = 0; nU.pad = 0;
         const int ia = cx2 - 1, ib = cy2 - 1;
         WSUpdate o;
-        wsCompute(st, cx2, cy2, cExisting != 0, nE, iL >= 0, nL, iU >= 0, nU, iD >= 0, nD, wsCharA(S, st, ia), wsCharB(S, st, ib), wsCharA(S, st, ia - d), wsCharA(S, st, ia + d),
+        wsCompute(st, cx2, cy2, cHad != 0, nE, hasL, nL, hasU, nU, nHad != 0, nD, wsCharA(S, st, ia), wsCharB(S, st, ib), wsCharA(S, st, ia - d), wsCharA(S, st, ia + d),
                   wsCharB(S, st, ib - d), wsCharB(S, st, ib + d), o);
         // (the first two puts may have taken the empty slot this cell's lookup ended at: wsPutNode checks the slot)
         if (o.put) wsPutNode(S, nodes, st, cx2, cy2, o.pen, o.insX, o.insY, o.fl, o.est, cSlot);
         if (st.overflow) break;
       }
-      (void)aExisting; (void)bExisting;
+      WS_TOC(dc, 15, tPuts);
       li = S->next[li] == 0xFFFF ? -1 : (int)S->next[li];
     }
     if (st.overflow || failed || haveLast) break;
@@ -553,10 +595,10 @@ XM_INL void wPathSearch(WSL_T S, WSNode* nodes, const IndexView& ix, const Param
 
 // runs the request waiting in `M` and appends its result to the memo
 template <class SL>
-XM_INL void wRunSearch(WSL_T S, WSNode* nodes, const IndexView& ix, const Params& params, const uint8_t* mateBase, int mateLen, WMemo* M) {
+XM_INL void wRunSearch(WSL_T S, WSNode* nodes, const IndexView& ix, const Params& params, const uint8_t* mateBase, int mateLen, WMemo* M, DevCounters* dc = nullptr) {
   const WSearchReq r = M->req;
   WSearchResult res;
-  wPathSearch(S, nodes, ix, params, mateBase, mateLen, r, res);
+  wPathSearch(S, nodes, ix, params, mateBase, mateLen, r, res, dc);
   WV_LANE0 {
     const int k = M->count;
     WSearchResult* dst = &M->res[k];
