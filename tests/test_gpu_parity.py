@@ -77,6 +77,10 @@ PASS_SHAPES = [
     {"XM_PAIR_LANES": "0"},                                                     # one lane per read in the gapped pass
     {"XM_HANDOVER": "0", "XM_PAIR_LANES": "0", "XM_FULL_LPW": "64"},            # both off, full waves
     {"XM_GAPPED_TMP_PCT": "25", "XM_SCRATCH_GIB": "1"},                         # small temporaries (HBM-mode searches overflow into the rerun passes), tiny region pool
+    {"XM_WAVE": "1"},                                                           # the wave-per-read form first (light tier, chain tiers with inline searches), lane-per-read passes for the rest
+    {"XM_WAVE": "1", "XM_WAVE_TIERS": "1"},                                     # its light tier only
+    {"XM_WAVE": "1", "XM_WAVE_TIERS": "2"},                                     # light + chain tier (no tier with the largest capacities)
+    {"XM_WAVE": "1", "XM_WAVE_INLINE_SEARCH": "0"},                             # every PathAligner search through the reads' memos and the search kernel
 ]
 
 
