@@ -106,6 +106,9 @@ typedef struct xm_index_info_t {
 } xm_index_info_t;
 
 const char* xm_last_error(void);
+/* First 16 hex digits of the SHA-256 over the library's sources (mapper_amd/csrc/*.h, *.hip in name order, then this header) at build
+ * time: lets a caller check that the loaded library was built from the sources it sits beside. */
+const char* xm_build_stamp(void);
 int xm_device_count(void);
 
 /* Replaces new SequenceDatabase + new HashBlock_Database(...).prepare() + new DuplicationDetector(...).helpSetup()

@@ -47,7 +47,7 @@ class XmIndexInfo(C.Structure):
                 ("hash_seconds", C.c_double), ("duplication_seconds", C.c_double)]
 
 
-EXPORTS = ["xm_last_error", "xm_device_count", "xm_index_build", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
+EXPORTS = ["xm_last_error", "xm_build_stamp", "xm_device_count", "xm_index_build", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
            "xm_index_table_info", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe", "xm_measure_random_gather"]
 
 
@@ -56,8 +56,30 @@ def build_library(force=False):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "xmapper_hip.h")]
     stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:
-        subprocess.check_call(["make", "-C", CSRC], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-j8", "-C", CSRC], stdout=subprocess.DEVNULL)
     return LIB_PATH
+
+
+def source_stamp():
+    """The digest the Makefile compiles into the library (xm_build_stamp): SHA-256 over csrc/*.h, *.hip in name order, then include/xmapper_hip.h."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(f for f in os.listdir(CSRC) if f.endswith(".h") or f.endswith(".hip")):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "xmapper_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_stamp():
+    return lib().xm_build_stamp().decode()
+
+
+def check_stamp():
+    """Raises when the loaded library was not built from the sources in this tree."""
+    have, want = build_stamp(), source_stamp()
+    if have != want:
+        raise RuntimeError("libxmapper_hip.so is stale: built from sources %s, the tree holds %s (run make -j8 -C mapper_amd/csrc)" % (have, want))
+    return have
 
 
 _lib = None
@@ -66,13 +88,15 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            try:
-                build_library()
-            except Exception as e:  # noqa: BLE001
-                raise ImportError("libxmapper_hip.so is missing and could not be built with hipcc; mapper_amd has no CPU fallback: %s" % e)
-        L = C.CDLL(os.environ.get("XM_LIB_PATH") or LIB_PATH)  # (XM_LIB_PATH: A/B experiments with another build of the same library)
+        path = os.environ.get("XM_LIB_PATH") or LIB_PATH  # (XM_LIB_PATH: A/B experiments with another build of the same library)
+        if not os.path.exists(path):
+            # no lazy build here: a process that runs under a profiler's preloaded library must not start make/hipcc children
+            # (and a half-built library must never be picked up silently); __graft_entry__.build() or `make -C mapper_amd/csrc` builds it
+            raise ImportError("%s is missing: build it first (python -c 'import __graft_entry__ as g; g.build()' or make -j8 -C mapper_amd/csrc); "
+                              "mapper_amd has no CPU fallback" % path)
+        L = C.CDLL(path)  # (XM_LIB_PATH: A/B experiments with another build of the same library)
         L.xm_last_error.restype = C.c_char_p
+        L.xm_build_stamp.restype = C.c_char_p
         L.xm_index_build.argtypes = [C.POINTER(XmRef), C.POINTER(XmBuildOpts), C.POINTER(C.c_void_p)]
         L.xm_index_save.argtypes = [C.c_void_p, C.c_char_p]
         L.xm_index_load.argtypes = [C.c_char_p, C.POINTER(XmRef), C.POINTER(XmBuildOpts), C.POINTER(C.c_void_p)]

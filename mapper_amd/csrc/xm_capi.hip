@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <atomic>
 #include <cstring>
 #include <cstdlib>
 #include <cstdio>
@@ -43,6 +44,14 @@ __device__ __forceinline__ void addCounters(DevCounters* g, const DevCounters& l
 static long long envInt(const char* name, long long dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoll(v) : dflt;
+}
+
+// experiment knobs are validated: a value outside [lo, hi] (or not a power of two where the capacities need one) is an error, not a silent corruption
+static long long envKnob(const char* name, long long dflt, long long lo, long long hi, bool pow2 = false) {
+  const long long v = envInt(name, dflt);
+  if (v < lo || v > hi || (pow2 && (v & (v - 1)) != 0))
+    throw std::runtime_error(std::string(name) + "=" + std::to_string(v) + " is not valid: expected " + (pow2 ? "a power of two in " : "a value in ") + std::to_string(lo) + ".." + std::to_string(hi));
+  return v;
 }
 
 #ifndef XM_WAVES_PER_SIMD
@@ -97,12 +106,19 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
       item = (unsigned long long)mine;
     } else {
       dealt = false;
-      if (taperUnit > 0 && laneInWave > 0) {
+      {
         // End of the work list (gapped pass): the lanes of a wave run their reads mostly one after the other, so when the list runs dry
         // every wave would still hold lanesPerWave unfinished reads and the launch would end with that long serial tail.  The higher
         // lanes therefore stop taking reads early; the last reads are spread one per wave.
-        long long remaining = nTodo - (long long)__hip_atomic_load(nextItem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (remaining < (long long)laneInWave * taperUnit) break;
+        // (pair mode: the read's first lane decides for both - two separate loads of the counter could differ, and a lane that left alone
+        // would leave its partner exchanging values with an inactive lane)
+        int leave = 0;
+        if (taperUnit > 0 && laneInWave > 0 && !second) {
+          long long remaining = nTodo - (long long)__hip_atomic_load(nextItem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          leave = remaining < (long long)laneInWave * taperUnit;
+        }
+        if (pairLanes) leave = __shfl(leave, physLane & ~1);
+        if (leave) break;
       }
       if (waveSync) {
         // Light pass: the lanes of a wave take their next reads together and meet again before the following batch, so that the
@@ -113,7 +129,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
         first = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)first);
         if ((long long)first >= nTodo) break;
         item = first + (unsigned)laneInWave;
-        if ((long long)item >= nTodo) continue;  // (the next batch is past the end for everybody)
+        if ((long long)item >= nTodo) break;  // (this was the last batch: lane 0, whose item is always inside it, fetches once more and leaves too)
       } else {
         item = 0;
         if (!second) item = atomicAdd(nextItem, 1ull);
@@ -451,6 +467,7 @@ struct xm_index {
   HostIndex host;
   bool hostOnly = false;
   int device = 0;
+  std::atomic<int> hashedLength{0};  // copy of host.maxHashedLength that xm_batch_stage may read while mu is held elsewhere (set by upload())
   std::mutex mu;
   // device residency
   DevBuf<int64_t> dContigStart, dSeqCumStart, dDupKeyStart;
@@ -508,6 +525,7 @@ struct xm_index {
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
     numCUs = prop.multiProcessorCount;
+    hashedLength.store(host.maxHashedLength);
     auto up = [&](auto& buf, const auto& vec) {
       buf.ensure(vec.size());
       if (!vec.empty()) HIP_CHECK(hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice));
@@ -551,6 +569,10 @@ struct xm_index {
 extern "C" {
 
 const char* xm_last_error(void) { return g_error.c_str(); }
+#ifndef XM_BUILD_STAMP
+#define XM_BUILD_STAMP "unstamped"
+#endif
+const char* xm_build_stamp(void) { return XM_BUILD_STAMP; }
 
 int xm_device_count(void) {
   int n = 0;
@@ -779,10 +801,12 @@ int xm_batch_stage(xm_index* idx, const xm_query_batch* b) {
     bool anyPaired = false;
     const int maxLen = validateBatch(b, &anyPaired);
     idx->stagedAnyPaired = anyPaired;
-    if (maxLen > idx->host.maxHashedLength) {  // the tables grow: that touches what a running xm_align_resident reads, so wait for it
+    if (maxLen > idx->hashedLength.load()) {  // the tables grow: that touches what a running xm_align_resident reads, so wait for it
       std::lock_guard<std::mutex> lock(idx->mu);
-      idx->host.ensureLength(maxLen);
-      idx->upload();
+      if (maxLen > idx->host.maxHashedLength) {
+        idx->host.ensureLength(maxLen);
+        idx->upload();
+      }
     }
     HIP_CHECK(hipSetDevice(idx->device));
     if (!idx->copyStream) { HIP_CHECK(hipStreamCreateWithFlags(&idx->copyStream, hipStreamNonBlocking)); HIP_CHECK(hipEventCreate(&idx->cev0)); HIP_CHECK(hipEventCreate(&idx->cev1)); }
@@ -899,7 +923,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // the scratch capacities are sized for ~150-300 bp mates at scale 1; batches of longer reads start at a larger scale instead of
     // sending every read through a pass that can only overflow
     int scale = idx->residentMaxLen <= 320 ? 1 : (idx->residentMaxLen <= 1280 ? 4 : 16), overflowScale = scale;
-    const int gappedScale = scale < 4 ? (int)envInt("XM_GAPPED_SCALE", 4) : scale * (int)envInt("XM_GAPPED_FACTOR", 4);
+    const int gappedScale = scale < 4 ? (int)envKnob("XM_GAPPED_SCALE", 4, 1, 64, true) : scale * (int)envKnob("XM_GAPPED_FACTOR", 4, 1, 64, true);
     bool heavy = false, defer = false, memoFresh = false, inlineRest = false;
     int searchRounds = 0;
     unsigned long long intCap = (unsigned long long)nq * 40 + 4096, dblCap = (unsigned long long)nq * 12 + 4096;
@@ -910,19 +934,19 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     double kernelMs = 0;
     int launches = 0;
     int64_t rerun = 0;
-    const size_t arenaUnit = (size_t)envInt("XM_ARENA_KB", 288) * 1024;  // scratch of a lane at scale 1 (experiment knob: the capacities do not follow it, a smaller arena only overflows earlier)
-    const long long scratchGiBWanted = envInt("XM_SCRATCH_GIB", 200);
-    const long long lightWaves = envInt("XM_LIGHT_WAVES", 8), fullWaves = envInt("XM_FULL_WAVES", 4), pathWaves = envInt("XM_PATH_WAVES", 4);
-    const long long fullLpw = envInt("XM_FULL_LPW", 32), lightLpw = envInt("XM_LIGHT_LPW", 64);
+    const size_t arenaUnit = (size_t)envKnob("XM_ARENA_KB", 288, 64, 16384) * 1024;  // scratch of a lane at scale 1 (experiment knob: the capacities do not follow it, a smaller arena only overflows earlier)
+    const long long scratchGiBWanted = envKnob("XM_SCRATCH_GIB", 200, 1, 280);
+    const long long lightWaves = envKnob("XM_LIGHT_WAVES", 8, 1, 16), fullWaves = envKnob("XM_FULL_WAVES", 4, 1, 16), pathWaves = envKnob("XM_PATH_WAVES", 4, 1, 16);
+    const long long fullLpw = envKnob("XM_FULL_LPW", 32, 1, 64), lightLpw = envKnob("XM_LIGHT_LPW", 64, 1, 64);
     const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
     const bool fullSync = envInt("XM_FULL_SYNC", 0) != 0;  // gapped pass: the lanes of a wave take their next reads together (no taper then)
     const bool lightSync = envInt("XM_LIGHT_SYNC", 0) != 0;  // lanes of a light-pass wave take reads together (measured: no gain)
-    const long long lightLevel = envInt("XM_LIGHT_LEVEL", 0);  // what the light pass still does itself (Caps::heavyAllowed)
-    const long long heavyHintThreshold = envInt("XM_HEAVY_HINT", 0);  // straight-alignment penalty x 8 from which a read is put first in the gapped pass and dealt out evenly (0: no order; measured: no gain, the pass is bound by the work per wave, not by its balance)
-    const long long taperWaves = envInt("XM_TAPER_PCT", 100);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
+    const long long lightLevel = envKnob("XM_LIGHT_LEVEL", 0, 0, 2);  // what the light pass still does itself (Caps::heavyAllowed)
+    const long long heavyHintThreshold = envKnob("XM_HEAVY_HINT", 0, 0, 1 << 20);  // straight-alignment penalty x 8 from which a read is put first in the gapped pass and dealt out evenly (0: no order; measured: no gain, the pass is bound by the work per wave, not by its balance)
+    const long long taperWaves = envKnob("XM_TAPER_PCT", 100, 0, 1000);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
     // a search round costs two launches whose time is the time of one read (a replay, a search) however few reads wait; once the
     // waiting reads no longer fill the GPU the rest is cheaper inline: one last chain pass, one read per wave
-    const long long deferMaxRounds = envInt("XM_DEFER_ROUNDS", 3), inlineBelow = envInt("XM_INLINE_BELOW", 8192);
+    const long long deferMaxRounds = envKnob("XM_DEFER_ROUNDS", 3, 0, 64), inlineBelow = envKnob("XM_INLINE_BELOW", 8192, 0, 1ll << 40);
     auto scratchBudget = [&]() -> unsigned long long {  // scratch: up to 200 GiB of the 288 GiB HBM, never more than 3/4 of what is free
       long long scratchGiB = scratchGiBWanted;
       size_t freeB = 0, totalB = 0;
@@ -938,7 +962,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // (Deferred searches replay a read from its start, which a consumed region does not allow: no hand-over then.)
     const bool pairMode = envInt("XM_PAIR_LANES", 1) != 0;
     // temporaries of a gapped-pass lane (reads that resume from a saved region): 7/12 of the arena of that scale by default (experiment knob: percent of it)
-    const long long gappedTmpPct = envInt("XM_GAPPED_TMP_PCT", 100);
+    const long long gappedTmpPct = envKnob("XM_GAPPED_TMP_PCT", 100, 5, 100);
     auto gappedTmpBytes = [&](size_t arena) -> size_t { return (size_t)((arena - arenaPersistBytes(arena)) * (size_t)gappedTmpPct / 100) & ~(size_t)15; };
     const bool handOver = envInt("XM_HANDOVER", 1) != 0 && !deferSearches;
     int hoMode = handOver ? 1 : 0;   // mode of the next launch
@@ -964,7 +988,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       WaveCtl wctl{0, 0, 0, ~0ull};
       HIP_CHECK(hipMemcpyAsync(idx->dWaveCtl.p, &wctl, sizeof(wctl), hipMemcpyHostToDevice, s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
-      const int lastTier = (int)envInt("XM_WAVE_TIERS", 3) - 1;  // (experiment knob: 1 = light tier only, 2 = light + chain tier)
+      const int lastTier = (int)envKnob("XM_WAVE_TIERS", 3, 1, 3) - 1;  // (experiment knob: 1 = light tier only, 2 = light + chain tier)
       int sWaves = 4, sLds = 1, sPerSimd = 4, memoBytes = 1, nodesPerWave = 1;
       xmSearchGeometry(&sWaves, &sLds, &sPerSimd, &memoBytes, &nodesPerWave);
       unsigned long long fallbackSoFar = 0;
@@ -976,7 +1000,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         xmWaveGeometry(wl.config, &wavesPerBlock, &ldsPerBlock, &wavesPerSimd);
         long long blocksPerCU = std::min<long long>((160 * 1024) / ldsPerBlock, (long long)(wavesPerSimd * 4) / wavesPerBlock);
         if (blocksPerCU < 1) blocksPerCU = 1;
-        wl.itemsPerFetch = (int)envInt(tier == 0 ? "XM_WAVE_FETCH" : "XM_WAVE_CHAIN_FETCH", tier == 0 ? 8 : 1);
+        wl.itemsPerFetch = (int)envKnob(tier == 0 ? "XM_WAVE_FETCH" : "XM_WAVE_CHAIN_FETCH", tier == 0 ? 8 : 1, 1, 1024);
         long long blocks = std::min<long long>((long long)idx->numCUs * blocksPerCU, (n + (long long)wavesPerBlock * wl.itemsPerFetch - 1) / ((long long)wavesPerBlock * wl.itemsPerFetch));
         if (blocks < 1) blocks = 1;
         wl.grid = (int)blocks; wl.block = wavesPerBlock * 64;
@@ -1080,6 +1104,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       if (nWaves < 1) nWaves = 1;
       if (hoMode != 1 && regionsTotal > 0) {  // the scratch cannot grow now: whole waves (and whole blocks of four) that fit behind the pool
         const long long cap = (long long)((idx->dArenas.n - regionsTotal) / arenaBytes);
+        if (cap < 1) throw std::runtime_error("the scratch behind the saved reads is smaller than one lane's arena (XM_SCRATCH_GIB / XM_ARENA_KB too small for this batch)");
         if (lpw > cap) lpw = (int)cap;
         long long w = cap / lpw;
         if (w >= 4) w &= ~3ll;

@@ -411,7 +411,7 @@ struct HostIndex {
           size_t j = i;
           while (j < v.size() && v[j].bucket == (uint32_t)b) j++;
           size_t cnt = j - i;
-          if (stored > 0x7FFFFFFFull) throw std::runtime_error("table too large for 31-bit bucket offsets");
+          if (stored + cnt > 0x7FFFFFFFull) throw std::runtime_error("table too large for 31-bit bucket offsets");
           if ((int64_t)cnt > (int64_t)t.maxCount) {
             off.push_back((uint32_t)stored | XM_OVERFULL);
           } else {
@@ -556,10 +556,56 @@ struct HostIndex {
       for (const Table& t : tables)
         if (t.capacity < 1 || t.offBase < 0 || t.posBase < 0 || (uint64_t)t.offBase + (uint64_t)t.capacity + 1 > bucketOff.size() || (uint64_t)t.posBase > positions.size())
           throw std::runtime_error("index cache: file is corrupt");
+      validateTables();
     } catch (...) {
       if (f) fclose(f);
       throw;
     }
+  }
+  // Everything the kernels index with values taken from the file is bounds-checked here, once, on load: a damaged file (or a foreign one
+  // over the same reference) must fail in xm_index_load, not read outside positions[] / refCodes[] on the GPU.
+  void validateTables() const {
+    const auto bad = [](const char* what) { throw std::runtime_error(std::string("index cache: file is corrupt (") + what + ")"); };
+    if (seqCumStart.empty() || seqCumStart[0] != 0) bad("sequence starts");
+    for (size_t i = 0; i + 1 < seqCumStart.size(); i++)
+      if (seqCumStart[i + 1] - seqCumStart[i] != (int64_t)contigLen[i >> 1]) bad("sequence starts");
+    uint64_t refTotal = 0;
+    for (size_t c = 0; c < contigLen.size(); c++) {
+      if (contigLen[c] < 0 || (uint64_t)contigStart[c] != refTotal) bad("contig starts");
+      refTotal += (uint64_t)contigLen[c];
+    }
+    if (refTotal != refCodes.size() || totalForwardSize != (int64_t)refTotal) bad("contig lengths");
+    const uint64_t encodedEnd = (uint64_t)seqCumStart.back();
+    const int nT = buildThreads(positions.size() + bucketOff.size());
+    for (size_t L = 0; L < tables.size(); L++) {
+      const Table& t = tables[L];
+      if (t.maxCount < 0) bad("table header");
+      const uint64_t stored = bucketOff[(size_t)(t.offBase + t.capacity)] & ~XM_OVERFULL;
+      if ((bucketOff[(size_t)(t.offBase + t.capacity)] & XM_OVERFULL) || (uint64_t)t.posBase + stored > positions.size()) bad("table extent");
+      std::vector<int> wrong((size_t)nT, 0);
+      parallelParts((size_t)t.capacity, nT, [&](int ti, size_t b, size_t e) {
+        for (size_t k = b; k < e; k++) {
+          const uint32_t o0 = bucketOff[(size_t)t.offBase + k] & ~XM_OVERFULL, o1 = bucketOff[(size_t)t.offBase + k + 1] & ~XM_OVERFULL;
+          if (o1 < o0 || o1 > stored) { wrong[(size_t)ti] = 1; return; }
+        }
+      });
+      for (int w : wrong) if (w) bad("bucket offsets");
+    }
+    {
+      std::vector<int> wrong((size_t)nT, 0);
+      parallelParts(positions.size(), nT, [&](int ti, size_t b, size_t e) {
+        for (size_t k = b; k < e; k++) if (positions[k] >= encodedEnd) { wrong[(size_t)ti] = 1; return; }
+      });
+      for (int w : wrong) if (w) bad("positions");
+    }
+    if (dupDone) {
+      if (dupKeyStart.size() != names.size() + 1 || dupKeyStart[0] != 0 || (uint64_t)dupKeyStart.back() != dupKeys.size()) bad("duplication keys");
+      for (size_t c = 0; c + 1 < dupKeyStart.size(); c++) {
+        if (dupKeyStart[c + 1] < dupKeyStart[c]) bad("duplication keys");
+        for (int64_t k = dupKeyStart[c]; k < dupKeyStart[c + 1]; k++)
+          if (dupKeys[(size_t)k] < 0 || dupKeys[(size_t)k] >= contigLen[c] || (k > dupKeyStart[c] && dupKeys[(size_t)k] <= dupKeys[(size_t)k - 1])) bad("duplication keys");
+      }
+    } else if (!dupKeys.empty()) bad("duplication keys");
   }
   // does this (loaded) index answer a build request for `other`'s reference with these settings?  (same resolution of defaults as build())
   bool matchesRequest(const HostIndex& other, int enableGapmers_, int minInteresting, int dupWindow_, int dupMinCopies_, int dupMinLen, int dupMaxLen) const {

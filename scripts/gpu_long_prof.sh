@@ -1,6 +1,8 @@
 #!/bin/bash
 # in-kernel wave-time profile of the gapped pass on 1,000 bp reads
 R=$GRAFT_REPO_ROOT
+# the library is built before any profiler starts: nothing under rocprofv3 may spawn make/hipcc (mapper_amd/_capi.py lib() never builds)
+make -j8 -C $R/mapper_amd/csrc > /dev/null || exit 1
 cd $R
 make -B -C mapper_amd/csrc EXTRA="-DXM_PROFILE=2" > /dev/null 2>&1
 cat > /tmp/lp.py <<'PY'

@@ -24,6 +24,21 @@ def test_capi_exports_every_declared_symbol():
     assert sorted(_capi.EXPORTS) == declared
 
 
+def test_missing_library_is_an_import_error_not_a_build():
+    """mapper_amd never builds the library behind the caller's back (a process under a profiler must not spawn make/hipcc) and has no CPU
+    fallback: a missing libxmapper_hip.so is an ImportError that says how to build it."""
+    import subprocess, sys
+    code = "import mapper_amd._capi as c\ntry:\n    c.lib()\nexcept ImportError as e:\n    print('IMPORT-ERROR', e)\n"
+    env = dict(os.environ, XM_LIB_PATH="/nonexistent/libxmapper_hip.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    assert "IMPORT-ERROR" in out.stdout and "make -j8 -C mapper_amd/csrc" in out.stdout, out.stdout + out.stderr
+
+
+def test_build_stamp_is_the_digest_of_the_sources():
+    """xm_build_stamp(): the library carries the digest of the sources it was compiled from; smoke() and bench.py refuse a stale one."""
+    assert api._capi.check_stamp() == api._capi.source_stamp()
+
+
 def test_library_refuses_to_align_without_gpu_index():
     """The product fails loudly instead of falling back to a CPU path."""
     db = api.ReferenceDatabase([("r", synth.synthetic_reference(5000))], host_only=True)
@@ -123,6 +138,17 @@ def test_index_cache_round_trip(tmp_path):
     H = api.ReferenceDatabase(refs, host_only=True, cache_dir=tmp_path)
     assert not H.cache_hit
     _same_index(B, H)
+    # a complete file whose tables are damaged: every offset and position the kernels would index with is bounds-checked on load
+    good = open(H.cache_file, "rb").read()
+    for frac in (0.35, 0.6, 0.8, 0.95):
+        at = int(len(good) * frac) & ~7
+        open(A.cache_file, "wb").write(good[:at] + b"\xff" * 64 + good[at + 64:])
+        with pytest.raises(RuntimeError, match="corrupt|another reference"):
+            api.ReferenceDatabase.load(A.cache_file, host_only=True)
+    open(A.cache_file, "wb").write(good)
+    I = api.ReferenceDatabase.load(A.cache_file, host_only=True)
+    _same_index(B, I)
+    I.close()
     for x in (A, B, C2, D, E, F, G, H):
         x.close()
 

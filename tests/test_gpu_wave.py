@@ -101,3 +101,22 @@ def test_64_bit_positions_on_a_small_reference(wave, monkeypatch):
         got, _ = gpu_align(db, b)
         assert streams_equal(got, want), first_difference(got, want, n)
     db.close()
+
+
+@pytest.mark.gpu
+def test_experiment_knobs_are_validated(monkeypatch):
+    """XM_* environment knobs outside their range are an error of the call (a scale that is not a power of two would break the hash capacities)."""
+    ref = synth.synthetic_reference(40_000, seed=3)
+    reads = synth.synthetic_single_end(ref, 64, seed=4)[0]
+    b = se_batch(reads)
+    db = api.ReferenceDatabase([("c", ref)], mode="mapper")
+    try:
+        for name, value in (("XM_GAPPED_SCALE", "3"), ("XM_FULL_LPW", "0"), ("XM_ARENA_KB", "1")):
+            monkeypatch.setenv(name, value)
+            with pytest.raises(RuntimeError, match=name):
+                db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, api.AlignmentParameters())
+            monkeypatch.delenv(name)
+        r = db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, api.AlignmentParameters())
+        assert len(r) == 64
+    finally:
+        db.close()
