@@ -106,7 +106,7 @@ typedef struct xm_index_info_t {
 } xm_index_info_t;
 
 const char* xm_last_error(void);
-/* First 16 hex digits of the SHA-256 over the library's sources (mapper_amd/csrc/*.h, *.hip in name order, then this header) at build
+/* First 16 hex digits of the SHA-256 over the library's sources (every .h and .hip file of mapper_amd/csrc in name order, then this header) at build
  * time: lets a caller check that the loaded library was built from the sources it sits beside. */
 const char* xm_build_stamp(void);
 int xm_device_count(void);
