@@ -223,6 +223,62 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_path_kernel(const i
   addCounters(counters, local);
 }
 
+// Test entry (xm_test_local_align): the reference's component-level known-answer tests (PathAligner_Test.java:10-39: PathAligner alone;
+// HashBlockAligner_Test.java:10-48: HashBlock_Aligner -> StraightAligner -> PathAligner_Runner) over two given texts, run by the code the align
+// kernel runs.  chain 0: one search, in the wave's LDS slot (mode 0) or in HBM mode (mode 1); chain 1: hashBlockAlign with the searches
+// slot-first as in the kernel (mode 0) or all in HBM mode (mode 1).  One lane works; out: found, nb, status, nodes, blocks; penalties.
+__global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(int chain, int mode, Params params, const uint8_t* query, int queryLength, const uint8_t* reference, int referenceLength,
+                                                            double maxIns, double maxDel, int scale, uint8_t* arena, unsigned long long arenaBytes, PNode* waveNodes, int blockCap,
+                                                            int32_t* outInts, double* outDbls) {
+  xmSetWaveNodes(waveNodes);
+  xmSetPairMode(0);
+  xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
+  if (threadIdx.x != 0) return;
+  DevCounters local;
+  memset(&local, 0, sizeof(local));
+  Caps caps = makeCaps(scale);
+  caps.searchInHbmOnly = mode == 1 ? 1 : 0;
+  Arena tmp;
+  tmp.init(arena, (size_t)arenaBytes);
+  int32_t status = XM_OK;
+  float hint = 0;
+  int32_t memoCursor = 0;
+  ExtEnv e;
+  e.caps = &caps; e.dc = &local; e.status = &status; e.tmp = &tmp;
+  e.query.base = query; e.query.len = queryLength; e.query.rc = 0; e.query.id = 0;
+  e.reference.base = reference; e.reference.len = referenceLength; e.reference.rc = 0; e.reference.id = 0;
+  e.contig = 0;
+  e.memo = nullptr; e.memoCursor = &memoCursor; e.heavyHint = &hint;
+  Matcher* slots = arenaArray<Matcher>(tmp, 3);
+  for (int i = 0; i < 3; i++) {
+    slots[i].present = arenaArray<uint8_t>(tmp, caps.maxSections);
+    slots[i].tables = arenaArray<int16_t>(tmp, caps.matcherEntries);
+    slots[i].tableCap = caps.matcherEntries;
+    slots[i].maxSections = caps.maxSections;
+    slots[i].nSections = 0;
+    slots[i].sectionLength = 0;
+  }
+  e.slotA = &slots[0]; e.slotB = &slots[1]; e.slotT = &slots[2];
+  SeqAl out;
+  out.blocks = arenaArray<ABlock>(tmp, caps.maxBlocks);
+  out.nb = 0; out.contig = 0; out.referenceReversed = 0; out.seqAId = 0; out.totalPenalty = 0; out.alignedPenalty = 0;
+  bool found = false;
+  if (tmp.overflow) status = XM_ST_OVERFLOW;
+  else {
+    const Section qs{0, queryLength}, rs{0, referenceLength};
+    Analysis an;  // AlignmentAnalysis as the tests construct it: nothing known about the offset, the two extension limits given
+    an.matcher = nullptr; an.predictedBestOffset = 0; an.lastCheckedOffset = 0; an.confidentAboutBestOffset = false;
+    an.maxInsertionExtensionPenalty = maxIns; an.maxDeletionExtensionPenalty = maxDel;
+    if (chain == 0) found = pathAlign(e, qs, rs, params, an, out);
+    else found = hashBlockAlign(e, qs, rs, params, an, out, e.slotB, NextStraight3());
+  }
+  outInts[0] = found && status == XM_OK ? 1 : 0; outInts[1] = found ? out.nb : 0; outInts[2] = status; outInts[3] = (int32_t)local.pathAlignerNodes;
+  if (found) {
+    for (int i = 0; i < out.nb && i < blockCap; i++) { outInts[4 + 4 * i] = out.blocks[i].startA; outInts[5 + 4 * i] = out.blocks[i].startB; outInts[6 + 4 * i] = out.blocks[i].lenA; outInts[7 + 4 * i] = out.blocks[i].lenB; }
+    outDbls[0] = out.totalPenalty; outDbls[1] = out.alignedPenalty;
+  }
+}
+
 // ---------------------------------------------------------------- pass bookkeeping on the device
 // After every pass the reads are sorted into the work lists of the passes still to come; only the list sizes travel to the host.
 struct PassCtl {
@@ -1366,6 +1422,74 @@ int xm_measure_random_gather(int device, int64_t table_bytes, int64_t accesses, 
     if (kernel_ms) *kernel_ms = best;
     return 0;
   } catch (std::exception& e) { return fail(std::string("xm_measure_random_gather: ") + e.what()); }
+}
+
+// Test-only entry (tests/test_gpu_kat.py): see xm_test_local_kernel above and xm_test_wave_search_kernel (xm_wave_kernel.hip).
+int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_params* p, const uint8_t* query, int32_t query_length, const uint8_t* reference, int32_t reference_length,
+                        double max_ins_ext, double max_del_ext, int32_t block_cap, int32_t* blocks, int32_t* num_blocks, double* penalties, int64_t* nodes_put) {
+  if (!p || !query || !reference || !blocks || !num_blocks || !penalties) { fail("xm_test_local_align: null argument"); return -1; }
+  if (chain < 0 || chain > 1 || mode < 0 || mode > 3 || (chain == 1 && mode > 1) || query_length < 1 || reference_length < 1 || query_length > 30000 || reference_length > 100000 || block_cap < 1)
+  { fail("xm_test_local_align: bad arguments (chain 0: modes 0 LDS slot, 1 HBM, 2 wave search with the search kernel's capacities, 3 with the inline capacities; chain 1: modes 0, 1)"); return -1; }
+  try {
+    if (device >= 0) HIP_CHECK(hipSetDevice(device));
+    Params params;
+    memset(&params, 0, sizeof(params));
+    params.MutationPenalty = p->MutationPenalty; params.InsertionStart_Penalty = p->InsertionStart_Penalty; params.InsertionExtension_Penalty = p->InsertionExtension_Penalty;
+    params.DeletionStart_Penalty = p->DeletionStart_Penalty; params.DeletionExtension_Penalty = p->DeletionExtension_Penalty; params.MaxErrorRate = p->MaxErrorRate;
+    params.UnalignedPenalty = p->UnalignedPenalty; params.AmbiguityPenalty = p->AmbiguityPenalty; params.Max_PenaltySpan = p->Max_PenaltySpan;
+    params.MaxNumMatches = p->MaxNumMatches; params.StartingInsertionStartFree = 0;
+    const int cap = block_cap < 256 ? block_cap : 256;
+    DevBuf<uint8_t> dq, dr, arena, nodes;
+    DevBuf<int32_t> dInts;
+    DevBuf<double> dDbls;
+    DevBuf<int64_t> dStart;
+    DevBuf<int32_t> dLen;
+    dq.ensure((size_t)query_length); dr.ensure((size_t)reference_length); dInts.ensure((size_t)4 + 4 * (size_t)cap); dDbls.ensure(2);
+    HIP_CHECK(hipMemcpy(dq.p, query, (size_t)query_length, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dr.p, reference, (size_t)reference_length, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(dInts.p, 0, sizeof(int32_t) * (4 + 4 * (size_t)cap)));
+    HIP_CHECK(hipMemset(dDbls.p, 0, sizeof(double) * 2));
+    if (mode >= 2) {
+      TestSearch t;
+      memset(&t, 0, sizeof(t));
+      t.big = mode == 2 ? 1 : 0;
+      const int64_t start0 = 0;
+      const int32_t len0 = reference_length;
+      dStart.ensure(1); dLen.ensure(1);
+      HIP_CHECK(hipMemcpy(dStart.p, &start0, 8, hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(dLen.p, &len0, 4, hipMemcpyHostToDevice));
+      t.ix.numContigs = 1; t.ix.refCodes = dr.p; t.ix.contigStart = dStart.p; t.ix.contigLen = dLen.p;
+      t.params = params; t.query = dq.p; t.queryLength = query_length; t.referenceLength = reference_length; t.predictedBestOffset = 0; t.confident = 0; t.blockCap = cap;
+      t.maxIns = max_ins_ext; t.maxDel = max_del_ext;
+      nodes.ensure((size_t)xmTestWaveSearchNodeBytes(t.big));
+      t.nodes = nodes.p; t.outInts = dInts.p; t.outDbls = dDbls.p;
+      const int rc = xmTestWaveSearchLaunch(t, 0);
+      if (rc != 0) throw std::runtime_error(std::string("test search launch: ") + hipGetErrorString((hipError_t)rc));
+    } else {
+      const int scale = 4;
+      const size_t arenaBytes = (size_t)288 * 1024 * scale;
+      arena.ensure(arenaBytes);
+      nodes.ensure((size_t)XM_PAL_NODES * 4 * sizeof(PNode));
+      hipLaunchKernelGGL(xm_test_local_kernel, dim3(1), dim3(256), 0, 0, (int)chain, (int)mode, params, (const uint8_t*)dq.p, (int)query_length, (const uint8_t*)dr.p, (int)reference_length,
+                         max_ins_ext, max_del_ext, scale, arena.p, (unsigned long long)arenaBytes, (PNode*)nodes.p, cap, dInts.p, dDbls.p);
+      HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    std::vector<int32_t> ints((size_t)4 + 4 * (size_t)cap);
+    double dbls[2];
+    HIP_CHECK(hipMemcpy(ints.data(), dInts.p, sizeof(int32_t) * ints.size(), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(dbls, dDbls.p, sizeof(dbls), hipMemcpyDeviceToHost));
+    dq.release(); dr.release(); arena.release(); nodes.release(); dInts.release(); dDbls.release(); dStart.release(); dLen.release();
+    if (nodes_put) *nodes_put = ints[3];
+    const int ok = mode >= 2 ? ints[0] : (ints[2] != XM_OK ? -1 : ints[0]);
+    if (ok < 0) { fail("xm_test_local_align: the search failed with status " + std::to_string(ints[2])); return -1; }
+    if (ok == 0) { *num_blocks = 0; return 1; }
+    if (ints[1] > cap) { fail("xm_test_local_align: more blocks than block_cap"); return -1; }
+    *num_blocks = ints[1];
+    memcpy(blocks, ints.data() + 4, sizeof(int32_t) * 4 * (size_t)ints[1]);
+    penalties[0] = dbls[0]; penalties[1] = dbls[1];
+    return 0;
+  } catch (std::exception& e) { fail(std::string("xm_test_local_align: ") + e.what()); return -1; }
 }
 
 }  // extern "C"

@@ -194,6 +194,7 @@ struct Caps {
   int32_t heavyAllowed;  // how far into the gapped chain a read may go before it stops with XM_ST_NEED_HEAVY: 0 = not at all (stops
                          // before HashBlock_Aligner), 1 = up to BlockAligner (the hash-block analysis runs, the piece-wise alignment does not), 2 = all
   int32_t deferPath;     // 1: a PathAligner search without a logged result is left as a request (XM_ST_NEED_PATH), needs a memo slot
+  int32_t searchInHbmOnly;  // test entry only (xm_test_local_align): every PathAligner search in HBM mode, the LDS slot is not tried
   int32_t maxLevels, maxPyramidBlocks, maxHistory, maxCounters, maxPending, maxQM, maxGoodAlignments, maxBlocks,
       maxNodes, nodeHash, gridCap, maxBuckets, bucketHash, matcherEntries, maxSections, maxPieces, maxCountMap, maxJoined;
 };
@@ -202,6 +203,7 @@ XM_INL Caps makeCaps(int scale) {
   c.scale = scale;
   c.heavyAllowed = 2;
   c.deferPath = 0;
+  c.searchInHbmOnly = 0;
   c.maxLevels = 48 * scale;
   c.maxPyramidBlocks = 1536 * scale;
   c.maxHistory = 192 * scale;

@@ -1253,7 +1253,8 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
     pr.qs = qs; pr.rs = rs; pr.params = p;
     pr.confident = an.confidentAboutBestOffset; pr.maxInsExt = an.maxInsertionExtensionPenalty; pr.maxDelExt = an.maxDeletionExtensionPenalty;
     pr.predictedBestOffset = an.predictedBestOffset;
-    bool ldsOverflow = false;
+    bool ldsOverflow = e.caps->searchInHbmOnly != 0;  // (test entry only: straight to the HBM-mode search)
+    if (!ldsOverflow) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(XM_WAVE_UNIFORM)
     // wave-per-read kernels (xm_wave_kernel.hip): every lane of the wave is on the same search with the same values, so the wave's slot
     // is simply used (all lanes write the same words)
@@ -1277,6 +1278,7 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
 #else
     found = pathSearchSlot(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, false);
 #endif
+    }
     if (ldsOverflow) found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, xmPairMode());
   }
   if (!found || *e.status) return false;

@@ -64,5 +64,19 @@ int xmWaveLaunch(const WaveLaunch& a, void* stream);
 void xmSearchGeometry(int* wavesPerBlock, int* ldsBytesPerBlock, int* wavesPerSimd, int* memoBytes, int* nodeBytesPerWave);
 int xmSearchLaunch(const SearchLaunch& a, void* stream);
 int xmMemoInitLaunch(WMemo* memoBase, long long n, void* stream);
+// test entry (xm_test_local_align): one wave-cooperative search over the whole of two given texts
+struct TestSearch {
+  int big;                   // 1: the search kernel's capacities, 0: those of the chain tiers' inline searches
+  IndexView ix;              // only refCodes / contigStart / contigLen of contig 0 are read
+  Params params;
+  const uint8_t* query;
+  int queryLength, referenceLength, predictedBestOffset, confident, blockCap;
+  double maxIns, maxDel;
+  void* nodes;               // xmTestWaveSearchNodeBytes(big) bytes
+  int32_t* outInts;          // ok, nb, status, nodesPut, then nb x (startA, startB, lenA, lenB)
+  double* outDbls;           // total penalty, aligned penalty
+};
+int xmTestWaveSearchNodeBytes(int big);
+int xmTestWaveSearchLaunch(const TestSearch& t, void* stream);
 
 }  // namespace xm

@@ -153,6 +153,24 @@ __global__ void __launch_bounds__(256) xm_wave_memo_init_kernel(WMemo* memoBase,
   if (i < n) { memoBase[i].count = 0; memoBase[i].pending = 0; }
 }
 
+// Test entry (xm_test_local_align, modes 2 and 3): ONE wave-cooperative PathAligner search over a query and a reference text given as they are
+// (the reference's PathAligner_Test cases), with the search kernel's capacities (BIG) or the capacities of the chain tiers' inline searches.
+template <class SL>
+__global__ void __launch_bounds__(64) xm_test_wave_search_kernel(TestSearch t) {
+  __shared__ SL lds;
+  XM_LDSP(SL)* S = (XM_LDSP(SL)*)&lds;
+  WSearchReq req;
+  req.seqAId = 0; req.contig = 0; req.qsStart = 0; req.qsEnd = t.queryLength; req.rsStart = 0; req.rsEnd = t.referenceLength;
+  req.predictedBestOffset = t.predictedBestOffset; req.confident = t.confident; req.startingInsertionStartFree = 0; req.pad = 0;
+  req.maxIns = t.maxIns; req.maxDel = t.maxDel; req.maxErrorRate = t.params.MaxErrorRate;
+  WSearchResult res;
+  wPathSearch(S, (WSNode*)t.nodes, t.ix, t.params, t.query, t.queryLength, req, res, nullptr);
+  if ((threadIdx.x & 63u) == 0) {
+    t.outInts[0] = res.ok; t.outInts[1] = res.nb; t.outInts[2] = res.status; t.outInts[3] = res.nodesPut;
+    for (int i = 0; i < res.nb && i < t.blockCap; i++) { t.outInts[4 + 4 * i] = res.blocks[i].startA; t.outInts[5 + 4 * i] = res.blocks[i].startB; t.outInts[6 + 4 * i] = res.blocks[i].lenA; t.outInts[7 + 4 * i] = res.blocks[i].lenB; }
+    t.outDbls[0] = res.totalPenalty; t.outDbls[1] = res.alignedPenalty;
+  }
+}
 #endif
 }  // namespace
 
@@ -194,6 +212,12 @@ int xmWaveLaunch(const WaveLaunch& a, void* stream) {
   if (a.config == 2) return xmWaveLaunch2(a, stream);
   if (a.config == 3) return xmWaveLaunch3(a, stream);
   return xmWaveLaunch4(a, stream);
+}
+int xmTestWaveSearchNodeBytes(int big) { return (big ? WSearchLdsKernel::kNodes : WSearchLdsInline::kNodes) * (int)sizeof(WSNode); }
+int xmTestWaveSearchLaunch(const TestSearch& t, void* stream) {
+  if (t.big) hipLaunchKernelGGL((xm_test_wave_search_kernel<WSearchLdsKernel>), dim3(1), dim3(64), 0, (hipStream_t)stream, t);
+  else hipLaunchKernelGGL((xm_test_wave_search_kernel<WSearchLdsInline>), dim3(1), dim3(64), 0, (hipStream_t)stream, t);
+  return (int)hipGetLastError();
 }
 int xmMemoInitLaunch(WMemo* memoBase, long long n, void* stream) {
   if (n <= 0) return 0;
