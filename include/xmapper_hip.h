@@ -115,6 +115,11 @@ int xm_device_count(void);
  * (Mapper.java:657-692, Api.java:41-69, HashBlock_Database.java:490-665, PackedMap.java:54-153, DuplicationDetector.java:97-436)
  * and uploads the result to HBM. */
 int xm_index_build(const xm_ref* ref, const xm_build_opts* opts, xm_index** out);
+/* A second residency of a built index on another GPU (or a second context on the same one): the host-side tables are shared by copy, the
+ * device tables are copied from the source's HBM (hipMemcpyPeer: xGMI between GPUs) instead of being built or uploaded again.  The reference
+ * shares one HashBlock_Database between all AlignerWorkers of a run (Mapper.java:912-1134); one replica per GPU is that sharing here
+ * (index replicated, reads sharded, no collective). */
+int xm_index_replicate(xm_index* source, int32_t device, xm_index** out);
 /* Binary index cache, in the spirit of --cache-dir (DirCache.java:19-60, HashBlock_Database.java:106-114,477-487, PackedMap.java:249-279:
  * the reference writes one "length-<n>" file per PackedMap under a directory keyed by its property map).  xm_index_save writes the
  * reference, every table hashed so far and the duplication map into ONE file (beside `path`, then renamed: concurrent writers are safe).

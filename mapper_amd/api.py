@@ -227,6 +227,17 @@ class ReferenceDatabase:
         self._h = h
         return self
 
+    def replicate(self, device):
+        """xm_index_replicate: a second residency of this index on GPU `device` (tables copied HBM to HBM, nothing built or uploaded twice)."""
+        other = ReferenceDatabase.__new__(ReferenceDatabase)
+        other._L = self._L
+        other.contigs, other._keep, other.cache_file, other.cache_hit = self.contigs, self._keep, self.cache_file, self.cache_hit
+        h = C.c_void_p()
+        if self._L.xm_index_replicate(self._h, int(device), C.byref(h)):
+            raise RuntimeError(self._L.xm_last_error().decode())
+        other._h = h
+        return other
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.xm_index_free(self._h)

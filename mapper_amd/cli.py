@@ -132,6 +132,12 @@ def parse_args(argv):
             o["batch_size"] = int(argv[i + 1]); i += 1
             if o["batch_size"] < 1:
                 raise UsageError("--batch-size must be >= 1")
+        elif a == "--gpus":  # (not a Mapper flag) align on GPUs 0..N-1: index replicated, batches dealt round-robin (mapper_amd/multi.py)
+            o["gpus"] = int(argv[i + 1]); i += 1
+            if o["gpus"] < 1:
+                raise UsageError("--gpus must be >= 1")
+        elif a == "--devices":  # (not a Mapper flag) explicit GPU ordinals, comma-separated; an ordinal may repeat (two contexts on one GPU)
+            o["devices"] = [int(x) for x in argv[i + 1].split(",")]; i += 1
         elif a == "--device":  # (not a Mapper flag) which GPU
             o["device"] = int(argv[i + 1]); i += 1
         elif a == "--spacing":
@@ -224,8 +230,14 @@ def run(argv, out=sys.stdout):
     queries = load_queries(o)
     ordered = api.sort_reference(contigs)  # Mapper.sortAndComplementReference: alignment results refer to this order
     names = [n for n, _ in ordered]
-    db = api.ReferenceDatabase(ordered, mode="mapper", enable_gapmers=o["enable_gapmers"], device=o["device"],
-                               max_query_length=max([len(s) for q, _ in queries for s in q.sequences] + [1]), cache_dir=o.get("cache_dir"))
+    devices = o.get("devices") or (list(range(o["gpus"])) if o.get("gpus", 1) > 1 else None)
+    max_query_length = max([len(s) for q, _ in queries for s in q.sequences] + [1])
+    if devices and len(devices) > 1:
+        from . import multi
+        db = multi.MultiGpuDatabase(ordered, devices, mode="mapper", enable_gapmers=o["enable_gapmers"], max_query_length=max_query_length, cache_dir=o.get("cache_dir"))
+    else:
+        db = api.ReferenceDatabase(ordered, mode="mapper", enable_gapmers=o["enable_gapmers"], device=devices[0] if devices else o["device"],
+                                   max_query_length=max_query_length, cache_dir=o.get("cache_dir"))
     batch_size = o.get("batch_size") or 1_000_000
     sam_out = None
     if o["out_sam"]:

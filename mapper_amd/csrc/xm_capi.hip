@@ -575,29 +575,36 @@ struct xm_index {
   int stagedMaxLen = 0;
   double stagedH2dMs = 0;
 
-  void upload() {
+  // Host tables -> HBM.  With `peer` (xm_index_replicate): the tables are copied from the peer's HBM instead (hipMemcpyPeer: over xGMI between
+  // two GPUs, a device-to-device copy on one), not sent over PCIe a second time; `host` is then already a copy of the peer's.
+  void upload(const xm_index* peer = nullptr) {
     HIP_CHECK(hipSetDevice(device));
     if (!stream) { HIP_CHECK(hipStreamCreate(&stream)); HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); }
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
     numCUs = prop.multiProcessorCount;
     hashedLength.store(host.maxHashedLength);
-    auto up = [&](auto& buf, const auto& vec) {
+    auto up = [&](auto& buf, const auto& vec, const auto& peerBuf) {
       buf.ensure(vec.size());
-      if (!vec.empty()) HIP_CHECK(hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice));
+      if (vec.empty()) return;
+      if (peer) HIP_CHECK(hipMemcpyPeer(buf.p, device, peerBuf.p, peer->device, vec.size() * sizeof(vec[0])));
+      else HIP_CHECK(hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice));
     };
-    up(dContigStart, host.contigStart); up(dContigLen, host.contigLen); up(dSeqCumStart, host.seqCumStart); up(dRefCodes, host.refCodes);
-    up(dTables, host.tables); up(dBucketOff, host.bucketOff); up(dDupKeyStart, host.dupKeyStart);
-    dDupKeys.ensure(host.dupKeys.size());
-    if (!host.dupKeys.empty()) HIP_CHECK(hipMemcpy(dDupKeys.p, host.dupKeys.data(), host.dupKeys.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    const xm_index& src = peer ? *peer : *this;
+    up(dContigStart, host.contigStart, src.dContigStart); up(dContigLen, host.contigLen, src.dContigLen); up(dSeqCumStart, host.seqCumStart, src.dSeqCumStart);
+    up(dRefCodes, host.refCodes, src.dRefCodes); up(dTables, host.tables, src.dTables); up(dBucketOff, host.bucketOff, src.dBucketOff);
+    up(dDupKeyStart, host.dupKeyStart, src.dDupKeyStart); up(dDupKeys, host.dupKeys, src.dDupKeys);
     // (XM_FORCE_POS64=1: test hook, the 64-bit position arrays of references beyond 2^32 encoded positions on a small reference)
-    posIs64 = host.seqCumStart.back() > 0xFFFFFFFFll || envInt("XM_FORCE_POS64", 0) != 0;
+    posIs64 = peer ? peer->posIs64 : (host.seqCumStart.back() > 0xFFFFFFFFll || envInt("XM_FORCE_POS64", 0) != 0);
     if (posIs64) {
-      up(dPositions64, host.positions);
+      up(dPositions64, host.positions, src.dPositions64);
+    } else if (peer) {
+      dPositions32.ensure(host.positions.size());
+      if (!host.positions.empty()) HIP_CHECK(hipMemcpyPeer(dPositions32.p, device, peer->dPositions32.p, peer->device, host.positions.size() * sizeof(uint32_t)));
     } else {
       std::vector<uint32_t> p32(host.positions.size());
       for (size_t i = 0; i < p32.size(); i++) p32[i] = (uint32_t)host.positions[i];
-      up(dPositions32, p32);
+      up(dPositions32, p32, dPositions32);
     }
     view.numContigs = host.numContigs(); view.minInterestingSize = host.minInterestingSize; view.maxHashedLength = host.maxHashedLength;
     view.enableGapmers = host.enableGapmers; view.posIs64 = posIs64 ? 1 : 0; view.dupWindow = host.dupWindow; view.dupGranularity = host.dupGranularity();
@@ -664,6 +671,35 @@ int xm_index_build(const xm_ref* ref, const xm_build_opts* optsIn, xm_index** ou
   } catch (std::exception& e) {
     delete idx;
     return fail(std::string("xm_index_build: ") + e.what());
+  }
+}
+
+int xm_index_replicate(xm_index* src, int32_t device, xm_index** out) {
+  if (!src || !out) return fail("xm_index_replicate: null argument");
+  if (src->hostOnly) return fail("xm_index_replicate: index was built with host_only=1");
+  xm_index* idx = nullptr;
+  try {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) throw std::runtime_error("no HIP device available");
+    if (device < 0 || device >= n) throw std::runtime_error("device " + std::to_string(device) + " does not exist (" + std::to_string(n) + " devices)");
+    std::lock_guard<std::mutex> lock(src->mu);  // (not while the source grows its tables)
+    idx = new xm_index();
+    idx->host = src->host;
+    idx->hostOnly = false;
+    idx->device = device;
+    idx->host.deviceForBuild = device;  // tables hashed later on demand (xm_index_ensure_length) are hashed on the replica's own GPU
+    if (device != src->device) {
+      int can = 0;
+      HIP_CHECK(hipDeviceCanAccessPeer(&can, device, src->device));
+      if (can) { HIP_CHECK(hipSetDevice(device)); hipError_t e = hipDeviceEnablePeerAccess(src->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_CHECK(e); (void)hipGetLastError(); }
+    }
+    idx->upload(src);
+    HIP_CHECK(hipDeviceSynchronize());
+    *out = idx;
+    return 0;
+  } catch (std::exception& e) {
+    delete idx;
+    return fail(std::string("xm_index_replicate: ") + e.what());
   }
 }
 

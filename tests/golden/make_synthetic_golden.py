@@ -29,6 +29,15 @@ def cases():
     return ref, {"single_end_4000": se_batch(reads), "paired_end_1500": pe_batch(m1, m2)}
 
 
+def full_cases():
+    """BASELINE.json configs[1] and configs[2] at full size, exactly the batches bench.py aligns on rank 0 (--config 1 / --config 2): 1,000,000
+    single-end reads and 1,000,000 pairs (--spacing 100 50) of 150 bp against the 5 Mb synthetic reference."""
+    ref = synth.synthetic_reference(5_000_000, seed=0xEC011)
+    reads = synth.synthetic_single_end(ref, 1_000_000, read_len=150, seed=0x5EED0001)[0]
+    m1, m2 = synth.synthetic_paired_end(ref, 1_000_000, read_len=150, seed=0x5EED0002)[:2]
+    return ref, {"configs1_single_end_1000000": lambda: se_batch(reads), "configs2_paired_end_1000000": lambda: pe_batch(m1, m2, 100.0, 50.0)}
+
+
 if __name__ == "__main__":
     ref, batches = cases()
     R = o.OracleReference([("ecoli_syn", ref)])
@@ -36,6 +45,15 @@ if __name__ == "__main__":
     for name, b in batches.items():
         s = R.align(b, o.make_params())
         out["digests"][name] = {"sha256": digest(s), "num_ints": int(len(s.ints)), "num_dbls": int(len(s.dbls))}
+    # the full-size batches (minutes of oracle time on a few cores): digests of the whole result streams + the oracle's work counters
+    out["full_reference"] = "synthetic_reference(5000000, seed=0xEC011)"
+    out["full_digests"] = {}
+    ref, batches = full_cases()
+    R = o.OracleReference([("ecoli_syn", ref)])
+    for name, make in batches.items():
+        s = R.align(make(), o.make_params(), threads=os.cpu_count())
+        out["full_digests"][name] = {"sha256": digest(s), "num_ints": int(len(s.ints)), "num_dbls": int(len(s.dbls)), "oracle_counters": [int(x) for x in s.counters[:9]]}
+        print(name, out["full_digests"][name], flush=True)
     with open(os.path.join(ROOT, "tests", "golden", "synthetic_golden.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(out)

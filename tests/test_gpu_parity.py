@@ -66,6 +66,25 @@ def test_golden_digests_and_oracle_parity():
     db.close()
 
 
+def test_full_size_golden_digests():
+    """BASELINE.json configs[1] and configs[2] at full size (the batches bench.py aligns): 1,000,000 single-end reads and 1,000,000 pairs against
+    the 5 Mb reference.  The whole result streams equal the oracle's (digests committed in tests/golden/synthetic_golden.json, made once by
+    tests/golden/make_synthetic_golden.py), and the device's work counters equal the oracle's (the roofline's byte
+    counts come from them)."""
+    from make_synthetic_golden import full_cases, digest
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "synthetic_golden.json")))["full_digests"]
+    ref, batches = full_cases()
+    db = api.ReferenceDatabase([("ecoli_syn", ref)], max_query_length=150)
+    for name, make in batches.items():
+        got, _ = gpu_align(db, make())
+        g = golden[name]
+        assert (len(got.ints), len(got.dbls)) == (g["num_ints"], g["num_dbls"]), name
+        assert digest(got) == g["sha256"], name
+        oc = g["oracle_counters"]
+        assert [int(x) for x in got.counters[:8]] == [oc[0], oc[1] + oc[2], oc[2], oc[3], oc[5], oc[6], oc[7], oc[8]], name
+    db.close()
+
+
 PASS_SHAPES = [
     {"XM_DEFER_PATH": "1"},                                                     # deferred PathAligner searches, default hand-over to the inline last pass
     {"XM_DEFER_PATH": "1", "XM_DEFER_ROUNDS": "1000", "XM_INLINE_BELOW": "0"},  # every search through xm_path_kernel
