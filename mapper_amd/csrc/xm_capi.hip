@@ -400,6 +400,18 @@ __global__ void __launch_bounds__(256) xm_gather_kernel(long long nq, const int6
   for (int k = 0; k < nd; k++) dd[k] = sd[k];
 }
 
+// Bucket lines of one table from its CSR form (IndexView::lines32 / lines64): one lane per bucket.
+template <typename W, typename P>
+__global__ void __launch_bounds__(256) xm_lines_kernel(Table t, const uint32_t* bucketOff, const P* positions, W* lines) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= t.capacity) return;
+  const uint32_t* off = bucketOff + t.offBase + k;
+  W line[8];
+  xmFillLine(line, off[0], off[1], positions + t.posBase);
+  W* dst = lines + (t.offBase + k) * 8;
+  for (int j = 0; j < 8; j++) dst[j] = line[j];
+}
+
 // PackedMap.getNumMatchesLowerBound + PackedMap.get for a batch of (used length, key): one lane per probe.
 __global__ void __launch_bounds__(256) xm_seed_probe_kernel(IndexView ix, long long n, const int32_t* usedLength, const int32_t* keys, int maxPerProbe,
                                                             int32_t* counts, int64_t* outPositions) {
@@ -409,13 +421,52 @@ __global__ void __launch_bounds__(256) xm_seed_probe_kernel(IndexView ix, long l
   if (used < 0 || used > ix.maxHashedLength) { counts[i] = -2; return; }
   const Table* t = &ix.tables[used];
   uint32_t k = packedKey(t, keys[i]);
-  const uint32_t* off = ix.bucketOff + t->offBase + k;
-  uint32_t o0 = off[0], o1 = off[1];
-  if (o0 & XM_OVERFULL) { counts[i] = -1; return; }
-  int count = (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
-  if (count > t->maxCount) { counts[i] = -1; return; }
-  counts[i] = count;
-  int64_t first = t->posBase + (int64_t)(o0 & ~XM_OVERFULL);
+  int count;
+  int64_t first;
+  if (ix.lines32 || ix.lines64) {  // bucket lines: one access returns the header and the first XM_LINE_SLOTS positions
+    const int64_t line = (t->offBase + k) * 8;
+    if (ix.lines64) {
+      const ulonglong2* lp = (const ulonglong2*)(ix.lines64 + line);
+      const ulonglong2 a = lp[0];
+      const uint32_t h = (uint32_t)a.x;
+      if (h & XM_OVERFULL) { counts[i] = -1; return; }
+      count = (int)h;
+      if (count > t->maxCount) { counts[i] = -1; return; }
+      counts[i] = count;
+      if (maxPerProbe > 0 && count > 0 && count <= XM_LINE_SLOTS) {
+        const int m = count < maxPerProbe ? count : maxPerProbe;
+        unsigned long long w[8];
+        w[0] = a.x; w[1] = a.y;
+        for (int q = 1; q < 4; q++) { const ulonglong2 b = lp[q]; w[2 * q] = b.x; w[2 * q + 1] = b.y; }
+        for (int j = 0; j < m; j++) outPositions[i * maxPerProbe + j] = (int64_t)w[1 + j];
+        return;
+      }
+    } else {
+      const uint4* lp = (const uint4*)(ix.lines32 + line);
+      const uint4 a = lp[0];
+      if (a.x & XM_OVERFULL) { counts[i] = -1; return; }
+      count = (int)a.x;
+      if (count > t->maxCount) { counts[i] = -1; return; }
+      counts[i] = count;
+      if (maxPerProbe > 0 && count > 0 && count <= XM_LINE_SLOTS) {
+        const int m = count < maxPerProbe ? count : maxPerProbe;
+        const uint4 b = lp[1];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        for (int j = 0; j < m; j++) outPositions[i * maxPerProbe + j] = (int64_t)w[1 + j];
+        return;
+      }
+    }
+    if (maxPerProbe <= 0 || count == 0) return;
+    first = t->posBase + (int64_t)(ix.bucketOff[t->offBase + k] & ~XM_OVERFULL);
+  } else {
+    const uint32_t* off = ix.bucketOff + t->offBase + k;
+    uint32_t o0 = off[0], o1 = off[1];
+    if (o0 & XM_OVERFULL) { counts[i] = -1; return; }
+    count = (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
+    if (count > t->maxCount) { counts[i] = -1; return; }
+    counts[i] = count;
+    first = t->posBase + (int64_t)(o0 & ~XM_OVERFULL);
+  }
   int m = count < maxPerProbe ? count : maxPerProbe;
   for (int j = 0; j < m; j++) outPositions[i * maxPerProbe + j] = ix.posIs64 ? (int64_t)ix.positions64[first + j] : (int64_t)ix.positions32[first + j];
 }
@@ -532,6 +583,8 @@ struct xm_index {
   DevBuf<Table> dTables;
   DevBuf<uint32_t> dBucketOff, dPositions32;
   DevBuf<uint64_t> dPositions64;
+  DevBuf<uint32_t> dLines32;  // bucket lines (IndexView::lines32 / lines64), built on the device from the CSR tables by upload()
+  DevBuf<uint64_t> dLines64;
   bool posIs64 = false;
   IndexView view;
   hipStream_t stream = nullptr;
@@ -606,6 +659,26 @@ struct xm_index {
       for (size_t i = 0; i < p32.size(); i++) p32[i] = (uint32_t)host.positions[i];
       up(dPositions32, p32, dPositions32);
     }
+    // bucket lines: 32 bytes (64 with 64-bit positions) per bucket, when they fit beside the index (XM_INDEX_LINES=0: CSR probes only)
+    view.lines32 = nullptr; view.lines64 = nullptr;
+    dLines32.release(); dLines64.release();
+    if (envInt("XM_INDEX_LINES", 1) != 0 && !host.bucketOff.empty()) {
+      const size_t words = host.bucketOff.size() * 8;
+      size_t freeB = 0, totalB = 0;
+      const size_t need = words * (posIs64 ? 8 : 4);
+      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && need < freeB / 2) {
+        if (posIs64) dLines64.ensure(words); else dLines32.ensure(words);
+        for (const Table& t : host.tables) {
+          if (t.capacity < 1) continue;
+          const unsigned grid = (unsigned)(((long long)t.capacity + 255) / 256);
+          if (posIs64) hipLaunchKernelGGL((xm_lines_kernel<uint64_t, uint64_t>), dim3(grid), dim3(256), 0, stream, t, (const uint32_t*)dBucketOff.p, (const uint64_t*)dPositions64.p, dLines64.p);
+          else hipLaunchKernelGGL((xm_lines_kernel<uint32_t, uint32_t>), dim3(grid), dim3(256), 0, stream, t, (const uint32_t*)dBucketOff.p, (const uint32_t*)dPositions32.p, dLines32.p);
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(stream));
+        view.lines32 = dLines32.p; view.lines64 = dLines64.p;
+      }
+    }
     view.numContigs = host.numContigs(); view.minInterestingSize = host.minInterestingSize; view.maxHashedLength = host.maxHashedLength;
     view.enableGapmers = host.enableGapmers; view.posIs64 = posIs64 ? 1 : 0; view.dupWindow = host.dupWindow; view.dupGranularity = host.dupGranularity();
     view.totalForwardAndReverseSize = host.totalForwardSize * 2;
@@ -616,7 +689,7 @@ struct xm_index {
   ~xm_index() {
     if (hostOnly) return;
     dContigStart.release(); dSeqCumStart.release(); dDupKeyStart.release(); dContigLen.release(); dDupKeys.release(); dRefCodes.release();
-    dTables.release(); dBucketOff.release(); dPositions32.release(); dPositions64.release(); dArenas.release(); dCodes.release();
+    dTables.release(); dBucketOff.release(); dPositions32.release(); dPositions64.release(); dLines32.release(); dLines64.release(); dArenas.release(); dCodes.release();
     dMateCount.release(); dMateLength.release(); dStatus.release(); dIntLen.release(); dDblLen.release(); dOutInts.release();
     dMateOffset.release(); dIntOff.release(); dDblOff.release(); dTodo.release(); dExpected.release(); dDeviation.release(); dOutDbls.release();
     dCursors.release(); dCounters.release();
@@ -1038,7 +1111,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const long long taperWaves = envKnob("XM_TAPER_PCT", 100, 0, 1000);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
     // a search round costs two launches whose time is the time of one read (a replay, a search) however few reads wait; once the
     // waiting reads no longer fill the GPU the rest is cheaper inline: one last chain pass, one read per wave
-    const long long deferMaxRounds = envKnob("XM_DEFER_ROUNDS", 3, 0, 64), inlineBelow = envKnob("XM_INLINE_BELOW", 8192, 0, 1ll << 40);
+    const long long deferMaxRounds = envKnob("XM_DEFER_ROUNDS", 3, 0, 1000000), inlineBelow = envKnob("XM_INLINE_BELOW", 8192, 0, 1ll << 40);
     auto scratchBudget = [&]() -> unsigned long long {  // scratch: up to 200 GiB of the 288 GiB HBM, never more than 3/4 of what is free
       long long scratchGiB = scratchGiBWanted;
       size_t freeB = 0, totalB = 0;

@@ -177,7 +177,22 @@ struct IndexView {
   const uint64_t* positions64;
   const int64_t* dupKeyStart;   // [numContigs+1]
   const int32_t* dupKeys;       // sorted duplication starts per forward contig (M/Readable_DuplicationDetector.java)
+  // Bucket lines (null: not built).  One line of eight words per bucket, at the bucket's index in bucketOff: word 0 = the bucket's count
+  // (bit 31: overfull), words 1..7 = its first positions.  A probe (PackedMap.getNumMatchesLowerBound, PackedMap.get) is then ONE access of
+  // 32 bytes (64 with 64-bit positions) that returns the header AND the hits; only buckets with more than XM_LINE_SLOTS positions (1.4 % of
+  // the buckets of a genome-like reference) still go through bucketOff + positions.  Built on the device from the CSR tables (xm_lines_kernel).
+  const uint32_t* lines32;
+  const uint64_t* lines64;
 };
+constexpr int XM_LINE_SLOTS = 7;
+constexpr int64_t XM_LINE_FLAG = 1ll << 62;  // an index "into positions" with this bit set addresses a word of the lines array instead
+// the line of bucket j (= t.offBase + k) from the CSR form; same code on the device (xm_lines_kernel) and in the host simulation
+template <typename W, typename P>
+XM_INL void xmFillLine(W* line, uint32_t o0, uint32_t o1, const P* tablePositions) {
+  const uint32_t first = o0 & ~XM_OVERFULL, count = (o1 & ~XM_OVERFULL) - first;
+  line[0] = (W)(count | (o0 & XM_OVERFULL));
+  for (uint32_t j = 0; j < (uint32_t)XM_LINE_SLOTS; j++) line[1 + j] = ((o0 & XM_OVERFULL) == 0 && j < count) ? (W)tablePositions[first + j] : (W)0;
+}
 
 XM_INL SeqView refView(const IndexView& ix, int contig, bool rc) {
   SeqView v;

@@ -497,9 +497,13 @@ XM_INL int numMatchesLowerBound(const IndexView& ix, const QBlock& b, DevCounter
   const Table* t = containingMap(ix, b.used, status);
   if (!t) return INT32_MAX;
   uint32_t k = packedKey(t, b.lookupKey());
+  if (dc) dc->headerProbes++;
+  if (ix.lines32 || ix.lines64) {  // bucket lines: the header is word 0 of the bucket's line
+    const uint32_t h = ix.lines64 ? (uint32_t)ix.lines64[(t->offBase + k) * 8] : ix.lines32[(t->offBase + k) * 8];
+    return (h & XM_OVERFULL) ? INT32_MAX : (int)h;
+  }
   const uint32_t* off = ix.bucketOff + t->offBase + k;
   uint32_t o0 = off[0], o1 = off[1];
-  if (dc) dc->headerProbes++;
   if (o0 & XM_OVERFULL) return INT32_MAX;
   return (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
 }
@@ -523,6 +527,11 @@ XM_INL RefPos decodePosition(const IndexView& ix, int64_t enc) {
   p.start = (int32_t)(enc - ix.seqCumStart[lo]);
   return p;
 }
+// position `idx` of the virtual positions array: a word of a bucket line (XM_LINE_FLAG) or an entry of the CSR positions
+XM_INL int64_t xmPositionAt(const IndexView& ix, int64_t idx) {
+  if (idx & XM_LINE_FLAG) { idx &= ~XM_LINE_FLAG; return ix.lines64 ? (int64_t)ix.lines64[idx] : (int64_t)ix.lines32[idx]; }
+  return ix.posIs64 ? (int64_t)ix.positions64[idx] : (int64_t)ix.positions32[idx];
+}
 // M/Readable_HashBlock_Database.java:22-38 / M/PackedMap.java:160-172.  returns -1 for Java null, else the hit count and
 // (firstIndex into positions, invert flag)
 XM_INL int matchBlock(const IndexView& ix, const QBlock& b, int64_t& first, bool& invert, DevCounters* dc, int32_t* status) {
@@ -530,19 +539,31 @@ XM_INL int matchBlock(const IndexView& ix, const QBlock& b, int64_t& first, bool
   const Table* t = containingMap(ix, b.used, status);
   if (!t) return -1;
   uint32_t k = packedKey(t, b.lookupKey());
-  const uint32_t* off = ix.bucketOff + t->offBase + k;
-  uint32_t o0 = off[0], o1 = off[1];
   if (dc) { dc->headerProbes++; dc->bucketFetches++; }
-  if (o0 & XM_OVERFULL) return -1;
-  int count = (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
-  if (count > t->maxCount) return -1;
-  first = t->posBase + (int64_t)(o0 & ~XM_OVERFULL);
+  int count;
+  if (ix.lines32 || ix.lines64) {
+    // bucket lines: the access that returns the count has brought the first XM_LINE_SLOTS positions with it (fetchHit reads them from the line)
+    const int64_t line = (t->offBase + k) * 8;
+    const uint32_t h = ix.lines64 ? (uint32_t)ix.lines64[line] : ix.lines32[line];
+    if (h & XM_OVERFULL) return -1;
+    count = (int)h;
+    if (count > t->maxCount) return -1;
+    if (count <= XM_LINE_SLOTS) first = XM_LINE_FLAG | (line + 1);
+    else first = t->posBase + (int64_t)(ix.bucketOff[t->offBase + k] & ~XM_OVERFULL);
+  } else {
+    const uint32_t* off = ix.bucketOff + t->offBase + k;
+    uint32_t o0 = off[0], o1 = off[1];
+    if (o0 & XM_OVERFULL) return -1;
+    count = (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
+    if (count > t->maxCount) return -1;
+    first = t->posBase + (int64_t)(o0 & ~XM_OVERFULL);
+  }
   invert = !b.isPrimaryPolarity();
   if (dc) dc->hitsFetched += (unsigned long long)count;
   return count;
 }
 XM_INL RefPos fetchHit(const IndexView& ix, int64_t idx, bool invert, int blockSpan) {
-  int64_t enc = ix.posIs64 ? (int64_t)ix.positions64[idx] : (int64_t)ix.positions32[idx];
+  int64_t enc = xmPositionAt(ix, idx);
   RefPos p = decodePosition(ix, enc);
   if (invert) {  // Readable_HashBlock_Database.reverseComplement :55-59
     p.start = ix.contigLen[p.contig] - p.start - blockSpan;

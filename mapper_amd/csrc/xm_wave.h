@@ -426,9 +426,13 @@ XM_INL int wNumMatchesLowerBound(WL_T L, const WEnv& e, const WQBlock& b) {
   if (b.used > ix.maxHashedLength) { L->status = XM_ST_NEED_GROW; return INT32_MAX; }
   const Table t = wTable(ix, b.used);
   const uint32_t k = packedKey(&t, wqLookupKey(b));
+  if (e.dc) e.dc->headerProbes++;
+  if (ix.lines32 || ix.lines64) {  // bucket lines (IndexView): the header is word 0 of the bucket's line
+    const uint32_t h = ix.lines64 ? (uint32_t)ix.lines64[(t.offBase + k) * 8] : ix.lines32[(t.offBase + k) * 8];
+    return (h & XM_OVERFULL) ? INT32_MAX : (int)h;
+  }
   const uint32_t* off = ix.bucketOff + t.offBase + k;
   const uint32_t o0 = off[0], o1 = off[1];
-  if (e.dc) e.dc->headerProbes++;
   if (o0 & XM_OVERFULL) return INT32_MAX;
   return (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
 }
@@ -721,13 +725,23 @@ WV_FN bool wCompStep(WL_T L, const WEnv& e, int mi) {
     if (qb.used > ix.maxHashedLength) { L->status = XM_ST_NEED_GROW; return false; }
     const Table t = wTable(ix, qb.used);
     const uint32_t k = packedKey(&t, wqLookupKey(qb));
-    const uint32_t* off = ix.bucketOff + t.offBase + k;
-    const uint32_t o0 = off[0], o1 = off[1];
     if (e.dc) { e.dc->headerProbes++; e.dc->bucketFetches++; }
-    if (o0 & XM_OVERFULL) continue;
-    nHits = (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
-    if (nHits > t.maxCount) continue;
-    first = t.posBase + (int64_t)(o0 & ~XM_OVERFULL);
+    if (ix.lines32 || ix.lines64) {
+      const int64_t line = (t.offBase + k) * 8;
+      const uint32_t h = ix.lines64 ? (uint32_t)ix.lines64[line] : ix.lines32[line];
+      if (h & XM_OVERFULL) continue;
+      nHits = (int)h;
+      if (nHits > t.maxCount) continue;
+      if (nHits <= XM_LINE_SLOTS) first = XM_LINE_FLAG | (line + 1);
+      else first = t.posBase + (int64_t)(ix.bucketOff[t.offBase + k] & ~XM_OVERFULL);
+    } else {
+      const uint32_t* off = ix.bucketOff + t.offBase + k;
+      const uint32_t o0 = off[0], o1 = off[1];
+      if (o0 & XM_OVERFULL) continue;
+      nHits = (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
+      if (nHits > t.maxCount) continue;
+      first = t.posBase + (int64_t)(o0 & ~XM_OVERFULL);
+    }
     invert = !wqPrimaryPolarity(qb);
     if (e.dc) e.dc->hitsFetched += (unsigned long long)nHits;
     break;
@@ -746,7 +760,7 @@ WV_FN bool wCompStep(WL_T L, const WEnv& e, int mi) {
     wvFence();
     WV_PAR
       if (wl >= nRound) continue;
-      const int64_t enc = ix.posIs64 ? (int64_t)ix.positions64[first + h0 + wl] : (int64_t)ix.positions32[first + h0 + wl];
+      const int64_t enc = xmPositionAt(ix, first + h0 + wl);
       RefPos rp = decodePosition(ix, enc);
       const int refLen = ix.contigLen[rp.contig];
       if (invert) { rp.start = refLen - rp.start - qb.len; rp.rc ^= 1; }  // Readable_HashBlock_Database.reverseComplement :55-59

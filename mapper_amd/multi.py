@@ -5,7 +5,12 @@ order.  No collective: reads are independent (the reference shares one HashBlock
 batches of queries the same way, Mapper.java:912-1134, AlignerWorker.java:92-175).
 
 bench.py's --gpus N keeps the one-process-per-GPU form of the benchmark contract (torch.distributed over RCCL); this module is the product's
-form of the same sharding, used by `python -m mapper_amd.cli --gpus N`."""
+form of the same sharding, used by `python -m mapper_amd.cli --gpus N`.
+
+The functions below the class (shard_range, gather_streams, reduce_histograms) are the one-process-per-GPU form of the same sharding:
+rank r aligns the contiguous shard shard_range(nq, r, world), the per-rank results are concatenated in rank order on the host, per-GPU
+histograms are summed on the host in fixed rank order as BASELINE.json's north_star prescribes; torch.distributed is plumbing only
+(nccl = RCCL on the GPU box, gloo in the CPU tests)."""
 import queue
 import threading
 
@@ -109,3 +114,43 @@ class MultiGpuDatabase:
         arrays = (api.ReferenceDatabase.batch_arrays(queries[s:s + batch_size]) for s in starts)
         for s, r in zip(starts, self.align_stream(arrays, parameters)):
             yield s, r
+
+
+import numpy as np  # noqa: E402
+
+
+def shard_range(nq, rank, world):
+    """Contiguous, balanced shard [lo, hi) of nq queries for `rank` of `world`."""
+    base, extra = divmod(int(nq), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_streams(dist, ints, dbls, int_off, dbl_off, rank, world):
+    """Gathers per-rank result streams on rank 0 and concatenates them in rank order (host side)."""
+    import torch
+    payload = [np.asarray(ints), np.asarray(dbls), np.asarray(int_off), np.asarray(dbl_off)]
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(payload, gathered, dst=0)
+    if rank != 0:
+        return None
+    out_i, out_d, io, do = [], [], [0], [0]
+    for p_i, p_d, p_io, p_do in gathered:
+        out_i.append(p_i)
+        out_d.append(p_d)
+        io.extend((np.asarray(p_io[1:]) + io[-1]).tolist())
+        do.extend((np.asarray(p_do[1:]) + do[-1]).tolist())
+    del torch
+    return np.concatenate(out_i), np.concatenate(out_d), np.asarray(io, dtype=np.int64), np.asarray(do, dtype=np.int64)
+
+
+def reduce_histograms(dist, hist, rank, world):
+    """Host-side sum of per-GPU histograms in fixed rank order (float accumulation order is therefore deterministic)."""
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(np.asarray(hist), gathered, dst=0)
+    if rank != 0:
+        return None
+    total = np.zeros_like(gathered[0])
+    for h in gathered:
+        total = total + h
+    return total

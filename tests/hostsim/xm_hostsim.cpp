@@ -26,7 +26,8 @@ static void markDump() { const char* names[6] = {"chunks", "counters", "history"
 struct SimIndex {
   HostIndex host;
   IndexView view;
-  std::vector<uint32_t> p32;
+  std::vector<uint32_t> p32, l32;
+  std::vector<uint64_t> l64;
   void refresh() {
     bool is64 = host.seqCumStart.back() > 0xFFFFFFFFll;
     p32.clear();
@@ -37,6 +38,20 @@ struct SimIndex {
     view.contigStart = host.contigStart.data(); view.contigLen = host.contigLen.data(); view.seqCumStart = host.seqCumStart.data(); view.refCodes = host.refCodes.data();
     view.tables = host.tables.data(); view.bucketOff = host.bucketOff.data(); view.positions32 = p32.data(); view.positions64 = (const uint64_t*)host.positions.data();
     view.dupKeyStart = host.dupKeyStart.data(); view.dupKeys = host.dupKeys.data();
+    // bucket lines (IndexView::lines32 / lines64), filled by the function the device kernel uses; XMSIM_LINES=0: CSR probes only
+    view.lines32 = nullptr; view.lines64 = nullptr;
+    l32.clear(); l64.clear();
+    const char* le = getenv("XMSIM_LINES");
+    if (!(le && *le && atoi(le) == 0)) {
+      if (is64) l64.assign(host.bucketOff.size() * 8, 0); else l32.assign(host.bucketOff.size() * 8, 0);
+      for (const Table& t : host.tables)
+        for (int64_t k = 0; k < t.capacity; k++) {
+          const uint32_t* off = host.bucketOff.data() + t.offBase + k;
+          if (is64) xmFillLine(l64.data() + (t.offBase + k) * 8, off[0], off[1], (const uint64_t*)host.positions.data() + t.posBase);
+          else xmFillLine(l32.data() + (t.offBase + k) * 8, off[0], off[1], p32.data() + t.posBase);
+        }
+      view.lines32 = is64 ? nullptr : l32.data(); view.lines64 = is64 ? l64.data() : nullptr;
+    }
   }
 };
 
