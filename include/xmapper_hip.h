@@ -156,8 +156,8 @@ int xm_batch_commit(xm_index* index);
 
 /* Bulk form of Readable_HashBlock_Database.getNumMatchesLowerBound + matchBlock / PackedMap.get (PackedMap.java:160-172,
  * 228-236) for n (used_length, lookup key) pairs: counts[i] = number of stored positions, -1 when the bucket is overfull or
- * holds more than the table's limit; positions are written to out_positions[i*max_per_probe ...] (at most max_per_probe each,
- * not reverse-complemented).  Device-resident micro-kernel used for the seed-lookup roofline measurement. */
+ * holds more than the table's limit; position j of probe i is written to out_positions[j*n + i] (at most max_per_probe each, probe-minor so
+ * that the lanes of a wavefront write neighbouring words; not reverse-complemented).  Device-resident micro-kernel used for the seed-lookup roofline measurement. */
 int xm_seed_probe(xm_index* index, int64_t n, const int32_t* used_length, const int32_t* keys, int32_t max_per_probe, int32_t* counts, int64_t* out_positions, double* kernel_ms);
 
 /* Measurement helper for the seed-lookup roofline (SURVEY.md section 8d asks for the achieved rate next to "a measured random-64 B-gather

@@ -401,11 +401,11 @@ class ReferenceDatabase:
         keys = np.ascontiguousarray(keys, dtype=np.int32)
         n = len(used)
         counts = np.zeros(n, np.int32)
-        pos = np.zeros((n, max(max_per_probe, 1)), np.int64)
+        pos = np.zeros((max(max_per_probe, 1), n), np.int64)  # (the C entry writes position j of probe i at [j, i])
         ms = C.c_double()
         if self._L.xm_seed_probe(self._h, n, used.ctypes.data, keys.ctypes.data, max_per_probe, counts.ctypes.data, pos.ctypes.data, C.byref(ms)):
             raise RuntimeError(self._L.xm_last_error().decode())
-        return counts, pos, ms.value
+        return counts, pos.T, ms.value
 
 
 def measure_random_gather(table_bytes=4 << 30, accesses=1 << 26, device=0):

@@ -427,7 +427,10 @@ __global__ void __launch_bounds__(256) xm_seed_probe_kernel(IndexView ix, long l
     const int64_t line = (t->offBase + k) * 8;
     if (ix.lines64) {
       const ulonglong2* lp = (const ulonglong2*)(ix.lines64 + line);
+      // (the whole line is requested at once: four 16-byte loads of one 64-byte sector in flight together, not a second round trip after the header)
       const ulonglong2 a = lp[0];
+      ulonglong2 b1 = a, b2 = a, b3 = a;
+      if (maxPerProbe > 0) { b1 = lp[1]; b2 = lp[2]; b3 = lp[3]; }
       const uint32_t h = (uint32_t)a.x;
       if (h & XM_OVERFULL) { counts[i] = -1; return; }
       count = (int)h;
@@ -435,24 +438,21 @@ __global__ void __launch_bounds__(256) xm_seed_probe_kernel(IndexView ix, long l
       counts[i] = count;
       if (maxPerProbe > 0 && count > 0 && count <= XM_LINE_SLOTS) {
         const int m = count < maxPerProbe ? count : maxPerProbe;
-        unsigned long long w[8];
-        w[0] = a.x; w[1] = a.y;
-        for (int q = 1; q < 4; q++) { const ulonglong2 b = lp[q]; w[2 * q] = b.x; w[2 * q + 1] = b.y; }
-        for (int j = 0; j < m; j++) outPositions[i * maxPerProbe + j] = (int64_t)w[1 + j];
+        const unsigned long long w[8] = {a.x, a.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
+        for (int j = 0; j < m; j++) outPositions[(long long)j * n + i] = (int64_t)w[1 + j];
         return;
       }
     } else {
       const uint4* lp = (const uint4*)(ix.lines32 + line);
-      const uint4 a = lp[0];
+      const uint4 a = lp[0], b = lp[1];
       if (a.x & XM_OVERFULL) { counts[i] = -1; return; }
       count = (int)a.x;
       if (count > t->maxCount) { counts[i] = -1; return; }
       counts[i] = count;
       if (maxPerProbe > 0 && count > 0 && count <= XM_LINE_SLOTS) {
         const int m = count < maxPerProbe ? count : maxPerProbe;
-        const uint4 b = lp[1];
         const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        for (int j = 0; j < m; j++) outPositions[i * maxPerProbe + j] = (int64_t)w[1 + j];
+        for (int j = 0; j < m; j++) outPositions[(long long)j * n + i] = (int64_t)w[1 + j];
         return;
       }
     }
@@ -468,7 +468,51 @@ __global__ void __launch_bounds__(256) xm_seed_probe_kernel(IndexView ix, long l
     first = t->posBase + (int64_t)(o0 & ~XM_OVERFULL);
   }
   int m = count < maxPerProbe ? count : maxPerProbe;
-  for (int j = 0; j < m; j++) outPositions[i * maxPerProbe + j] = ix.posIs64 ? (int64_t)ix.positions64[first + j] : (int64_t)ix.positions32[first + j];
+  for (int j = 0; j < m; j++) outPositions[(long long)j * n + i] = ix.posIs64 ? (int64_t)ix.positions64[first + j] : (int64_t)ix.positions32[first + j];
+}
+
+// The same bulk probe over bucket lines, the way a wavefront should read them: G adjacent lanes share a probe and each loads 16 bytes of the
+// bucket's line (G = 4 with 64-bit positions: a 64-byte line; G = 2 with 32-bit positions: 32 bytes), so the memory pipeline sees ONE request per
+// line instead of G, and the header and all seven inline positions arrive together.  Buckets with more than XM_LINE_SLOTS positions fall back
+// to the CSR arrays (lane 0 of the group).
+template <int G>
+__global__ void __launch_bounds__(256) xm_seed_probe_lines_kernel(IndexView ix, long long n, const int32_t* usedLength, const int32_t* keys, int maxPerProbe,
+                                                                  int32_t* counts, int64_t* outPositions) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = tid / G;
+  const int part = (int)(tid % G);
+  const bool live = i < n;
+  const int used = live ? usedLength[i] : 0;
+  const bool bad = used < 0 || used > ix.maxHashedLength;
+  const Table* t = &ix.tables[bad ? 0 : used];
+  const uint32_t k = packedKey(t, live ? keys[i] : 0);
+  const int64_t line = (t->offBase + k) * 8;
+  unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // this lane's words of the line (two 64-bit or four 32-bit ones)
+  if (live && !bad) {
+    if (G == 4) { const ulonglong2 v = ((const ulonglong2*)(ix.lines64 + line))[part]; w0 = v.x; w1 = v.y; }
+    else { const uint4 v = ((const uint4*)(ix.lines32 + line))[part]; w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w; }
+  }
+  const uint32_t h = (uint32_t)__shfl((unsigned int)w0, (int)(threadIdx.x & 63u) - part);  // word 0 of the line: lane 0 of the group
+  if (!live) return;
+  if (bad) { if (part == 0) counts[i] = -2; return; }
+  int count = (h & XM_OVERFULL) ? -1 : (int)h;
+  if (count > t->maxCount) count = -1;
+  if (part == 0) counts[i] = count;
+  if (count <= 0 || maxPerProbe <= 0) return;
+  if (count <= XM_LINE_SLOTS) {
+    // word index of this lane's words in the line: G == 4: 2 * part, 2 * part + 1;  G == 2: 4 * part .. 4 * part + 3;  position j = word j + 1
+    const int perLane = 8 / G;
+    const unsigned long long mine[4] = {w0, w1, w2, w3};
+    for (int q = 0; q < perLane; q++) {
+      const int j = part * perLane + q - 1;
+      if (j >= 0 && j < count && j < maxPerProbe) outPositions[(long long)j * n + i] = (int64_t)mine[q];
+    }
+    return;
+  }
+  if (part != 0) return;
+  const int64_t first = t->posBase + (int64_t)(ix.bucketOff[t->offBase + k] & ~XM_OVERFULL);
+  const int m = count < maxPerProbe ? count : maxPerProbe;
+  for (int j = 0; j < m; j++) outPositions[(long long)j * n + i] = ix.posIs64 ? (int64_t)ix.positions64[first + j] : (int64_t)ix.positions32[first + j];
 }
 
 // Measurement helper: one random 64-byte sector per access out of a table far larger than the caches, 16 bytes of it read.
@@ -1487,7 +1531,13 @@ int xm_seed_probe(xm_index* idx, int64_t n, const int32_t* usedLength, const int
     int block = 256;
     int grid = (int)((n + block - 1) / block);
     HIP_CHECK(hipEventRecord(idx->ev0, s));
-    if (n > 0) hipLaunchKernelGGL(xm_seed_probe_kernel, dim3(grid), dim3(block), 0, s, idx->view, (long long)n, dUsed.p, dKeys.p, (int)maxPerProbe, dCounts.p, dPos.p);
+    IndexView view = idx->view;
+    if (envInt("XM_PROBE_NO_LINES", 0) != 0) { view.lines32 = nullptr; view.lines64 = nullptr; }  // measurement: the CSR probe (two dependent accesses) on the same index
+    if (n > 0 && view.lines64 && maxPerProbe > 0)
+      hipLaunchKernelGGL((xm_seed_probe_lines_kernel<4>), dim3((unsigned)((n * 4 + block - 1) / block)), dim3(block), 0, s, view, (long long)n, dUsed.p, dKeys.p, (int)maxPerProbe, dCounts.p, dPos.p);
+    else if (n > 0 && view.lines32 && maxPerProbe > 0)
+      hipLaunchKernelGGL((xm_seed_probe_lines_kernel<2>), dim3((unsigned)((n * 2 + block - 1) / block)), dim3(block), 0, s, view, (long long)n, dUsed.p, dKeys.p, (int)maxPerProbe, dCounts.p, dPos.p);
+    else if (n > 0) hipLaunchKernelGGL(xm_seed_probe_kernel, dim3(grid), dim3(block), 0, s, view, (long long)n, dUsed.p, dKeys.p, (int)maxPerProbe, dCounts.p, dPos.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(idx->ev1, s));
     HIP_CHECK(hipStreamSynchronize(s));

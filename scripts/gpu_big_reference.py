@@ -43,6 +43,29 @@ contig = r.ints[io[one] + 4]; rev = r.ints[io[one] + 5]; sa = r.ints[io[one] + 7
 ok = (contig == where[one, 0]) & (rev == where[one, 2]) & (np.abs((sb - sa) - where[one, 1]) <= 3)
 print("aligned %d reads in %.2f s (kernel %.1f ms): %.2f %% aligned, %.2f %% of those at their origin (contig, strand, offset), reruns %d" %
       (nq, dt, r.kernel_ms, 100.0 * one.mean(), 100.0 * ok.mean(), r.counters[11]), flush=True)
+# seed lookups on this index (far larger than every cache): bucket lines against CSR probes, next to the random-sector ceiling
+rng = np.random.default_rng(12345)
+n = 32_000_000
+used = rng.integers(i["min_interesting_size"], i["max_hashed_length"] + 1, size=n, dtype=np.int32)
+keys = rng.integers(-2**31, 2**31 - 1, size=n, dtype=np.int64).astype(np.int32)
+sectors_per_s, _ = api.measure_random_gather(16 << 30, 1 << 27, 0)
+print("random 64 B sector gather ceiling: %.1f G sectors/s = %.0f GB/s" % (sectors_per_s / 1e9, sectors_per_s * 64 / 1e9), flush=True)
+for no_lines in ("1", "0"):
+    os.environ["XM_PROBE_NO_LINES"] = no_lines
+    db.seed_probe(used[:4096], keys[:4096], 0)
+    c0, _, ms_hdr = db.seed_probe(used, keys, 0)
+    c4, pos, ms_pos = db.seed_probe(used[:n // 2], keys[:n // 2], 7)
+    fetched = int(np.minimum(np.maximum(c4, 0), 7).sum())
+    pb = i["position_bytes"]
+    print("seed probe (%s): header only %.1f G probes/s = %.0f GB/s of 64 B sectors (%.1f %% of the 8 TB/s peak, %.0f %% of the gather ceiling); with positions %.1f G probes/s, "
+          "%.2f positions per probe, algorithmic %.0f GB/s (8 B header + %d B per position)" %
+          ("CSR: bucketOff then positions" if no_lines == "1" else "bucket lines", n / ms_hdr / 1e6, n / ms_hdr / 1e6 * 64, n / ms_hdr / 1e6 * 64 / 80.0, 100.0 * (n / (ms_hdr * 1e-3)) / sectors_per_s,
+           (n // 2) / ms_pos / 1e6, fetched / (n // 2), (8.0 * (n // 2) + pb * fetched) / (ms_pos * 1e-3) / 1e9, pb), flush=True)
+    if no_lines == "1":
+        ref_counts, ref_pos = c4.copy(), pos.copy()
+    else:
+        assert np.array_equal(ref_counts, c4) and np.array_equal(ref_pos, pos), "bucket lines and CSR probes disagree"
+os.environ["XM_PROBE_NO_LINES"] = "0"
 assert i["position_bytes"] == (8 if 2 * nc * clen > 0xFFFFFFFF else 4)
 assert one.mean() > 0.99 and ok.mean() > 0.99
 print("ok")
