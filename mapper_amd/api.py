@@ -169,7 +169,7 @@ def index_cache_path(cache_dir, contigs, opts):
 class ReferenceDatabase:
     """ReferenceDatabase.java: HashBlock_Database + DuplicationDetector of a reference, resident in HBM."""
 
-    def __init__(self, contigs, mode="mapper", enable_gapmers=True, max_query_length=0, device=-1, host_only=False, dup=None, cache_dir=None):
+    def __init__(self, contigs, mode="mapper", enable_gapmers=True, max_query_length=0, device=-1, host_only=False, dup=None, cache_dir=None, min_interesting_size=-1):
         """contigs: list of (name, IUPAC text or code array), already in Mapper.sortAndComplementReference order
         (use sort_reference()).  mode 'mapper' = Mapper.run assembly (duplication window 1000), 'api' = Api.newDatabase (window 1).
         cache_dir: --cache-dir (Mapper.java:264, DirCache.java:19-60): the index is read from / written to a file under
@@ -179,7 +179,7 @@ class ReferenceDatabase:
         ref, self._keep = _capi.make_ref(self.contigs)
         o = _capi.XmBuildOpts()
         o.enable_gapmers = 1 if enable_gapmers else 0
-        o.min_interesting_size = -1
+        o.min_interesting_size = int(min_interesting_size)  # (-1: from the reference's size, HashBlock_Database.java:52; tests pin the value a 3 Gb reference gets)
         o.max_hashed_length = int(max_query_length)
         o.dup_window = 1 if mode == "api" else 1000
         o.dup_min_copies = 2

@@ -11,7 +11,10 @@
 // it); prefix sums over the buckets give the CSR offsets and each record's slot.  All of it is streaming HBM work (sort passes, scans).
 // Records are made in groups of consecutive tables whose record count fits the memory budget (first a counting run over all levels, then
 // one hashing run per group), which is the reference's multi-pass hashing for large genomes (M/HashBlock_Database.java:57-61,183-215).
-// Contigs with ambiguity codes need the conditional multi blocks: such references are hashed by the host builder.
+// Contigs with ambiguity codes (GRCh38's N-runs, IUPAC codes): the GPU hashes every block that lies clear of the ambiguous bases (a block depends
+// on the bases of its own span only, so those are the blocks of the plain rule), the conditional multi blocks over the ambiguous bases
+// (M/MultiHashBlock.java, M/HashBlock_ParentRow.java:109-165) come from the host's windows around them (HostIndex::multiRecordsNearAmbiguity) and
+// join the records before the sort; PackedMap.add's duplicate suppression for multi records (:124-153) is a pass over the sorted records.
 #define XM_NOINL_LINKAGE inline  // the out-of-line functions of the shared headers are defined (strongly) by xm_capi.hip
 #include <cstring>
 #include <hip/hip_runtime.h>
@@ -61,6 +64,8 @@ struct LevelArgs {
   unsigned long long* recKey; unsigned long long* recPos; unsigned long long recCap;
   uint32_t* mergeFlag;
   LevelCtl* ctl;
+  const uint32_t* ambPrefix;     // null, or [contigLen + 1]: ambiguous bases before position i (a block over one emits nothing here)
+  int posShift;                  // 1 (reference with ambiguity codes): positions are stored shifted left by one, bit 0 = the record comes from a multi block
 };
 
 __global__ void xmb_level0_kernel(const uint8_t* codes, long long n, HBlock* out) {
@@ -86,8 +91,11 @@ __global__ void __launch_bounds__(256) xmb_level_kernel(LevelArgs a) {
   }
   if (i < a.n) {
     const HBlock blk = a.cur[i];
+    const bool clean = !a.ambPrefix || a.ambPrefix[blk.start + blk.len] == a.ambPrefix[blk.start];
     if (blk.len <= a.maxLen) {  // (a longer block's gapmer uses at least blk.len bases)
       if (a.ctl->anyShort == 0) a.ctl->anyShort = 1;
+    }
+    if (blk.len <= a.maxLen && clean) {
       SeqView seq;
       seq.base = a.contig; seq.len = a.contigLen; seq.rc = 0; seq.id = 0;
       QBlock g;
@@ -106,12 +114,12 @@ __global__ void __launch_bounds__(256) xmb_level_kernel(LevelArgs a) {
           const unsigned long long table = (unsigned long long)(unsigned)(g.used - a.gLo) << 32;
           if (primary) {  // M/PackedMap.java:107-112
             int32_t r = g.fwd % cap; if (r < 0) r += cap;
-            k0 = table | (unsigned)r; p0 = (unsigned long long)(a.fwdBase + g.start);
+            k0 = table | (unsigned)r; p0 = (unsigned long long)(a.fwdBase + g.start) << a.posShift;
             nOut = 1;
           }
           if (secondary) {  // :113-118
             int32_t r = g.rev % cap; if (r < 0) r += cap;
-            const unsigned long long k = table | (unsigned)r, p = (unsigned long long)(a.rcBase + (a.contigLen - (g.start + g.len)));
+            const unsigned long long k = table | (unsigned)r, p = (unsigned long long)(a.rcBase + (a.contigLen - (g.start + g.len))) << a.posShift;
             if (nOut == 0) { k0 = k; p0 = p; } else { k1 = k; p1 = p; }
             nOut++;
           }
@@ -154,6 +162,31 @@ __global__ void __launch_bounds__(256) xmb_merge_kernel(const HBlock* cur, long 
   if (i >= n) return;
   if (flag[i]) next[offset[i]] = mergeBlocks(cur[i], cur[i + 1]);
   if (i == n - 1) ctl->nNext = (unsigned long long)offset[i] + flag[i];
+}
+
+__global__ void xmb_amb_flag_kernel(const uint8_t* codes, long long n, uint32_t* flag) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = bpIsAmbiguous(codes[i]) ? 1u : 0u;
+  if (i == n) flag[i] = 0u;
+}
+// sorted records of an ambiguous reference (position << 1 | multi): PackedMap.add with preventDuplicates (:124-153) - a record from a multi block
+// is not added when its bucket already holds that position (= the record before it in (table, bucket, position, single-before-multi) order)
+__global__ void xmb_keep_kernel(const unsigned long long* key, const unsigned long long* pos, unsigned long long n, uint32_t* keep) {
+  unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const bool dup = (pos[r] & 1ull) != 0 && r > 0 && key[r - 1] == key[r] && (pos[r - 1] >> 1) == (pos[r] >> 1);
+  keep[r] = dup ? 0u : 1u;
+}
+__global__ void xmb_compact_kernel(const unsigned long long* key, const unsigned long long* pos, unsigned long long n, const uint32_t* keep, const unsigned long long* slot,
+                                   unsigned long long* outKey, unsigned long long* outPos) {
+  unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n || !keep[r]) return;
+  outKey[slot[r]] = key[r];
+  outPos[slot[r]] = pos[r] >> 1;
+}
+__global__ void xmb_widen_kernel(const uint32_t* in, unsigned long long n, unsigned long long* out) {
+  unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) out[r] = in[r];
 }
 
 struct TableDesc { unsigned long long bucketBase; int32_t capacity, maxCount; };  // bucketBase: first of the table's capacity + 1 offset entries in the group
@@ -311,12 +344,37 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
   BuildBuf<unsigned long long> dKeyA, dPosA, dKeyB, dPosB;
   unsigned long long recCap = 0;
 
+  // reference with ambiguity codes: the multi blocks' records come from the host (windows around the ambiguous bases), the GPU skips every block
+  // over an ambiguous base (prefix counts of the ambiguous bases of the contig being hashed)
+  const bool amb = h.referenceIsAmbiguous();
+  std::vector<std::vector<HostIndex::Rec>> multiRecs((size_t)maxLen + 1);
+  std::vector<char> contigAmb((size_t)h.numContigs(), 0);
+  BuildBuf<uint32_t> dAmbFlag, dAmbPrefix;
+  if (amb) {
+    std::vector<int> capInt(capacity.begin(), capacity.end());
+    h.multiRecordsNearAmbiguity(lo, maxLen, capInt, multiRecs);
+    for (int c = 0; c < h.numContigs(); c++) {
+      const uint8_t* b = h.refCodes.data() + h.contigStart[(size_t)c];
+      for (int32_t i = 0; i < h.contigLen[(size_t)c]; i++) if (bpIsAmbiguous(b[i])) { contigAmb[(size_t)c] = 1; break; }
+    }
+    dAmbFlag.ensure((size_t)longest + 1); dAmbPrefix.ensure((size_t)longest + 1);
+  }
+
   // every level of every contig: counting run (emit = 0) or the records of the tables [gLo, gHi]
   auto hashAll = [&](int emit, int gLo, int gHi) {
     for (int c = 0; c < h.numContigs(); c++) {
       long long n = h.contigLen[(size_t)c];
       const uint8_t* contig = dCodes.p + h.contigStart[(size_t)c];
       hipLaunchKernelGGL(xmb_level0_kernel, dim3(gridFor((unsigned long long)n)), dim3(256), 0, s, contig, n, dCur.p);
+      const uint32_t* ambPrefix = nullptr;
+      if (amb && contigAmb[(size_t)c]) {
+        hipLaunchKernelGGL(xmb_amb_flag_kernel, dim3(gridFor((unsigned long long)n + 1)), dim3(256), 0, s, contig, n, dAmbFlag.p);
+        size_t bytes = 0;
+        XMB_CHECK(rocprim::exclusive_scan(nullptr, bytes, dAmbFlag.p, dAmbPrefix.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), s));
+        dTemp.ensure(bytes);
+        XMB_CHECK(rocprim::exclusive_scan(dTemp.p, bytes, dAmbFlag.p, dAmbPrefix.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), s));
+        ambPrefix = dAmbPrefix.p;
+      }
       HBlock* cur = dCur.p;
       HBlock* next = dNext.p;
       while (n > 0) {
@@ -326,6 +384,7 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
         a.gLo = gLo; a.gHi = gHi; a.emit = emit; a.capacity = dCapacity.p;
         a.fwdBase = h.encodePosition(c, false, 0); a.rcBase = h.encodePosition(c, true, 0);
         a.hist = dHist.p; a.recKey = dKeyA.p; a.recPos = dPosA.p; a.recCap = recCap; a.mergeFlag = dFlag.p; a.ctl = dCtl.p;
+        a.ambPrefix = ambPrefix; a.posShift = amb ? 1 : 0;
         hipLaunchKernelGGL(xmb_level_kernel, dim3(gridFor((unsigned long long)n)), dim3(256), 0, s, a);
         size_t bytes = 0;
         XMB_CHECK(rocprim::exclusive_scan(nullptr, bytes, dFlag.p, dOffset.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
@@ -347,6 +406,7 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
   hashAll(0, 0, 0);
   std::vector<unsigned long long> hist((size_t)maxLen + 1);
   XMB_CHECK(hipMemcpy(hist.data(), dHist.p, hist.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (int L = 0; L <= maxLen; L++) hist[(size_t)L] += multiRecs[(size_t)L].size();
   auto t1 = std::chrono::steady_clock::now();
 
   // groups of consecutive tables whose records fit the budget (a sort needs both record arrays twice + its own scratch)
@@ -399,11 +459,27 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
       hashAll(1, gLo, gHi);
       LevelCtl ctl;
       XMB_CHECK(hipMemcpy(&ctl, dCtl.p, sizeof(ctl), hipMemcpyDeviceToHost));
-      if (ctl.nRec != nRecs) throw std::runtime_error("internal error: index build counted " + std::to_string(nRecs) + " records and emitted " + std::to_string(ctl.nRec));
+      unsigned long long hostRecs = 0;
+      for (int L = gLo; L <= gHi; L++) hostRecs += multiRecs[(size_t)L].size();
+      if (ctl.nRec + hostRecs != nRecs) throw std::runtime_error("internal error: index build counted " + std::to_string(nRecs) + " records and emitted " + std::to_string(ctl.nRec + hostRecs));
+      if (hostRecs > 0) {  // the multi blocks' records (host windows) behind the GPU's: key = (table, bucket), position << 1 | 1
+        std::vector<unsigned long long> hk((size_t)hostRecs), hp((size_t)hostRecs);
+        size_t at = 0;
+        for (int L = gLo; L <= gHi; L++)
+          for (const HostIndex::Rec& r : multiRecs[(size_t)L]) {
+            hk[at] = ((unsigned long long)(unsigned)(L - gLo) << 32) | r.bucket;
+            hp[at] = ((r.pos & ~HostIndex::REC_MULTI) << 1) | 1ull;
+            at++;
+          }
+        XMB_CHECK(hipMemcpyAsync(dKeyA.p + ctl.nRec, hk.data(), sizeof(unsigned long long) * hk.size(), hipMemcpyHostToDevice, s));
+        XMB_CHECK(hipMemcpyAsync(dPosA.p + ctl.nRec, hp.data(), sizeof(unsigned long long) * hp.size(), hipMemcpyHostToDevice, s));
+        XMB_CHECK(hipStreamSynchronize(s));
+      }
       mark(tHash, tm);
       // (L, bucket, position): stable sort by position, then by (L, bucket)
       unsigned posBits = 1;
       while (posBits < 64 && ((unsigned long long)h.seqCumStart.back() >> posBits) != 0) posBits++;
+      if (amb) posBits++;  // (positions are shifted left by one, bit 0 = multi: single before multi at the same position)
       unsigned tableBits = 1;
       while ((1 << tableBits) < nTables) tableBits++;
       size_t bytes = 0;
@@ -414,6 +490,25 @@ bool deviceHashLengths(HostIndex& h, int minLen, int maxLen, int device) {
       dTemp.ensure(bytes);
       XMB_CHECK(rocprim::radix_sort_pairs(dTemp.p, bytes, dKeyB.p, dKeyA.p, dPosB.p, dPosA.p, (size_t)nRecs, 0, 32 + tableBits, s));
       sortedKey = dKeyA.p; sortedPos = dPosA.p;
+      if (amb) {  // duplicate suppression of the multi records, positions back to their plain form, records compacted into the other pair of arrays
+        BuildBuf<uint32_t> dKeep;
+        BuildBuf<unsigned long long> dKeep64, dSlot;
+        dKeep.ensure((size_t)nRecs); dKeep64.ensure((size_t)nRecs); dSlot.ensure((size_t)nRecs);
+        hipLaunchKernelGGL(xmb_keep_kernel, dim3(gridFor(nRecs)), dim3(256), 0, s, sortedKey, sortedPos, nRecs, dKeep.p);
+        hipLaunchKernelGGL(xmb_widen_kernel, dim3(gridFor(nRecs)), dim3(256), 0, s, dKeep.p, nRecs, dKeep64.p);
+        scanU64(dTemp, dKeep64.p, dSlot.p, (size_t)nRecs, s);
+        hipLaunchKernelGGL(xmb_compact_kernel, dim3(gridFor(nRecs)), dim3(256), 0, s, sortedKey, sortedPos, nRecs, dKeep.p, dSlot.p, dKeyB.p, dPosB.p);
+        XMB_CHECK(hipGetLastError());
+        unsigned long long lastSlot = 0;
+        uint32_t lastKeep = 0;
+        XMB_CHECK(hipMemcpyAsync(&lastSlot, dSlot.p + (nRecs - 1), sizeof(lastSlot), hipMemcpyDeviceToHost, s));
+        XMB_CHECK(hipMemcpyAsync(&lastKeep, dKeep.p + (nRecs - 1), sizeof(lastKeep), hipMemcpyDeviceToHost, s));
+        XMB_CHECK(hipStreamSynchronize(s));
+        totalRecs -= nRecs;
+        nRecs = lastSlot + lastKeep;
+        totalRecs += nRecs;
+        sortedKey = dKeyB.p; sortedPos = dPosB.p;
+      }
       mark(tSort, tm);
     }
     auto tm2 = std::chrono::steady_clock::now();

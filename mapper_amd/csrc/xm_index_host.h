@@ -20,6 +20,7 @@
 #include <stdexcept>
 #include <cmath>
 #include <thread>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <mutex>
@@ -232,6 +233,168 @@ struct HostIndex {
     return out;
   }
 
+  // one block (a single block, or one possibility of a multi block) -> its gapmer -> records
+  void emitBlockRecords(const SeqView& seq, int c, const HBlock& b, uint32_t fromMulti, int lo, int maxLen, const std::vector<int>& capacity, std::vector<std::vector<Rec>>& recs) const {
+    const int n = seq.len;
+    QBlock g;
+    int st;
+    if (enableGapmers) {
+      st = withGapAndExtension(b, seq, g);
+      if (st == 0) return;
+    } else {
+      g.start = b.start; g.len = b.len; g.used = b.len; g.fwd = b.fwd; g.rev = b.rev; g.flags = b.flags;
+    }
+    int used = g.used;
+    if (used < lo || used > maxLen) return;
+    bool rml = (g.flags & F_RML) != 0, rmr = (g.flags & F_RMR) != 0;
+    bool primary = (rml != rmr) ? rml : (g.fwd >= g.rev);     // M/HashBlock.java:329-334
+    bool secondary = (rml != rmr) ? rmr : (g.fwd <= g.rev);   // :336-340
+    int cap = capacity[(size_t)used];
+    if (primary) {  // M/PackedMap.java:107-112
+      int32_t r = g.fwd % cap; if (r < 0) r += cap;
+      recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, false, g.start) | (fromMulti ? REC_MULTI : 0)});
+    }
+    if (secondary) {  // :113-118
+      int32_t r = g.rev % cap; if (r < 0) r += cap;
+      recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, true, n - (g.start + g.len)) | (fromMulti ? REC_MULTI : 0)});
+    }
+  }
+  // The pyramid with conditional multi blocks over positions [ws, we) of contig c, level by level, emitting the records of every block with
+  // len <= maxLen (onlyMulti: only those of multi blocks, i.e. of blocks over an ambiguous base).  A block depends on the bases of its own
+  // span only (a level is an ordered list whose block ends never decrease, and a block is merged from two neighbours of that list), so a
+  // window computes every block whose span lies inside it exactly as the whole contig would.
+  //
+  // Long runs of N (GRCh38 has runs of megabases): with ws2 >= 0 the window is [ws, we) + [ws2, we2) with the middle of the run left out.
+  // Inside a run every position looks the same, and its blocks stop existing after a few levels (the possibilities multiply past
+  // HashBlock_ParentRow.maxNumCombinationsToExpand); from that level on the last block before the run's interior and the first one behind it are
+  // neighbours in the level's list (which matters: merges and the combination limit see that neighbour).  The two halves are therefore built
+  // level by level on their own until nothing is left in the inner quarter of either, then joined into one list.  The blocks next to the cut of
+  // the first half miss their right neighbours; they lie in the part of the run that has died by then.  Returns false (nothing emitted) when the
+  // run's interior would emit records of its own (only with a small minInterestingSize): the caller then takes the window whole.
+  bool hashAmbiguousWindow(int c, int ws, int we, bool onlyMulti, int lo, int maxLen, const std::vector<int>& capacity, std::vector<std::vector<Rec>>& recs, int ws2 = -1, int we2 = -1, int halfN = 0) const {
+    SeqView seq = contigView(c, false);
+    auto level0 = [&](int from, int to, std::vector<HEntry>& cur) {
+      cur.assign((size_t)(to - from), HEntry());
+      for (int i = from; i < to; i++) {
+        uint8_t code = seq.base[i];
+        HEntry& e = cur[(size_t)(i - from)];
+        if (bpIsAmbiguous(code)) {  // HashBlock_BaseRow.get: one possibility per base the code can stand for, A C G T order
+          e.multi = true;
+          for (int bit = 0; bit < 4; bit++) if (code & (1 << bit)) e.poss.push_back(HPoss{hblock0((uint8_t)(1 << bit), i), true, HCond(1, std::make_pair((int32_t)i, (uint8_t)(1 << bit)))});
+        } else {
+          e.single = hblock0(code, i);
+        }
+      }
+    };
+    std::vector<HEntry> cur, curB;
+    level0(ws, we, cur);
+    bool joined = ws2 < 0;
+    if (!joined) level0(ws2, we2, curB);
+    // the first half ends and the second begins with halfN positions of the run.  [we - halfN/2, we - halfN/4) of the first half is far from the
+    // run's start and from the cut: what lives there lives at every position of the left-out middle (the blocks between it and the cut miss right
+    // neighbours and may outlive it: they are dropped at the join); the same for [ws2, ws2 + halfN/2) of the second half, whose blocks are all exact
+    const int deepA = we - halfN / 2, probeEndA = we - halfN / 4, deepEndB = ws2 + halfN / 2;
+    std::vector<std::vector<Rec>> mine((size_t)maxLen + 1);  // (kept apart until the window is known to be usable)
+    auto emitList = [&](const std::vector<HEntry>& list, bool& anyShort, int from, int to) {  // entries starting in [from, to)
+      for (const HEntry& e : list) {
+        const int st = e.start();
+        if (st < from || st >= to) continue;
+        if (e.minLength() > maxLen) continue;
+        anyShort = true;
+        if (!e.multi) { if (!onlyMulti && e.single.len <= maxLen) emitBlockRecords(seq, c, e.single, 0, lo, maxLen, capacity, mine); }
+        else for (const HPoss& p : e.poss) if (p.hasBlock && p.block.len <= maxLen) emitBlockRecords(seq, c, p.block, 1, lo, maxLen, capacity, mine);
+      }
+    };
+    auto startsIn = [&](const std::vector<HEntry>& list, int from, int to) { for (const HEntry& e : list) { const int st = e.start(); if (st >= from && st < to) return true; } return false; };
+    auto numRecords = [&]() { size_t n = 0; for (auto& v : mine) n += v.size(); return n; };
+    while (!cur.empty() || !curB.empty()) {
+      bool anyShort = false;
+      if (!joined && !startsIn(cur, deepA, probeEndA) && !startsIn(curB, ws2, deepEndB)) {
+        std::vector<HEntry> both;
+        for (const HEntry& e : cur) if (e.start() < deepA) both.push_back(e);
+        both.insert(both.end(), curB.begin(), curB.end());
+        cur.swap(both);
+        curB.clear();
+        joined = true;
+      }
+      if (joined) emitList(cur, anyShort, INT32_MIN, INT32_MAX);
+      else {
+        emitList(cur, anyShort, INT32_MIN, deepA);
+        emitList(curB, anyShort, deepEndB, INT32_MAX);
+        // the deep parts stand for every position of the run's middle: records from there would have to be repeated for each of them
+        const size_t before = numRecords();
+        bool deepShort = false;
+        emitList(cur, deepShort, deepA, probeEndA);
+        emitList(curB, deepShort, ws2, deepEndB);
+        if (numRecords() != before) return false;
+        anyShort = true;  // (the middle of the run is still alive: the halves go on)
+      }
+      if (!anyShort) break;
+      std::vector<HEntry> next = nextLevelMulti(cur);
+      cur.swap(next);
+      if (!joined) { std::vector<HEntry> nextB = nextLevelMulti(curB); curB.swap(nextB); }
+    }
+    for (int L = 0; L <= maxLen; L++) recs[(size_t)L].insert(recs[(size_t)L].end(), mine[(size_t)L].begin(), mine[(size_t)L].end());
+    return true;
+  }
+  // Hybrid build (xm_index_device.hip): the GPU hashes every block that lies clear of the ambiguous bases; the blocks over an ambiguous base are
+  // the multi blocks of the windows around them (a block that is emitted is at most maxLen long, so maxLen + 2 bases on either side of a run of
+  // ambiguous bases hold every such block whole).  Ambiguous bases less than two margins apart share a window; all host threads work on the
+  // windows.  recs[L] += the multi records.
+  void multiRecordsNearAmbiguity(int lo, int maxLen, const std::vector<int>& capacity, std::vector<std::vector<Rec>>& recs) const {
+    struct Win { int c, ws, we, ws2, we2; };
+    std::vector<Win> wins;
+    const int margin = maxLen + 2;
+    // a run of N longer than this is not held whole: 2 * half positions of it stay in the window (XM_BUILD_SPLICE_MIN: test hook)
+    int spliceMin = 1 << 16;
+    if (const char* e = getenv("XM_BUILD_SPLICE_MIN")) { if (*e) spliceMin = std::max(64, atoi(e)); }
+    const int half = std::max(32, spliceMin / 4);
+    for (int c = 0; c < numContigs(); c++) {
+      SeqView seq = contigView(c, false);
+      const int n = seq.len;
+      int i = 0;
+      while (i < n) {
+        if (!bpIsAmbiguous(seq.base[i])) { i++; continue; }
+        // the cluster [i, last]: ambiguous bases less than two margins apart; the longest run of plain N inside it
+        int last = i, runStart = -1, runLen = 0, bestStart = -1, bestLen = 0;
+        for (int j = i; j < n && j - last <= 2 * margin; j++) {
+          if (bpIsAmbiguous(seq.base[j])) last = j;
+          if (seq.base[j] == 15) { if (runLen == 0) runStart = j; runLen++; if (runLen > bestLen) { bestLen = runLen; bestStart = runStart; } }
+          else runLen = 0;
+        }
+        const int from = std::max(0, i - margin), to = std::min(n, last + 1 + margin);
+        if (bestLen >= spliceMin) wins.push_back(Win{c, from, bestStart + half, bestStart + bestLen - half, to});
+        else wins.push_back(Win{c, from, to, -1, -1});
+        i = last + 1;
+      }
+    }
+    const int nT = buildThreads(wins.size() * 4096);
+    std::vector<std::vector<std::vector<Rec>>> part((size_t)nT, std::vector<std::vector<Rec>>((size_t)maxLen + 1));
+    std::vector<size_t> nextJob(1, 0);
+    std::mutex jobMu;
+    std::atomic<int> nSplit{0}, nWholeAfterAll{0};
+    parallelParts((size_t)nT, nT, [&](int t, size_t, size_t) {
+      while (true) {
+        size_t job;
+        { std::lock_guard<std::mutex> lock(jobMu); job = nextJob[0]++; }
+        if (job >= wins.size()) break;
+        const Win& w = wins[job];
+        if (w.ws2 >= 0 && hashAmbiguousWindow(w.c, w.ws, w.we, true, lo, maxLen, capacity, part[(size_t)t], w.ws2, w.we2, half)) { nSplit++; continue; }
+        if (w.ws2 >= 0) nWholeAfterAll++;
+        hashAmbiguousWindow(w.c, w.ws, w.ws2 < 0 ? w.we : w.we2, true, lo, maxLen, capacity, part[(size_t)t]);
+      }
+    });
+    for (int t = 0; t < nT; t++)
+      for (int L = 0; L <= maxLen; L++) {
+        recs[(size_t)L].insert(recs[(size_t)L].end(), part[(size_t)t][(size_t)L].begin(), part[(size_t)t][(size_t)L].end());
+        std::vector<Rec>().swap(part[(size_t)t][(size_t)L]);
+      }
+    lastSplitWindows = nSplit.load(); lastWholeWindows = (int)wins.size() - nSplit.load(); lastSplitRefused = nWholeAfterAll.load();
+    if (getenv("XM_TRACE_BUILD")) fprintf(stderr, "[xm] multi blocks near ambiguous bases: %zu windows (%d with the middle of a long run of N left out, %d such runs taken whole after all)\n",
+                                          wins.size(), nSplit.load(), nWholeAfterAll.load());
+  }
+  mutable int lastSplitWindows = 0, lastWholeWindows = 0, lastSplitRefused = 0;
+
   // Hash every gapmer with minLen <= used <= maxLen and append tables [minLen..maxLen].  Tables below minInterestingSize and
   // tables that receive no record are the reference's PackedMap(1, 1) placeholders (M/HashBlock_Database.java:387-393).
   // set by the library when a GPU is there (xm_index_device.hip): the same tables, hashed, sorted and cut into CSR form on the device
@@ -249,7 +412,7 @@ struct HostIndex {
     return hasAmbiguity != 0;
   }
   void hashLengths(int minLen, int maxLen) {
-    if (deviceHasher && deviceForBuild >= 0 && !referenceIsAmbiguous()) {
+    if (deviceHasher && deviceForBuild >= 0) {  // (references with ambiguity codes too: the GPU hashes what lies clear of them, multiRecordsNearAmbiguity the rest)
       const char* e = getenv("XM_DEVICE_BUILD");  // 0: hash on the host even though a GPU is there
       if (!(e && *e && atoi(e) == 0) && deviceHasher(*this, minLen, maxLen, deviceForBuild)) { builtOnDevice = true; return; }
     }
@@ -267,61 +430,26 @@ struct HostIndex {
     }
     std::vector<std::vector<Rec>> recs((size_t)maxLen + 1);
     int lo = std::max(minLen, minInterestingSize);
+    const char* hy = getenv("XM_BUILD_HYBRID_ON_HOST");
+    const bool hybridOnHost = hy && *hy && atoi(hy) != 0;
+    bool anyHybrid = false;
     for (int c = 0; c < numContigs(); c++) {
       SeqView seq = contigView(c, false);
       int n = seq.len;
-      // one block (a single block, or one possibility of a multi block) -> its gapmer -> records
-      auto emit = [&](const HBlock& b, uint32_t fromMulti, std::vector<std::vector<Rec>>& recs) {
-        QBlock g;
-        int st;
-        if (enableGapmers) {
-          st = withGapAndExtension(b, seq, g);
-          if (st == 0) return;
-        } else {
-          g.start = b.start; g.len = b.len; g.used = b.len; g.fwd = b.fwd; g.rev = b.rev; g.flags = b.flags;
-        }
-        int used = g.used;
-        if (used < lo || used > maxLen) return;
-        bool rml = (g.flags & F_RML) != 0, rmr = (g.flags & F_RMR) != 0;
-        bool primary = (rml != rmr) ? rml : (g.fwd >= g.rev);     // M/HashBlock.java:329-334
-        bool secondary = (rml != rmr) ? rmr : (g.fwd <= g.rev);   // :336-340
-        int cap = capacity[(size_t)used];
-        if (primary) {  // M/PackedMap.java:107-112
-          int32_t r = g.fwd % cap; if (r < 0) r += cap;
-          recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, false, g.start) | (fromMulti ? REC_MULTI : 0)});
-        }
-        if (secondary) {  // :113-118
-          int32_t r = g.rev % cap; if (r < 0) r += cap;
-          recs[(size_t)used].push_back(Rec{(uint32_t)r, (uint64_t)encodePosition(c, true, n - (g.start + g.len)) | (fromMulti ? REC_MULTI : 0)});
-        }
-      };
+      auto emit = [&](const HBlock& b, uint32_t fromMulti, std::vector<std::vector<Rec>>& recs) { emitBlockRecords(seq, c, b, fromMulti, lo, maxLen, capacity, recs); };
       bool ambiguous = false;
       for (int i = 0; i < n && !ambiguous; i++) if (bpIsAmbiguous(seq.base[i])) ambiguous = true;
-      if (ambiguous) {
-        std::vector<HEntry> cur((size_t)n);
-        for (int i = 0; i < n; i++) {
-          uint8_t code = seq.base[i];
-          HEntry& e = cur[(size_t)i];
-          if (bpIsAmbiguous(code)) {  // HashBlock_BaseRow.get: one possibility per base the code can stand for, A C G T order
-            e.multi = true;
-            for (int bit = 0; bit < 4; bit++) if (code & (1 << bit)) e.poss.push_back(HPoss{hblock0((uint8_t)(1 << bit), i), true, HCond(1, std::make_pair((int32_t)i, (uint8_t)(1 << bit)))});
-          } else {
-            e.single = hblock0(code, i);
-          }
-        }
-        while (!cur.empty()) {
-          bool anyShort = false;
-          for (const HEntry& e : cur) {
-            if (e.minLength() > maxLen) continue;
-            anyShort = true;
-            if (!e.multi) { if (e.single.len <= maxLen) emit(e.single, 0, recs); }
-            else for (const HPoss& p : e.poss) if (p.hasBlock && p.block.len <= maxLen) emit(p.block, 1, recs);
-          }
-          if (!anyShort) break;
-          std::vector<HEntry> next = nextLevelMulti(cur);
-          cur.swap(next);
-        }
+      // XM_BUILD_HYBRID_ON_HOST=1 (test hook): the composition the GPU build uses for references with ambiguity codes, on the host - the plain
+      // rule over the whole contig for the blocks that lie clear of the ambiguous bases + the multi blocks of the windows around them
+      if (ambiguous && !hybridOnHost) {
+        hashAmbiguousWindow(c, 0, n, false, lo, maxLen, capacity, recs);
         continue;
+      }
+      std::vector<uint32_t> ambPrefix;
+      if (ambiguous) {
+        ambPrefix.assign((size_t)n + 1, 0);
+        for (int i = 0; i < n; i++) ambPrefix[(size_t)i + 1] = ambPrefix[(size_t)i] + (bpIsAmbiguous(seq.base[i]) ? 1u : 0u);
+        anyHybrid = true;
       }
       // plain ACGT contig: every level is cut into consecutive parts, one per host thread; a part emits the records of its blocks and
       // merges its pairs (the pair that straddles two parts belongs to the left one); parts are concatenated in order
@@ -340,7 +468,7 @@ struct HostIndex {
             const HBlock& blk = cur[i];
             if (blk.len <= maxLen) {  // (a longer block's gapmer uses at least blk.len bases)
               anyShort = true;
-              emit(blk, 0, partRecs[(size_t)t]);
+              if (ambPrefix.empty() || ambPrefix[(size_t)(blk.start + blk.len)] == ambPrefix[(size_t)blk.start]) emit(blk, 0, partRecs[(size_t)t]);
             }
             if (i + 1 < cur.size() && shouldMergeBlocks(blk, cur[i + 1])) nx.push_back(mergeBlocks(blk, cur[i + 1]));
           }
@@ -360,6 +488,7 @@ struct HostIndex {
           std::vector<Rec>().swap(src);
         }
     }
+    if (anyHybrid) multiRecordsNearAmbiguity(lo, maxLen, capacity, recs);
     if ((int)tables.size() < maxLen + 1) tables.resize((size_t)maxLen + 1);
     // every table on its own (sort, duplicate suppression, CSR), tables in parallel; then concatenated in order of L
     const int nTables = maxLen - minLen + 1;

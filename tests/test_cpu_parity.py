@@ -173,6 +173,53 @@ def test_index_builder_with_ambiguous_reference_matches_oracle(mode, n):
     P.close()
 
 
+@pytest.mark.parametrize("case", ["scattered", "dense", "n_runs", "edges"])
+def test_hybrid_build_composition_equals_whole_contig_multi_builder(case, monkeypatch):
+    """References with ambiguity codes on the GPU build (xm_index_device.hip): blocks clear of the ambiguous bases by the plain rule + the multi
+    blocks of windows around the ambiguous bases (HostIndex::multiRecordsNearAmbiguity, windows cut into pieces).  The same composition run on
+    the host (XM_BUILD_HYBRID_ON_HOST=1) must give the tables and duplication keys of the whole-contig multi builder
+    (HashBlock_ParentRow.java:69-191), which the oracle pins."""
+    rng = np.random.default_rng(5)
+    if case == "scattered":
+        contigs = [("a", ambiguous_reference(60_000, seed=21, n_runs=10, n_codes=80)), ("b", ambiguous_reference(9_000, seed=22))]
+    elif case == "dense":  # ambiguous bases closer together than a window margin: clusters merge
+        r = synth.synthetic_reference(30_000, seed=23).copy()
+        r[rng.integers(0, 30_000, size=2500)] = 15
+        contigs = [("a", r), ("clean", synth.synthetic_reference(8_000, seed=24))]
+    elif case == "n_runs":  # runs longer than a piece of a window (65,536 positions) and runs of a few hundred
+        r = synth.synthetic_reference(400_000, seed=25).copy()
+        r[50_000:190_000] = 15
+        r[250_000:250_700] = 15
+        r[300_000:300_003] = 15
+        r[320_000:323_000] = 15
+        r[323_050] = 15      # a long run with other ambiguous bases in its cluster
+        r[319_990] = 5
+        r2 = synth.synthetic_reference(30_000, seed=27).copy()
+        r2[:9_000] = 15      # a long run at the start of a contig, one at the end
+        r2[-5_000:] = 15
+        contigs = [("a", r), ("b", r2)]
+    else:  # ambiguous bases at both ends of a contig and a contig that is nothing but N
+        r = synth.synthetic_reference(20_000, seed=26).copy()
+        r[:40] = 15
+        r[-25:] = 15
+        r[7000] = 5
+        contigs = [("a", r), ("n", np.full(300, 15, np.uint8))]
+    monkeypatch.setenv("XM_DEVICE_BUILD", "0")
+    for mis in (-1, 13):  # minInterestingSize from the reference's size (7 here), and the value a 3 Gb reference gets (HashBlock_Database.java:52)
+        monkeypatch.delenv("XM_BUILD_HYBRID_ON_HOST", raising=False)
+        monkeypatch.delenv("XM_BUILD_SPLICE_MIN", raising=False)
+        A = api.ReferenceDatabase(contigs, host_only=True, max_query_length=150, min_interesting_size=mis)
+        monkeypatch.setenv("XM_BUILD_HYBRID_ON_HOST", "1")
+        B = api.ReferenceDatabase(contigs, host_only=True, max_query_length=150, min_interesting_size=mis)
+        _same_index(A, B)
+        # runs of N longer than XM_BUILD_SPLICE_MIN are not held whole (their middle is left out of the window; with minInterestingSize 7 the middle
+        # of a run emits records of its own, and the window is taken whole after all): same tables again
+        monkeypatch.setenv("XM_BUILD_SPLICE_MIN", "2048")
+        C2 = api.ReferenceDatabase(contigs, host_only=True, max_query_length=150, min_interesting_size=mis)
+        _same_index(A, C2)
+        A.close(); B.close(); C2.close()
+
+
 def test_kernel_logic_with_ambiguous_reference():
     """Reads (plain and with ambiguity codes of their own) against a reference with N runs and IUPAC codes: kernel logic vs oracle."""
     ref = ambiguous_reference(200_000, seed=0xA3C, n_runs=60, n_codes=600)

@@ -11,17 +11,32 @@ from helpers import se_batch, pe_batch, streams_equal
 from mapper_amd import api, synth
 
 NC, CLEN = 10, 230_000_000
+MB = 1_000_000
 
 
 @pytest.fixture(scope="module")
 def big():
+    """Ten contigs of 230 M bases; every megabase holds a run of 10,000 N at its middle (1 % of the reference, the shape SURVEY.md section 8(d) gives
+    config 4), so the index is built the way GRCh38's is: blocks clear of the N-runs hashed on the GPU, the multi blocks at their ends by the host."""
     contigs = []
     for c in range(NC):
         parts = [synth.synthetic_reference(min(50_000_000, CLEN - o), seed=0xB16 + 1000 * c + o // 50_000_000) for o in range(0, CLEN, 50_000_000)]
-        contigs.append(("chr%02d" % c, np.concatenate(parts)))
+        text = np.concatenate(parts)
+        runs = text[: (CLEN // MB) * MB].reshape(-1, MB)
+        runs[:, 500_000:510_000] = 15
+        contigs.append(("chr%02d" % c, text))
     db = api.ReferenceDatabase(contigs, max_query_length=150)
     yield contigs, db
     db.close()
+
+
+def sample_reads(contig, per, seed):
+    """Reads from the first 400 kb of 25 megabases spread over the contig (clear of the N-runs): (reads, starts in the contig, strands)."""
+    reads, starts, strands = [], [], []
+    for k, mb in enumerate(range(3, CLEN // MB, (CLEN // MB) // 25)[:25]):
+        r, st, sd = synth.synthetic_single_end(contig[mb * MB: mb * MB + 400_000], per // 25, seed=seed + k)
+        reads.append(r); starts.append(st + mb * MB); strands.append(sd)
+    return np.concatenate(reads), np.concatenate(starts), np.concatenate(strands)
 
 
 def first_alignment(r):
@@ -36,12 +51,12 @@ def first_alignment(r):
 def test_big_reference_properties(big):
     contigs, db = big
     info = db.info()
-    assert info["position_bytes"] == 8 and info["total_forward_size"] == NC * CLEN and info["built_on_device"] == 1
+    assert info["position_bytes"] == 8 and info["total_forward_size"] == NC * CLEN and info["built_on_device"] == 1  # (N-runs and all)
     params = api.AlignmentParameters()
     per = 20_000
     reads, where = [], []
     for c in (0, NC // 2, NC - 1):
-        r, starts, strand = synth.synthetic_single_end(contigs[c][1], per, seed=0x5EED + c)
+        r, starts, strand = sample_reads(contigs[c][1], per, seed=0x5EED + 100 * c)
         reads.append(r)
         where.append(np.stack([np.full(per, c), starts, strand], axis=1))
     reads, where = np.concatenate(reads), np.concatenate(where)
@@ -61,7 +76,7 @@ def test_big_reference_properties(big):
     r3 = db.align_arrays(sb.mate_count, sb.mate_offset, sb.mate_length, sb.codes, sb.expected_inner, sb.deviation, params)
     assert np.array_equal(r3.ints, r1.ints[r1.int_off[lo]:r1.int_off[hi]]) and np.array_equal(r3.dbls.view(np.int64), r1.dbls[r1.dbl_off[lo]:r1.dbl_off[hi]].view(np.int64))
     # pairs from the last contig (the highest encoded positions: beyond 2^32)
-    m1, m2, starts1, inner, strand = synth.synthetic_paired_end(contigs[NC - 1][1], 10_000, seed=0x9A1)
+    m1, m2, starts1, inner, strand = synth.synthetic_paired_end(contigs[NC - 1][1][200 * MB: 200 * MB + 400_000], 10_000, seed=0x9A1)
     pb = pe_batch(m1, m2, 100.0, 50.0)
     rp = db.align_arrays(pb.mate_count, pb.mate_offset, pb.mate_length, pb.codes, pb.expected_inner, pb.deviation, params)
     io = rp.int_off[:-1]

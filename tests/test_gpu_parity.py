@@ -258,10 +258,50 @@ def test_index_hashed_on_the_gpu_equals_host_builder(mode, contigs, gapmers, gro
     D.close(); H.close()
 
 
-def test_ambiguous_reference_is_hashed_on_the_host():
-    db = api.ReferenceDatabase([("amb", ambiguous_reference(20_000, seed=3))])
-    assert db.info()["built_on_device"] == 0
-    db.close()
+def n_run_reference(n, seed, run=10_000, fraction=0.01, codes=200):
+    """A reference the shape of SURVEY.md section 8(d) config 4: runs of N of `run` bases over `fraction` of it, plus a few scattered IUPAC codes."""
+    ref = synth.synthetic_reference(n, seed=seed).copy()
+    rng = np.random.default_rng(seed)
+    for _ in range(max(1, int(n * fraction / run))):
+        p0 = int(rng.integers(0, n - run))
+        ref[p0:p0 + run] = 15
+    ref[rng.integers(0, n, size=codes)] = np.array([5, 10, 3, 12, 6, 9, 7, 11, 13, 14, 15], np.uint8)[rng.integers(0, 11, size=codes)]
+    return ref
+
+
+@pytest.mark.parametrize("case,group", [("scattered", None), ("scattered", "30000"), ("n_runs_20Mb", None), ("long_run", None)])
+def test_reference_with_ambiguity_codes_hashed_on_the_gpu_equals_host_builder(case, group, monkeypatch):
+    """References with ambiguity codes (GRCh38's N-runs; HashBlock_ParentRow.java:109-165, MultiHashBlock.java): the GPU hashes what lies clear of
+    the ambiguous bases, the conditional multi blocks come from the host's windows around them (long runs of N with their middle left out) and join
+    the records before the sort.  Tables and duplication keys must be those of the host's whole-contig multi builder (which the CPU tier checks
+    against the oracle), also with the records made in several groups; and reads align as the oracle says."""
+    mis = -1
+    if case == "scattered":
+        refs = [("a", ambiguous_reference(120_000, seed=31, n_runs=12, n_codes=150)), ("b", ambiguous_reference(9_000, seed=32)), ("clean", synth.synthetic_reference(30_000, seed=33))]
+    elif case == "n_runs_20Mb":
+        refs = [("chr%d" % i, n_run_reference(n, seed=40 + i)) for i, n in enumerate((12_000_000, 6_000_000, 2_000_000))]
+        mis = 13  # (what a 3 Gb reference gets, HashBlock_Database.java:52)
+    else:
+        r = synth.synthetic_reference(600_000, seed=34).copy()
+        r[100_000:300_000] = 15   # longer than the 65,536 positions a window holds of a run
+        r[400_000:400_900] = 15
+        refs = [("a", r)]
+        mis = 13
+    if group:
+        monkeypatch.setenv("XM_BUILD_GROUP_RECORDS", group)
+    monkeypatch.setenv("XM_DEVICE_BUILD", "1")
+    D = api.ReferenceDatabase(refs, max_query_length=150, min_interesting_size=mis)
+    monkeypatch.setenv("XM_DEVICE_BUILD", "0")
+    H = api.ReferenceDatabase(refs, max_query_length=150, min_interesting_size=mis)
+    assert D.info()["built_on_device"] == 1 and H.info()["built_on_device"] == 0
+    _tables_equal(D, H, "build")
+    if case == "scattered":
+        R = o.OracleReference(refs)
+        b = se_batch(synth.synthetic_single_end(refs[0][1], 3000, seed=35, indel_prob=0.3)[0])
+        got, _ = gpu_align(D, b)
+        want = R.align(b, o.make_params(), threads=os.cpu_count())
+        assert streams_equal(got, want), first_difference(got, want, 1)
+    D.close(); H.close()
 
 
 def test_index_from_cache_aligns_the_same(tmp_path):
