@@ -17,7 +17,11 @@ EXE = os.path.join(ROOT, "bindings", "_build", "binding_test")
 
 
 def build():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "bindings")], stdout=subprocess.DEVNULL)
+    import fcntl
+    os.makedirs(os.path.join(ROOT, "bindings", "_build"), exist_ok=True)
+    with open(os.path.join(ROOT, "bindings", "_build", ".lock"), "w") as lock:  # (pytest-xdist workers build side by side)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "bindings")], stdout=subprocess.DEVNULL)
     return EXE
 
 
