@@ -13,7 +13,7 @@ if kind == "se":
 else:
     m1, m2 = synth.synthetic_paired_end(ref, nq)[:2]; b = pe_batch(m1, m2, 100.0, 50.0)
 names = {0: "TOTAL", 2: "WALK", 3: "STEP", 4: "UNGAPPED", 5: "HITS", 6: "CHAIN", 10: "CONFIDENT", 11: "ALIGNMATCH", 12: "MATEINIT", 13: "WRITE", 14: "OPTIMISTIC"}
-for heavy in ("3",):
+for heavy in (os.environ.get("TIERS", "3"),):
     os.environ["XM_WAVE_TIERS"] = heavy
     for rep in range(2):
         r = db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, api.AlignmentParameters())
