@@ -165,6 +165,21 @@ int xm_seed_probe(xm_index* index, int64_t n, const int32_t* used_length, const 
  * kernel_ms = best of two timed launches.  No reference counterpart. */
 int xm_measure_random_gather(int device, int64_t table_bytes, int64_t accesses, double* kernel_ms);
 
+/* Pile-up of the alignments on the reference: what MatchDatabase.addAlignments / groupByPosition hand the
+ * mutation and VCF writers (Mapper.java:700-708,758-785; behaviour pinned by MatchDatabase_Test.java:12-69 and MutationsWriter_Test.java:18-134).
+ * xm_pileup_add_last accumulates, on the device, the alignments of the index's last xm_align_batch / xm_align_resident call (result streams and
+ * batch still in HBM): per forward reference position the depth and the counts of differing query bases (A, C, G, T), in integer units of
+ * 1 / XM_PILEUP_UNIT read bases (a query with n alignments adds 1/n per alignment; the mates of a pair add 1/2 each where they overlap), and one
+ * event per insertion / deletion block: eight int64 = contig, position (startB of the block), type (1 insertion, 2 deletion), length, query
+ * ordinal (over all batches added), mate | reversed << 1, startA, weight.  Several GPUs: one pile-up per replica, summed by the host in rank order. */
+#define XM_PILEUP_UNIT 1441440ull
+typedef struct xm_pileup xm_pileup;
+int xm_pileup_new(xm_index* index, xm_pileup** out);
+int xm_pileup_add_last(xm_pileup* pileup, int64_t* num_events);
+int xm_pileup_read(xm_pileup* pileup, int32_t contig, int64_t first, int64_t n, uint64_t* depth, uint64_t* alt /* [4][n] */);
+int64_t xm_pileup_events(xm_pileup* pileup, int64_t first, int64_t n, int64_t* out /* [8 * n] */);
+void xm_pileup_free(xm_pileup* pileup);
+
 /* TEST-ONLY entry (tests/test_gpu_kat.py; not part of the drop-in boundary): the reference's component-level known-answer tests run by the
  * device code of the align kernels over two given texts.  chain 0 = PathAligner alone (PathAligner_Test.java:10-39): mode 0 the lane-per-read
  * search in the wave's LDS slot, 1 the same search in HBM mode, 2 the wave-cooperative search with the search kernel's capacities, 3 with the

@@ -301,7 +301,7 @@ class ReferenceDatabase:
         if self._L.xm_batch_commit(self._h):
             raise RuntimeError(self._L.xm_last_error().decode())
 
-    def align_stream(self, batches, parameters):
+    def align_stream(self, batches, parameters, on_aligned=None):
         """Aligns a sequence of batches (each a tuple of upload_arrays' six arrays) and yields their BatchResults in order.  The copy of
         batch k+1 to HBM runs on a second host thread and a second stream while batch k is being aligned (the
         reference's workers fetch their next batch the same way, AlignerWorker.java:92-175)."""
@@ -331,6 +331,7 @@ class ReferenceDatabase:
 
         t = threading.Thread(target=uploader, daemon=True)
         t.start()
+        count = 0
         try:
             while True:
                 token = ready.get()
@@ -339,6 +340,9 @@ class ReferenceDatabase:
                 if isinstance(token, BaseException):
                     raise token
                 r = self.align_resident(parameters)
+                if on_aligned is not None:  # (while the batch and its result streams are still resident: pileup.MatchDatabase.add_last)
+                    on_aligned(count)
+                count += 1
                 aligned.release()
                 yield r
         finally:
@@ -371,13 +375,14 @@ class ReferenceDatabase:
         codes = np.concatenate(chunks) if chunks else np.zeros(1, np.uint8)
         return mc, mo, ml, codes, ei, dv
 
-    def align_batches(self, queries, parameters, batch_size):
+    def align_batches(self, queries, parameters, batch_size, on_aligned=None):
         """Aligns `queries` in batches of `batch_size` (AlignerWorker takes its queries batch by batch too, AlignerWorker.java:92-231) and
         yields (first query index, BatchResult) per batch; the next batch is packed and copied to HBM while the current one is aligned
-        (align_stream)."""
+        (align_stream).  on_aligned(replica, first query index, queries of the batch) is called while the batch is still resident."""
         starts = list(range(0, len(queries), max(1, int(batch_size))))
         arrays = (self.batch_arrays(queries[s:s + batch_size]) for s in starts)
-        for s, r in zip(starts, self.align_stream(arrays, parameters)):
+        hook = (lambda k: on_aligned(0, starts[k], queries[starts[k]:starts[k] + batch_size])) if on_aligned else None
+        for s, r in zip(starts, self.align_stream(arrays, parameters, on_aligned=hook)):
             yield s, r
 
     def align_batch(self, queries, parameters):

@@ -18,7 +18,7 @@ import numpy as np
 
 from . import api, sam
 
-JAVA_HOST_ONLY = {"--out-vcf": 1, "--out-mutations": 1, "--out-ancestor": 1, "--out-refs-map-count": 1,
+JAVA_HOST_ONLY = {"--out-vcf": 1, "--out-ancestor": 1, "--out-refs-map-count": 1,
                   "--distinguish-query-ends": 1, "--infer-ancestors": 0, "--verify-consistent-db": 0,
                   "--vcf-exclude-non-mutations": 0, "--vcf-omit-support-reads": 0}
 IGNORED = {"--verbose": 0, "-v": 0, "-vv": 0, "--verbose-alignment": 0, "--verbose-reference": 0, "--verbosity-auto": 0, "--num-threads": 1,
@@ -126,6 +126,8 @@ def parse_args(argv):
                 raise UsageError("--ambiguity-penalty must be >= 0")
         elif a == "--max-num-matches":
             o["maxNumMatches"] = int(argv[i + 1]); i += 1
+        elif a == "--out-mutations":  # Mapper.java:187: the mutations file (mapper_amd/pileup.py; accumulated on the GPU)
+            o["out_mutations"] = argv[i + 1]; i += 1
         elif a == "--cache-dir":  # Mapper.java:264: keep the hashed reference between runs
             o["cache_dir"] = argv[i + 1]; i += 1
         elif a == "--batch-size":  # (not a Mapper flag) queries per GPU batch; batches are streamed (upload of the next one during the alignment of the current one)
@@ -158,7 +160,7 @@ def derive_parameters(o):
         raise UsageError("--reference is required")
     if len(o["queries"]) + len(o["paired"]) < 1:
         raise UsageError("--queries or --paired-queries is required")
-    if o["out_sam"] is None and o["out_unaligned"] is None and not o["no_output"]:
+    if o["out_sam"] is None and o["out_unaligned"] is None and not o.get("out_mutations") and not o["no_output"]:
         raise UsageError("No output specified. Try --out-sam <output path>, or if you really don't want to generate an output file, --no-output")
     if o["maxErrorRate"] >= 0 and o["mutationPenalty"] >= 0 and o["paired_without_spacing"]:
         raise UsageError("Customized alignment penalties (--snp-penalty) and penalty threshold (--max-penalty) without customizing spacing penalty "
@@ -246,7 +248,13 @@ def run(argv, out=sys.stdout):
     un_out = open(o["out_unaligned"], "w") if o["out_unaligned"] else None
     num_aligned = total_len = num_indels = 0
     total_penalty = 0.0
-    results = db.align_batches([q for q, _ in queries], params, batch_size)
+    match_db = None
+    on_aligned = None
+    if o.get("out_mutations"):  # Mapper.java:700-708: the MatchDatabase listens to every batch; here it accumulates on the GPU while the batch is resident
+        from . import pileup
+        match_db = pileup.MatchDatabase(db.replicas if hasattr(db, "replicas") else db)
+        on_aligned = lambda replica, first_query, qs: match_db.add_last(qs, replica=replica)  # noqa: E731
+    results = db.align_batches([q for q, _ in queries], params, batch_size, on_aligned=on_aligned)
     first, result, nxt = 0, None, 0
     for qi, (q, quals) in enumerate(queries):
         if qi >= nxt:  # the next batch's results (queries are written in input order)
@@ -273,6 +281,10 @@ def run(argv, out=sys.stdout):
         sam_out.close()
     if un_out:
         un_out.close()
+    if match_db is not None:  # Mapper.java:758-785
+        with open(o["out_mutations"], "w") as f:
+            match_db.write_mutations(f)
+        match_db.close()
     n = len(queries)
     out.write("\nStatistics: \n")
     out.write(" Alignment rate                : %d%% of queries (%d/%d)\n" % (num_aligned * 100 // n if n else 0, num_aligned, n))

@@ -15,6 +15,8 @@
 #include <vector>
 #include <mutex>
 #include <atomic>
+#include <array>
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include <cstdio>
@@ -276,6 +278,86 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(i
   if (found) {
     for (int i = 0; i < out.nb && i < blockCap; i++) { outInts[4 + 4 * i] = out.blocks[i].startA; outInts[5 + 4 * i] = out.blocks[i].startB; outInts[6 + 4 * i] = out.blocks[i].lenA; outInts[7 + 4 * i] = out.blocks[i].lenB; }
     outDbls[0] = out.totalPenalty; outDbls[1] = out.alignedPenalty;
+  }
+}
+
+// ---------------------------------------------------------------- pile-up of the alignments on the reference
+// What MatchDatabase.addAlignments / groupByPosition feed the mutation and VCF writers with (M/Mapper.java:700-708,758-785; the classes are
+// un-vendored, the behaviour is pinned by T/MatchDatabase_Test.java and T/MutationsWriter_Test.java): per forward reference position the depth
+// and the counts of differing query bases, plus one event per insertion / deletion block.  One lane per query walks its result stream in HBM.
+// Counts are integers in units of 1 / XM_PILEUP_UNIT of a read base (a query with n alignments adds 1/n per alignment, the two mates of a pair
+// add 1/2 each where they overlap: T/MatchDatabase_Test.java:38-69), so sums do not depend on the order of the atomic adds.
+struct PileupView {
+  unsigned long long* depth;     // [totalForwardSize]
+  unsigned long long* alt;       // [4][totalForwardSize]: query base A, C, G, T where it differs from an unambiguous reference base
+  long long total;
+  long long* events;             // 7 per event: contig, position, type (1 insertion, 2 deletion), length, query, mate | reversed << 1, startA; weight in [7]
+  unsigned long long eventCap;
+  unsigned long long* eventCount;
+  long long queryBase;           // index of the batch's first query among all queries added so far
+};
+__global__ void __launch_bounds__(256) xm_pileup_kernel(IndexView ix, BatchView batch, const int32_t* ints, const int64_t* intOff, PileupView pv) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= batch.nq) return;
+  const int32_t* p = ints + intOff[q];
+  const int numComponents = *p++;
+  for (int c = 0; c < numComponents; c++) {
+    const int numAlignments = *p++;
+    if (numAlignments < 1) continue;
+    const unsigned long long w = XM_PILEUP_UNIT / (unsigned long long)numAlignments;
+    for (int a = 0; a < numAlignments; a++) {
+      p++;  // innerDistance
+      const int numSequences = *p++;
+      // the reference interval of each sequence alignment first (mates of a pair share the depth where they overlap)
+      int contigOf[2] = {-1, -1};
+      long long lo[2] = {0, 0}, hi[2] = {0, 0};
+      {
+        const int32_t* t = p;
+        for (int sq = 0; sq < numSequences && sq < 2; sq++) {
+          contigOf[sq] = t[0];
+          const int nb = t[2];
+          t += 3;
+          lo[sq] = t[1]; hi[sq] = t[4 * (nb - 1) + 1] + t[4 * (nb - 1) + 3];
+          t += 4 * nb;
+        }
+      }
+      long long ovLo = 0, ovHi = 0;
+      if (numSequences == 2 && contigOf[0] == contigOf[1]) { ovLo = lo[0] > lo[1] ? lo[0] : lo[1]; ovHi = hi[0] < hi[1] ? hi[0] : hi[1]; }
+      for (int sq = 0; sq < numSequences; sq++) {
+        const int contig = *p++;
+        const int reversed = *p++;
+        const int nb = *p++;
+        const int mate = numComponents > 1 ? c : sq;
+        const uint8_t* read = batch.codes + batch.mateOffset[q * 2 + mate];
+        const int readLen = batch.mateLength[q * 2 + mate];
+        const long long base = ix.contigStart[contig];
+        for (int b = 0; b < nb; b++, p += 4) {
+          const int startA = p[0], startB = p[1], lenA = p[2], lenB = p[3];
+          if (lenA == lenB) {
+            for (int i = 0; i < lenA; i++) {
+              const long long pos = startB + i;
+              const unsigned long long wi = (pos >= ovLo && pos < ovHi) ? w / 2 : w;
+              const uint8_t r = ix.refCodes[base + pos];
+              const int k = startA + i;
+              const uint8_t qb = reversed ? bpComplement(read[readLen - 1 - k]) : read[k];
+              atomicAdd(&pv.depth[base + pos], wi);
+              if (!bpIsAmbiguous(r) && !bpIsAmbiguous(qb) && qb != r) atomicAdd(&pv.alt[(long long)encodedCharToInt(qb) * pv.total + base + pos], wi);
+            }
+          } else {
+            if (lenA == 0) for (int i = 0; i < lenB; i++) {  // a deletion: the read spans these reference bases
+              const long long pos = startB + i;
+              atomicAdd(&pv.depth[base + pos], (pos >= ovLo && pos < ovHi) ? w / 2 : w);
+            }
+            const unsigned long long at = atomicAdd(pv.eventCount, 1ull);
+            if (at < pv.eventCap) {
+              long long* e = pv.events + at * 8;
+              e[0] = contig; e[1] = startB; e[2] = lenA > 0 ? 1 : 2; e[3] = lenA > 0 ? lenA : lenB; e[4] = pv.queryBase + q; e[5] = mate | (reversed << 1); e[6] = startA;
+              e[7] = (long long)((startB >= ovLo && startB < ovHi) ? w / 2 : w);
+            }
+          }
+        }
+      }
+    }
   }
 }
 
@@ -658,6 +740,8 @@ struct xm_index {
   DevBuf<DevCounters> dCounters;
   int numCUs = 0;
   int64_t residentNq = -1;   // batch kept in HBM by xm_batch_upload
+  int64_t residentGen = 0, lastAlignedGen = -1;  // which resident batch the streams of the last align call belong to
+  int64_t lastAlignedNq = -1;  // queries whose result streams (dFinalInts / dFinalDbls / dFinalIntOff) are still in HBM from the last align call (xm_pileup_add_last)
   int residentMaxLen = 0;    // longest mate of that batch
   double residentH2dMs = 0;
   // second set of batch buffers: xm_batch_stage copies the next batch on its own stream while xm_align_resident works on the resident one
@@ -744,6 +828,14 @@ struct xm_index {
     if (stream) (void)hipStreamDestroy(stream);
     if (copyStream) (void)hipStreamDestroy(copyStream);
   }
+};
+
+struct xm_pileup {
+  xm_index* index = nullptr;
+  DevBuf<unsigned long long> dDepth, dAlt, dEventCount;
+  DevBuf<long long> dEvents;
+  long long total = 0, queriesAdded = 0;
+  std::vector<long long> events;  // (host) 8 per event, in the order of the calls
 };
 
 extern "C" {
@@ -986,6 +1078,7 @@ static void uploadBatchLocked(xm_index* idx, const xm_query_batch* b) {
     idx->residentH2dMs = ms;
   }
   idx->residentNq = nq;
+  idx->residentGen++;
   idx->residentMaxLen = maxLen;
 }
 
@@ -1052,6 +1145,7 @@ int xm_batch_commit(xm_index* idx) {
     std::lock_guard<std::mutex> lock(idx->mu);  // (waits for a running xm_align_resident)
     idx->dMateCount.swapWith(idx->sMateCount); idx->dMateOffset.swapWith(idx->sMateOffset); idx->dMateLength.swapWith(idx->sMateLength);
     idx->dCodes.swapWith(idx->sCodes); idx->dExpected.swapWith(idx->sExpected); idx->dDeviation.swapWith(idx->sDeviation);
+    idx->residentGen++;
     idx->residentNq = idx->stagedNq; idx->residentMaxLen = idx->stagedMaxLen; idx->residentH2dMs = idx->stagedH2dMs; idx->residentAnyPaired = idx->stagedAnyPaired;
     idx->stagedNq = -1;
     return 0;
@@ -1491,6 +1585,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     HIP_CHECK(hipGetLastError());
     res->ints = (int32_t*)g_pinned->get(sizeof(int32_t) * (usedI ? usedI : 1), &box->bytesInts);
     res->dbls = (double*)g_pinned->get(sizeof(double) * (usedD ? usedD : 1), &box->bytesDbls);
+    idx->lastAlignedNq = nq;
+    idx->lastAlignedGen = idx->residentGen;
     HIP_CHECK(hipMemcpyAsync(res->int_off, idx->dFinalIntOff.p, sizeof(int64_t) * (size_t)(nq + 1), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(res->dbl_off, idx->dFinalDblOff.p, sizeof(int64_t) * (size_t)(nq + 1), hipMemcpyDeviceToHost, s));
     if (usedI) HIP_CHECK(hipMemcpyAsync(res->ints, idx->dFinalInts.p, sizeof(int32_t) * usedI, hipMemcpyDeviceToHost, s));
@@ -1581,6 +1677,99 @@ int xm_measure_random_gather(int device, int64_t table_bytes, int64_t accesses, 
     if (kernel_ms) *kernel_ms = best;
     return 0;
   } catch (std::exception& e) { return fail(std::string("xm_measure_random_gather: ") + e.what()); }
+}
+
+int xm_pileup_new(xm_index* idx, xm_pileup** out) {
+  if (!idx || !out) return fail("xm_pileup_new: null argument");
+  if (idx->hostOnly) return fail("xm_pileup_new: index was built with host_only=1");
+  xm_pileup* p = nullptr;
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    HIP_CHECK(hipSetDevice(idx->device));
+    p = new xm_pileup();
+    p->index = idx;
+    p->total = idx->host.totalForwardSize;
+    p->dDepth.ensure((size_t)p->total); p->dAlt.ensure((size_t)p->total * 4); p->dEventCount.ensure(1);
+    HIP_CHECK(hipMemset(p->dDepth.p, 0, sizeof(unsigned long long) * (size_t)p->total));
+    HIP_CHECK(hipMemset(p->dAlt.p, 0, sizeof(unsigned long long) * (size_t)p->total * 4));
+    *out = p;
+    return 0;
+  } catch (std::exception& e) { delete p; return fail(std::string("xm_pileup_new: ") + e.what()); }
+}
+
+int xm_pileup_add_last(xm_pileup* p, int64_t* num_events) {
+  if (!p || !p->index) return fail("xm_pileup_add_last: null argument");
+  xm_index* idx = p->index;
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (idx->lastAlignedNq < 0 || idx->lastAlignedNq != idx->residentNq || idx->lastAlignedGen != idx->residentGen)
+      throw std::runtime_error("the batch of the last align call is no longer resident (call xm_pileup_add_last after xm_align_batch / xm_align_resident, before the next batch is uploaded or committed)");
+    HIP_CHECK(hipSetDevice(idx->device));
+    hipStream_t s = idx->stream;
+    const int64_t nq = idx->lastAlignedNq;
+    if (nq > 0) {
+      const unsigned long long cap = (unsigned long long)idx->dFinalInts.n / 4 + 1;  // (an event is a block: at least four ints of the stream)
+      p->dEvents.ensure((size_t)cap * 8);
+      HIP_CHECK(hipMemsetAsync(p->dEventCount.p, 0, sizeof(unsigned long long), s));
+      BatchView bv{nq, idx->dMateCount.p, idx->dMateOffset.p, idx->dMateLength.p, idx->dCodes.p, idx->dExpected.p, idx->dDeviation.p};
+      PileupView pv{p->dDepth.p, p->dAlt.p, p->total, p->dEvents.p, cap, p->dEventCount.p, p->queriesAdded};
+      hipLaunchKernelGGL(xm_pileup_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, idx->view, bv, (const int32_t*)idx->dFinalInts.p, (const int64_t*)idx->dFinalIntOff.p, pv);
+      HIP_CHECK(hipGetLastError());
+      unsigned long long n = 0;
+      HIP_CHECK(hipMemcpyAsync(&n, p->dEventCount.p, sizeof(n), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      if (n > cap) throw std::runtime_error("internal error: more indel events than blocks");
+      const size_t at = p->events.size();
+      p->events.resize(at + (size_t)n * 8);
+      if (n) HIP_CHECK(hipMemcpy(p->events.data() + at, p->dEvents.p, sizeof(long long) * (size_t)n * 8, hipMemcpyDeviceToHost));
+      // the order of the atomic appends is not fixed: events of a call are put in (query, position) order
+      std::vector<std::array<long long, 8>> ev((size_t)n);
+      for (size_t i = 0; i < (size_t)n; i++) for (int k = 0; k < 8; k++) ev[i][(size_t)k] = p->events[at + i * 8 + (size_t)k];
+      std::sort(ev.begin(), ev.end(), [](const std::array<long long, 8>& a, const std::array<long long, 8>& b) {
+        if (a[4] != b[4]) return a[4] < b[4];
+        if (a[0] != b[0]) return a[0] < b[0];
+        if (a[1] != b[1]) return a[1] < b[1];
+        if (a[5] != b[5]) return a[5] < b[5];
+        return a[6] < b[6];
+      });
+      for (size_t i = 0; i < (size_t)n; i++) for (int k = 0; k < 8; k++) p->events[at + i * 8 + (size_t)k] = ev[i][(size_t)k];
+    }
+    p->queriesAdded += nq;
+    if (num_events) *num_events = (int64_t)(p->events.size() / 8);
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_pileup_add_last: ") + e.what()); }
+}
+
+int xm_pileup_read(xm_pileup* p, int32_t contig, int64_t first, int64_t n, uint64_t* depth, uint64_t* alt) {
+  if (!p || !p->index || !depth || !alt) return fail("xm_pileup_read: null argument");
+  xm_index* idx = p->index;
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (contig < 0 || contig >= idx->host.numContigs() || first < 0 || n < 0 || first + n > idx->host.contigLen[(size_t)contig]) throw std::runtime_error("range outside of the contig");
+    HIP_CHECK(hipSetDevice(idx->device));
+    const size_t at = (size_t)idx->host.contigStart[(size_t)contig] + (size_t)first;
+    if (n) {
+      HIP_CHECK(hipMemcpy(depth, p->dDepth.p + at, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
+      for (int b = 0; b < 4; b++) HIP_CHECK(hipMemcpy(alt + (size_t)b * (size_t)n, p->dAlt.p + (size_t)b * (size_t)p->total + at, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
+    }
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_pileup_read: ") + e.what()); }
+}
+
+int64_t xm_pileup_events(xm_pileup* p, int64_t first, int64_t n, int64_t* out) {
+  if (!p || (n > 0 && !out)) return -1;
+  const int64_t have = (int64_t)(p->events.size() / 8);
+  if (first < 0 || first > have) return -1;
+  const int64_t m = std::min<int64_t>(n, have - first);
+  if (m > 0) memcpy(out, p->events.data() + (size_t)first * 8, sizeof(int64_t) * (size_t)m * 8);
+  return m;
+}
+
+void xm_pileup_free(xm_pileup* p) {
+  if (!p) return;
+  if (p->index) (void)hipSetDevice(p->index->device);
+  p->dDepth.release(); p->dAlt.release(); p->dEventCount.release(); p->dEvents.release();
+  delete p;
 }
 
 // Test-only entry (tests/test_gpu_kat.py): see xm_test_local_kernel above and xm_test_wave_search_kernel (xm_wave_kernel.hip).

@@ -36,8 +36,9 @@ class MultiGpuDatabase:
             r.close()
         self.replicas = []
 
-    def align_stream(self, batches, parameters, depth=2):
-        """batches: iterable of upload_arrays' six-array tuples; yields their BatchResults in order.  Batch k is aligned by replica k mod N."""
+    def align_stream(self, batches, parameters, depth=2, on_aligned=None):
+        """batches: iterable of upload_arrays' six-array tuples; yields their BatchResults in order.  Batch k is aligned by replica k mod N.
+        on_aligned(replica, k) is called on the replica's thread while batch k is still resident there."""
         n = len(self.replicas)
         inbox = [queue.Queue(maxsize=depth) for _ in range(n)]    # batches on their way to GPU g
         outbox = [queue.Queue(maxsize=depth) for _ in range(n)]   # results of GPU g, in its own order
@@ -64,7 +65,8 @@ class MultiGpuDatabase:
 
         def worker(g):
             try:
-                for r in self.replicas[g].align_stream(feed(g), parameters):
+                hook = (lambda j: on_aligned(g, g + j * n)) if on_aligned else None
+                for r in self.replicas[g].align_stream(feed(g), parameters, **({"on_aligned": hook} if hook else {})):
                     if not put(outbox[g], r):
                         return
                 put(outbox[g], None)
@@ -107,12 +109,13 @@ class MultiGpuDatabase:
             for t in threads:
                 t.join(timeout=60)
 
-    def align_batches(self, queries, parameters, batch_size):
+    def align_batches(self, queries, parameters, batch_size, on_aligned=None):
         """Same contract as ReferenceDatabase.align_batches: yields (first query index, BatchResult) per batch, in order."""
         from . import api
         starts = list(range(0, len(queries), max(1, int(batch_size))))
         arrays = (api.ReferenceDatabase.batch_arrays(queries[s:s + batch_size]) for s in starts)
-        for s, r in zip(starts, self.align_stream(arrays, parameters)):
+        hook = (lambda g, k: on_aligned(g, starts[k], queries[starts[k]:starts[k] + batch_size])) if on_aligned else None
+        for s, r in zip(starts, self.align_stream(arrays, parameters, on_aligned=hook)):
             yield s, r
 
 

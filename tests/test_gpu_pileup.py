@@ -1,0 +1,127 @@
+"""the pile-up of alignments on the reference (device) and the mutations file (host), against what the
+reference's own tests pin - tests/golden/mutations_reference.json transcribes src/test/java/MutationsWriter_Test.java:18-134 and
+src/test/java/MatchDatabase_Test.java:12-69 (inputs and expected values)."""
+import io
+import json
+import os
+import numpy as np
+import pytest
+
+from mapper_amd import api, pileup, synth, multi
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "mutations_reference.json")))
+
+
+def build(query_texts, reference, params=None):
+    db = api.ReferenceDatabase([("ref", reference)], mode="api")
+    queries = [api.Query(*[api.encode(t) for t in qt]) if isinstance(qt, (list, tuple)) else api.Query(api.encode(qt)) for qt in query_texts]
+    r = db.align_batch(queries, api.AlignmentParameters(**(params or FIX["alignment_parameters"])))
+    m = pileup.MatchDatabase(db)
+    m.add_last(queries)
+    return db, m, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FIX["mutation_cases"], ids=[c["name"] for c in FIX["mutation_cases"]])
+def test_mutations_writer_cases(case):
+    db, m, _ = build([case["query"]], case["reference"])
+    out = io.StringIO()
+    m.write_mutations(out, pileup.MutationDetectionParameters(**case.get("filter", {})))
+    lines = [l for l in out.getvalue().split("\n") if l and not l.startswith("#") and not l.startswith("CHR")]  # (withoutMetadataLines, MutationsWriter_Test.java:144-154)
+    assert lines == case["expected"]
+    m.close(); db.close()
+
+
+@pytest.mark.gpu
+def test_match_database_counts():
+    c = FIX["match_database_cases"][0]
+    db, m, _ = build([c["query"]], c["reference"], dict(FIX["alignment_parameters"], MaxErrorRate=0.5))
+    assert np.array_equal(m.depth(0), np.ones(len(c["reference"])))
+    m.close(); db.close()
+    # overlapping mates: mate 2 is given as sequenced (reverse complement), the pair overlaps on reference positions 3..7
+    c = FIX["match_database_cases"][1]
+    ref = c["reference"] * 1
+    q1, q2 = c["query1"], api.decode(api.reverse_complement(api.encode(c["query2"])))
+    db = api.ReferenceDatabase([("ref", ref)], mode="api")
+    q = api.Query(api.encode(q1), api.encode(q2), expected_inner_distance=0.0, spacing_deviation_per_unit_penalty=1.0)
+    r = db.align_batch([q], api.AlignmentParameters(**dict(FIX["alignment_parameters"], MaxErrorRate=1.0)))
+    comps = r.query_alignments(0)
+    if len(comps) == 1 and len(comps[0]) == 1 and len(comps[0][0].components) == 2:  # (the aligner found the pair as the reference's test builds it)
+        m = pileup.MatchDatabase(db)
+        m.add_last([q])
+        assert np.array_equal(m.depth(0), np.ones(len(ref)))
+        m.close()
+    db.close()
+
+
+@pytest.mark.gpu
+def test_pileup_on_a_synthetic_batch_and_two_replicas():
+    """Depth and substitution counts of a few thousand reads equal a host recount from the decoded alignments; two replicas (batches dealt
+    between them) sum to the same pile-up as one."""
+    ref = synth.synthetic_reference(150_000, seed=61)
+    reads = synth.synthetic_single_end(ref, 4000, seed=62, indel_prob=0.3)[0]
+    queries = [api.Query(r) for r in reads]
+    params = api.AlignmentParameters()
+    db = api.ReferenceDatabase([("r", ref)])
+    res = db.align_batch(queries, params)
+    m = pileup.MatchDatabase(db)
+    n_events = m.add_last(queries)
+    depth = np.zeros(len(ref))
+    alt = np.zeros((4, len(ref)))
+    events = 0
+    for q in range(len(queries)):
+        comps = res.query_alignments(q)
+        for comp in comps:
+            for al in comp:
+                w = 1.0 / len(comp)
+                for sa in al.components:
+                    qq = api.reverse_complement(reads[q]) if sa.reference_reversed else reads[q]
+                    for b in sa.sections:
+                        if b.lengthA == b.lengthB:
+                            depth[b.startB:b.startB + b.lengthB] += w
+                            for i in range(b.lengthA):
+                                if qq[b.startA + i] != ref[b.startB + i]:
+                                    alt[{1: 0, 2: 1, 4: 2, 8: 3}[int(qq[b.startA + i])], b.startB + i] += w
+                        else:
+                            events += 1
+                            if b.lengthA == 0:
+                                depth[b.startB:b.startB + b.lengthB] += w
+    assert n_events == events and events > 500
+    got_depth, got_alt = m._sum(0)
+    assert np.allclose(got_depth / pileup.UNIT, depth, atol=1e-9) and np.allclose(got_alt / pileup.UNIT, alt, atol=1e-9)
+    muts = m.mutations()
+    assert len(muts) > 1000 and all(c == 0 and 1 <= p <= len(ref) for c, p, *_ in muts)
+    # the same through two replicas
+    two = multi.MultiGpuDatabase([("r", ref)], [0, 0])
+    m2 = pileup.MatchDatabase(two.replicas)
+    half = len(queries) // 2
+    for rep, qs in ((0, queries[:half]), (1, queries[half:])):
+        two.replicas[rep].align_batch(qs, params)
+        m2.add_last(qs, replica=rep)
+    d2, a2 = m2._sum(0)
+    assert np.array_equal(d2, got_depth) and np.array_equal(a2, got_alt)
+    assert m2.mutations() == muts
+    m.close(); m2.close(); db.close(); two.close()
+
+
+@pytest.mark.gpu
+def test_cli_out_mutations(tmp_path):
+    """`--out-mutations` (Mapper.java:187,758-785) through the command line, one GPU and two contexts, small batches: the same file."""
+    from mapper_amd import cli
+    ref = synth.synthetic_reference(80_000, seed=71)
+    reads = synth.synthetic_single_end(ref, 900, seed=72, indel_prob=0.3)[0]
+    with open(tmp_path / "ref.fasta", "w") as f:
+        f.write(">chrSyn\n" + api.decode(ref) + "\n")
+    with open(tmp_path / "reads.fastq", "w") as f:
+        for i, r in enumerate(reads):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, api.decode(r), "I" * len(r)))
+    outs = []
+    for extra in ([], ["--devices", "0,0", "--batch-size", "128"]):
+        path = tmp_path / ("mut%d.txt" % len(outs))
+        assert cli.run(["--reference", str(tmp_path / "ref.fasta"), "--queries", str(tmp_path / "reads.fastq"), "--out-mutations", str(path)] + extra, out=io.StringIO()) == 0
+        outs.append(open(path).read())
+    assert outs[0] == outs[1]
+    body = [l.split("\t") for l in outs[0].split("\n") if l and not l.startswith("#") and not l.startswith("CHR")]
+    assert len(body) > 500 and all(l[0] == "chrSyn" and len(l) == 6 for l in body)
+    assert any(set(l[2]) == {"-"} for l in body) and any(set(l[3]) == {"-"} for l in body)  # insertions and deletions are there
