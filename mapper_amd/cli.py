@@ -8,7 +8,7 @@ SURVEY.md section 8(f) rank 1.  What is pinned by the reference: the flag names 
 derivation of AlignmentParameters from them (:409-453), reference sorting (:1151-1172), the SAM record format
 (SamWriter_Test.java) and the statistics lines of Mapper.run (:786-796).  The SAM header, `--out-unaligned` and the other writers
 live in the un-vendored QuickVariants module: the header written here is the minimal SAM-spec one and is marked [unpinned]; the
-VCF / mutations / ancestry / refs-map-count outputs stay with the Java host (`--cache-dir` is
+VCF / ancestry outputs stay with the Java host (`--cache-dir` is
 honoured: the index goes to one file under it, api.index_cache_path) and are refused here with a message saying so.
 """
 import gzip
@@ -18,7 +18,7 @@ import numpy as np
 
 from . import api, sam
 
-JAVA_HOST_ONLY = {"--out-vcf": 1, "--out-ancestor": 1, "--out-refs-map-count": 1,
+JAVA_HOST_ONLY = {"--out-vcf": 1, "--out-ancestor": 1,
                   "--distinguish-query-ends": 1, "--infer-ancestors": 0, "--verify-consistent-db": 0,
                   "--vcf-exclude-non-mutations": 0, "--vcf-omit-support-reads": 0}
 IGNORED = {"--verbose": 0, "-v": 0, "-vv": 0, "--verbose-alignment": 0, "--verbose-reference": 0, "--verbosity-auto": 0, "--num-threads": 1,
@@ -126,6 +126,8 @@ def parse_args(argv):
                 raise UsageError("--ambiguity-penalty must be >= 0")
         elif a == "--max-num-matches":
             o["maxNumMatches"] = int(argv[i + 1]); i += 1
+        elif a == "--out-refs-map-count":  # Mapper.java:197: how many queries mapped to each combination of references
+            o["out_refs_map_count"] = argv[i + 1]; i += 1
         elif a == "--out-mutations":  # Mapper.java:187: the mutations file (mapper_amd/pileup.py; accumulated on the GPU)
             o["out_mutations"] = argv[i + 1]; i += 1
         elif a == "--cache-dir":  # Mapper.java:264: keep the hashed reference between runs
@@ -160,7 +162,7 @@ def derive_parameters(o):
         raise UsageError("--reference is required")
     if len(o["queries"]) + len(o["paired"]) < 1:
         raise UsageError("--queries or --paired-queries is required")
-    if o["out_sam"] is None and o["out_unaligned"] is None and not o.get("out_mutations") and not o["no_output"]:
+    if o["out_sam"] is None and o["out_unaligned"] is None and not o.get("out_mutations") and not o.get("out_refs_map_count") and not o["no_output"]:
         raise UsageError("No output specified. Try --out-sam <output path>, or if you really don't want to generate an output file, --no-output")
     if o["maxErrorRate"] >= 0 and o["mutationPenalty"] >= 0 and o["paired_without_spacing"]:
         raise UsageError("Customized alignment penalties (--snp-penalty) and penalty threshold (--max-penalty) without customizing spacing penalty "
@@ -248,6 +250,7 @@ def run(argv, out=sys.stdout):
     un_out = open(o["out_unaligned"], "w") if o["out_unaligned"] else None
     num_aligned = total_len = num_indels = 0
     total_penalty = 0.0
+    refs_map = {} if o.get("out_refs_map_count") else None
     match_db = None
     on_aligned = None
     if o.get("out_mutations"):  # Mapper.java:700-708: the MatchDatabase listens to every batch; here it accumulates on the GPU while the batch is resident
@@ -264,6 +267,9 @@ def run(argv, out=sys.stdout):
         aligned = any(len(c) > 0 for c in comps)
         if aligned:
             num_aligned += 1
+            if refs_map is not None:  # ReferenceAlignmentCounter [QuickVariants, inferred]: the set of contigs a query's alignments lie on
+                key = tuple(sorted({names[sa.contig] for comp in comps for al in comp for sa in al.components}))
+                refs_map[key] = refs_map.get(key, 0) + 1
             for comp in comps:  # AlignmentCounter [QuickVariants, inferred]: every reported alignment's aligned length, penalty and indels
                 for al in comp:
                     for k, sa in enumerate(al.components):
@@ -281,6 +287,10 @@ def run(argv, out=sys.stdout):
         sam_out.close()
     if un_out:
         un_out.close()
+    if refs_map is not None:  # Mapper.java:747-756 (referenceAlignmentCounter.sumAlignments); [unpinned format]: one line per combination, most frequent first
+        with open(o["out_refs_map_count"], "w") as f:
+            for key, count in sorted(refs_map.items(), key=lambda kv: (-kv[1], kv[0])):
+                f.write("%s\t%d\n" % (",".join(key), count))
     if match_db is not None:  # Mapper.java:758-785
         with open(o["out_mutations"], "w") as f:
             match_db.write_mutations(f)

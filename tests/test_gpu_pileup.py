@@ -125,3 +125,19 @@ def test_cli_out_mutations(tmp_path):
     body = [l.split("\t") for l in outs[0].split("\n") if l and not l.startswith("#") and not l.startswith("CHR")]
     assert len(body) > 500 and all(l[0] == "chrSyn" and len(l) == 6 for l in body)
     assert any(set(l[2]) == {"-"} for l in body) and any(set(l[3]) == {"-"} for l in body)  # insertions and deletions are there
+
+
+@pytest.mark.gpu
+def test_cli_out_refs_map_count(tmp_path):
+    """`--out-refs-map-count` (Mapper.java:197,747-756): reads from two contigs are counted under the contig they map to ([unpinned] file format)."""
+    from mapper_amd import cli
+    a, b = synth.synthetic_reference(60_000, seed=81), synth.synthetic_reference(40_000, seed=82)
+    ra, rb = synth.synthetic_single_end(a, 300, seed=83)[0], synth.synthetic_single_end(b, 200, seed=84)[0]
+    with open(tmp_path / "ref.fasta", "w") as f:
+        f.write(">chrA\n" + api.decode(a) + "\n>chrB\n" + api.decode(b) + "\n")
+    with open(tmp_path / "reads.fastq", "w") as f:
+        for i, r in enumerate(list(ra) + list(rb)):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, api.decode(r), "I" * len(r)))
+    assert cli.run(["--reference", str(tmp_path / "ref.fasta"), "--queries", str(tmp_path / "reads.fastq"), "--out-refs-map-count", str(tmp_path / "counts.txt")], out=io.StringIO()) == 0
+    counts = dict(l.split("\t") for l in open(tmp_path / "counts.txt").read().split("\n") if l)
+    assert int(counts["chrA"]) >= 295 and int(counts["chrB"]) >= 195 and sum(int(v) for v in counts.values()) <= 500
