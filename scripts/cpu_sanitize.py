@@ -22,6 +22,9 @@ S.align(pe_batch(m1, m2, 100.0, 50.0), o.make_params()); print("pe ok")
 aref = ambiguous_reference(100_000, seed=0xA3C, n_runs=30, n_codes=300)
 S2 = hs.SimReference([("amb", aref)])
 S2.align(se_batch(synth.synthetic_single_end(aref, 1500, seed=51)[0]), o.make_params()); print("ambiguous ref ok")
+nref = ref[:120_000].copy(); nref[30_000:36_000] = 15; nref[90_000:90_400] = 15; nref[:50] = 15  # runs of N (one longer than XM_BUILD_SPLICE_MIN when that is set)
+S3 = hs.SimReference([("nruns", nref)])
+S3.align(se_batch(synth.synthetic_single_end(nref[40_000:88_000], 500, seed=52)[0]), o.make_params()); print("N-run ref ok")
 long_reads = synth.synthetic_single_end(ref, 100, read_len=1000, sub_rate=0.05, indel_prob=0.9, seed=77)[0]
 S.align(se_batch(long_reads), o.make_params()); print("long ok")
 print("all ok")

@@ -9,3 +9,5 @@ python scripts/cpu_sanitize.py                                             # lig
 XMSIM_INLINE=1 python scripts/cpu_sanitize.py                              # plain inline run
 XMSIM_NO_HANDOVER=1 python scripts/cpu_sanitize.py                         # light pass -> re-seeding gapped pass, two deferred rounds
 XMSIM_NO_HANDOVER=1 XMSIM_DEFER_ROUNDS=100 python scripts/cpu_sanitize.py  # every search deferred
+XMSIM_WAVE=1 python scripts/cpu_sanitize.py                                # the wave-per-read form (tiers, inline searches, memo rounds) in the host simulation
+XM_BUILD_HYBRID_ON_HOST=1 XM_BUILD_SPLICE_MIN=2048 python scripts/cpu_sanitize.py  # index: plain rule + windows of multi blocks around ambiguous bases (the GPU build's composition), long runs of N split
