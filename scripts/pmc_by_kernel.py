@@ -1,4 +1,4 @@
-"""Sums rocprofv3 --pmc counter_collection csv files per (kernel, counter): mean per dispatch."""
+"""Sums rocprofv3 --pmc counter_collection csv files per (kernel, counter): total over the run, dispatches, and mean per dispatch."""
 import csv, glob, os, sys, collections
 for d in sys.argv[1:]:
     acc = collections.defaultdict(lambda: [0.0, 0])
@@ -6,7 +6,9 @@ for d in sys.argv[1:]:
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
             if "xm_wave_kernel" in k:
-                k = "xm_wave_kernel:" + ("LightSE" if "LightSE" in k else ("LightPE" if "LightPE" in k else "Heavy"))
+                k = "xm_wave_kernel:" + next((c for c in ("LightSE", "LightPE", "MidSE", "MidPE", "Heavy") if c in k), "?")
+            elif "xm_wave_search_kernel" in k:
+                k = "xm_wave_search_kernel"
             elif "xm_align_kernel" in k:
                 k = "xm_align_kernel"
             else:
@@ -14,5 +16,4 @@ for d in sys.argv[1:]:
             acc[(k, row["Counter_Name"])][0] += float(row["Counter_Value"]); acc[(k, row["Counter_Name"])][1] += 1
     print("==", d)
     for (k, c), (v, n) in sorted(acc.items()):
-        if "wave_kernel" in k or "align_kernel" in k:
-            print("%-44s %-22s mean/dispatch %16.0f  dispatches %d" % (k, c, v / n, n))
+        print("%-30s %-20s total %18.0f  dispatches %4d  mean/dispatch %16.0f" % (k, c, v, n, v / n))
