@@ -140,6 +140,10 @@ def parse_args(argv):
             o["gpus"] = int(argv[i + 1]); i += 1
             if o["gpus"] < 1:
                 raise UsageError("--gpus must be >= 1")
+        elif a == "--contexts":  # (not a Mapper flag) contexts per GPU: batches are aligned by several contexts of a GPU at the same time (fills idle wave slots)
+            o["contexts"] = int(argv[i + 1]); i += 1
+            if o["contexts"] < 1:
+                raise UsageError("--contexts must be >= 1")
         elif a == "--devices":  # (not a Mapper flag) explicit GPU ordinals, comma-separated; an ordinal may repeat (two contexts on one GPU)
             o["devices"] = [int(x) for x in argv[i + 1].split(",")]; i += 1
         elif a == "--device":  # (not a Mapper flag) which GPU
@@ -235,6 +239,8 @@ def run(argv, out=sys.stdout):
     ordered = api.sort_reference(contigs)  # Mapper.sortAndComplementReference: alignment results refer to this order
     names = [n for n, _ in ordered]
     devices = o.get("devices") or (list(range(o["gpus"])) if o.get("gpus", 1) > 1 else None)
+    if o.get("contexts", 1) > 1:
+        devices = [d for d in (devices or [o["device"]]) for _ in range(o["contexts"])]
     max_query_length = max([len(s) for q, _ in queries for s in q.sequences] + [1])
     if devices and len(devices) > 1:
         from . import multi

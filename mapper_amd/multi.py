@@ -24,6 +24,13 @@ class MultiGpuDatabase:
             raise ValueError("at least one device")
         kw.pop("device", None)
         self.devices = [int(d) for d in devices]
+        # several contexts on one GPU (a repeated ordinal) share its HBM: a context sizes its scratch from XM_SCRATCH_GIB (default: up to 200 GiB),
+        # so the budget is divided between them unless the caller has set it.  Three contexts of 80 GiB align ~10 % more reads per second than
+        # one of 200 GiB (profiles/r02/NOTES.md): the waves of one context's gapped pass leave slots idle that another context's passes fill.
+        import os
+        most = max(self.devices.count(d) for d in set(self.devices))
+        if most > 1 and "XM_SCRATCH_GIB" not in os.environ:
+            os.environ["XM_SCRATCH_GIB"] = str(max(8, 240 // most))
         first = api.ReferenceDatabase(contigs, device=self.devices[0], **kw)
         self.replicas = [first] + [first.replicate(d) for d in self.devices[1:]]
         self.contigs = first.contigs

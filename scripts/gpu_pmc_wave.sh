@@ -7,7 +7,7 @@ mkdir -p $O
 make -j8 -C $R/mapper_amd/csrc > /dev/null || exit 1
 cd /tmp && export TMPDIR=/tmp
 export XM_WAVE=1
-Q="--cpu-sample 0 --seed-probes 0 --wave-steps 0 --steps 3"
+Q="--cpu-sample 0 --seed-probes 0 --wave-steps 0 --contexts 1 --steps 3"
 rocprofv3 --pmc FETCH_SIZE -d $O/pmcF -o pmc --output-format csv -- python3 $R/bench.py $Q > $O/pmcF.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmcW -o pmc --output-format csv -- python3 $R/bench.py $Q > $O/pmcW.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES -d $O/pmcS -o pmc --output-format csv -- python3 $R/bench.py $Q > $O/pmcS.log 2>&1
