@@ -100,9 +100,9 @@ def test_cli_gpus_flag(tmp_path):
         for i, r in enumerate(reads):
             f.write("@r%d\n%s\n+\n%s\n" % (i, api.decode(r), "I" * len(r)))
     outs = []
-    for extra in ([], ["--devices", "0,0", "--batch-size", "100"]):
+    for extra in ([], ["--devices", "0,0", "--batch-size", "100"], ["--contexts", "3", "--batch-size", "64"]):
         sam_path = tmp_path / ("out%d.sam" % len(outs))
         buf = io.StringIO()
         assert cli.run(["--reference", str(tmp_path / "ref.fasta"), "--queries", str(tmp_path / "reads.fastq"), "--out-sam", str(sam_path)] + extra, out=buf) == 0
         outs.append((open(sam_path).read(), buf.getvalue()))
-    assert outs[0] == outs[1] and outs[0][0].count("\n") > 600
+    assert outs[0] == outs[1] == outs[2] and outs[0][0].count("\n") > 600
