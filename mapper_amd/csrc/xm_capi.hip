@@ -1621,6 +1621,7 @@ int xm_seed_probe(xm_index* idx, int64_t n, const int32_t* usedLength, const int
     hipStream_t s = idx->stream;
     DevBuf<int32_t> dUsed, dKeys, dCounts;
     DevBuf<int64_t> dPos;
+    struct Release { DevBuf<int32_t>&a, &b, &c; DevBuf<int64_t>& d; ~Release() { a.release(); b.release(); c.release(); d.release(); } } releaseAll{dUsed, dKeys, dCounts, dPos};
     dUsed.ensure((size_t)n); dKeys.ensure((size_t)n); dCounts.ensure((size_t)n); dPos.ensure((size_t)n * (size_t)(maxPerProbe > 0 ? maxPerProbe : 1));
     HIP_CHECK(hipMemcpyAsync(dUsed.p, usedLength, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(dKeys.p, keys, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
@@ -1642,7 +1643,6 @@ int xm_seed_probe(xm_index* idx, int64_t n, const int32_t* usedLength, const int
     if (kernelMs) *kernelMs = ms;
     HIP_CHECK(hipMemcpy(counts, dCounts.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
     if (outPositions && maxPerProbe > 0) HIP_CHECK(hipMemcpy(outPositions, dPos.p, sizeof(int64_t) * (size_t)n * (size_t)maxPerProbe, hipMemcpyDeviceToHost));
-    dUsed.release(); dKeys.release(); dCounts.release(); dPos.release();
     return 0;
   } catch (std::exception& e) { return fail(std::string("xm_seed_probe: ") + e.what()); }
 }
@@ -1653,6 +1653,7 @@ int xm_measure_random_gather(int device, int64_t table_bytes, int64_t accesses, 
     if (table_bytes < 4096 || accesses < 1) return fail("xm_measure_random_gather: bad arguments");
     DevBuf<uint4> table;
     DevBuf<unsigned int> sink;
+    struct Release { DevBuf<uint4>& a; DevBuf<unsigned int>& b; ~Release() { a.release(); b.release(); } } releaseAll{table, sink};
     const size_t nSectors = (size_t)table_bytes / 64;
     table.ensure(nSectors * 4);
     sink.ensure(1);
@@ -1694,7 +1695,10 @@ int xm_pileup_new(xm_index* idx, xm_pileup** out) {
     HIP_CHECK(hipMemset(p->dAlt.p, 0, sizeof(unsigned long long) * (size_t)p->total * 4));
     *out = p;
     return 0;
-  } catch (std::exception& e) { delete p; return fail(std::string("xm_pileup_new: ") + e.what()); }
+  } catch (std::exception& e) {
+    if (p) { p->dDepth.release(); p->dAlt.release(); p->dEventCount.release(); delete p; }
+    return fail(std::string("xm_pileup_new: ") + e.what());
+  }
 }
 
 int xm_pileup_add_last(xm_pileup* p, int64_t* num_events) {
@@ -1792,6 +1796,10 @@ int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_pa
     DevBuf<double> dDbls;
     DevBuf<int64_t> dStart;
     DevBuf<int32_t> dLen;
+    struct Release {  // (DevBuf has no destructor: the buffers of this call are released on every way out)
+      DevBuf<uint8_t>&a, &b, &c, &d; DevBuf<int32_t>&e; DevBuf<double>& f; DevBuf<int64_t>& g; DevBuf<int32_t>& h;
+      ~Release() { a.release(); b.release(); c.release(); d.release(); e.release(); f.release(); g.release(); h.release(); }
+    } releaseAll{dq, dr, arena, nodes, dInts, dDbls, dStart, dLen};
     dq.ensure((size_t)query_length); dr.ensure((size_t)reference_length); dInts.ensure((size_t)4 + 4 * (size_t)cap); dDbls.ensure(2);
     HIP_CHECK(hipMemcpy(dq.p, query, (size_t)query_length, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dr.p, reference, (size_t)reference_length, hipMemcpyHostToDevice));
@@ -1827,7 +1835,6 @@ int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_pa
     double dbls[2];
     HIP_CHECK(hipMemcpy(ints.data(), dInts.p, sizeof(int32_t) * ints.size(), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(dbls, dDbls.p, sizeof(dbls), hipMemcpyDeviceToHost));
-    dq.release(); dr.release(); arena.release(); nodes.release(); dInts.release(); dDbls.release(); dStart.release(); dLen.release();
     if (nodes_put) *nodes_put = ints[3];
     const int ok = mode >= 2 ? ints[0] : (ints[2] != XM_OK ? -1 : ints[0]);
     if (ok < 0) { fail("xm_test_local_align: the search failed with status " + std::to_string(ints[2])); return -1; }
