@@ -74,6 +74,10 @@ struct HandOver {
   unsigned long long* cursor;      // next unused region
 };
 
+#ifdef XM_READ_TIMES
+// diagnostic builds (-DXM_READ_TIMES, XM_READ_TIMES_FILE=path): shader-clock ticks the last pass spent on every read, written to the file
+__device__ unsigned long long* xm_read_times = nullptr;
+#endif
 // One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed, int lanesPerWave,
                                                        uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters,
@@ -150,6 +154,9 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
     in.expectedInner = in.nMates > 1 ? batch.expectedInner[q] : 0.0;
     in.deviation = in.nMates > 1 ? batch.deviation[q] : 1.0;
     ReadResult rr;
+#ifdef XM_READ_TIMES
+    const unsigned long long readT0 = clock64();
+#endif
     DevCounters before = local;
     // deferred-search gapped pass (memoBase != null): the read's memo slot carries its finished calls from replay to replay
     MemoHdr* memo = memoBase ? (MemoHdr*)(memoBase + (size_t)slotOf[q] * XM_MEMO_SLOT_BYTES) : nullptr;
@@ -178,6 +185,9 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
       runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed, memo, deferPath != 0);
     }
     int32_t st = cx.status;
+#ifdef XM_READ_TIMES
+    if (xm_read_times && !second) xm_read_times[q] = clock64() - readT0;
+#endif
     if (st != XM_OK) local = before;  // work of a read that is rerun by a later pass is counted there
     if (second) continue;             // (pair mode: the first lane of the read publishes)
     if (st == XM_OK) {
@@ -1219,6 +1229,16 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     //      reads that waited (replay from their memo slots) -> ... until no read waits;
     //  (3) reads whose scratch overflowed are rerun with inline searches and 16x, 64x, ... the scratch.
     // The work lists are built on the GPU (xm_classify_kernel); every pass appends to the same result arenas.
+#ifdef XM_READ_TIMES
+    DevBuf<unsigned long long> dReadTimes;
+    const char* readTimesFile = getenv("XM_READ_TIMES_FILE");
+    if (readTimesFile && *readTimesFile) {
+      dReadTimes.ensure((size_t)nq);
+      HIP_CHECK(hipMemset(dReadTimes.p, 0, sizeof(unsigned long long) * (size_t)nq));
+      unsigned long long* ptr = dReadTimes.p;
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(xm_read_times), &ptr, sizeof(ptr)));
+    }
+#endif
     const int64_t* todo = nullptr;  // device list of the current pass; null on the first pass = all reads
     long long nTodo = nq;
     unsigned long long pendingHeavy = 0, pendingScale = 0, pendingPath = 0;
@@ -1573,6 +1593,16 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     HIP_CHECK(hipEventRecord(e0, s));
     const long long nBlocks = (nq + XM_SCAN_PER_BLOCK - 1) / XM_SCAN_PER_BLOCK;
     idx->dBlockI.ensure((size_t)nBlocks); idx->dBlockD.ensure((size_t)nBlocks);
+#ifdef XM_READ_TIMES
+    if (dReadTimes.p) {
+      std::vector<unsigned long long> t((size_t)nq);
+      HIP_CHECK(hipMemcpy(t.data(), dReadTimes.p, sizeof(unsigned long long) * (size_t)nq, hipMemcpyDeviceToHost));
+      unsigned long long* none = nullptr;
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(xm_read_times), &none, sizeof(none)));
+      if (FILE* f = fopen(readTimesFile, "wb")) { fwrite(t.data(), sizeof(unsigned long long), t.size(), f); fclose(f); }
+      dReadTimes.release();
+    }
+#endif
     idx->dFinalIntOff.ensure((size_t)nq + 1); idx->dFinalDblOff.ensure((size_t)nq + 1);
     const size_t usedI = (size_t)std::min(cursors[0], intCap), usedD = (size_t)std::min(cursors[1], dblCap);  // upper bounds of the totals
     idx->dFinalInts.ensure(usedI); idx->dFinalDbls.ensure(usedD);
