@@ -264,7 +264,7 @@ struct HostIndex {
   // span only (a level is an ordered list whose block ends never decrease, and a block is merged from two neighbours of that list), so a
   // window computes every block whose span lies inside it exactly as the whole contig would.
   //
-  // Long runs of N (GRCh38 has runs of megabases): with ws2 >= 0 the window is [ws, we) + [ws2, we2) with the middle of the run left out.
+  // Runs of N (GRCh38 has runs of megabases; 2 048 and longer are treated this way): with ws2 >= 0 the window is [ws, we) + [ws2, we2) with the middle of the run left out.
   // Inside a run every position looks the same, and its blocks stop existing after a few levels (the possibilities multiply past
   // HashBlock_ParentRow.maxNumCombinationsToExpand); from that level on the last block before the run's interior and the first one behind it are
   // neighbours in the level's list (which matters: merges and the combination limit see that neighbour).  The two halves are therefore built
@@ -346,7 +346,7 @@ struct HostIndex {
     std::vector<Win> wins;
     const int margin = maxLen + 2;
     // a run of N longer than this is not held whole: 2 * half positions of it stay in the window (XM_BUILD_SPLICE_MIN: test hook)
-    int spliceMin = 1 << 16;
+    int spliceMin = 2048;
     if (const char* e = getenv("XM_BUILD_SPLICE_MIN")) { if (*e) spliceMin = std::max(64, atoi(e)); }
     const int half = std::max(32, spliceMin / 4);
     for (int c = 0; c < numContigs(); c++) {
