@@ -311,6 +311,92 @@ double xmo_kat_base_penalty(char a, char b, double mutationPenalty, double ambig
   return p.getPenalty(Basepairs::encode(a), Basepairs::encode(b));
 }
 
+// T/MultiHashBlock_Test.java:84-133 (checkExpandingAmbiguitiesInto): hashing `ambiguous` must offer, among the possibilities of the blocks that start
+// at 0 and end at the end of the text, the block that `text` hashes to (same start, end and forward hash).  0 = it does; 1 = it does not;
+// 2 = `text` itself has no single block over its whole length (the reference's test then skips, or fails with "Not a hashblock")
+static void katHashString(const Sequence* sequence, std::vector<HashBlock>& results) {  // hashString :135-171
+  HashBlock_Stream stream(sequence, true, nullptr);
+  while (true) {
+    std::shared_ptr<HashBlock_Row> row = stream.getNextBatch();
+    if (!row) break;
+    MultiBlockP block = row->get(0);
+    if (!block) break;
+    for (auto& c : block->getPossibilities())
+      if (c.hasBlock && c.block.getEndIndex() == sequence->getLength()) results.push_back(c.block);
+  }
+}
+int xmo_kat_multi_contains(const char* text, const char* ambiguous) {
+  try {
+    std::unique_ptr<Sequence> a = makeSequence("q", text), b = makeSequence("q", ambiguous);
+    std::vector<HashBlock> options, expanded;
+    katHashString(a.get(), options);
+    if (options.size() != 1) return 2;
+    katHashString(b.get(), expanded);
+    for (const HashBlock& p : expanded)
+      if (p.getStartIndex() == options[0].getStartIndex() && p.getEndIndex() == options[0].getEndIndex() && p.getForwardHash() == options[0].getForwardHash()) return 0;
+    return 1;
+  } catch (std::exception& e) { g_error = e.what(); return 3; }
+}
+
+// T/SequenceDatabase_Test.java:16-42,118-132: encodePosition / decodePosition round trips on numSequences repeating sequences of
+// sequenceLength - i bases (positions 0, 100, length - 100, length - 1 of every sequence).  0 = all round trips hold.
+int xmo_kat_position_codec(int numSequences, int sequenceLength) {
+  try {
+    SequenceDatabase db;
+    for (int i = 0; i < numSequences; i++) {
+      std::unique_ptr<Sequence> s(new Sequence());
+      s->name = "seq" + std::to_string(i);
+      s->repeatedLength = sequenceLength - i;
+      db.addForward(std::move(s));
+    }
+    for (const Sequence* s : db.all) {
+      const int n = s->getLength();
+      for (int position : {0, 100, n - 100, n - 1}) {
+        if (position < 0 || position >= n) continue;
+        const SequencePosition d = db.decodePosition(db.encodePosition(s, position));
+        if (d.sequence != s || d.startIndex != position) return 1;
+      }
+    }
+    return 0;
+  } catch (std::exception& e) { g_error = e.what(); return 3; }
+}
+
+// T/PackedMap_Test.java:13-49 testLargeReferenceSize: eight repeating sequences of (int)Math.pow(2, 31) = Integer.MAX_VALUE bases (+ their reverse
+// complements: 2^35 encoded positions), PackedMap(5, 10, db, 1), twenty blocks HashBlock(i, 1, i % 10, -(i % 10) - 1) of the first sequence:
+// get(i) must return the two positions i and i + 10.  0 = it does.
+int xmo_kat_packed_map_large() {
+  try {
+    SequenceDatabase db;
+    for (int i = 0; i < 8; i++) {
+      std::unique_ptr<Sequence> s(new Sequence());
+      s->name = std::to_string(i);
+      s->repeatedLength = INT32_MAX;
+      db.addForward(std::move(s));
+    }
+    const int keyCapacity = 10;
+    PackedMap map(5, keyCapacity, &db, 1);
+    std::vector<HashBlock> blocks;
+    for (int i = 0; i < keyCapacity * 2; i++) {
+      blocks.push_back(HashBlock(i, 1, i % keyCapacity, -(i % keyCapacity) - 1));
+    }
+    map.add(db.forward(0), blocks, false);
+    // and, beyond the reference's test, the same twenty blocks on the LAST sequence: its encoded positions need more than 34 bits
+    PackedMap last(5, keyCapacity, &db, 2);
+    last.add(db.forward(7), blocks, false);
+    for (int i = 0; i < keyCapacity; i++) {
+      for (PackedMap* m : {&map, &last}) {
+        std::vector<SequencePosition> got;
+        if (!m->get(i, INT32_MAX, got) || got.size() != 2) return 1;
+        int a0 = got[0].startIndex, a1 = got[1].startIndex;
+        if (a1 < a0) std::swap(a0, a1);
+        if (a0 != i || a1 != i + keyCapacity) return 2;
+        if (got[0].sequence != db.forward(m == &map ? 0 : 7) || got[1].sequence != got[0].sequence) return 3;
+      }
+    }
+    return 0;
+  } catch (std::exception& e) { g_error = e.what(); return 3; }
+}
+
 // T/HashBlock_Test.java:30-92 checkSymmetry; returns 0 when every block is symmetric, else a failure code
 int xmo_kat_hash_symmetry(const char* text) {
   try {

@@ -83,8 +83,12 @@ struct Sequence {
   std::vector<uint8_t> codes;             // one Basepairs code per base
   const Sequence* complementedFrom = nullptr;  // non-null <=> this is a reverse complement
   int contigIndex = -1;                   // index of the forward contig in the SequenceDatabase (-1: a query)
-  int getLength() const { return (int)codes.size(); }
-  uint8_t encodedCharAt(int i) const { return codes[(size_t)i]; }
+  // T/RepeatingSequence.java:9-12: a Sequence of one repeated base, so that the reference's tests can "allocate" contigs of 2^30 .. 2^31 bases
+  // (T/SequenceDatabase_Test.java:117, T/PackedMap_Test.java:59); repeatedLength >= 0 selects it
+  int repeatedLength = -1;
+  uint8_t repeatedCode = 1;
+  int getLength() const { return repeatedLength >= 0 ? repeatedLength : (int)codes.size(); }
+  uint8_t encodedCharAt(int i) const { return repeatedLength >= 0 ? repeatedCode : codes[(size_t)i]; }
   char charAt(int i) const { return Basepairs::decode(codes[(size_t)i]); }
   std::string getRange(int start, int len) const {
     std::string s((size_t)len, '?');
@@ -106,8 +110,11 @@ static inline std::unique_ptr<Sequence> makeReverseComplement(const Sequence& f)
   std::unique_ptr<Sequence> s(new Sequence());
   s->name = f.name;
   int n = f.getLength();
-  s->codes.resize((size_t)n);
-  for (int i = 0; i < n; i++) s->codes[(size_t)i] = Basepairs::complement(f.codes[(size_t)(n - 1 - i)]);
+  if (f.repeatedLength >= 0) { s->repeatedLength = f.repeatedLength; s->repeatedCode = Basepairs::complement(f.repeatedCode); }
+  else {
+    s->codes.resize((size_t)n);
+    for (int i = 0; i < n; i++) s->codes[(size_t)i] = Basepairs::complement(f.codes[(size_t)(n - 1 - i)]);
+  }
   s->complementedFrom = &f;
   s->contigIndex = f.contigIndex;
   return s;

@@ -314,6 +314,80 @@ int64_t xmsim_dup_keys(void* idxp, int contig, int32_t* out, int64_t cap) {
   return bb - a;
 }
 
+// T/MultiHashBlock_Test.java:84-133 through the product's reference-side multi blocks (HostIndex::nextLevelMulti, the code that hashes the windows
+// around ambiguous bases): the possibilities of the blocks that start at 0 and end at the end of `ambiguous` (4-bit codes) must hold the block the
+// plain rule makes of `text`.  0 = they do; 1 = they do not; 2 = `text` has no single block over its whole length.
+int xmsim_kat_multi_contains(const uint8_t* text, const uint8_t* ambiguous, int len) {
+  // the plain pyramid of `text`: the block at 0 that ends at len, if a level has one
+  bool have = false;
+  HBlock want{};
+  {
+    std::vector<HBlock> cur((size_t)len), next;
+    for (int i = 0; i < len; i++) cur[(size_t)i] = HostIndex::hblock0(text[i], i);
+    while (!cur.empty()) {
+      if (cur[0].start == 0 && cur[0].len == len) { have = true; want = cur[0]; }
+      next.clear();
+      for (size_t i = 0; i + 1 < cur.size(); i++) if (shouldMergeBlocks(cur[i], cur[i + 1])) next.push_back(mergeBlocks(cur[i], cur[i + 1]));
+      cur.swap(next);
+    }
+  }
+  if (!have) return 2;
+  std::vector<HostIndex::HEntry> cur((size_t)len);
+  for (int i = 0; i < len; i++) {
+    HostIndex::HEntry& e = cur[(size_t)i];
+    const uint8_t code = ambiguous[i];
+    if (bpIsAmbiguous(code)) {
+      e.multi = true;
+      for (int bit = 0; bit < 4; bit++) if (code & (1 << bit)) e.poss.push_back(HostIndex::HPoss{HostIndex::hblock0((uint8_t)(1 << bit), i), true, HostIndex::HCond(1, std::make_pair((int32_t)i, (uint8_t)(1 << bit)))});
+    } else e.single = HostIndex::hblock0(code, i);
+  }
+  while (!cur.empty()) {
+    for (const HostIndex::HEntry& e : cur) {
+      if (e.start() != 0) continue;
+      for (const HostIndex::HPoss& p : HostIndex::possibilitiesOf(e))
+        if (p.hasBlock && p.block.start == 0 && p.block.len == len && p.block.fwd == want.fwd) return 0;
+    }
+    std::vector<HostIndex::HEntry> nx = HostIndex::nextLevelMulti(cur);
+    cur.swap(nx);
+  }
+  return 1;
+}
+
+// T/SequenceDatabase_Test.java:16-42,118-132 through the product's position codec: HostIndex::encodePosition / decode on the host and decodePosition
+// (xm_seed.h, what the kernels run) over the same cumulative starts, for numSequences contigs of sequenceLength - i bases and their reverse
+// complements; positions 0, 100, length - 100, length - 1.  0 = every round trip holds.
+int xmsim_kat_position_codec(int numSequences, int sequenceLength) {
+  HostIndex h;
+  int64_t off = 0;
+  for (int i = 0; i < numSequences; i++) {
+    const int64_t len = (int64_t)sequenceLength - i;
+    h.contigStart.push_back(off); h.contigLen.push_back((int32_t)len);
+    h.seqCumStart.push_back(2 * off); h.seqCumStart.push_back(2 * off + len);
+    off += len;
+  }
+  h.seqCumStart.push_back(2 * off);
+  h.totalForwardSize = off;
+  IndexView v;
+  memset(&v, 0, sizeof(v));
+  v.numContigs = numSequences; v.seqCumStart = h.seqCumStart.data(); v.contigLen = h.contigLen.data(); v.contigStart = h.contigStart.data();
+  for (int c = 0; c < numSequences; c++)
+    for (int rc = 0; rc < 2; rc++) {
+      const int n = h.contigLen[(size_t)c];
+      const int positions[4] = {0, 100, n - 100, n - 1};
+      for (int k = 0; k < 4; k++) {
+        const int position = positions[k];
+        if (position < 0 || position >= n) continue;
+        const int64_t enc = h.encodePosition(c, rc != 0, position);
+        int dc = -1, ds = -1; bool drc = false;
+        h.decode(enc, dc, drc, ds);
+        if (dc != c || drc != (rc != 0) || ds != position) return 1;
+        const RefPos p = decodePosition(v, enc);
+        if (p.contig != c || (p.rc != 0) != (rc != 0) || p.start != position) return 2;
+      }
+    }
+  return 0;
+}
+
 // read-side pyramid dump in the layout of oracle xmo_pyramid_dump (14 ints per block)
 int64_t xmsim_pyramid_dump(const uint8_t* codes, int len, int32_t* out, int64_t capRows) {
   std::vector<PBlock> blocks((size_t)len * 64 + 64);

@@ -42,6 +42,8 @@ def lib():
         L.xmsim_dup_keys.restype = C.c_int64
         L.xmsim_pyramid_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
         L.xmsim_pyramid_dump.restype = C.c_int64
+        L.xmsim_kat_multi_contains.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.xmsim_kat_position_codec.argtypes = [C.c_int, C.c_int]
         L.xmsim_set_wave_mode.argtypes = [C.c_int]
         L.xmsim_wave_status_counts.argtypes = [C.c_void_p, C.c_int]
         _lib = L

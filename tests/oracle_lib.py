@@ -96,6 +96,9 @@ def lib():
         L.xmo_align_batch.restype = C.POINTER(_Result)
         L.xmo_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xmo_result_free.argtypes = [C.POINTER(_Result)]
+        L.xmo_kat_multi_contains.argtypes = [C.c_char_p, C.c_char_p]
+        L.xmo_kat_position_codec.argtypes = [C.c_int, C.c_int]
+        L.xmo_kat_packed_map_large.argtypes = []
         L.xmo_kat_local_align.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_double, C.c_double, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_double)]
         L.xmo_kat_hash_symmetry.argtypes = [C.c_char_p]
         L.xmo_kat_base_penalty.argtypes = [C.c_char, C.c_char, C.c_double, C.c_double]

@@ -104,3 +104,51 @@ def test_examples_plumbing():
     # a 12-base query allows penalty 1.2 < one insertion (2.1): the inserted base ends up unaligned + 1 SNP (penalty 1.1)
     assert aligned["query4-insertion"][0].penalty == 1.1
     assert any(b.lengthA == 0 for al in aligned["query5-deletion"] for b in al.components[0].sections)
+
+
+def _with_ns(text, k):
+    """Every way to replace exactly k bases of text by N, in the order of T/MultiHashBlock_Test.java:173-195 (addAmbiguities)."""
+    if k < 1:
+        return [text]
+    if k > len(text):
+        return []
+    return ["N" + t for t in _with_ns(text[1:], k - 1)] + [text[0] + t for t in _with_ns(text[1:], k)]
+
+
+def _multi_pairs():
+    out = []
+    for c in KAT["multi_cases"]["expanding"]:
+        for k in range(c["maxNumAmbiguities"] + 1):
+            out += [(c["text"], a, False) for a in _with_ns(c["text"], k)]
+    out += [(t, a, True) for t, a in KAT["multi_cases"]["into"]]
+    return out
+
+
+def test_multi_hashblock_expansion():
+    """T/MultiHashBlock_Test.java:12-77: an ambiguous text offers, among the possibilities of its blocks, the block of every text it can stand
+    for - the oracle's literal MultiHashBlock / HashBlock_ParentRow.expand, and the product's reference-side multi blocks (HostIndex::nextLevelMulti,
+    which hashes the windows around ambiguous bases for the index), through the host simulation."""
+    import hostsim_lib as hs
+    pairs = _multi_pairs()
+    assert len(pairs) > 600
+    for text, ambiguous, must_be_a_block in pairs:
+        r = o.lib().xmo_kat_multi_contains(text.encode(), ambiguous.encode())
+        assert r == 0 or (r == 2 and not must_be_a_block), (text, ambiguous, r)
+        t, a = o.encode(text), o.encode(ambiguous)
+        r2 = hs.lib().xmsim_kat_multi_contains(t.ctypes.data, a.ctypes.data, len(t))
+        assert r2 == r, (text, ambiguous, r, r2)
+
+
+@pytest.mark.parametrize("case", KAT["codec_cases"]["cases"], ids=[c["name"] for c in KAT["codec_cases"]["cases"]])
+def test_position_codec_round_trip_at_scale(case):
+    """T/SequenceDatabase_Test.java:16-42: encodePosition / decodePosition round trips on 16 x 2^30 and 8192 x 2^21 bases (repeating sequences,
+    T/RepeatingSequence.java): the oracle's SequenceDatabase, and the product's codec (HostIndex::encodePosition / decode, and decodePosition of
+    xm_seed.h as the kernels run it)."""
+    import hostsim_lib as hs
+    assert o.lib().xmo_kat_position_codec(case["numSequences"], case["sequenceLength"]) == 0
+    assert hs.lib().xmsim_kat_position_codec(case["numSequences"], case["sequenceLength"]) == 0
+
+
+def test_packed_map_with_large_reference():
+    """T/PackedMap_Test.java:13-49: buckets keep their positions when the encoded positions need 35 bits."""
+    assert o.lib().xmo_kat_packed_map_large() == 0
