@@ -269,7 +269,7 @@ def n_run_reference(n, seed, run=10_000, fraction=0.01, codes=200):
     return ref
 
 
-@pytest.mark.parametrize("case,group", [("scattered", None), ("scattered", "30000"), ("n_runs_20Mb", None), ("long_run", None)])
+@pytest.mark.parametrize("case,group", [("scattered", None), ("scattered", "30000"), ("n_runs_50Mb", None), ("long_run", None)])
 def test_reference_with_ambiguity_codes_hashed_on_the_gpu_equals_host_builder(case, group, monkeypatch):
     """References with ambiguity codes (GRCh38's N-runs; HashBlock_ParentRow.java:109-165, MultiHashBlock.java): the GPU hashes what lies clear of
     the ambiguous bases, the conditional multi blocks come from the host's windows around them (long runs of N with their middle left out) and join
@@ -278,8 +278,8 @@ def test_reference_with_ambiguity_codes_hashed_on_the_gpu_equals_host_builder(ca
     mis = -1
     if case == "scattered":
         refs = [("a", ambiguous_reference(120_000, seed=31, n_runs=12, n_codes=150)), ("b", ambiguous_reference(9_000, seed=32)), ("clean", synth.synthetic_reference(30_000, seed=33))]
-    elif case == "n_runs_20Mb":
-        refs = [("chr%d" % i, n_run_reference(n, seed=40 + i)) for i, n in enumerate((12_000_000, 6_000_000, 2_000_000))]
+    elif case == "n_runs_50Mb":
+        refs = [("chr%d" % i, n_run_reference(n, seed=40 + i)) for i, n in enumerate((30_000_000, 14_000_000, 6_000_000))]
         mis = 13  # (what a 3 Gb reference gets, HashBlock_Database.java:52)
     else:
         r = synth.synthetic_reference(600_000, seed=34).copy()
