@@ -7,6 +7,12 @@ host and their ordering) over one batch of synthetic input that is already resid
 With --gpus N each rank owns one GPU, holds a replica of the index and aligns its own 1 M reads (no collective on the data
 path; scaling = weak).  Rank 0 prints ONE JSON line.
 
+The steps of a rank are dealt to --contexts contexts of its GPU (default 3: the index replicated on the GPU with xm_index_replicate,
+each context with its own resident copy of the batch, host thread, stream and share of the scratch) that align at the same time - how
+the product aligns a stream of batches (`python -m mapper_amd --contexts 3`, mapper_amd/multi.py): the wave slots one context's gapped
+pass leaves idle (its tail, the host gaps between its passes, its result copy) are filled by the others' passes, +12 % reads/s.  At
+N=1 the line also carries `single_context`: the same kernel with one launch on the GPU at a time (--contexts 1 makes that the headline).
+
 The line carries `roofline` (algorithmic bytes of SURVEY.md §8(d) per second of align-kernel time, against the 8 TB/s
 HBM peak) and `cpu_baseline` (the CPU oracle, a port of the Java path, timed on this box's host cores on a bounded
 sample).  The oracle is only the checker/baseline here; nothing under oracle/ is on the measured GPU path.
@@ -27,7 +33,7 @@ import numpy as np  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (configs[1]: 1,000,000)")
     ap.add_argument("--ref-len", type=int, default=5_000_000)
@@ -38,7 +44,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads of the same workload timed on the host cores (0 = skip); default: the whole batch (about a second on the GPU box's 256 cores)")
     ap.add_argument("--config", default="1", choices=["1", "2", "4shape"], help="1: BASELINE.json configs[1] (single-end 150 bp, the headline); 2: configs[2] shape (2x150 bp pairs, --spacing 100 50); "
                     "4shape: the 1,000 bp queries --split-queries-past-size 1000 makes of configs[4]'s reads, against the same 5 Mb reference")
-    ap.add_argument("--contexts", type=int, default=3, help="contexts of the extra pipelined measurement at N=1 (several contexts of the GPU aligning their batches at the same time; 1 = skip)")
+    ap.add_argument("--contexts", type=int, default=3, help="contexts per GPU: the steps are dealt to this many contexts of the GPU that align their resident batches at the same time (1: one launch at a time)")
+    ap.add_argument("--single-context-steps", type=int, default=3, help="steps of the one-launch-at-a-time measurement beside the headline at N=1 (0 = skip)")
     ap.add_argument("--wave-steps", type=int, default=2, help="steps of the opt-in wave-per-read form (XM_WAVE=1) measured beside the headline (0 = skip)")
     args = ap.parse_args()
 
@@ -90,32 +97,77 @@ def main():
         reads_per_query = 1
     params = api.AlignmentParameters()  # Mapper.main defaults
 
-    t0 = time.time()
-    db = api.ReferenceDatabase([("ecoli_syn", ref)], mode="mapper", max_query_length=args.read_len, device=local_rank)
-    index_build_s = time.time() - t0
-    db.upload_arrays(mc, mo, ml, codes, exp_in, dev_in)  # inputs resident in HBM before the timed region
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        r = db.align_resident(params)
+    def run_steps(contexts, steps):
+        """`steps` passes of the hot path, each over one resident batch, dealt to the contexts (one host thread and stream each) as they become free.
+        -> (seconds, summed kernel ms, launches, d2h ms, microseconds by pass, last result of context 0)"""
+        import threading
+        lock = threading.Lock()
+        state = {"next": 0, "kernel_ms": 0.0, "launches": 0, "d2h_ms": 0.0, "pass_us": np.zeros(4), "last": None, "error": None}
+
+        def work(i):
+            try:
+                while True:
+                    with lock:
+                        if state["next"] >= steps:
+                            return
+                        state["next"] += 1
+                    rr = contexts[i].align_resident(params)
+                    with lock:
+                        state["kernel_ms"] += rr.kernel_ms
+                        state["launches"] += rr.kernel_launches
+                        state["d2h_ms"] += rr.d2h_ms
+                        state["pass_us"] += np.asarray(rr.counters[12:16], dtype=np.float64)
+                        if i == 0 or state["last"] is None:
+                            state["last"] = rr
+            except BaseException as e:  # noqa: BLE001
+                state["error"] = e
+        t_start = time.perf_counter()
+        if len(contexts) == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(i,)) for i in range(len(contexts))]
+            [x.start() for x in th]
+            [x.join() for x in th]
+        if state["error"] is not None:
+            raise state["error"]
+        return time.perf_counter() - t_start, state["kernel_ms"], state["launches"], state["d2h_ms"], state["pass_us"], state["last"]
+
+    # One context at a time first (at N=1, when the headline uses several): the kernel's own numbers, one launch on the GPU at a time
+    single = None
+    n_ctx = max(1, args.contexts)
+    if n_ctx > 1 and world == 1 and args.single_context_steps > 0:
+        one = api.ReferenceDatabase([("ecoli_syn", ref)], mode="mapper", max_query_length=args.read_len, device=local_rank)
+        one.upload_arrays(mc, mo, ml, codes, exp_in, dev_in)
+        run_steps([one], max(1, args.warmup))
+        torch.cuda.synchronize()
+        k1 = args.single_context_steps
+        sec, kms, nl, _, pus, _ = run_steps([one], k1)
+        single = {"value": round(nq * reads_per_query * k1 / sec / 1e6, 4), "unit": "Mreads/s", "steps": k1, "ms_per_step": round(sec / k1 * 1e3, 3),
+                  "kernel_ms_per_step": round(kms / k1, 3), "launches_per_step": nl / k1,
+                  "kernel_ms_by_pass": {"light_pass": round(pus[0] / k1 / 1e3, 3), "gapped_and_rerun_passes": round(pus[3] / k1 / 1e3, 3)},
+                  "note": "one context with the whole scratch budget, one launch on the GPU at a time (the round-1 way of running the same kernel)"}
+        one.close()
+    if n_ctx > 1:
+        # several contexts share the GPU's HBM: the scratch budget (default: up to 200 GiB for one context) is divided between them
+        os.environ.setdefault("XM_SCRATCH_GIB", str(max(8, 240 // n_ctx)))
+
+    t0 = time.time()
+    db = api.ReferenceDatabase([("ecoli_syn", ref)], mode="mapper", max_query_length=args.read_len, device=local_rank)
+    index_build_s = time.time() - t0
+    ctx = [db] + [db.replicate(local_rank) for _ in range(n_ctx - 1)]
+    for c_ in ctx:
+        c_.upload_arrays(mc, mo, ml, codes, exp_in, dev_in)  # inputs resident in HBM before the timed region: every context has its batch
+
+    if args.warmup > 0:
+        run_steps(ctx, args.warmup * n_ctx)  # (every context allocates its scratch and runs every pass once)
     barrier()
-    t_start = time.perf_counter()
-    kernel_ms = 0.0
-    launches = 0
-    d2h_ms = 0.0
-    pass_us = np.zeros(4)
-    for _ in range(args.steps):
-        r = db.align_resident(params)
-        kernel_ms += r.kernel_ms
-        launches += r.kernel_launches
-        d2h_ms += r.d2h_ms
-        pass_us += np.asarray(r.counters[12:16], dtype=np.float64)
+    elapsed, kernel_ms, launches, d2h_ms, pass_us, r = run_steps(ctx, args.steps)
     barrier()
-    elapsed = time.perf_counter() - t_start
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -131,13 +183,20 @@ def main():
         achieved = (alg_bytes * args.steps / max(launches, 1)) / (avg_launch_ms * 1e-3) / 1e9  # GB/s: bytes per launch / avg launch duration
         aligned = int(sum(1 for q in range(nq) if r.ints[r.int_off[q] + 1] > 0)) if nq <= 2_000_000 else -1
 
-        # host buffers in (xm_align_batch: H2D copy + the same passes): the PCIe-inclusive rate, never the headline value
+        # host buffers in (xm_align_batch: H2D copy + the same passes), every context at the same time: the PCIe-inclusive rate, never the headline value
+        import threading
+        rps = [None] * len(ctx)
+
+        def with_host_buffers(i):
+            for _ in range(2):
+                rps[i] = ctx[i].align_arrays(mc, mo, ml, codes, exp_in, dev_in, params)
         t1 = time.perf_counter()
-        for _ in range(2):
-            rp = db.align_arrays(mc, mo, ml, codes, exp_in, dev_in, params)
-        pcie_s = (time.perf_counter() - t1) / 2
-        pcie = {"value": round(nq * reads_per_query / pcie_s / 1e6, 4), "unit": "Mreads/s", "ms_per_step": round(pcie_s * 1e3, 3), "h2d_ms": round(rp.h2d_ms, 3),
-                "note": "xm_align_batch with host buffers in (pageable numpy arrays), one batch after the other, no overlap of copy and alignment"}
+        th = [threading.Thread(target=with_host_buffers, args=(i,)) for i in range(len(ctx))]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        pcie_s = (time.perf_counter() - t1) / (2 * len(ctx))
+        pcie = {"value": round(nq * reads_per_query / pcie_s / 1e6, 4), "unit": "Mreads/s", "ms_per_step": round(pcie_s * 1e3, 3), "h2d_ms": round(rps[0].h2d_ms, 3),
+                "note": "xm_align_batch with host buffers in (pageable numpy arrays) in every context, no overlap of a context's copy with its own alignment"}
 
         # the opt-in wave-per-read form (XM_WAVE=1: one wavefront per read, state in LDS, xm_wave_kernel.hip) on the same resident batch
         wave = None
@@ -253,13 +312,21 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "xm_align_kernel", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_step": int(alg_bytes), "bytes_per_read": round(alg_bytes / nq, 1),
+                         "concurrent_launches": n_ctx, "frac_of_all_concurrent_launches": round(alg_bytes * args.steps / elapsed / 1e9 / 8000.0, 6),
                          "kernel_ms_per_step": round(kernel_ms / args.steps, 3), "launches_per_step": launches / args.steps,
                          "result_d2h_ms_per_step": round(d2h_ms / args.steps, 3),
                          "kernel_ms_by_pass": {"light_pass": round(pass_us[0] / args.steps / 1e3, 3), "gapped_and_rerun_passes": round(pass_us[3] / args.steps / 1e3, 3)},
                          "traffic_rate": None if traffic is None else round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1),
-                         "note": "achieved/peak/frac: algorithmic bytes against the 8 TB/s stream peak.  traffic (PMC) is per-lane scratch in HBM, touched in "
+                         "note": "achieved/peak/frac: algorithmic bytes of one launch over that launch's duration, against the 8 TB/s stream peak; with several contexts "
+                                 "the launches of the contexts share the GPU, so a launch lasts longer than it would alone (single_context has the kernel's numbers with one "
+                                 "launch at a time) and frac_of_all_concurrent_launches is the algorithmic rate of the GPU as a whole.  traffic (PMC) is per-lane scratch in HBM, touched in "
                                  "scattered 32-64 B pieces: traffic_rate (GB/s, traffic / average launch duration) is to be read against this GPU's measured "
                                  "random-64-B-sector ceiling (seed_probe.random_64B_gather_ceiling_sectors_per_s x 64 B), not against the stream peak"},
+            "contexts": {"per_gpu": n_ctx, "scratch_gib_each": int(os.environ["XM_SCRATCH_GIB"]) if n_ctx > 1 else None,
+                         "note": "a step is one whole pass of the hot path over one resident batch; the steps are dealt to %d contexts of the GPU (index replicated with "
+                                 "xm_index_replicate, a resident copy of the batch, a host thread, a stream and a share of the scratch each) that align at the same time: the wave "
+                                 "slots one context's gapped pass leaves idle are filled by the others' passes (profiles/r02/NOTES.md 12, 14)" % n_ctx if n_ctx > 1 else "one context"},
+            "single_context": single,
             "cpu_baseline": cpu,
             "build": build,
             "bit_identical": same,
@@ -271,44 +338,8 @@ def main():
         }
         if same is False or (golden is not None and not golden["matches_committed"]) or (wave is not None and not wave["bit_identical_to_default_path"]) or counters.get("equal") is False:
             rc = 1  # a parity failure is not a measurement
-    db.close()
-    if rank == 0 and world == 1 and args.contexts > 1 and line is not None:
-        # Several contexts on the GPU, each with its own resident copy of the batch and its own scratch, aligning at the same time (mapper_amd/multi.py,
-        # `--contexts` of the command line): the idle wave slots of one context's gapped pass are filled by the others' passes.  Reported beside the
-        # headline, which stays the single-context number (one launch at a time: the roofline's per-launch accounting stays clean).
-        try:
-            import threading
-            os.environ["XM_SCRATCH_GIB"] = str(max(8, 240 // args.contexts))
-            first = api.ReferenceDatabase([("ecoli_syn", ref)], mode="mapper", max_query_length=args.read_len, device=local_rank)
-            ctx = [first] + [first.replicate(local_rank) for _ in range(args.contexts - 1)]
-            for c_ in ctx:
-                c_.upload_arrays(mc, mo, ml, codes, exp_in, dev_in)
-                c_.align_resident(params)
-            reps = 3
-            outs = [None] * len(ctx)
-
-            def work(i):
-                for _ in range(reps):
-                    outs[i] = ctx[i].align_resident(params)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            th = [threading.Thread(target=work, args=(i,)) for i in range(len(ctx))]
-            [x.start() for x in th]
-            [x.join() for x in th]
-            torch.cuda.synchronize()
-            per_step = (time.perf_counter() - t1) / (reps * len(ctx))
-            same_p = all(np.array_equal(o_.ints, r.ints) and np.array_equal(o_.dbls.view(np.int64), r.dbls.view(np.int64)) for o_ in outs)
-            line["pipelined_contexts"] = {"contexts": args.contexts, "scratch_gib_each": int(os.environ["XM_SCRATCH_GIB"]), "steps": reps * len(ctx),
-                                          "value": round(nq * reads_per_query / per_step / 1e6, 4), "unit": "Mreads/s", "ms_per_step": round(per_step * 1e3, 3),
-                                          "kernel_ms_of_one_step_in_each_context": [round(o_.kernel_ms, 1) for o_ in outs], "bit_identical_to_headline": bool(same_p),
-                                          "note": "not the headline: %d contexts (index replicated on the same GPU, a copy of the batch and a third of the scratch each) align their "
-                                                  "batches at the same time; a step is still one whole pass over one batch" % args.contexts}
-            for c_ in ctx:
-                c_.close()
-            if not same_p:
-                rc = 1
-        except Exception as e:  # noqa: BLE001  (an extra measurement must not lose the headline line)
-            line["pipelined_contexts"] = {"error": str(e)[:300]}
+    for c_ in ctx:
+        c_.close()
     if rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
     if dist is not None:

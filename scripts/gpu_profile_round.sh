@@ -10,12 +10,12 @@ cd $R
 make -j8 -C $R/mapper_amd/csrc > /dev/null || exit 1
 timeout 900 python3 bench.py > $O/bench_full.log 2>&1
 tail -n 1 $O/bench_full.log > $O/bench_line.json
-timeout 600 python3 bench.py --config 2 --seed-probes 0 --steps 3 2> $O/bench_config2.err | tail -n 1 > $O/bench_config2.json
-timeout 600 python3 bench.py --config 4shape --reads 150000 --seed-probes 0 --steps 3 2> $O/bench_config4shape.err | tail -n 1 > $O/bench_config4shape.json
+timeout 600 python3 bench.py --config 2 --seed-probes 0 --steps 9 2> $O/bench_config2.err | tail -n 1 > $O/bench_config2.json
+timeout 600 python3 bench.py --config 4shape --reads 150000 --seed-probes 0 --steps 9 2> $O/bench_config4shape.err | tail -n 1 > $O/bench_config4shape.json
 cd /tmp && export TMPDIR=/tmp
-Q="--cpu-sample 0 --seed-probes 0 --wave-steps 0 --contexts 1"
-# (the stats run keeps the two steps of the opt-in wave-per-read form, so its kernels are listed beside the default path's)
-rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py --cpu-sample 0 --seed-probes 0 --contexts 1 > $O/stats.log 2>&1
+Q="--cpu-sample 0 --seed-probes 0 --wave-steps 0 --single-context-steps 0"
+# (the profiled command is the headline measurement alone: the default contexts and steps, without the extra measurements of the bench line)
+rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py --cpu-sample 0 --seed-probes 0 --wave-steps 0 --single-context-steps 0 > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/pmcF -o pmc --output-format csv -- python3 $R/bench.py $Q > $O/pmcF.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmcW -o pmc --output-format csv -- python3 $R/bench.py $Q > $O/pmcW.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES -d $O/pmcS -o pmc --output-format csv -- python3 $R/bench.py $Q > $O/pmcS.log 2>&1

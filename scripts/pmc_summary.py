@@ -37,7 +37,7 @@ for k, cs in out.items():
         hbm[k.split("(")[0]] = (cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024.0
 if len(hbm) == 2:
     hbm["mean_over_the_two_launches_of_a_step"] = sum(hbm.values()) / 2.0
-out["_note"] = ("rocprofv3 --pmc passes over `python3 bench.py --cpu-sample 0 --seed-probes 0` (scripts/gpu_profile_round.sh, summarised by "
+out["_note"] = ("rocprofv3 --pmc passes over `python3 bench.py --cpu-sample 0 --seed-probes 0 --wave-steps 0 --single-context-steps 0` (the headline measurement alone; scripts/gpu_profile_round.sh, summarised by "
                 "scripts/pmc_summary.py), mean per launch over %s launches of each pass; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them "
                 "(narrow scattered accesses: no gfx950 wide-load correction applies); SQ_* in quad-cycles" % sorted(set(launches.values())))
 out["hbm_bytes_per_launch"] = hbm
