@@ -239,8 +239,15 @@ def run(argv, out=sys.stdout):
     ordered = api.sort_reference(contigs)  # Mapper.sortAndComplementReference: alignment results refer to this order
     names = [n for n, _ in ordered]
     devices = o.get("devices") or (list(range(o["gpus"])) if o.get("gpus", 1) > 1 else None)
-    if o.get("contexts", 1) > 1:
-        devices = [d for d in (devices or [o["device"]]) for _ in range(o["contexts"])]
+    batch_size = o.get("batch_size") or 1_000_000
+    contexts = o.get("contexts")
+    if contexts is None:
+        # a job of several batches on a reference that leaves room in HBM: three contexts per GPU align their batches at the same time
+        # (+12-17 % reads per second on MI355X, profiles/r02/NOTES.md 12); one batch, or a genome-sized index: one context
+        n_batches = (len(queries) + batch_size - 1) // batch_size
+        contexts = 3 if devices is None and n_batches >= 3 and sum(len(t) for _, t in contigs) <= 500_000_000 else 1
+    if contexts > 1:
+        devices = [d for d in (devices or [o["device"]]) for _ in range(contexts)]
     max_query_length = max([len(s) for q, _ in queries for s in q.sequences] + [1])
     if devices and len(devices) > 1:
         from . import multi
@@ -248,7 +255,6 @@ def run(argv, out=sys.stdout):
     else:
         db = api.ReferenceDatabase(ordered, mode="mapper", enable_gapmers=o["enable_gapmers"], device=devices[0] if devices else o["device"],
                                    max_query_length=max_query_length, cache_dir=o.get("cache_dir"))
-    batch_size = o.get("batch_size") or 1_000_000
     sam_out = None
     if o["out_sam"]:
         sam_out = sys.stdout if o["out_sam"] == "-" else open(o["out_sam"], "w")
