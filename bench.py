@@ -152,14 +152,14 @@ def main():
                   "kernel_ms_by_pass": {"light_pass": round(pus[0] / k1 / 1e3, 3), "gapped_and_rerun_passes": round(pus[3] / k1 / 1e3, 3)},
                   "note": "one context with the whole scratch budget, one launch on the GPU at a time (the round-1 way of running the same kernel)"}
         one.close()
-    if n_ctx > 1:
-        # several contexts share the GPU's HBM: the scratch budget (default: up to 200 GiB for one context) is divided between them
-        os.environ.setdefault("XM_SCRATCH_GIB", str(max(8, 240 // n_ctx)))
-
     t0 = time.time()
     db = api.ReferenceDatabase([("ecoli_syn", ref)], mode="mapper", max_query_length=args.read_len, device=local_rank)
     index_build_s = time.time() - t0
-    ctx = [db] + [db.replicate(local_rank) for _ in range(n_ctx - 1)]
+    ctx = [db] + [db.new_context() for _ in range(n_ctx - 1)]  # contexts share the index (host tables and tables in HBM), xm_context_new
+    if n_ctx > 1:
+        n_use, scratch_each = api.divide_scratch(ctx, local_rank)  # what is free now, in equal parts
+        ctx = ctx[:n_use]
+        n_ctx = len(ctx)
     for c_ in ctx:
         c_.upload_arrays(mc, mo, ml, codes, exp_in, dev_in)  # inputs resident in HBM before the timed region: every context has its batch
 
@@ -322,7 +322,7 @@ def main():
                                  "launch at a time) and frac_of_all_concurrent_launches is the algorithmic rate of the GPU as a whole.  traffic (PMC) is per-lane scratch in HBM, touched in "
                                  "scattered 32-64 B pieces: traffic_rate (GB/s, traffic / average launch duration) is to be read against this GPU's measured "
                                  "random-64-B-sector ceiling (seed_probe.random_64B_gather_ceiling_sectors_per_s x 64 B), not against the stream peak"},
-            "contexts": {"per_gpu": n_ctx, "scratch_gib_each": int(os.environ["XM_SCRATCH_GIB"]) if n_ctx > 1 else None,
+            "contexts": {"per_gpu": n_ctx, "scratch_gib_each": round(scratch_each / 2**30, 1) if n_ctx > 1 else None,
                          "note": "a step is one whole pass of the hot path over one resident batch; the steps are dealt to %d contexts of the GPU (index replicated with "
                                  "xm_index_replicate, a resident copy of the batch, a host thread, a stream and a share of the scratch each) that align at the same time: the wave "
                                  "slots one context's gapped pass leaves idle are filled by the others' passes (profiles/r02/NOTES.md 12, 14)" % n_ctx if n_ctx > 1 else "one context"},

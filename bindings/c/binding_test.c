@@ -30,7 +30,7 @@ static int64_t rd64(FILE* f) { int64_t v; if (fread(&v, 8, 1, f) != 1) { fprintf
 
 static int do_symbols(void) {
   /* taking the addresses makes the linker resolve every entry point of the header */
-  const void* fns[] = {(const void*)xm_last_error, (const void*)xm_build_stamp, (const void*)xm_device_count, (const void*)xm_index_build, (const void*)xm_index_replicate, (const void*)xm_index_save,
+  const void* fns[] = {(const void*)xm_last_error, (const void*)xm_build_stamp, (const void*)xm_device_count, (const void*)xm_index_build, (const void*)xm_index_replicate, (const void*)xm_context_new, (const void*)xm_context_set_scratch, (const void*)xm_device_memory, (const void*)xm_index_save,
                        (const void*)xm_index_load, (const void*)xm_index_ensure_length, (const void*)xm_index_free, (const void*)xm_index_get_info,
                        (const void*)xm_index_table_info, (const void*)xm_index_table_dump, (const void*)xm_index_dup_keys, (const void*)xm_align_batch,
                        (const void*)xm_result_free, (const void*)xm_batch_upload, (const void*)xm_batch_stage, (const void*)xm_batch_commit,

@@ -55,6 +55,21 @@ final class NativeAligner implements AutoCloseable {
     this.indexHandle = buildIndex(codes, names, enableGapmers, duplicationWindow, maxQueryLength, device);
   }
 
+  private NativeAligner(NativeAligner other) {
+    this.contigs = other.contigs;
+    this.parameters = other.parameters;
+    this.indexHandle = newContext(other.indexHandle);
+  }
+
+  /**
+   * A view of the same index for another AlignerWorker thread, as HashBlock_Database.view() hands every worker its own
+   * (HashBlock_Database.java:129-133): its own GPU stream, batch buffers and scratch; the tables are shared, nothing is copied.
+   * Calls on one NativeAligner serialise, so a run with N workers on a GPU makes one NativeAligner and N - 1 views of it.
+   */
+  NativeAligner view() {
+    return new NativeAligner(this);
+  }
+
   /** The batch form of AlignerWorker.align(Query) (AlignerWorker.java:256-261): element q of the result belongs to batch.get(q). */
   List<QueryAlignments> align(List<Query> batch) {
     int nq = batch.size();
@@ -165,6 +180,7 @@ final class NativeAligner implements AutoCloseable {
   }
 
   private static native long buildIndex(byte[][] contigCodes, String[] names, boolean enableGapmers, int duplicationWindow, int maxQueryLength, int device);
+  private static native long newContext(long handle);
   private static native void freeIndex(long handle);
   private static native boolean alignBatch(long handle, double[] parameters9, int maxNumMatches, int[] mateCount, long[] mateOffset, int[] mateLength, ByteBuffer codes,
                                            double[] expectedInnerDistance, double[] spacingDeviationPerUnitPenalty, ResultStreams out);

@@ -130,6 +130,15 @@ done:
   return (jlong)(intptr_t)idx;
 }
 
+/* private static native long newContext(long handle): a further context of the index for another AlignerWorker thread (xm_context_new: own stream,
+ * batch buffers and scratch over the same tables, as the workers share one HashBlock_Database through views, HashBlock_Database.java:129-133) */
+JNIEXPORT jlong JNICALL Java_mapper_NativeAligner_newContext(JNIEnv* env, jclass cls, jlong handle) {
+  xm_index* ctx = NULL;
+  (void)cls;
+  if (xm_context_new((xm_index*)(intptr_t)handle, &ctx) != 0) { xmj_throw(env, "Failed to make a context of the reference index: "); return 0; }
+  return (jlong)(intptr_t)ctx;
+}
+
 /* private static native void freeIndex(long handle) */
 JNIEXPORT void JNICALL Java_mapper_NativeAligner_freeIndex(JNIEnv* env, jclass cls, jlong handle) {
   (void)env; (void)cls;

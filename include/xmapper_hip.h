@@ -13,8 +13,12 @@
  *
  * Errors: like the reference (any worker exception aborts the run, AlignerWorker.java:195-197, Mapper.java:1070-1077)
  * a failing call returns non-zero, produces no partial result, and xm_last_error() describes it.
- * Threading: an xm_index is immutable after build (xm_index_ensure_length excepted) and may be shared; calls that use
- * the GPU serialise per index.
+ * Threading: the reference shares one HashBlock_Database between all AlignerWorker threads through per-thread views
+ * (HashBlock_Database.java:129-133, Mapper.java:1026-1040; Api.java:78 "thread-safe").  Here an xm_index handle is one such view - a CONTEXT:
+ * its own HIP stream, batch buffers, scratch and result pool over tables that every context of the index shares (host tables: all contexts;
+ * tables in HBM: the contexts of one GPU).  Calls on one context serialise; contexts run side by side, one host thread each
+ * (xm_context_new for a further context on the same GPU, xm_index_replicate for one on another GPU).  Tables that grow
+ * (xm_index_ensure_length, a batch with longer mates) grow for every context; the launches that read them are waited for.
  */
 #ifndef XMAPPER_HIP_H
 #define XMAPPER_HIP_H
@@ -115,11 +119,20 @@ int xm_device_count(void);
  * (Mapper.java:657-692, Api.java:41-69, HashBlock_Database.java:490-665, PackedMap.java:54-153, DuplicationDetector.java:97-436)
  * and uploads the result to HBM. */
 int xm_index_build(const xm_ref* ref, const xm_build_opts* opts, xm_index** out);
-/* A second residency of a built index on another GPU (or a second context on the same one): the host-side tables are shared by copy, the
- * device tables are copied from the source's HBM (hipMemcpyPeer: xGMI between GPUs) instead of being built or uploaded again.  The reference
- * shares one HashBlock_Database between all AlignerWorkers of a run (Mapper.java:912-1134); one replica per GPU is that sharing here
- * (index replicated, reads sharded, no collective). */
+/* A further context of a built index (see "Threading" above).  xm_context_new: on the source's GPU; host tables and tables in HBM are the
+ * source's own (no copy of either: a 3 Gb reference's ~130 GB of tables and bucket lines exist once per GPU however many contexts align on it).
+ * xm_index_replicate: on `device`; the host tables are shared, and when `device` is another GPU the tables are copied from the source's HBM
+ * (hipMemcpyPeer: xGMI between GPUs) instead of being built or uploaded again (device == the source's: the same as xm_context_new).  The
+ * reference shares one HashBlock_Database between all AlignerWorkers of a run (Mapper.java:912-1134); one copy per GPU is that sharing here
+ * (index replicated, reads sharded, no collective).  Every handle is released with xm_index_free, in any order: the
+ * shared tables go with the last one. */
+int xm_context_new(xm_index* source, xm_index** out);
 int xm_index_replicate(xm_index* source, int32_t device, xm_index** out);
+/* Upper limit of the scratch (HBM) a context may allocate for its passes (0: the default, up to 200 GiB).  A context never takes more than 3/4
+ * of what is free when it sizes its scratch, and settles for less when the allocation fails; callers that run several contexts on one GPU divide
+ * what xm_device_memory reports as free (after the index is resident) between them.  No reference counterpart (the JVM's -Xmx is the analogue). */
+int xm_context_set_scratch(xm_index* context, int64_t bytes);
+int xm_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes);
 /* Binary index cache, in the spirit of --cache-dir (DirCache.java:19-60, HashBlock_Database.java:106-114,477-487, PackedMap.java:249-279:
  * the reference writes one "length-<n>" file per PackedMap under a directory keyed by its property map).  xm_index_save writes the
  * reference, every table hashed so far and the duplication map into ONE file (beside `path`, then renamed: concurrent writers are safe).

@@ -47,7 +47,7 @@ class XmIndexInfo(C.Structure):
                 ("hash_seconds", C.c_double), ("duplication_seconds", C.c_double)]
 
 
-EXPORTS = ["xm_last_error", "xm_build_stamp", "xm_device_count", "xm_index_build", "xm_index_replicate", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
+EXPORTS = ["xm_last_error", "xm_build_stamp", "xm_device_count", "xm_index_build", "xm_index_replicate", "xm_context_new", "xm_context_set_scratch", "xm_device_memory", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
            "xm_index_table_info", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe", "xm_measure_random_gather", "xm_test_local_align", "xm_pileup_new", "xm_pileup_add_last", "xm_pileup_read", "xm_pileup_events", "xm_pileup_free"]
 
 
@@ -100,6 +100,9 @@ def lib():
         L.xm_index_build.argtypes = [C.POINTER(XmRef), C.POINTER(XmBuildOpts), C.POINTER(C.c_void_p)]
         L.xm_index_save.argtypes = [C.c_void_p, C.c_char_p]
         L.xm_index_replicate.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        L.xm_context_new.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.xm_context_set_scratch.argtypes = [C.c_void_p, C.c_int64]
+        L.xm_device_memory.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.xm_index_load.argtypes = [C.c_char_p, C.POINTER(XmRef), C.POINTER(XmBuildOpts), C.POINTER(C.c_void_p)]
         L.xm_index_ensure_length.argtypes = [C.c_void_p, C.c_int32]
         L.xm_index_free.argtypes = [C.c_void_p]

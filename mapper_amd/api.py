@@ -228,7 +228,8 @@ class ReferenceDatabase:
         return self
 
     def replicate(self, device):
-        """xm_index_replicate: a second residency of this index on GPU `device` (tables copied HBM to HBM, nothing built or uploaded twice)."""
+        """xm_index_replicate: a further context of this index on GPU `device`.  The host tables are shared; on another GPU the tables are copied
+        HBM to HBM (nothing built or uploaded twice), on this index's own GPU the context reads the very same tables (= new_context)."""
         other = ReferenceDatabase.__new__(ReferenceDatabase)
         other._L = self._L
         other.contigs, other._keep, other.cache_file, other.cache_hit = self.contigs, self._keep, self.cache_file, self.cache_hit
@@ -237,6 +238,23 @@ class ReferenceDatabase:
             raise RuntimeError(self._L.xm_last_error().decode())
         other._h = h
         return other
+
+    def new_context(self):
+        """xm_context_new: a further context on the same GPU - own stream, batch buffers, scratch and results over the same tables, as the reference's
+        AlignerWorker threads share one HashBlock_Database through per-thread views (HashBlock_Database.java:129-133)."""
+        other = ReferenceDatabase.__new__(ReferenceDatabase)
+        other._L = self._L
+        other.contigs, other._keep, other.cache_file, other.cache_hit = self.contigs, self._keep, self.cache_file, self.cache_hit
+        h = C.c_void_p()
+        if self._L.xm_context_new(self._h, C.byref(h)):
+            raise RuntimeError(self._L.xm_last_error().decode())
+        other._h = h
+        return other
+
+    def set_scratch(self, nbytes):
+        """xm_context_set_scratch: upper limit of the HBM this context allocates as scratch for its passes (0: the default)."""
+        if self._L.xm_context_set_scratch(self._h, int(nbytes)):
+            raise RuntimeError(self._L.xm_last_error().decode())
 
     def close(self):
         if getattr(self, "_h", None):
@@ -420,6 +438,28 @@ def measure_random_gather(table_bytes=4 << 30, accesses=1 << 26, device=0):
     if L.xm_measure_random_gather(device, table_bytes, accesses, C.byref(ms)):
         raise RuntimeError(L.xm_last_error().decode())
     return accesses / (ms.value * 1e-3), ms.value
+
+
+def device_memory(device=0):
+    """xm_device_memory: (free, total) bytes of HBM on GPU `device` right now."""
+    L = _capi.lib()
+    f, t = C.c_int64(), C.c_int64()
+    if L.xm_device_memory(int(device), C.byref(f), C.byref(t)):
+        raise RuntimeError(L.xm_last_error().decode())
+    return f.value, t.value
+
+
+def divide_scratch(contexts, device, reserve=24 << 30, most=200 << 30):
+    """Several contexts on one GPU: what is free now (the index is resident) minus a reserve for batches, result arenas and pile-ups, in equal
+    parts; a context that would get less than 8 GiB is not worth having -> (how many of `contexts` to use, bytes each)."""
+    free, _ = device_memory(device)
+    n = len(contexts)
+    while n > 1 and (free - reserve) // n < (8 << 30):
+        n -= 1
+    share = max(1 << 30, min(most, (free - reserve) // max(n, 1)))
+    for c in contexts[:n]:
+        c.set_scratch(share)
+    return n, share
 
 
 def sort_reference(contigs):

@@ -188,15 +188,20 @@ def derive_parameters(o):
                                    Max_PenaltySpan=span)
 
 
+def split_sections(length, max_length):
+    """SequenceSplitter.java:9-38: a sequence longer than max_length becomes (length - 1) / max_length + 1 sections, section k covering
+    [length * k / n, length * (k + 1) / n) (integer division in 64 bits, :35-38).  -> list of (start, end)."""
+    num = (length - 1) // max_length + 1
+    return [(length * k // num, length * (k + 1) // num) for k in range(num)]
+
+
 def load_queries(o):
     """-> list of (api.Query, qualities or None) in input order: --queries files first, then --paired-queries files, as Mapper.main adds them."""
     out = []
     for path, split in o["queries"]:
         for name, text, qual in read_sequences(path):
             if split > 0:  # SequenceSplitter.java:9-40: equal sections of at most `split` bases (the sections carry no quality; their names are [unpinned])
-                num = (len(text) - 1) // split + 1
-                for k in range(num):
-                    a, b = len(text) * k // num, len(text) * (k + 1) // num
+                for a, b in split_sections(len(text), split):
                     out.append((api.Query(text[a:b], name=name), [None]))
             else:
                 out.append((api.Query(text, name=name), [qual]))
@@ -242,10 +247,11 @@ def run(argv, out=sys.stdout):
     batch_size = o.get("batch_size") or 1_000_000
     contexts = o.get("contexts")
     if contexts is None:
-        # a job of several batches on a reference that leaves room in HBM: three contexts per GPU align their batches at the same time
-        # (+12-17 % reads per second on MI355X, profiles/r02/NOTES.md 12); one batch, or a genome-sized index: one context
+        # a job of several batches: three contexts per GPU align their batches at the same time (+12-17 % reads per second on MI355X,
+        # profiles/r02/NOTES.md 12).  Contexts share the index (xm_context_new), so a genome-sized one is no obstacle; they divide the HBM that
+        # is free once it is resident, and a GPU with room for fewer contexts uses fewer (api.divide_scratch)
         n_batches = (len(queries) + batch_size - 1) // batch_size
-        contexts = 3 if devices is None and n_batches >= 3 and sum(len(t) for _, t in contigs) <= 500_000_000 else 1
+        contexts = 3 if devices is None and n_batches >= 3 else 1
     if contexts > 1:
         devices = [d for d in (devices or [o["device"]]) for _ in range(contexts)]
     max_query_length = max([len(s) for q, _ in queries for s in q.sequences] + [1])

@@ -14,6 +14,8 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <shared_mutex>
+#include <memory>
 #include <atomic>
 #include <array>
 #include <algorithm>
@@ -314,8 +316,10 @@ __global__ void __launch_bounds__(256) xm_pileup_kernel(IndexView ix, BatchView 
   for (int c = 0; c < numComponents; c++) {
     const int numAlignments = *p++;
     if (numAlignments < 1) continue;
-    const unsigned long long w = XM_PILEUP_UNIT / (unsigned long long)numAlignments;
     for (int a = 0; a < numAlignments; a++) {
+      // a query's alignments share one read's worth of weight exactly: UNIT / n each, the first UNIT mod n of them one unit more (n above 16 need not
+      // divide UNIT; the sums over a query then still come out whole)
+      const unsigned long long w = XM_PILEUP_UNIT / (unsigned long long)numAlignments + ((unsigned long long)a < XM_PILEUP_UNIT % (unsigned long long)numAlignments ? 1ull : 0ull);
       p++;  // innerDistance
       const int numSequences = *p++;
       // the reference interval of each sequence alignment first (mates of a pair share the depth where they overlap)
@@ -327,7 +331,7 @@ __global__ void __launch_bounds__(256) xm_pileup_kernel(IndexView ix, BatchView 
           contigOf[sq] = t[0];
           const int nb = t[2];
           t += 3;
-          lo[sq] = t[1]; hi[sq] = t[4 * (nb - 1) + 1] + t[4 * (nb - 1) + 3];
+          if (nb > 0) { lo[sq] = t[1]; hi[sq] = t[4 * (nb - 1) + 1] + t[4 * (nb - 1) + 3]; }
           t += 4 * nb;
         }
       }
@@ -346,7 +350,7 @@ __global__ void __launch_bounds__(256) xm_pileup_kernel(IndexView ix, BatchView 
           if (lenA == lenB) {
             for (int i = 0; i < lenA; i++) {
               const long long pos = startB + i;
-              const unsigned long long wi = (pos >= ovLo && pos < ovHi) ? w / 2 : w;
+              const unsigned long long wi = (pos >= ovLo && pos < ovHi) ? (sq == 0 ? w / 2 : w - w / 2) : w;
               const uint8_t r = ix.refCodes[base + pos];
               const int k = startA + i;
               const uint8_t qb = reversed ? bpComplement(read[readLen - 1 - k]) : read[k];
@@ -356,13 +360,13 @@ __global__ void __launch_bounds__(256) xm_pileup_kernel(IndexView ix, BatchView 
           } else {
             if (lenA == 0) for (int i = 0; i < lenB; i++) {  // a deletion: the read spans these reference bases
               const long long pos = startB + i;
-              atomicAdd(&pv.depth[base + pos], (pos >= ovLo && pos < ovHi) ? w / 2 : w);
+              atomicAdd(&pv.depth[base + pos], (pos >= ovLo && pos < ovHi) ? (sq == 0 ? w / 2 : w - w / 2) : w);
             }
             const unsigned long long at = atomicAdd(pv.eventCount, 1ull);
             if (at < pv.eventCap) {
               long long* e = pv.events + at * 8;
               e[0] = contig; e[1] = startB; e[2] = lenA > 0 ? 1 : 2; e[3] = lenA > 0 ? lenA : lenB; e[4] = pv.queryBase + q; e[5] = mate | (reversed << 1); e[6] = startA;
-              e[7] = (long long)((startB >= ovLo && startB < ovHi) ? w / 2 : w);
+              e[7] = (long long)((startB >= ovLo && startB < ovHi) ? (sq == 0 ? w / 2 : w - w / 2) : w);
             }
           }
         }
@@ -637,6 +641,19 @@ struct DevBuf {
     n = count ? count : 1;
     HIP_CHECK(hipMalloc((void**)&p, n * sizeof(T)));
   }
+  // like ensure, but an allocation the GPU has no room for returns false (the buffer is then empty) instead of throwing
+  bool tryEnsure(size_t count) {
+    if (count <= n && p) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    const size_t want = count ? count : 1;
+    n = 0;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) { (void)hipGetLastError(); p = nullptr; return false; }
+    HIP_CHECK(e);
+    n = want;
+    return true;
+  }
   // grow to `count`, keeping the first `keep` elements
   void growKeep(size_t count, size_t keep, hipStream_t s) {
     if (count <= n && p) return;
@@ -706,13 +723,21 @@ struct ResultBox {
 
 }  // namespace
 
-struct xm_index {
+// The tables of one reference, hashed once and shared by every context and replica of the index: the reference shares one HashBlock_Database
+// between all AlignerWorkers of a run through per-thread views (HashBlock_Database.java:129-133, Mapper.java:1026-1040, Api.java:78).
+struct HostShare {
   HostIndex host;
-  bool hostOnly = false;
+  std::mutex mu;                     // growth of the host tables (Readable_HashBlock_Database.getContainingMap, :108-113), save
+  std::atomic<int> hashedLength{0};  // copy of host.maxHashedLength readable without mu
+};
+
+// The same tables in one GPU's HBM: one per (index, device), shared by every context of the index on that GPU.
+struct DeviceTables {
+  std::shared_ptr<HostShare> hs;
   int device = 0;
-  std::atomic<int> hashedLength{0};  // copy of host.maxHashedLength that xm_batch_stage may read while mu is held elsewhere (set by upload())
-  std::mutex mu;
-  // device residency
+  std::shared_mutex rw;      // align / probe calls of any number of contexts hold it shared while their kernels read the tables; (re)upload holds it exclusive
+  std::mutex allocMu;        // contexts of one GPU size and allocate their scratch one after the other (they all look at the same free memory)
+  int uploadedLength = -1;   // host.maxHashedLength the device tables hold
   DevBuf<int64_t> dContigStart, dSeqCumStart, dDupKeyStart;
   DevBuf<int32_t> dContigLen, dDupKeys;
   DevBuf<uint8_t> dRefCodes;
@@ -723,65 +748,25 @@ struct xm_index {
   DevBuf<uint64_t> dLines64;
   bool posIs64 = false;
   IndexView view;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // per-call scratch kept across calls
-  DevBuf<uint8_t> dArenas, dCodes;
-  DevBuf<int32_t> dMateCount, dMateLength, dStatus, dIntLen, dDblLen, dOutInts;
-  DevBuf<int64_t> dMateOffset, dIntOff, dDblOff, dTodo;
-  DevBuf<double> dExpected, dDeviation, dOutDbls;
-  DevBuf<unsigned long long> dCursors;  // [0],[1] result cursors, [2] next item
-  DevBuf<int64_t> dListHeavy, dListHeavyLate, dListScale[2], dListOut[2], dListPath[2], dFinalIntOff, dFinalDblOff;
-  DevBuf<int32_t> dSlotOf, dRegionOf;
-  DevBuf<uint8_t> dMemo;
-  DevBuf<PNode> dWaveNodes;  // per wave: node payloads of its LDS-mode search
-  // wave-per-read passes
-  DevBuf<int64_t> dListWaveHeavy, dListWaveNext, dListWaveSearch[2], dListFallback;
-  DevBuf<uint8_t> dWaveMemo;
-  DevBuf<int32_t> dWaveSlotOf;
-  DevBuf<WaveCtl> dWaveCtl;
-  DevBuf<uint8_t> dWaveArenas;
-  DevBuf<PNode> dWaveNodes2;
-  bool residentAnyPaired = false, stagedAnyPaired = false;
-  DevBuf<PassCtl> dCtl;
-  DevBuf<long long> dBlockI, dBlockD;
-  DevBuf<int32_t> dFinalInts;
-  DevBuf<double> dFinalDbls;
-  DevBuf<DevCounters> dCounters;
   int numCUs = 0;
-  int64_t residentNq = -1;   // batch kept in HBM by xm_batch_upload
-  int64_t residentGen = 0, lastAlignedGen = -1;  // which resident batch the streams of the last align call belong to
-  int64_t lastAlignedNq = -1;  // queries whose result streams (dFinalInts / dFinalDbls / dFinalIntOff) are still in HBM from the last align call (xm_pileup_add_last)
-  int residentMaxLen = 0;    // longest mate of that batch
-  double residentH2dMs = 0;
-  // second set of batch buffers: xm_batch_stage copies the next batch on its own stream while xm_align_resident works on the resident one
-  std::mutex stageMu;
-  hipStream_t copyStream = nullptr;
-  hipEvent_t cev0 = nullptr, cev1 = nullptr;
-  DevBuf<uint8_t> sCodes;
-  DevBuf<int32_t> sMateCount, sMateLength;
-  DevBuf<int64_t> sMateOffset;
-  DevBuf<double> sExpected, sDeviation;
-  int64_t stagedNq = -1;
-  int stagedMaxLen = 0;
-  double stagedH2dMs = 0;
+  hipStream_t stream = nullptr;
 
-  // Host tables -> HBM.  With `peer` (xm_index_replicate): the tables are copied from the peer's HBM instead (hipMemcpyPeer: over xGMI between
-  // two GPUs, a device-to-device copy on one), not sent over PCIe a second time; `host` is then already a copy of the peer's.
-  void upload(const xm_index* peer = nullptr) {
+  // Host tables -> HBM (caller holds hs->mu and rw exclusively).  With `peer` (a replica on another GPU): the tables are copied from the peer's HBM
+  // instead (hipMemcpyPeer: over xGMI), not sent over PCIe a second time.
+  void upload(const DeviceTables* peer = nullptr) {
+    const HostIndex& host = hs->host;
     HIP_CHECK(hipSetDevice(device));
-    if (!stream) { HIP_CHECK(hipStreamCreate(&stream)); HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); }
+    if (!stream) HIP_CHECK(hipStreamCreate(&stream));
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
     numCUs = prop.multiProcessorCount;
-    hashedLength.store(host.maxHashedLength);
     auto up = [&](auto& buf, const auto& vec, const auto& peerBuf) {
       buf.ensure(vec.size());
       if (vec.empty()) return;
       if (peer) HIP_CHECK(hipMemcpyPeer(buf.p, device, peerBuf.p, peer->device, vec.size() * sizeof(vec[0])));
       else HIP_CHECK(hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice));
     };
-    const xm_index& src = peer ? *peer : *this;
+    const DeviceTables& src = peer ? *peer : *this;
     up(dContigStart, host.contigStart, src.dContigStart); up(dContigLen, host.contigLen, src.dContigLen); up(dSeqCumStart, host.seqCumStart, src.dSeqCumStart);
     up(dRefCodes, host.refCodes, src.dRefCodes); up(dTables, host.tables, src.dTables); up(dBucketOff, host.bucketOff, src.dBucketOff);
     up(dDupKeyStart, host.dupKeyStart, src.dDupKeyStart); up(dDupKeys, host.dupKeys, src.dDupKeys);
@@ -823,25 +808,102 @@ struct xm_index {
     view.contigStart = dContigStart.p; view.contigLen = dContigLen.p; view.seqCumStart = dSeqCumStart.p; view.refCodes = dRefCodes.p;
     view.tables = dTables.p; view.bucketOff = dBucketOff.p; view.positions32 = dPositions32.p; view.positions64 = dPositions64.p;
     view.dupKeyStart = dDupKeyStart.p; view.dupKeys = dDupKeys.p;
+    uploadedLength = host.maxHashedLength;
+    hs->hashedLength.store(host.maxHashedLength);
+  }
+  ~DeviceTables() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+// An xm_index handle is a CONTEXT of an index: what one host thread needs to align batches on one GPU - a stream, batch buffers, scratch and a
+// result pool of its own - over tables it shares with every other context of the same index (HostShare: all of them; DeviceTables: those on
+// its GPU).  xm_index_build / xm_index_load make the first context; xm_context_new and xm_index_replicate add contexts.
+struct xm_index {
+  std::shared_ptr<HostShare> hs;
+  std::shared_ptr<DeviceTables> dt;  // null with host_only
+  bool hostOnly = false;
+  int device = 0;
+  long long scratchBytes = 0;        // xm_context_set_scratch: upper limit of this context's scratch (0: XM_SCRATCH_GIB / the default)
+  std::mutex mu;                     // calls on one context serialise; contexts run side by side
+  HostIndex& host() { return hs->host; }
+  const HostIndex& host() const { return hs->host; }
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // per-call scratch kept across calls
+  DevBuf<uint8_t> dArenas, dCodes;
+  DevBuf<int32_t> dMateCount, dMateLength, dStatus, dIntLen, dDblLen, dOutInts;
+  DevBuf<int64_t> dMateOffset, dIntOff, dDblOff, dTodo;
+  DevBuf<double> dExpected, dDeviation, dOutDbls;
+  DevBuf<unsigned long long> dCursors;  // [0],[1] result cursors, [2] next item
+  DevBuf<int64_t> dListHeavy, dListHeavyLate, dListScale[2], dListOut[2], dListPath[2], dFinalIntOff, dFinalDblOff;
+  DevBuf<int32_t> dSlotOf, dRegionOf;
+  DevBuf<uint8_t> dMemo;
+  DevBuf<PNode> dWaveNodes;  // per wave: node payloads of its LDS-mode search
+  // wave-per-read passes
+  DevBuf<int64_t> dListWaveHeavy, dListWaveNext, dListWaveSearch[2], dListFallback;
+  DevBuf<uint8_t> dWaveMemo;
+  DevBuf<int32_t> dWaveSlotOf;
+  DevBuf<WaveCtl> dWaveCtl;
+  DevBuf<uint8_t> dWaveArenas;
+  DevBuf<PNode> dWaveNodes2;
+  bool residentAnyPaired = false, stagedAnyPaired = false;
+  DevBuf<PassCtl> dCtl;
+  DevBuf<long long> dBlockI, dBlockD;
+  DevBuf<int32_t> dFinalInts;
+  DevBuf<double> dFinalDbls;
+  DevBuf<DevCounters> dCounters;
+  int64_t residentNq = -1;   // batch kept in HBM by xm_batch_upload
+  int64_t residentGen = 0, lastAlignedGen = -1;  // which resident batch the streams of the last align call belong to
+  int64_t lastAlignedNq = -1;  // queries whose result streams (dFinalInts / dFinalDbls / dFinalIntOff) are still in HBM from the last align call (xm_pileup_add_last)
+  int residentMaxLen = 0;    // longest mate of that batch
+  double residentH2dMs = 0;
+  // second set of batch buffers: xm_batch_stage copies the next batch on its own stream while xm_align_resident works on the resident one
+  std::mutex stageMu;
+  hipStream_t copyStream = nullptr;
+  hipEvent_t cev0 = nullptr, cev1 = nullptr;
+  DevBuf<uint8_t> sCodes;
+  DevBuf<int32_t> sMateCount, sMateLength;
+  DevBuf<int64_t> sMateOffset;
+  DevBuf<double> sExpected, sDeviation;
+  int64_t stagedNq = -1;
+  int stagedMaxLen = 0;
+  double stagedH2dMs = 0;
+
+  void initContext() {  // stream and events of this context (the device tables exist)
+    HIP_CHECK(hipSetDevice(device));
+    if (!stream) { HIP_CHECK(hipStreamCreate(&stream)); HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); }
+  }
+  // Readable_HashBlock_Database.getContainingMap's growth (:108-113) for a batch whose longest mate is maxLen, then the device tables brought up to
+  // the host's: any context may grow the shared tables; every GPU's copy follows before its next launch.  Called without rw held.
+  void ensureTablesFor(int maxLen) {
+    if (maxLen > hs->hashedLength.load()) {
+      std::lock_guard<std::mutex> lock(hs->mu);
+      if (maxLen > hs->host.maxHashedLength) { hs->host.ensureLength(maxLen); hs->hashedLength.store(hs->host.maxHashedLength); }
+    }
+    if (dt && dt->uploadedLength < hs->hashedLength.load()) {
+      std::lock_guard<std::mutex> lock(hs->mu);
+      std::unique_lock<std::shared_mutex> wr(dt->rw);  // (waits for the launches of every context of this GPU)
+      if (dt->uploadedLength < hs->host.maxHashedLength) dt->upload();
+    }
   }
   ~xm_index() {
     if (hostOnly) return;
-    dContigStart.release(); dSeqCumStart.release(); dDupKeyStart.release(); dContigLen.release(); dDupKeys.release(); dRefCodes.release();
-    dTables.release(); dBucketOff.release(); dPositions32.release(); dPositions64.release(); dLines32.release(); dLines64.release(); dArenas.release(); dCodes.release();
-    dMateCount.release(); dMateLength.release(); dStatus.release(); dIntLen.release(); dDblLen.release(); dOutInts.release();
-    dMateOffset.release(); dIntOff.release(); dDblOff.release(); dTodo.release(); dExpected.release(); dDeviation.release(); dOutDbls.release();
-    dCursors.release(); dCounters.release();
+    (void)hipSetDevice(device);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (cev0) (void)hipEventDestroy(cev0);
     if (cev1) (void)hipEventDestroy(cev1);
     if (stream) (void)hipStreamDestroy(stream);
     if (copyStream) (void)hipStreamDestroy(copyStream);
-  }
+  }  // (every DevBuf member releases its memory itself; the shared tables go with their last context)
 };
 
 struct xm_pileup {
-  xm_index* index = nullptr;
+  xm_index* index = nullptr;            // the context whose batches are added (xm_pileup_add_last needs it alive; read / events / free do not)
+  std::shared_ptr<HostShare> hs;
+  int device = 0;
   DevBuf<unsigned long long> dDepth, dAlt, dEventCount;
   DevBuf<long long> dEvents;
   long long total = 0, queriesAdded = 0;
@@ -871,7 +933,8 @@ int xm_index_build(const xm_ref* ref, const xm_build_opts* optsIn, xm_index** ou
   xm_index* idx = nullptr;
   try {
     idx = new xm_index();
-    idx->host.setReference(ref->num_contigs, ref->names, ref->codes, ref->lengths);
+    idx->hs = std::make_shared<HostShare>();
+    idx->host().setReference(ref->num_contigs, ref->names, ref->codes, ref->lengths);
     idx->hostOnly = o.host_only != 0;
     if (!idx->hostOnly) {
       int n = 0;
@@ -880,11 +943,17 @@ int xm_index_build(const xm_ref* ref, const xm_build_opts* optsIn, xm_index** ou
       int dev = o.device;
       if (dev < 0) HIP_CHECK(hipGetDevice(&dev));
       idx->device = dev;
-      idx->host.deviceHasher = &deviceHashLengths;  // the tables are hashed on this GPU (references without ambiguity codes)
-      idx->host.deviceForBuild = dev;
+      idx->host().deviceHasher = &deviceHashLengths;  // the tables are hashed on this GPU (references without ambiguity codes)
+      idx->host().deviceForBuild = dev;
     }
-    idx->host.build(o.enable_gapmers, o.min_interesting_size, o.max_hashed_length, o.dup_window, o.dup_min_copies, o.dup_min_length, o.dup_max_length);
-    if (!idx->hostOnly) idx->upload();
+    idx->host().build(o.enable_gapmers, o.min_interesting_size, o.max_hashed_length, o.dup_window, o.dup_min_copies, o.dup_min_length, o.dup_max_length);
+    idx->hs->hashedLength.store(idx->host().maxHashedLength);
+    if (!idx->hostOnly) {
+      idx->dt = std::make_shared<DeviceTables>();
+      idx->dt->hs = idx->hs; idx->dt->device = idx->device;
+      idx->dt->upload();
+      idx->initContext();
+    }
     *out = idx;
     return 0;
   } catch (std::exception& e) {
@@ -901,19 +970,27 @@ int xm_index_replicate(xm_index* src, int32_t device, xm_index** out) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1) throw std::runtime_error("no HIP device available");
     if (device < 0 || device >= n) throw std::runtime_error("device " + std::to_string(device) + " does not exist (" + std::to_string(n) + " devices)");
-    std::lock_guard<std::mutex> lock(src->mu);  // (not while the source grows its tables)
     idx = new xm_index();
-    idx->host = src->host;
+    idx->hs = src->hs;          // the host tables are shared, never copied
     idx->hostOnly = false;
     idx->device = device;
-    idx->host.deviceForBuild = device;  // tables hashed later on demand (xm_index_ensure_length) are hashed on the replica's own GPU
-    if (device != src->device) {
+    idx->scratchBytes = src->scratchBytes;
+    if (device == src->device) {
+      idx->dt = src->dt;        // a context on the same GPU reads the same tables in HBM
+    } else {
       int can = 0;
       HIP_CHECK(hipDeviceCanAccessPeer(&can, device, src->device));
       if (can) { HIP_CHECK(hipSetDevice(device)); hipError_t e = hipDeviceEnablePeerAccess(src->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_CHECK(e); (void)hipGetLastError(); }
+      std::lock_guard<std::mutex> lock(src->hs->mu);            // (not while the tables grow)
+      std::shared_lock<std::shared_mutex> rd(src->dt->rw);      // (nor while the source's copy is brought up to them)
+      idx->dt = std::make_shared<DeviceTables>();
+      idx->dt->hs = idx->hs; idx->dt->device = device;
+      std::unique_lock<std::shared_mutex> wr(idx->dt->rw);
+      if (src->dt->uploadedLength == src->hs->host.maxHashedLength) idx->dt->upload(src->dt.get());  // HBM to HBM (xGMI)
+      else idx->dt->upload();
+      HIP_CHECK(hipDeviceSynchronize());
     }
-    idx->upload(src);
-    HIP_CHECK(hipDeviceSynchronize());
+    idx->initContext();
     *out = idx;
     return 0;
   } catch (std::exception& e) {
@@ -922,11 +999,35 @@ int xm_index_replicate(xm_index* src, int32_t device, xm_index** out) {
   }
 }
 
+int xm_context_new(xm_index* index, xm_index** out) {
+  if (!index || !out) return fail("xm_context_new: null argument");
+  return xm_index_replicate(index, index->device, out);
+}
+
+int xm_context_set_scratch(xm_index* idx, int64_t bytes) {
+  if (!idx) return fail("xm_context_set_scratch: null argument");
+  if (bytes < 0) return fail("xm_context_set_scratch: negative size");
+  std::lock_guard<std::mutex> lock(idx->mu);
+  idx->scratchBytes = bytes;
+  return 0;
+}
+
+int xm_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes) {
+  try {
+    HIP_CHECK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_device_memory: ") + e.what()); }
+}
+
 int xm_index_save(xm_index* idx, const char* path) {
   if (!idx || !path) return fail("xm_index_save: null argument");
   try {
-    std::lock_guard<std::mutex> lock(idx->mu);
-    idx->host.save(path);
+    std::lock_guard<std::mutex> lock(idx->hs->mu);
+    idx->host().save(path);
     return 0;
   } catch (std::exception& e) { return fail(std::string("xm_index_save: ") + e.what()); }
 }
@@ -940,11 +1041,12 @@ int xm_index_load(const char* path, const xm_ref* ref, const xm_build_opts* opts
   xm_index* idx = nullptr;
   try {
     idx = new xm_index();
-    idx->host.load(path);
+    idx->hs = std::make_shared<HostShare>();
+    idx->host().load(path);
     if (ref) {  // the file must answer exactly this build request (the reference's cache keys, M/HashBlock_Database.java:106-114)
       HostIndex want;
       want.setReference(ref->num_contigs, ref->names, ref->codes, ref->lengths);
-      if (!idx->host.matchesRequest(want, o.enable_gapmers, o.min_interesting_size, o.dup_window, o.dup_min_copies, o.dup_min_length, o.dup_max_length))
+      if (!idx->host().matchesRequest(want, o.enable_gapmers, o.min_interesting_size, o.dup_window, o.dup_min_copies, o.dup_min_length, o.dup_max_length))
         throw std::runtime_error("the file was built from another reference or with other settings");
     }
     idx->hostOnly = o.host_only != 0;
@@ -955,11 +1057,17 @@ int xm_index_load(const char* path, const xm_ref* ref, const xm_build_opts* opts
       int dev = o.device;
       if (dev < 0) HIP_CHECK(hipGetDevice(&dev));
       idx->device = dev;
-      idx->host.deviceHasher = &deviceHashLengths;
-      idx->host.deviceForBuild = dev;
+      idx->host().deviceHasher = &deviceHashLengths;
+      idx->host().deviceForBuild = dev;
     }
-    if (o.max_hashed_length > idx->host.maxHashedLength) idx->host.ensureLength(o.max_hashed_length);
-    if (!idx->hostOnly) idx->upload();
+    if (o.max_hashed_length > idx->host().maxHashedLength) idx->host().ensureLength(o.max_hashed_length);
+    idx->hs->hashedLength.store(idx->host().maxHashedLength);
+    if (!idx->hostOnly) {
+      idx->dt = std::make_shared<DeviceTables>();
+      idx->dt->hs = idx->hs; idx->dt->device = idx->device;
+      idx->dt->upload();
+      idx->initContext();
+    }
     *out = idx;
     return 0;
   } catch (std::exception& e) {
@@ -971,10 +1079,7 @@ int xm_index_load(const char* path, const xm_ref* ref, const xm_build_opts* opts
 int xm_index_ensure_length(xm_index* idx, int32_t length) {
   if (!idx) return fail("null index");
   try {
-    std::lock_guard<std::mutex> lock(idx->mu);
-    if (length <= idx->host.maxHashedLength) return 0;
-    idx->host.ensureLength(length);
-    if (!idx->hostOnly) idx->upload();
+    idx->ensureTablesFor(length);
     return 0;
   } catch (std::exception& e) { return fail(std::string("xm_index_ensure_length: ") + e.what()); }
 }
@@ -983,9 +1088,9 @@ void xm_index_free(xm_index* idx) { delete idx; }
 
 int xm_index_get_info(const xm_index* idx, xm_index_info_t* info) {
   if (!idx || !info) return fail("null argument");
-  const HostIndex& h = idx->host;
+  const HostIndex& h = idx->host();
   info->num_contigs = h.numContigs(); info->min_interesting_size = h.minInterestingSize; info->max_hashed_length = h.maxHashedLength;
-  info->enable_gapmers = h.enableGapmers; info->dup_window = h.dupWindow; info->position_bytes = (idx->hostOnly ? h.seqCumStart.back() > 0xFFFFFFFFll : idx->posIs64) ? 8 : 4;
+  info->enable_gapmers = h.enableGapmers; info->dup_window = h.dupWindow; info->position_bytes = (idx->hostOnly ? h.seqCumStart.back() > 0xFFFFFFFFll : idx->dt->posIs64) ? 8 : 4;
   info->total_forward_size = h.totalForwardSize;
   info->num_positions = (int64_t)h.positions.size();
   info->index_bytes = (int64_t)(h.bucketOff.size() * 4 + h.positions.size() * (size_t)info->position_bytes + h.refCodes.size() + h.dupKeys.size() * 4);
@@ -997,7 +1102,7 @@ int xm_index_get_info(const xm_index* idx, xm_index_info_t* info) {
 
 int xm_index_table_info(const xm_index* idx, int32_t L, int32_t* capacity, int32_t* maxCount, int64_t* numStored, int64_t* numOverfull) {
   if (!idx) return fail("null index");
-  const HostIndex& h = idx->host;
+  const HostIndex& h = idx->host();
   if (L < 0 || L > h.maxHashedLength) return fail("length not hashed");
   const Table& t = h.tables[(size_t)L];
   *capacity = t.capacity; *maxCount = t.maxCount;
@@ -1010,7 +1115,7 @@ int xm_index_table_info(const xm_index* idx, int32_t L, int32_t* capacity, int32
 
 int xm_index_table_dump(const xm_index* idx, int32_t L, int32_t* counts, int64_t* positionsOut) {
   if (!idx) return fail("null index");
-  const HostIndex& h = idx->host;
+  const HostIndex& h = idx->host();
   if (L < 0 || L > h.maxHashedLength) return fail("length not hashed");
   const Table& t = h.tables[(size_t)L];
   int64_t w = 0;
@@ -1025,8 +1130,8 @@ int xm_index_table_dump(const xm_index* idx, int32_t L, int32_t* counts, int64_t
 }
 
 int64_t xm_index_dup_keys(const xm_index* idx, int32_t contig, int32_t* out, int64_t cap) {
-  if (!idx || contig < 0 || contig >= idx->host.numContigs()) return -1;
-  const HostIndex& h = idx->host;
+  if (!idx || contig < 0 || contig >= idx->host().numContigs()) return -1;
+  const HostIndex& h = idx->host();
   int64_t a = h.dupKeyStart[(size_t)contig], b = h.dupKeyStart[(size_t)contig + 1];
   for (int64_t i = a; i < b && i - a < cap; i++) out[i - a] = h.dupKeys[(size_t)i];
   return b - a;
@@ -1063,10 +1168,7 @@ static void uploadBatchLocked(xm_index* idx, const xm_query_batch* b) {
   bool anyPaired = false;
   const int maxLen = validateBatch(b, &anyPaired);
   idx->residentAnyPaired = anyPaired;
-  if (maxLen > idx->host.maxHashedLength) {  // Readable_HashBlock_Database.getContainingMap growth, done before the launch
-    idx->host.ensureLength(maxLen);
-    idx->upload();
-  }
+  idx->ensureTablesFor(maxLen);  // Readable_HashBlock_Database.getContainingMap growth, done before the launch
   HIP_CHECK(hipSetDevice(idx->device));
   hipStream_t s = idx->stream;
   idx->residentNq = -1;
@@ -1113,13 +1215,7 @@ int xm_batch_stage(xm_index* idx, const xm_query_batch* b) {
     bool anyPaired = false;
     const int maxLen = validateBatch(b, &anyPaired);
     idx->stagedAnyPaired = anyPaired;
-    if (maxLen > idx->hashedLength.load()) {  // the tables grow: that touches what a running xm_align_resident reads, so wait for it
-      std::lock_guard<std::mutex> lock(idx->mu);
-      if (maxLen > idx->host.maxHashedLength) {
-        idx->host.ensureLength(maxLen);
-        idx->upload();
-      }
-    }
+    idx->ensureTablesFor(maxLen);  // (tables that grow wait for the launches that read them: DeviceTables::rw)
     HIP_CHECK(hipSetDevice(idx->device));
     if (!idx->copyStream) { HIP_CHECK(hipStreamCreateWithFlags(&idx->copyStream, hipStreamNonBlocking)); HIP_CHECK(hipEventCreate(&idx->cev0)); HIP_CHECK(hipEventCreate(&idx->cev1)); }
     hipStream_t s = idx->copyStream;
@@ -1192,6 +1288,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const int64_t nq = idx->residentNq;
     HIP_CHECK(hipSetDevice(idx->device));
     hipStream_t s = idx->stream;
+    // the shared tables stay as they are while this call's kernels read them (another context that grows them waits; so does this one's next growth)
+    std::shared_lock<std::shared_mutex> tablesInUse(idx->dt->rw);
+    const IndexView view = idx->dt->view;
+    const int numCUs = idx->dt->numCUs;
     res->num_queries = nq;
     res->int_off = (int64_t*)g_pinned->get(sizeof(int64_t) * (size_t)(nq + 1), &box->bytesIntOff);
     res->dbl_off = (int64_t*)g_pinned->get(sizeof(int64_t) * (size_t)(nq + 1), &box->bytesDblOff);
@@ -1258,7 +1358,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     int launches = 0;
     int64_t rerun = 0;
     const size_t arenaUnit = (size_t)envKnob("XM_ARENA_KB", 288, 64, 16384) * 1024;  // scratch of a lane at scale 1 (experiment knob: the capacities do not follow it, a smaller arena only overflows earlier)
-    const long long scratchGiBWanted = envKnob("XM_SCRATCH_GIB", 200, 1, 280);
+    // scratch limit of this context: xm_context_set_scratch, else XM_SCRATCH_GIB (experiment knob), else 200 GiB
+    const unsigned long long scratchWanted = idx->scratchBytes > 0 ? (unsigned long long)idx->scratchBytes : (unsigned long long)envKnob("XM_SCRATCH_GIB", 200, 1, 280) << 30;
+    int scratchShift = 0;  // halved after an allocation the GPU had no room for (another process, or contexts that were given more than there is)
     const long long lightWaves = envKnob("XM_LIGHT_WAVES", 8, 1, 16), fullWaves = envKnob("XM_FULL_WAVES", 4, 1, 16), pathWaves = envKnob("XM_PATH_WAVES", 4, 1, 16);
     const long long fullLpw = envKnob("XM_FULL_LPW", 32, 1, 64), lightLpw = envKnob("XM_LIGHT_LPW", 64, 1, 64);
     const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
@@ -1270,14 +1372,20 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // a search round costs two launches whose time is the time of one read (a replay, a search) however few reads wait; once the
     // waiting reads no longer fill the GPU the rest is cheaper inline: one last chain pass, one read per wave
     const long long deferMaxRounds = envKnob("XM_DEFER_ROUNDS", 3, 0, 1000000), inlineBelow = envKnob("XM_INLINE_BELOW", 8192, 0, 1ll << 40);
-    auto scratchBudget = [&]() -> unsigned long long {  // scratch: up to 200 GiB of the 288 GiB HBM, never more than 3/4 of what is free
-      long long scratchGiB = scratchGiBWanted;
+    auto scratchBudget = [&]() -> unsigned long long {  // scratch: up to the limit, never more than 3/4 of what is free now (+ what this context already holds)
+      unsigned long long want = scratchWanted >> scratchShift;
       size_t freeB = 0, totalB = 0;
       if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-        long long avail = (long long)(((freeB + idx->dArenas.n) / 4 * 3) >> 30);
-        if (scratchGiB > avail) scratchGiB = avail < 1 ? 1 : avail;
+        const unsigned long long avail = (unsigned long long)(freeB + idx->dArenas.n) / 4 * 3;
+        if (want > avail) want = avail;
       }
-      return (unsigned long long)scratchGiB << 30;
+      return want < (64ull << 20) ? (64ull << 20) : want;
+    };
+    // contexts of one GPU size and allocate their scratch one after the other: they all look at the same free memory
+    auto allocScratch = [&](size_t bytes) -> bool {
+      if (idx->dArenas.tryEnsure(bytes)) return true;
+      if (++scratchShift > 8) throw std::runtime_error("no room in HBM for the scratch of even a few lanes (" + std::to_string(bytes >> 20) + " MiB asked)");
+      return false;
     };
     auto scratchLanes = [&](size_t arenaBytes) -> long long { return (long long)(scratchBudget() / arenaBytes); };
     // light pass -> gapped pass hand-over (HandOver, SavedRead): the reads the light pass stops in front of the gapped chain keep their seeding
@@ -1324,10 +1432,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         long long blocksPerCU = std::min<long long>((160 * 1024) / ldsPerBlock, (long long)(wavesPerSimd * 4) / wavesPerBlock);
         if (blocksPerCU < 1) blocksPerCU = 1;
         wl.itemsPerFetch = (int)envKnob(tier == 0 ? "XM_WAVE_FETCH" : "XM_WAVE_CHAIN_FETCH", tier == 0 ? 8 : 1, 1, 1024);
-        long long blocks = std::min<long long>((long long)idx->numCUs * blocksPerCU, (n + (long long)wavesPerBlock * wl.itemsPerFetch - 1) / ((long long)wavesPerBlock * wl.itemsPerFetch));
+        long long blocks = std::min<long long>((long long)numCUs * blocksPerCU, (n + (long long)wavesPerBlock * wl.itemsPerFetch - 1) / ((long long)wavesPerBlock * wl.itemsPerFetch));
         if (blocks < 1) blocks = 1;
         wl.grid = (int)blocks; wl.block = wavesPerBlock * 64;
-        wl.ix = idx->view; wl.params = params; wl.batch = bv; wl.todo = list; wl.nTodo = n; wl.out = ov; wl.nextItem = idx->dCursors.p + 2; wl.counters = idx->dCounters.p;
+        wl.ix = view; wl.params = params; wl.batch = bv; wl.todo = list; wl.nTodo = n; wl.out = ov; wl.nextItem = idx->dCursors.p + 2; wl.counters = idx->dCounters.p;
         wl.memoBase = (WMemo*)idx->dWaveMemo.p; wl.slotOf = idx->dWaveSlotOf.p;
         wl.waveNodes = nullptr;
         if (tier >= 1 && envInt("XM_WAVE_INLINE_SEARCH", 1) != 0) {  // (0: every search through the memo and the search kernel)
@@ -1360,10 +1468,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       };
       auto launchSearches = [&](const int64_t* list, long long n) {
         SearchLaunch sl;
-        long long blocks = std::min<long long>((long long)idx->numCUs * std::min<long long>((160 * 1024) / sLds, (long long)(sPerSimd * 4) / sWaves), (n + sWaves - 1) / sWaves);
+        long long blocks = std::min<long long>((long long)numCUs * std::min<long long>((160 * 1024) / sLds, (long long)(sPerSimd * 4) / sWaves), (n + sWaves - 1) / sWaves);
         if (blocks < 1) blocks = 1;
         sl.grid = (int)blocks; sl.block = sWaves * 64;
-        sl.ix = idx->view; sl.params = params; sl.batch = bv; sl.list = list; sl.n = n; sl.memoBase = (WMemo*)idx->dWaveMemo.p; sl.slotOf = idx->dWaveSlotOf.p; sl.nextItem = idx->dCursors.p + 2;
+        sl.ix = view; sl.params = params; sl.batch = bv; sl.list = list; sl.n = n; sl.memoBase = (WMemo*)idx->dWaveMemo.p; sl.slotOf = idx->dWaveSlotOf.p; sl.nextItem = idx->dCursors.p + 2;
         idx->dWaveArenas.ensure((size_t)blocks * sWaves * (size_t)nodesPerWave);  // (node payloads: bytes per wave)
         sl.waveNodes = idx->dWaveArenas.p; sl.counters = idx->dCounters.p;
         HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
@@ -1408,13 +1516,14 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
     }
     while (nTodo > 0) {
+      std::unique_lock<std::mutex> sizing(idx->dt->allocMu);
       size_t arenaBytes = arenaUnit * (size_t)scale;  // bytes of scratch a lane owns in this launch
       if (hoMode == 1) arenaBytes -= arenaPersistBytes(arenaBytes);                                // temporaries only (+ one region of the pool per lane)
       else if (hoMode == 2) arenaBytes = regionBytes + gappedTmpBytes(arenaBytes);  // a region for reads without saved state + temporaries
       // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped chain
       // diverges inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  The XM_* variables are experiment knobs.
       // a pass over few reads spreads them over all the wave slots of the GPU (the time of a launch is its longest wave)
-      const long long waveSlots = (long long)idx->numCUs * 4 * (heavy ? fullWaves : lightWaves);
+      const long long waveSlots = (long long)numCUs * 4 * (heavy ? fullWaves : lightWaves);
       int lpw = (int)(heavy ? fullLpw : lightLpw);  // active lanes per wave
       if (heavy) lpw = (int)std::max(1ll, std::min((long long)lpw, (nTodo + waveSlots - 1) / waveSlots));
       long long lanes = waveSlots * lpw;
@@ -1448,18 +1557,19 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         nRegions = lanes + extra;
         regionsTotal = (size_t)nRegions * regionBytes;
         const size_t gappedArena = arenaUnit * (size_t)gappedScale, gappedLane = regionBytes + gappedTmpBytes(gappedArena);
-        long long gappedLanes = std::min((long long)nq, (long long)idx->numCUs * 4 * fullWaves * fullLpw);
+        long long gappedLanes = std::min((long long)nq, (long long)numCUs * 4 * fullWaves * fullLpw);
         gappedLanes = std::min(gappedLanes, std::max(1ll, ((long long)budget - (long long)regionsTotal) / (long long)gappedLane));
         size_t behind = std::max((size_t)lanes * arenaBytes, (size_t)gappedLanes * gappedLane);
         behind = std::max(behind, gappedArena);  // (a rerun after a full result arena runs plain, at least one lane of it)
-        idx->dArenas.ensure(regionsTotal + behind + 1024);
+        if (!allocScratch(regionsTotal + behind + 1024)) { regionsTotal = 0; nRegions = 0; continue; }  // (sized again with half the budget)
         const unsigned long long firstFree = (unsigned long long)lanes;
         HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 3, &firstFree, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
       } else if (regionsTotal > 0) {
         if (regionsTotal + (size_t)lanes * arenaBytes > idx->dArenas.n) throw std::runtime_error("internal error: scratch layout (hand-over)");
       } else {
-        idx->dArenas.ensure((size_t)lanes * arenaBytes);
+        if (!allocScratch((size_t)lanes * arenaBytes)) continue;
       }
+      sizing.unlock();
       const int pairLanes = (heavy && lpw <= 32 && !defer && !fullSync && pairMode) ? 1 : 0;  // two lanes per read (xm_extend.h, xmSetPairMode)
       uint8_t* laneArenas = idx->dArenas.p + regionsTotal;
       HandOver ho{hoMode, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
@@ -1472,7 +1582,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 2, &firstItem, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
       HIP_CHECK(hipEventRecord(e0, s));
-      hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, idx->view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
+      hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
                          laneArenas, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
                          defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
                          (heavy && !fullSync) ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, ((!heavy && lightSync) || (heavy && fullSync)) ? 1 : 0,
@@ -1534,7 +1644,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       if (pendingPath > 0) {  // (defer) run the waiting searches, then replay their reads
         const long long nPath = (long long)pendingPath;
         searchRounds++;
-        const long long pslots = (long long)idx->numCUs * 4 * pathWaves;
+        const long long pslots = (long long)numCUs * 4 * pathWaves;
         const int plpw = (int)std::max(1ll, std::min(64ll, (nPath + pslots - 1) / pslots));
         long long pl = std::min(pslots * plpw, scratchLanes(arenaBytes));
         if (pl > nPath) pl = nPath;
@@ -1658,7 +1768,8 @@ int xm_seed_probe(xm_index* idx, int64_t n, const int32_t* usedLength, const int
     int block = 256;
     int grid = (int)((n + block - 1) / block);
     HIP_CHECK(hipEventRecord(idx->ev0, s));
-    IndexView view = idx->view;
+    std::shared_lock<std::shared_mutex> tablesInUse(idx->dt->rw);
+    IndexView view = idx->dt->view;
     if (envInt("XM_PROBE_NO_LINES", 0) != 0) { view.lines32 = nullptr; view.lines64 = nullptr; }  // measurement: the CSR probe (two dependent accesses) on the same index
     if (n > 0 && view.lines64 && maxPerProbe > 0)
       hipLaunchKernelGGL((xm_seed_probe_lines_kernel<4>), dim3((unsigned)((n * 4 + block - 1) / block)), dim3(block), 0, s, view, (long long)n, dUsed.p, dKeys.p, (int)maxPerProbe, dCounts.p, dPos.p);
@@ -1719,7 +1830,9 @@ int xm_pileup_new(xm_index* idx, xm_pileup** out) {
     HIP_CHECK(hipSetDevice(idx->device));
     p = new xm_pileup();
     p->index = idx;
-    p->total = idx->host.totalForwardSize;
+    p->hs = idx->hs;
+    p->device = idx->device;
+    p->total = idx->host().totalForwardSize;
     p->dDepth.ensure((size_t)p->total); p->dAlt.ensure((size_t)p->total * 4); p->dEventCount.ensure(1);
     HIP_CHECK(hipMemset(p->dDepth.p, 0, sizeof(unsigned long long) * (size_t)p->total));
     HIP_CHECK(hipMemset(p->dAlt.p, 0, sizeof(unsigned long long) * (size_t)p->total * 4));
@@ -1747,7 +1860,8 @@ int xm_pileup_add_last(xm_pileup* p, int64_t* num_events) {
       HIP_CHECK(hipMemsetAsync(p->dEventCount.p, 0, sizeof(unsigned long long), s));
       BatchView bv{nq, idx->dMateCount.p, idx->dMateOffset.p, idx->dMateLength.p, idx->dCodes.p, idx->dExpected.p, idx->dDeviation.p};
       PileupView pv{p->dDepth.p, p->dAlt.p, p->total, p->dEvents.p, cap, p->dEventCount.p, p->queriesAdded};
-      hipLaunchKernelGGL(xm_pileup_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, idx->view, bv, (const int32_t*)idx->dFinalInts.p, (const int64_t*)idx->dFinalIntOff.p, pv);
+      std::shared_lock<std::shared_mutex> tablesInUse(idx->dt->rw);
+      hipLaunchKernelGGL(xm_pileup_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, idx->dt->view, bv, (const int32_t*)idx->dFinalInts.p, (const int64_t*)idx->dFinalIntOff.p, pv);
       HIP_CHECK(hipGetLastError());
       unsigned long long n = 0;
       HIP_CHECK(hipMemcpyAsync(&n, p->dEventCount.p, sizeof(n), hipMemcpyDeviceToHost, s));
@@ -1775,13 +1889,13 @@ int xm_pileup_add_last(xm_pileup* p, int64_t* num_events) {
 }
 
 int xm_pileup_read(xm_pileup* p, int32_t contig, int64_t first, int64_t n, uint64_t* depth, uint64_t* alt) {
-  if (!p || !p->index || !depth || !alt) return fail("xm_pileup_read: null argument");
-  xm_index* idx = p->index;
+  if (!p || !p->hs || !depth || !alt) return fail("xm_pileup_read: null argument");
   try {
-    std::lock_guard<std::mutex> lock(idx->mu);
-    if (contig < 0 || contig >= idx->host.numContigs() || first < 0 || n < 0 || first + n > idx->host.contigLen[(size_t)contig]) throw std::runtime_error("range outside of the contig");
-    HIP_CHECK(hipSetDevice(idx->device));
-    const size_t at = (size_t)idx->host.contigStart[(size_t)contig] + (size_t)first;
+    const HostIndex& host = p->hs->host;  // (the pile-up shares the reference with its index: it outlives the context it was made from)
+    if (contig < 0 || contig >= host.numContigs() || first < 0 || n < 0 || first + n > host.contigLen[(size_t)contig]) throw std::runtime_error("range outside of the contig");
+    HIP_CHECK(hipSetDevice(p->device));
+    HIP_CHECK(hipDeviceSynchronize());  // (adds of a context's stream that may still be running)
+    const size_t at = (size_t)host.contigStart[(size_t)contig] + (size_t)first;
     if (n) {
       HIP_CHECK(hipMemcpy(depth, p->dDepth.p + at, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
       for (int b = 0; b < 4; b++) HIP_CHECK(hipMemcpy(alt + (size_t)b * (size_t)n, p->dAlt.p + (size_t)b * (size_t)p->total + at, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
@@ -1801,7 +1915,7 @@ int64_t xm_pileup_events(xm_pileup* p, int64_t first, int64_t n, int64_t* out) {
 
 void xm_pileup_free(xm_pileup* p) {
   if (!p) return;
-  if (p->index) (void)hipSetDevice(p->index->device);
+  (void)hipSetDevice(p->device);
   p->dDepth.release(); p->dAlt.release(); p->dEventCount.release(); p->dEvents.release();
   delete p;
 }
@@ -1826,7 +1940,7 @@ int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_pa
     DevBuf<double> dDbls;
     DevBuf<int64_t> dStart;
     DevBuf<int32_t> dLen;
-    struct Release {  // (DevBuf has no destructor: the buffers of this call are released on every way out)
+    struct Release {  // (the buffers of this call are released on every way out)
       DevBuf<uint8_t>&a, &b, &c, &d; DevBuf<int32_t>&e; DevBuf<double>& f; DevBuf<int64_t>& g; DevBuf<int32_t>& h;
       ~Release() { a.release(); b.release(); c.release(); d.release(); e.release(); f.release(); g.release(); h.release(); }
     } releaseAll{dq, dr, arena, nodes, dInts, dDbls, dStart, dLen};

@@ -24,15 +24,30 @@ class MultiGpuDatabase:
             raise ValueError("at least one device")
         kw.pop("device", None)
         self.devices = [int(d) for d in devices]
-        # several contexts on one GPU (a repeated ordinal) share its HBM: a context sizes its scratch from XM_SCRATCH_GIB (default: up to 200 GiB),
-        # so the budget is divided between them unless the caller has set it.  Three contexts of 80 GiB align ~10 % more reads per second than
-        # one of 200 GiB (profiles/r02/NOTES.md): the waves of one context's gapped pass leave slots idle that another context's passes fill.
-        import os
-        most = max(self.devices.count(d) for d in set(self.devices))
-        if most > 1 and "XM_SCRATCH_GIB" not in os.environ:
-            os.environ["XM_SCRATCH_GIB"] = str(max(8, 240 // most))
+        # contexts of one GPU (a repeated ordinal) share the index's tables in its HBM (xm_context_new: no copy) and divide what is free after the
+        # index is resident as their scratch (api.divide_scratch; a GPU with room for fewer contexts than asked uses fewer).  Three contexts
+        # align ~10 % more reads per second than one (profiles/r02/NOTES.md): the waves of one context's gapped pass leave slots idle
+        # that another context's passes fill.
         first = api.ReferenceDatabase(contigs, device=self.devices[0], **kw)
-        self.replicas = [first] + [first.replicate(d) for d in self.devices[1:]]
+        by_device = {self.devices[0]: first}
+        self.replicas = [first]
+        for d in self.devices[1:]:
+            if d in by_device:
+                self.replicas.append(by_device[d].new_context())
+            else:
+                by_device[d] = first.replicate(d)
+                self.replicas.append(by_device[d])
+        keep = []
+        for d in by_device:
+            mine = [r for r, dd in zip(self.replicas, self.devices) if dd == d]
+            n = api.divide_scratch(mine, d)[0] if len(mine) > 1 else 1
+            keep += mine[:n]
+            for r in mine[n:]:
+                r.close()
+        order = {id(r): k for k, r in enumerate(self.replicas)}
+        keep.sort(key=lambda r: order[id(r)])
+        self.devices = [dd for r, dd in zip(self.replicas, self.devices) if any(r is k for k in keep)]
+        self.replicas = keep
         self.contigs = first.contigs
 
     def info(self):

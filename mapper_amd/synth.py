@@ -83,15 +83,16 @@ def _mutate_reads(ref, starts, strand, read_len, r_sub, r_indel, sub_rate, indel
     return out
 
 
-def synthetic_single_end(ref, n_reads, read_len=150, seed=0x5EED0001, sub_rate=0.01, indel_prob=0.05, chunk=200_000):
-    """Config 2: n_reads x read_len single-end reads. Returns (codes [n, read_len] uint8, starts, strand)."""
+def synthetic_single_end(ref, n_reads, read_len=150, seed=0x5EED0001, sub_rate=0.01, indel_prob=0.05, chunk=200_000, at=None):
+    """Config 2: n_reads x read_len single-end reads. Returns (codes [n, read_len] uint8, starts, strand).
+    at: template starts to use instead of drawing them (genome_wide_starts: reads sampled over a many-contig reference laid out in one array)."""
     outs, all_starts, all_strand = [], [], []
     span = read_len + 3
     for c0 in range(0, n_reads, chunk):
         n = min(chunk, n_reads - c0)
         base = np.uint64(seed) + np.uint64(c0) * np.uint64(0x1000003)
         r0 = splitmix64(base, 2 * n)
-        starts = (r0[:n] % np.uint64(len(ref) - span)).astype(np.int64)
+        starts = (r0[:n] % np.uint64(len(ref) - span)).astype(np.int64) if at is None else np.asarray(at[c0:c0 + n], dtype=np.int64)
         strand = (r0[n:] >> np.uint64(63)).astype(np.uint8)
         r_sub = splitmix64(base ^ np.uint64(0xA5A5A5A5), n * span)
         r_ind = splitmix64(base ^ np.uint64(0x5A5A5A5A), n * 4)
@@ -101,9 +102,10 @@ def synthetic_single_end(ref, n_reads, read_len=150, seed=0x5EED0001, sub_rate=0
     return np.concatenate(outs), np.concatenate(all_starts), np.concatenate(all_strand)
 
 
-def synthetic_paired_end(ref, n_pairs, read_len=150, seed=0x5EED0002, sub_rate=0.01, indel_prob=0.05, chunk=200_000):
+def synthetic_paired_end(ref, n_pairs, read_len=150, seed=0x5EED0002, sub_rate=0.01, indel_prob=0.05, chunk=200_000, at=None):
     """Config 3: FR pairs, inner distance round(N(100, 30^2)) clipped to [-100, 400]; mate 2 is the reverse
-    complement strand (Illumina FR).  Returns (mate1 [n, L], mate2 [n, L], starts1, inner, strand)."""
+    complement strand (Illumina FR).  Returns (mate1 [n, L], mate2 [n, L], starts1, inner, strand).
+    at: fragment starts to use instead of drawing them (a fragment spans at most 2 * read_len + 400 + 3 bases)."""
     m1s, m2s, st, inn, sd = [], [], [], [], []
     span = read_len + 3
     for c0 in range(0, n_pairs, chunk):
@@ -115,7 +117,7 @@ def synthetic_paired_end(ref, n_pairs, read_len=150, seed=0x5EED0002, sub_rate=0
         z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2 * np.pi * u2)
         inner = np.clip(np.rint(100 + 30 * z), -100, 400).astype(np.int64)
         frag = 2 * read_len + inner
-        starts1 = (r0[2 * n:3 * n] % np.uint64(len(ref) - 2 * read_len - 400 - span)).astype(np.int64)
+        starts1 = (r0[2 * n:3 * n] % np.uint64(len(ref) - 2 * read_len - 400 - span)).astype(np.int64) if at is None else np.asarray(at[c0:c0 + n], dtype=np.int64)
         strand = (r0[3 * n:] >> np.uint64(63)).astype(np.uint8)
         starts2 = starts1 + frag - read_len
         z8 = np.zeros(n, dtype=np.uint8)
@@ -128,3 +130,124 @@ def synthetic_paired_end(ref, n_pairs, read_len=150, seed=0x5EED0002, sub_rate=0
         b2 = np.where(rev[:, None], a, b)
         m1s.append(a2); m2s.append(b2); st.append(starts1); inn.append(inner); sd.append(strand)
     return np.concatenate(m1s), np.concatenate(m2s), np.concatenate(st), np.concatenate(inn), np.concatenate(sd)
+
+
+def _parallel(fn, items, workers=None):
+    """fn over items on a few threads (numpy releases the GIL in the array passes these generators are made of)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    workers = workers or max(1, min(16, (os.cpu_count() or 2) // 2))
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(fn, items))
+
+
+# ---------------------------------------------------------------- configs[3] / configs[4]: the GRCh38-shaped reference of SURVEY.md section 8(d)
+# chr1..chr22, chrX, chrY of GRCh38 (primary assembly): 3,088,269,832 bases in 24 contigs
+GRCH38_LENGTHS = (248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622, 133275309,
+                  114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415)
+GRCH38_NAMES = tuple("chr%d" % i for i in range(1, 23)) + ("chrX", "chrY")
+
+
+def grch38_shaped_reference(scale=1.0, seed=0x6C38, n_fraction=0.01, n_run=10_000, chunk=50_000_000):
+    """24 contigs with the real chromosome lengths (times `scale`, for tests that want the shape at a size an
+    oracle can hash), i.i.d. uniform ACGT, and `n_fraction` of the positions in runs of `n_run` N (one run at a seeded place in each of a contig's
+    equal segments).  Returns (contigs, whole, starts, runs): contigs = [(name, view into whole)], starts[c] = offset of contig c in `whole`,
+    runs[c] = sorted starts of the N-runs of contig c.  `whole` is one array so that reads can be sampled genome-wide with one gather."""
+    lengths = [max(int(n * scale), 4 * n_run if n_fraction > 0 else 1000) for n in GRCH38_LENGTHS]
+    total = int(sum(lengths))
+    whole = np.empty(total, dtype=np.uint8)
+    starts = np.zeros(len(lengths) + 1, dtype=np.int64)
+    starts[1:] = np.cumsum(lengths)
+    def fill(o):
+        n = min(chunk, total - o)
+        whole[o:o + n] = synthetic_reference(n, seed=seed + 0x9E37 * (o // chunk))
+    _parallel(fill, range(0, total, chunk))
+    contigs, runs = [], []
+    for c, n in enumerate(lengths):
+        view = whole[starts[c]:starts[c + 1]]
+        k = int(round(n * n_fraction / n_run)) if n_fraction > 0 else 0
+        rs = np.zeros(k, dtype=np.int64)
+        if k > 0:
+            seg = n // k
+            r = splitmix64(seed ^ (0xA11CE + 7919 * c), k)
+            rs = np.arange(k, dtype=np.int64) * seg + (r % np.uint64(max(seg - n_run, 1))).astype(np.int64)
+            for s in rs:
+                view[s:s + n_run] = 15
+        contigs.append((GRCH38_NAMES[c], view))
+        runs.append(rs)
+    return contigs, whole, starts, runs
+
+
+def genome_wide_starts(starts, runs, n, span, seed, n_run=10_000):
+    """n template starts (global offsets into `whole`) drawn uniformly over the genome; a template of `span` bases that would cross a contig end or
+    touch an N-run is moved to the first place behind the obstacle where it fits (reads come from sequenced DNA: no N inside them).
+    Returns (global starts, contig of each, start within the contig)."""
+    total = int(starts[-1])
+    g = (splitmix64(seed, n) % np.uint64(total)).astype(np.int64)
+    contig = np.searchsorted(starts, g, side="right") - 1
+    local = g - starts[contig]
+    for c in np.unique(contig):
+        sel = np.nonzero(contig == c)[0]
+        clen = int(starts[c + 1] - starts[c])
+        x = np.minimum(local[sel], clen - span)
+        rs = runs[c]
+        for _ in range(3):  # (moving behind one run can land on nothing else: runs are a segment apart; the loop is belt and braces)
+            if len(rs) == 0:
+                break
+            j = np.searchsorted(rs, x + span - 1, side="right") - 1   # last run starting at or before the template's end
+            hit = (j >= 0) & (rs[np.maximum(j, 0)] + n_run > x)
+            x = np.where(hit, rs[np.maximum(j, 0)] + n_run, x)
+            over = x > clen - span
+            x = np.where(over, np.maximum(rs[np.maximum(j, 0)] - span, 0), x)
+        local[sel] = x
+    return starts[contig] + local, contig, local
+
+
+def synthetic_long_reads(whole, gstarts, read_len=10_000, seed=0x5EED0004, sub_rate=0.05, indel_rate=0.05, strand=None):
+    """configs[4]'s long reads: per base a substitution with probability sub_rate and an indel EVENT (insertion or deletion, fair, of 1-3 bases)
+    with probability indel_rate.  (SURVEY.md section 8(d) says "5 % substitution + 5 % indel (long-read-like)"; read per base, as here, such reads carry
+    ~15 penalty units per 100 bases against the default --max-penalty of 10 per 100, so the reference aligns almost none of them: the tests use these
+    rates for the config as stated and milder ones to see reads come home.)  Template = whole[g : g + read_len * 1.25]; returns codes [n, read_len]."""
+    n = len(gstarts)
+    span = read_len + read_len // 4 + 8
+    out = np.empty((n, read_len), dtype=np.uint8)
+    thr_sub = np.uint32(min(int(sub_rate * 2**32), 2**32 - 1))
+    thr_indel = np.uint32(min(int(indel_rate * 2**32), 2**32 - 1))
+    gstarts = np.asarray(gstarts, dtype=np.int64)
+    batch = 128
+
+    def some(b0):  # `batch` reads at once, their templates laid end to end (every pass below is one array operation over all of them)
+        m = min(batch, n - b0)
+        t = whole[(gstarts[b0:b0 + m, None] + np.arange(span)[None, :]).reshape(-1)]
+        T = len(t)
+        r = splitmix64(np.uint64(seed) + np.uint64(b0) * np.uint64(0x1000003), 2 * T)
+        ra, rb = r[:T], r[T:]
+        do_sub = ((ra >> np.uint64(32)).astype(np.uint32) < thr_sub) & (t != 15)
+        which = ((ra & np.uint64(0xFFFF)) % np.uint64(3)).astype(np.int64) + 1
+        idx = np.log2(np.where(t == 15, 1, t)).astype(np.int64)
+        t = np.where(do_sub, _CODES[(idx + which) & 3], t)
+        ev = (rb >> np.uint64(32)).astype(np.uint32) < thr_indel
+        is_ins = ((rb >> np.uint64(8)) & np.uint64(1)).astype(bool)
+        ln = ((rb >> np.uint64(9)) % np.uint64(3)).astype(np.int64) + 1
+        ins = np.where(ev & is_ins, ln, 0)          # bases inserted in front of template base j
+        dele = np.zeros(T + 4, dtype=np.int64)      # a deletion event at j drops bases j .. j + ln - 1 (the tail of a template is never reached)
+        for L in (1, 2, 3):
+            at = np.nonzero(ev & ~is_ins & (ln == L))[0]
+            for k in range(L):
+                dele[at + k] = 1
+        count = ins + (1 - dele[:T])
+        ends = np.cumsum(count)
+        src = np.repeat(np.arange(T), count)
+        within = np.arange(len(src)) - (ends - count)[src]
+        inserted = within < ins[src]
+        rnd = _CODES[((rb[src] >> (np.uint64(12) + np.uint64(2) * within.astype(np.uint64))) & np.uint64(3)).astype(np.int64)]
+        seq = np.where(inserted, rnd, t[src])
+        first = np.concatenate([[0], ends[span - 1::span][:-1]])  # where each read's bases start in `seq`
+        if ((ends[span - 1::span] - first) < read_len).any():
+            raise ValueError("template too short for the requested indel rate")
+        out[b0:b0 + m] = seq[first[:, None] + np.arange(read_len)[None, :]]
+    _parallel(some, range(0, n, batch))
+    if strand is not None:
+        rev = strand.astype(bool)
+        out[rev] = _COMP[out[rev][:, ::-1]]
+    return out

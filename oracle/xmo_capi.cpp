@@ -121,6 +121,9 @@ int xmo_ref_add_contig_codes(void* r, const char* name, const uint8_t* codes, in
 int xmo_ref_finish(void* r, int mode, int enableGapmers) {
   try { ((ReferenceDatabase*)r)->finish(mode == 1, enableGapmers != 0); return 0; } catch (std::exception& e) { g_error = e.what(); return 1; }
 }
+int xmo_ref_finish_min_interesting(void* r, int mode, int enableGapmers, int minInterestingSize) {
+  try { ((ReferenceDatabase*)r)->finish(mode == 1, enableGapmers != 0, minInterestingSize); return 0; } catch (std::exception& e) { g_error = e.what(); return 1; }
+}
 int xmo_ref_finish_custom_dup(void* r, int minDup, int maxDup, int copies, int window) {
   try { ((ReferenceDatabase*)r)->finishCustomDup(minDup, maxDup, copies, window); return 0; } catch (std::exception& e) { g_error = e.what(); return 1; }
 }

@@ -28,11 +28,13 @@ struct ReferenceDatabase {  // M/ReferenceDatabase.java + M/Api.java:41-69 / M/M
 
   // apiMode=true:  Api.newDatabase (HashBlock_Database(refSequences), duplication window 1)
   // apiMode=false: Mapper.run      (hint max = chooseMaxDuplicationLength, duplication window 1000)
-  void finish(bool apiMode, bool enableGapmers = true) {
+  // minInterestingSize > 0: the constructor argument of M/HashBlock_Database.java:34 (tests force the 13 a 3 Gb reference gets, :52, on a
+  // reference the oracle can hash)
+  void finish(bool apiMode, bool enableGapmers = true, int minInterestingSize = -1) {
     int minDup = HashBlock_Database::chooseMinDuplicationLength(sequences);
     int maxDup = HashBlock_Database::chooseMaxDuplicationLength(sequences);
-    if (apiMode) hashblockDatabase.reset(new HashBlock_Database(&sequences, -1, -1, -1, enableGapmers));
-    else hashblockDatabase.reset(new HashBlock_Database(&sequences, -1, maxDup, -1, enableGapmers));
+    if (apiMode) hashblockDatabase.reset(new HashBlock_Database(&sequences, minInterestingSize, -1, -1, enableGapmers));
+    else hashblockDatabase.reset(new HashBlock_Database(&sequences, minInterestingSize, maxDup, -1, enableGapmers));
     duplicationDetector.reset(new DuplicationDetector(hashblockDatabase.get(), minDup, maxDup, 2, apiMode ? 1 : 1000));
   }
   // SamWriter_Test-style assembly: DuplicationDetector(db, 1, 2, 2, 1)

@@ -84,6 +84,7 @@ def lib():
         L.xmo_ref_add_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.xmo_ref_add_contig_codes.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
         L.xmo_ref_finish.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.xmo_ref_finish_min_interesting.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.xmo_ref_finish_custom_dup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.xmo_ref_require_size.argtypes = [C.c_void_p, C.c_int]
         L.xmo_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -182,7 +183,7 @@ class Streams:
 
 
 class OracleReference:
-    def __init__(self, contigs, mode="mapper", enable_gapmers=True, custom_dup=None):
+    def __init__(self, contigs, mode="mapper", enable_gapmers=True, custom_dup=None, min_interesting_size=-1):
         """contigs: list of (name, text-or-codes) in the order Mapper.sortAndComplementReference would produce."""
         self.L = lib()
         self.h = C.c_void_p(self.L.xmo_ref_new())
@@ -193,6 +194,8 @@ class OracleReference:
             self.L.xmo_ref_add_contig_codes(self.h, name.encode(), codes.ctypes.data, len(codes))
         if custom_dup:
             rc = self.L.xmo_ref_finish_custom_dup(self.h, *custom_dup)
+        elif min_interesting_size > 0:  # HashBlock_Database's constructor argument (HashBlock_Database.java:34), as a 3 Gb reference would derive it (:52)
+            rc = self.L.xmo_ref_finish_min_interesting(self.h, 1 if mode == "api" else 0, 1 if enable_gapmers else 0, int(min_interesting_size))
         else:
             rc = self.L.xmo_ref_finish(self.h, 1 if mode == "api" else 0, 1 if enable_gapmers else 0)
         if rc:

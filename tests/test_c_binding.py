@@ -28,7 +28,7 @@ def build():
 def test_plain_c_program_links_every_entry_point():
     exe = build()
     out = subprocess.run([exe, "symbols"], capture_output=True, text=True)
-    assert out.returncode == 0 and out.stdout.startswith("symbols 27 stamp "), out.stdout + out.stderr
+    assert out.returncode == 0 and out.stdout.startswith("symbols 30 stamp "), out.stdout + out.stderr
 
 
 def test_error_contract_from_c():
@@ -43,7 +43,7 @@ def test_jni_shim_is_complete_source():
     JNI entry point, and both parts compile as C99 (the JNI part is syntax-checked only where a jni.h exists)."""
     src = open(os.path.join(ROOT, "bindings", "java", "xmapper_jni.c")).read()
     java = open(os.path.join(ROOT, "bindings", "java", "mapper", "NativeAligner.java")).read()
-    for name in ("buildIndex", "freeIndex", "alignBatch"):
+    for name in ("buildIndex", "newContext", "freeIndex", "alignBatch"):
         assert "native" in java and name in java
         assert "Java_mapper_NativeAligner_" + name in src
     assert "/* pin each" not in src and "..." not in src.split("part 2")[1]

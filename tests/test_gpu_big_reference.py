@@ -1,97 +1,149 @@
-"""GRCh38-scale property test (BASELINE.json configs[3] / configs[4] live on such a reference; no oracle finishes at this size): 2.3 G bases in ten
-contigs = more than 2^32 encoded positions, so the index takes the paths a 5 Mb reference never takes - 64-bit position arrays on the device,
-64-byte bucket lines, tables hashed on the GPU in groups.  Properties: reads sampled from known places come back to them (contig, strand, offset);
-the same batch aligned twice gives the same streams (determinism); a query's result does not depend on the batch it travels in (batch invariance);
-pairs (--spacing 100 50) come back with both mates at their origins; the bucket-line probe and the CSR probe return the same positions."""
-import os
+"""BASELINE.json configs[3] and configs[4] on one GPU, on the reference SURVEY.md section 8(d) states for them: synthetic 3.1 Gb in 24 contigs with the
+real GRCh38 chromosome lengths, i.i.d. ACGT, 1 % of the positions in N-runs of 10 kb, seed 0x6C38 (mapper_amd/synth.py::grch38_shaped_reference).  No
+oracle finishes at this size (the oracle checks the same regime - minInterestingSize 13, several contigs, N-runs - on a 15 Mb reference of the same
+shape: tests/test_gpu_parity.py::test_grch38_regime_alignments_equal_oracle), so the checks are properties:
+  * configs[3]: 1,000,000 pairs 2 x 150 bp sampled genome-wide (seed 0x5EED0003, --spacing 100 50) come back as pairs with both mates at their origins;
+  * configs[4]: 100,000 reads of 10 kb (seed 0x5EED0004) cut by --split-queries-past-size 1000 (the command line's splitter, SequenceSplitter.java:17,35-38)
+    into 1,000,000 queries of 1 kb: with the error rates as stated (5 % substitutions + 5 % indel events per base: above --max-penalty, almost nothing
+    aligns) and with milder ones (2 % + 0.2 %), every section that aligns sits where it came from;
+  * determinism (the same batch twice gives the same streams) and batch invariance (a query's result does not depend on the batch it travels in);
+  * the index takes the paths a 5 Mb reference never takes: 64-bit position arrays, 64-byte bucket lines, tables hashed on the GPU in groups with the
+    multi blocks around the N-runs from the host; the bucket-line probe and the CSR probe return the same positions.
+The 8-GPU sharding of these configs (index replicated, batches dealt to GPUs) is what tests/test_multi_gpu.py and tests/test_multirank.py cover."""
 import numpy as np
 import pytest
 
-from helpers import se_batch, pe_batch, streams_equal
-from mapper_amd import api, synth
-
-NC, CLEN = 10, 230_000_000
-MB = 1_000_000
+from helpers import pe_batch, streams_equal
+import oracle_lib
+from mapper_amd import api, cli, synth
 
 
 @pytest.fixture(scope="module")
-def big():
-    """Ten contigs of 230 M bases; every megabase holds a run of 10,000 N at its middle (1 % of the reference, the shape SURVEY.md section 8(d) gives
-    config 4), so the index is built the way GRCh38's is: blocks clear of the N-runs hashed on the GPU, the multi blocks at their ends by the host."""
-    contigs = []
-    for c in range(NC):
-        parts = [synth.synthetic_reference(min(50_000_000, CLEN - o), seed=0xB16 + 1000 * c + o // 50_000_000) for o in range(0, CLEN, 50_000_000)]
-        text = np.concatenate(parts)
-        runs = text[: (CLEN // MB) * MB].reshape(-1, MB)
-        runs[:, 500_000:510_000] = 15
-        contigs.append(("chr%02d" % c, text))
-    db = api.ReferenceDatabase(contigs, max_query_length=150)
-    yield contigs, db
+def grch():
+    contigs, whole, starts, runs = synth.grch38_shaped_reference()
+    db = api.ReferenceDatabase(contigs, max_query_length=1000)
+    yield contigs, whole, starts, runs, db
     db.close()
 
 
-def sample_reads(contig, per, seed):
-    """Reads from the first 400 kb of 25 megabases spread over the contig (clear of the N-runs): (reads, starts in the contig, strands)."""
-    reads, starts, strands = [], [], []
-    for k, mb in enumerate(range(3, CLEN // MB, (CLEN // MB) // 25)[:25]):
-        r, st, sd = synth.synthetic_single_end(contig[mb * MB: mb * MB + 400_000], per // 25, seed=seed + k)
-        reads.append(r); starts.append(st + mb * MB); strands.append(sd)
-    return np.concatenate(reads), np.concatenate(starts), np.concatenate(strands)
-
-
 def first_alignment(r):
-    """Per query: (has exactly >= 1 alignment, contig, reversed, startB - startA) of the first sequence of the first alignment."""
+    """Per query with at least one alignment: (mask, contig, reversed, startB - startA) of the first sequence of the first alignment."""
     io = r.int_off[:-1]
-    one = r.ints[io + 1] >= 1
+    one = (r.ints[io] >= 1) & (r.ints[np.minimum(io + 1, len(r.ints) - 1)] >= 1)
     idx = io[one]
     return one, r.ints[idx + 4], r.ints[idx + 5], r.ints[idx + 8] - r.ints[idx + 7]
 
 
+def arrays(b):
+    return (b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation)
+
+
 @pytest.mark.gpu
-def test_big_reference_properties(big):
-    contigs, db = big
+def test_config3_pairs_on_the_grch38_shaped_reference(grch):
+    contigs, whole, starts, runs, db = grch
     info = db.info()
-    assert info["position_bytes"] == 8 and info["total_forward_size"] == NC * CLEN and info["built_on_device"] == 1  # (N-runs and all)
+    assert info["num_contigs"] == 24 and info["total_forward_size"] == sum(synth.GRCH38_LENGTHS) == 3_088_269_832
+    assert info["position_bytes"] == 8 and info["built_on_device"] == 1 and info["min_interesting_size"] == 13  # HashBlock_Database.java:52
+    assert abs(float((whole[:50_000_000] == 15).mean()) - 0.01) < 0.002
     params = api.AlignmentParameters()
-    per = 20_000
-    reads, where = [], []
-    for c in (0, NC // 2, NC - 1):
-        r, starts, strand = sample_reads(contigs[c][1], per, seed=0x5EED + 100 * c)
-        reads.append(r)
-        where.append(np.stack([np.full(per, c), starts, strand], axis=1))
-    reads, where = np.concatenate(reads), np.concatenate(where)
-    b = se_batch(reads)
-    arrays = (b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation)
-    r1 = db.align_arrays(*arrays, params)
-    one, contig, rev, off = first_alignment(r1)
-    assert one.mean() > 0.99
-    ok = (contig == where[one, 0]) & (rev == where[one, 2]) & (np.abs(off - where[one, 1]) <= 3)
-    assert ok.mean() > 0.99
-    # determinism
-    r2 = db.align_arrays(*arrays, params)
-    assert streams_equal(r1, r2)
-    # batch invariance: a slice from the middle, aligned on its own
-    lo, hi = 25_000, 27_000
-    sb = se_batch(reads[lo:hi])
-    r3 = db.align_arrays(sb.mate_count, sb.mate_offset, sb.mate_length, sb.codes, sb.expected_inner, sb.deviation, params)
-    assert np.array_equal(r3.ints, r1.ints[r1.int_off[lo]:r1.int_off[hi]]) and np.array_equal(r3.dbls.view(np.int64), r1.dbls[r1.dbl_off[lo]:r1.dbl_off[hi]].view(np.int64))
-    # pairs from the last contig (the highest encoded positions: beyond 2^32)
-    m1, m2, starts1, inner, strand = synth.synthetic_paired_end(contigs[NC - 1][1][200 * MB: 200 * MB + 400_000], 10_000, seed=0x9A1)
+    n = 1_000_000
+    frag = 2 * 150 + 400 + 3 + 153
+    g, contig, local = synth.genome_wide_starts(starts, runs, n, frag, seed=0x5EED0003 ^ 0xF00D)
+    m1, m2, starts1, inner, strand = synth.synthetic_paired_end(whole, n, seed=0x5EED0003, at=g)
     pb = pe_batch(m1, m2, 100.0, 50.0)
-    rp = db.align_arrays(pb.mate_count, pb.mate_offset, pb.mate_length, pb.codes, pb.expected_inner, pb.deviation, params)
-    io = rp.int_off[:-1]
-    paired = (rp.ints[io] == 1) & (rp.ints[io + 1] >= 1) & (rp.ints[io + 3] == 2)
+    r1 = db.align_arrays(*arrays(pb), params)
+    io = r1.int_off[:-1]
+    paired = (r1.ints[io] == 1) & (r1.ints[io + 1] >= 1) & (r1.ints[io + 3] == 2)
     assert paired.mean() > 0.97
-    assert (rp.ints[io[paired] + 4] == NC - 1).mean() > 0.999
+    # both mates on the fragment's contig; the first sequence alignment is mate 1's: it starts where the fragment starts (forward fragment) or where
+    # its right end lies (reverse fragment), give or take the read's own indel
+    idx = io[paired]
+    assert (r1.ints[idx + 4] == contig[paired]).mean() > 0.999
+    off1 = r1.ints[idx + 8] - r1.ints[idx + 7]
+    want = np.where(strand[paired] == 0, local[paired], local[paired] + 150 + inner[paired])
+    assert (np.abs(off1 - want) <= 3).mean() > 0.995
+    # determinism, on a part of the batch (the whole batch again would only repeat the minute)
+    sl = slice(400_000, 460_000)
+    sb = pe_batch(m1[sl], m2[sl], 100.0, 50.0)
+    r2 = db.align_arrays(*arrays(sb), params)
+    r3 = db.align_arrays(*arrays(sb), params)
+    assert streams_equal(r2, r3)
+    # batch invariance: the same queries inside the big batch
+    lo, hi = sl.start, sl.stop
+    assert np.array_equal(r2.ints, r1.ints[r1.int_off[lo]:r1.int_off[hi]]) and np.array_equal(r2.dbls.view(np.int64), r1.dbls[r1.dbl_off[lo]:r1.dbl_off[hi]].view(np.int64))
+    c = r1.counters
+    print("configs[3] shape on one GPU: %d pairs, kernel %.1f ms, %.1f header probes and %.1f hits per pair, %.2f %% paired" % (n, r1.kernel_ms, c[1] / n, c[3] / n, 100 * paired.mean()))
+
+
+def split_batch(reads, size):
+    """--split-queries-past-size `size` over reads [n, L]: the sections the command line makes (cli.split_sections), as one batch without copying bases."""
+    n, L = reads.shape
+    sections = cli.split_sections(L, size)
+    k = len(sections)
+    a = np.array([s for s, _ in sections], dtype=np.int64)
+    ln = np.array([e - s for s, e in sections], dtype=np.int32)
+    nq = n * k
+    mo = np.zeros(2 * nq, np.int64)
+    mo[0::2] = (np.arange(n, dtype=np.int64)[:, None] * L + a[None, :]).reshape(-1)
+    ml = np.zeros(2 * nq, np.int32)
+    ml[0::2] = np.tile(ln, n)
+    b = oracle_lib.QueryBatch.from_arrays(np.ones(nq, np.int32), mo, ml, np.ascontiguousarray(reads.reshape(-1)), np.zeros(nq), np.ones(nq))
+    return b, a, k
 
 
 @pytest.mark.gpu
-def test_bucket_lines_equal_csr_probes_on_the_big_index(big, monkeypatch):
-    _, db = big
+def test_config4_long_reads_through_the_splitter(grch):
+    contigs, whole, starts, runs, db = grch
+    params = api.AlignmentParameters()
+    L = 10_000
+    span = L + L // 4 + 8
+    assert cli.split_sections(L, 1000) == [(1000 * k, 1000 * (k + 1)) for k in range(10)] and cli.split_sections(2500, 1000) == [(0, 833), (833, 1666), (1666, 2500)]
+    # (a) the config as stated: 100,000 reads, 5 % substitutions + 5 % indel events per base -> 1,000,000 queries of 1,000 bases
+    n = 100_000
+    g, contig, local = synth.genome_wide_starts(starts, runs, n, span, seed=0x5EED0004 ^ 0xF00D)
+    strand = (synth.splitmix64(0x5EED0004 ^ 0x57A, n) >> np.uint64(63)).astype(np.uint8)
+    reads = synth.synthetic_long_reads(whole, g, L, seed=0x5EED0004, sub_rate=0.05, indel_rate=0.05, strand=strand)
+    b, a, k = split_batch(reads, 1000)
+    r1 = db.align_arrays(*arrays(b), params)
+    one, ctg, rev, off = first_alignment(r1)
+    q = np.nonzero(one)[0]
+    # a section that aligns at all sits on its read's contig and strand, within the drift its indels allow (a read's sections share its origin)
+    if len(q):
+        read = q // k
+        assert (ctg == contig[read]).mean() > 0.99 and (rev == strand[read]).mean() > 0.99
+    frac_stated = one.mean()
+    sl = slice(300_000, 320_000)
+    sb = oracle_lib.QueryBatch.from_arrays(b.mate_count[sl], b.mate_offset[2 * sl.start:2 * sl.stop], b.mate_length[2 * sl.start:2 * sl.stop], b.codes, b.expected_inner[sl], b.deviation[sl])
+    r2 = db.align_arrays(*arrays(sb), params)
+    assert np.array_equal(r2.ints, r1.ints[r1.int_off[sl.start]:r1.int_off[sl.stop]]) and np.array_equal(r2.dbls.view(np.int64), r1.dbls[r1.dbl_off[sl.start]:r1.dbl_off[sl.stop]].view(np.int64))
+    # (b) reads a long-read aligner would be given after polishing: 2 % substitutions, 0.2 % indel events per base: the sections come home
+    n2 = 20_000
+    reads2 = synth.synthetic_long_reads(whole, g[:n2], L, seed=0x5EED0004 + 1, sub_rate=0.02, indel_rate=0.002, strand=strand[:n2])
+    b2, a2, _ = split_batch(reads2, 1000)
+    r3 = db.align_arrays(*arrays(b2), params)
+    one2, ctg2, rev2, off2 = first_alignment(r3)
+    assert one2.mean() > 0.9
+    q2 = np.nonzero(one2)[0]
+    read2, sec2 = q2 // k, q2 % k
+    # where a section came from in its contig: forward reads: local + a (+- the indels before it); reverse reads: the read is the reverse
+    # complement of the template's first ~L bases, so section j of it covers template [L' - a_j - 1000, L' - a_j) with L' within the indel drift of L
+    fwd = strand[read2] == 0
+    want = np.where(fwd, local[read2] + a2[sec2], local[read2] + (L - a2[sec2] - 1000))
+    assert (ctg2 == contig[read2]).mean() > 0.999 and (rev2 == strand[read2]).mean() > 0.999
+    assert (np.abs(off2 - want) <= 120).mean() > 0.99
+    r4 = db.align_arrays(*arrays(b2), params)
+    assert streams_equal(r3, r4)
+    print("configs[4] shape on one GPU: %d queries of 1 kb as stated (%.2f %% aligned), kernel %.1f ms; %d milder ones (%.1f %% aligned), kernel %.1f ms" %
+          (len(one), 100 * frac_stated, r1.kernel_ms, len(one2), 100 * one2.mean(), r3.kernel_ms))
+
+
+@pytest.mark.gpu
+def test_bucket_lines_equal_csr_probes_on_the_big_index(grch, monkeypatch):
+    db = grch[4]
     info = db.info()
     rng = np.random.default_rng(99)
     n = 2_000_000
-    used = rng.integers(info["min_interesting_size"], info["max_hashed_length"] + 1, size=n, dtype=np.int32)
+    used = rng.integers(info["min_interesting_size"], 151, size=n, dtype=np.int32)
     keys = rng.integers(-2**31, 2**31 - 1, size=n, dtype=np.int64).astype(np.int32)
     monkeypatch.setenv("XM_PROBE_NO_LINES", "1")
     c0, p0, _ = db.seed_probe(used, keys, 8)

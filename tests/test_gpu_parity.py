@@ -401,3 +401,41 @@ def test_full_size_properties():
     want = R.align(se_batch(reads[:n]), o.make_params(), threads=os.cpu_count())
     assert np.array_equal(want.ints, a1.ints[:a1.int_off[n]]) and np.array_equal(want.dbls.view(np.int64), a1.dbls[:a1.dbl_off[n]].view(np.int64))
     db.close()
+
+
+def test_grch38_regime_alignments_equal_oracle():
+    """The regime of the walk a 3 Gb reference puts the path in, against the oracle: minInterestingSize = 13 (HashBlock_Database.java:52; passed as the
+    constructor argument of :34 on both sides, as the reference itself would derive it from 3.1 G bases) changes which tables exist and how
+    HashBlockPath.advanceToNextPosition moves (HashBlockPath.java:143-195).  Reference: the GRCh38-shaped one of SURVEY.md section 8(d) at 1/200 of its
+    size (24 contigs, 15 Mb, N-runs of 10 kb; synth.grch38_shaped_reference) - what the oracle can hash; 64-bit position arrays forced as a 3 Gb
+    index has them.  150 bp reads, pairs (--spacing 100 50) and 1 kb reads sampled genome-wide: streams bit for bit, work counters equal."""
+    contigs, whole, starts, runs = synth.grch38_shaped_reference(scale=0.005)
+    assert len(contigs) == 24 and sum(len(r) for r in runs) >= 10
+    os.environ["XM_FORCE_POS64"] = "1"
+    try:
+        db = api.ReferenceDatabase(contigs, max_query_length=1000, min_interesting_size=13)
+    finally:
+        del os.environ["XM_FORCE_POS64"]
+    info = db.info()
+    assert info["min_interesting_size"] == 13 and info["position_bytes"] == 8 and info["built_on_device"] == 1
+    R = o.OracleReference(contigs, min_interesting_size=13)
+    params, oparams = api.AlignmentParameters(), o.make_params()
+    batches = {}
+    g, _, _ = synth.genome_wide_starts(starts, runs, 6000, 153, seed=0x13A)
+    batches["150 bp"] = se_batch(synth.synthetic_single_end(whole, 6000, seed=0x13B, indel_prob=0.3, at=g)[0])
+    g, _, _ = synth.genome_wide_starts(starts, runs, 3000, 900, seed=0x13C)
+    m1, m2 = synth.synthetic_paired_end(whole, 3000, seed=0x13D, indel_prob=0.2, at=g)[:2]
+    batches["pairs"] = pe_batch(m1, m2, 100.0, 50.0)
+    g, _, _ = synth.genome_wide_starts(starts, runs, 400, 1003, seed=0x13E)
+    batches["1 kb"] = se_batch(synth.synthetic_single_end(whole, 400, read_len=1000, seed=0x13F, indel_prob=0.3, at=g)[0])
+    # reads that touch an N-run: the templates start just in front of runs
+    near = np.concatenate([starts[c] + runs[c][:2] - 100 for c in range(24) if len(runs[c])])
+    batches["at N-runs"] = se_batch(synth.synthetic_single_end(whole, len(near), seed=0x140, at=near)[0])
+    for name, b in batches.items():
+        got, _ = gpu_align(db, b, params)
+        want = R.align(b, oparams, threads=os.cpu_count())
+        assert streams_equal(got, want), name + ": " + str(first_difference(got, want, b.nq))
+        wc = [int(x) for x in want.counters[:9]]  # (the oracle counts probes and fetches apart; compared as bench.py compares them)
+        assert [int(x) for x in got.counters[:8]] == [wc[0], wc[1] + wc[2], wc[2], wc[3], wc[5], wc[6], wc[7], wc[8]], name
+    assert R.index_info()[0] == 13
+    db.close()

@@ -106,3 +106,66 @@ def test_cli_gpus_flag(tmp_path):
         assert cli.run(["--reference", str(tmp_path / "ref.fasta"), "--queries", str(tmp_path / "reads.fastq"), "--out-sam", str(sam_path)] + extra, out=buf) == 0
         outs.append((open(sam_path).read(), buf.getvalue()))
     assert outs[0] == outs[1] == outs[2] and outs[0][0].count("\n") > 600
+
+
+@pytest.mark.gpu
+def test_contexts_share_one_index():
+    """xm_context_new (SURVEY.md section 8(b) "Threading"; HashBlock_Database.java:129-133, Mapper.java:1026-1040): contexts of one index read the same
+    tables - no second copy in host memory or in HBM - align at the same time from their own host threads with the results one context gives alone,
+    see the tables any of them grows, and are freed in any order."""
+    import psutil
+    ref = synth.synthetic_reference(40_000_000, seed=0xC0)
+    first = api.ReferenceDatabase([("r", ref)], device=0, max_query_length=150)
+    index_bytes = first.info()["index_bytes"]
+    assert index_bytes > 300 << 20
+    proc = psutil.Process()
+    free0, rss0 = api.device_memory(0)[0], proc.memory_info().rss
+    ctx = [first] + [first.new_context() for _ in range(3)]
+    free1, rss1 = api.device_memory(0)[0], proc.memory_info().rss
+    assert free0 - free1 < index_bytes // 8, "a context must not copy the tables in HBM"
+    assert rss1 - rss0 < index_bytes // 8, "a context must not copy the host tables"
+    params = api.AlignmentParameters()
+    reads = synth.synthetic_single_end(ref, 40_000, seed=0xC1, indel_prob=0.3)[0]
+    parts = [se_batch(reads[i * 10_000:(i + 1) * 10_000]) for i in range(4)]
+    arrays = [(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation) for b in parts]
+    want = [first.align_arrays(*a, params) for a in arrays]
+    n, share = api.divide_scratch(ctx, 0)
+    assert n == 4 and share >= 8 << 30
+    got = [None] * 4
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = ctx[i].align_arrays(*arrays[i], params)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for g, w in zip(got, want):
+        assert streams_equal(g, w)
+    # one context grows the tables (longer mates) while the others keep aligning: all of them see the grown tables afterwards
+    long_reads = se_batch(synth.synthetic_single_end(ref, 300, read_len=400, seed=0xC2)[0])
+    la = (long_reads.mate_count, long_reads.mate_offset, long_reads.mate_length, long_reads.codes, long_reads.expected_inner, long_reads.deviation)
+
+    def grow():
+        try:
+            got[3] = ctx[3].align_arrays(*la, params)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)] + [threading.Thread(target=grow)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for i in range(3):
+        assert streams_equal(got[i], want[i])
+    assert all(c.info()["max_hashed_length"] >= 400 for c in ctx)
+    again = ctx[1].align_arrays(*la, params)
+    assert streams_equal(again, got[3])
+    # any order of release; the last handle keeps the tables alive
+    ctx[0].close(); ctx[2].close()
+    last = ctx[1].align_arrays(*arrays[1], params)
+    assert streams_equal(last, want[1])
+    ctx[1].close(); ctx[3].close()
