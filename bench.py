@@ -42,12 +42,21 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a one-GPU box)")
     ap.add_argument("--force-device", type=int, default=-1, help="testing: every rank uses this GPU instead of its LOCAL_RANK")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads of the same workload timed on the host cores (0 = skip); default: the whole batch (about a second on the GPU box's 256 cores)")
-    ap.add_argument("--config", default="1", choices=["1", "2", "4shape"], help="1: BASELINE.json configs[1] (single-end 150 bp, the headline); 2: configs[2] shape (2x150 bp pairs, --spacing 100 50); "
-                    "4shape: the 1,000 bp queries --split-queries-past-size 1000 makes of configs[4]'s reads, against the same 5 Mb reference")
+    ap.add_argument("--config", default="1", choices=["1", "2", "4shape", "3shape", "4", "4mild"],
+                    help="1: BASELINE.json configs[1] (single-end 150 bp, the headline); 2: configs[2] shape (2x150 bp pairs, --spacing 100 50); "
+                    "4shape: the 1,000 bp queries --split-queries-past-size 1000 makes of configs[4]'s reads, against the same 5 Mb reference; "
+                    "3shape / 4 / 4mild: configs[3] / configs[4] on ONE GPU against the 3.1 Gb GRCh38-shaped reference of SURVEY.md section 8(d) "
+                    "(pairs; 10 kb reads split at 1000 with the error rates as stated; the same with 2 %% substitutions + 0.2 %% indel events)")
+    ap.add_argument("--stream-batches", type=int, default=4, help="batches of the PCIe-inclusive streamed measurement (api.align_stream: the upload of batch k+1 overlaps the alignment of batch k; 0 = skip)")
+    ap.add_argument("--seed-index-mb", type=int, default=500, help="size (M bases) of the second, HBM-resident index the seed-probe leg builds so that its probes miss every cache (0 = probes on the workload's own index only)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts per GPU: the steps are dealt to this many contexts of the GPU that align their resident batches at the same time (1: one launch at a time)")
     ap.add_argument("--single-context-steps", type=int, default=3, help="steps of the one-launch-at-a-time measurement beside the headline at N=1 (0 = skip)")
     ap.add_argument("--wave-steps", type=int, default=2, help="steps of the opt-in wave-per-read form (XM_WAVE=1) measured beside the headline (0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched bare: this process starts the N ranks itself (fresh children, one per GPU) before it has touched a GPU, and only waits for them
+        return spawn_ranks(args.gpus)
 
     rc = 0
     line = None
@@ -72,29 +81,56 @@ def main():
     from mapper_amd import api, synth, _capi
     build = _capi.check_stamp()  # refuses to measure a library that was not built from the sources in the tree
 
-    ref = synth.synthetic_reference(args.ref_len, seed=0xEC011)
-    if args.config == "2":
-        m1, m2 = synth.synthetic_paired_end(ref, args.reads, read_len=args.read_len, seed=0x5EED0002 + 7919 * rank)[:2]
-        nq, L = m1.shape
-        codes = np.ascontiguousarray(np.concatenate([m1, m2], axis=1).reshape(-1))
-        mc = np.full(nq, 2, np.int32)
-        mo = np.zeros(2 * nq, np.int64); mo[0::2] = np.arange(nq, dtype=np.int64) * 2 * L; mo[1::2] = mo[0::2] + L
-        ml = np.full(2 * nq, L, np.int32)
-        exp_in, dev_in = np.full(nq, 100.0), np.full(nq, 50.0)  # --spacing 100 50
-        reads_per_query = 2
+    big = args.config in ("3shape", "4", "4mild")   # the 3.1 Gb GRCh38-shaped reference of SURVEY.md section 8(d), on one GPU
+    build_kw = {}
+    if big:
+        grch = synth.grch38_shaped_reference()
+        contigs, whole, gstarts, gruns = grch
+        ref = whole
+        args.ref_len = int(len(whole))
     else:
-        if args.config == "4shape":
-            args.read_len = 1000
-            reads = synth.synthetic_single_end(ref, args.reads, read_len=1000, seed=0x5EED0004 + 7919 * rank)[0]
-        else:
-            reads = synth.synthetic_single_end(ref, args.reads, read_len=args.read_len, seed=0x5EED0001 + 7919 * rank)[0]
-        nq, L = reads.shape
-        codes = np.ascontiguousarray(reads.reshape(-1))
-        mc = np.ones(nq, np.int32)
-        mo = np.zeros(2 * nq, np.int64); mo[0::2] = np.arange(nq, dtype=np.int64) * L
-        ml = np.zeros(2 * nq, np.int32); ml[0::2] = L
-        exp_in, dev_in = np.zeros(nq), np.ones(nq)
-        reads_per_query = 1
+        ref = synth.synthetic_reference(args.ref_len, seed=0xEC011)
+        contigs = [("ecoli_syn", ref)]
+
+    def make_queries(cfg, n_reads, source, seed_shift, where=None):
+        """-> (mc, mo, ml, codes, exp_in, dev_in, reads_per_query, read_len) of one batch of config `cfg` sampled from `source` (one array)."""
+        if cfg in ("2", "3shape"):
+            seed = (0x5EED0002 if cfg == "2" else 0x5EED0003) + seed_shift
+            m1, m2 = synth.synthetic_paired_end(source, n_reads, read_len=150, seed=seed, at=where)[:2]
+            n, L = m1.shape
+            codes_ = np.ascontiguousarray(np.concatenate([m1, m2], axis=1).reshape(-1))
+            mo_ = np.zeros(2 * n, np.int64); mo_[0::2] = np.arange(n, dtype=np.int64) * 2 * L; mo_[1::2] = mo_[0::2] + L
+            return np.full(n, 2, np.int32), mo_, np.full(2 * n, L, np.int32), codes_, np.full(n, 100.0), np.full(n, 50.0), 2, L  # --spacing 100 50
+        if cfg in ("4", "4mild"):
+            # 10 kb reads cut by --split-queries-past-size 1000 (cli.split_sections = SequenceSplitter.java:17,35-38): a query = a section
+            from mapper_amd import cli
+            sub, ind = (0.05, 0.05) if cfg == "4" else (0.02, 0.002)
+            strand = (synth.splitmix64((0x5EED0004 + seed_shift) ^ 0x57A, n_reads) >> np.uint64(63)).astype(np.uint8)
+            reads_ = synth.synthetic_long_reads(source, where, 10_000, seed=0x5EED0004 + seed_shift, sub_rate=sub, indel_rate=ind, strand=strand)
+            sections = cli.split_sections(10_000, 1000)
+            k = len(sections)
+            n = n_reads * k
+            mo_ = np.zeros(2 * n, np.int64)
+            mo_[0::2] = (np.arange(n_reads, dtype=np.int64)[:, None] * 10_000 + np.array([a_ for a_, _ in sections], dtype=np.int64)[None, :]).reshape(-1)
+            ml_ = np.zeros(2 * n, np.int32); ml_[0::2] = np.tile(np.array([b_ - a_ for a_, b_ in sections], dtype=np.int32), n_reads)
+            return np.ones(n, np.int32), mo_, ml_, np.ascontiguousarray(reads_.reshape(-1)), np.zeros(n), np.ones(n), 1, 1000
+        L = 1000 if cfg == "4shape" else args.read_len
+        reads_ = synth.synthetic_single_end(source, n_reads, read_len=L, seed=(0x5EED0004 if cfg == "4shape" else 0x5EED0001) + seed_shift, at=where)[0]
+        n = len(reads_)
+        mo_ = np.zeros(2 * n, np.int64); mo_[0::2] = np.arange(n, dtype=np.int64) * L
+        ml_ = np.zeros(2 * n, np.int32); ml_[0::2] = L
+        return np.ones(n, np.int32), mo_, ml_, np.ascontiguousarray(reads_.reshape(-1)), np.zeros(n), np.ones(n), 1, L
+
+    def sample_starts(cfg, n_reads, starts_, runs_, seed_shift):
+        span = {"3shape": 2 * 150 + 400 + 3 + 153, "4": 10_000 + 2_500 + 8, "4mild": 10_000 + 2_500 + 8}[cfg]
+        return synth.genome_wide_starts(starts_, runs_, n_reads, span, seed=(0x5EED0003 if cfg == "3shape" else 0x5EED0004) ^ 0xF00D ^ seed_shift)[0]
+
+    if big:
+        n_src = args.reads if args.config == "3shape" else max(1, args.reads // 10)   # --reads counts queries (sections) for the long reads
+        mc, mo, ml, codes, exp_in, dev_in, reads_per_query, args.read_len = make_queries(args.config, n_src, whole, 7919 * rank, sample_starts(args.config, n_src, gstarts, gruns, 7919 * rank))
+    else:
+        mc, mo, ml, codes, exp_in, dev_in, reads_per_query, args.read_len = make_queries(args.config, args.reads, ref, 7919 * rank)
+    nq = len(mc)
     params = api.AlignmentParameters()  # Mapper.main defaults
 
     def barrier():
@@ -137,27 +173,28 @@ def main():
             raise state["error"]
         return time.perf_counter() - t_start, state["kernel_ms"], state["launches"], state["d2h_ms"], state["pass_us"], state["last"]
 
+    t0 = time.time()
+    db = api.ReferenceDatabase(contigs, mode="mapper", max_query_length=args.read_len, device=local_rank)
+    index_build_s = time.time() - t0
     # One context at a time first (at N=1, when the headline uses several): the kernel's own numbers, one launch on the GPU at a time
     single = None
     n_ctx = max(1, args.contexts)
+    scratch_each = None
     if n_ctx > 1 and world == 1 and args.single_context_steps > 0:
-        one = api.ReferenceDatabase([("ecoli_syn", ref)], mode="mapper", max_query_length=args.read_len, device=local_rank)
-        one.upload_arrays(mc, mo, ml, codes, exp_in, dev_in)
-        run_steps([one], max(1, args.warmup))
+        db.upload_arrays(mc, mo, ml, codes, exp_in, dev_in)
+        run_steps([db], max(1, args.warmup))
         torch.cuda.synchronize()
         k1 = args.single_context_steps
-        sec, kms, nl, _, pus, _ = run_steps([one], k1)
+        sec, kms, nl, _, pus, _ = run_steps([db], k1)
         single = {"value": round(nq * reads_per_query * k1 / sec / 1e6, 4), "unit": "Mreads/s", "steps": k1, "ms_per_step": round(sec / k1 * 1e3, 3),
                   "kernel_ms_per_step": round(kms / k1, 3), "launches_per_step": nl / k1,
                   "kernel_ms_by_pass": {"light_pass": round(pus[0] / k1 / 1e3, 3), "gapped_and_rerun_passes": round(pus[3] / k1 / 1e3, 3)},
-                  "note": "one context with the whole scratch budget, one launch on the GPU at a time (the round-1 way of running the same kernel)"}
-        one.close()
-    t0 = time.time()
-    db = api.ReferenceDatabase([("ecoli_syn", ref)], mode="mapper", max_query_length=args.read_len, device=local_rank)
-    index_build_s = time.time() - t0
+                  "note": "one context with the whole scratch budget, one launch on the GPU at a time"}
     ctx = [db] + [db.new_context() for _ in range(n_ctx - 1)]  # contexts share the index (host tables and tables in HBM), xm_context_new
     if n_ctx > 1:
-        n_use, scratch_each = api.divide_scratch(ctx, local_rank)  # what is free now, in equal parts
+        n_use, scratch_each = api.divide_scratch(ctx, local_rank)  # what is free now (the index is resident), in equal parts
+        for c_ in ctx[n_use:]:
+            c_.close()
         ctx = ctx[:n_use]
         n_ctx = len(ctx)
     for c_ in ctx:
@@ -183,6 +220,7 @@ def main():
         achieved = (alg_bytes * args.steps / max(launches, 1)) / (avg_launch_ms * 1e-3) / 1e9  # GB/s: bytes per launch / avg launch duration
         aligned = int(sum(1 for q in range(nq) if r.ints[r.int_off[q] + 1] > 0)) if nq <= 2_000_000 else -1
 
+        extras = world == 1   # (N > 1: the line carries the headline only; the other ranks must not wait at the barrier for rank 0's side measurements)
         # host buffers in (xm_align_batch: H2D copy + the same passes), every context at the same time: the PCIe-inclusive rate, never the headline value
         import threading
         rps = [None] * len(ctx)
@@ -190,17 +228,37 @@ def main():
         def with_host_buffers(i):
             for _ in range(2):
                 rps[i] = ctx[i].align_arrays(mc, mo, ml, codes, exp_in, dev_in, params)
-        t1 = time.perf_counter()
-        th = [threading.Thread(target=with_host_buffers, args=(i,)) for i in range(len(ctx))]
-        [x.start() for x in th]
-        [x.join() for x in th]
-        pcie_s = (time.perf_counter() - t1) / (2 * len(ctx))
-        pcie = {"value": round(nq * reads_per_query / pcie_s / 1e6, 4), "unit": "Mreads/s", "ms_per_step": round(pcie_s * 1e3, 3), "h2d_ms": round(rps[0].h2d_ms, 3),
-                "note": "xm_align_batch with host buffers in (pageable numpy arrays) in every context, no overlap of a context's copy with its own alignment"}
+        pcie = None
+        if extras:
+            t1 = time.perf_counter()
+            th = [threading.Thread(target=with_host_buffers, args=(i,)) for i in range(len(ctx))]
+            [x.start() for x in th]
+            [x.join() for x in th]
+            pcie_s = (time.perf_counter() - t1) / (2 * len(ctx))
+            pcie = {"value": round(nq * reads_per_query / pcie_s / 1e6, 4), "unit": "Mreads/s", "ms_per_step": round(pcie_s * 1e3, 3), "h2d_ms": round(rps[0].h2d_ms, 3),
+                    "note": "xm_align_batch with host buffers in (pageable numpy arrays) in every context, no overlap of a context's copy with its own alignment"}
+        # the product's way of taking host buffers (api.align_stream, what `python -m mapper_amd` runs): batches staged on a second stream and host thread
+        # while the previous one is aligned, one stream of batches per context; PCIe-inclusive, never the headline value
+        streamed = None
+        if extras and args.stream_batches > 0:
+            counts = [0] * len(ctx)
+
+            def stream(i):
+                for _ in ctx[i].align_stream(iter([(mc, mo, ml, codes, exp_in, dev_in)] * args.stream_batches), params):
+                    counts[i] += 1
+            t1 = time.perf_counter()
+            th = [threading.Thread(target=stream, args=(i,)) for i in range(len(ctx))]
+            [x.start() for x in th]
+            [x.join() for x in th]
+            st_s = (time.perf_counter() - t1) / max(1, sum(counts))
+            streamed = {"value": round(nq * reads_per_query / st_s / 1e6, 4), "unit": "Mreads/s", "ms_per_batch": round(st_s * 1e3, 3), "batches": sum(counts), "contexts": len(ctx),
+                        "note": "api.align_stream: host buffers in, the H2D copy of batch k+1 overlapped with the alignment of batch k, %d batches per context" % args.stream_batches}
+            for c_ in ctx:
+                c_.upload_arrays(mc, mo, ml, codes, exp_in, dev_in)  # (the legs below align the resident batch again)
 
         # the opt-in wave-per-read form (XM_WAVE=1: one wavefront per read, state in LDS, xm_wave_kernel.hip) on the same resident batch
         wave = None
-        if args.wave_steps > 0 and args.read_len <= 256:
+        if extras and args.wave_steps > 0 and args.read_len <= 256 and not big:
             os.environ["XM_WAVE"] = "1"
             try:
                 rw = db.align_resident(params)
@@ -236,7 +294,31 @@ def main():
         cpu = None
         same = None
         counters = {"device": [int(x) for x in r.counters[:11]]}
-        if args.cpu_sample > 0:
+        if extras and args.cpu_sample > 0 and big:
+            # No oracle hashes 3.1 G bases in bounded time (15 Mb take it a minute), so the CPU path is timed on the same workload against the
+            # SAME-SHAPED reference at 1/200 of its size (24 contigs, N-runs) with the minInterestingSize a 3 Gb reference gets (13,
+            # HashBlock_Database.java:52) - the regime of the walk is the big reference's, the tables are smaller (cache-friendlier: flatters the CPU).
+            import oracle_lib
+            sc, sw, ss, sr = synth.grch38_shaped_reference(scale=0.005)
+            n_small = min(args.cpu_sample, 100_000 if args.config == "3shape" else 20_000)
+            n_src = n_small if args.config == "3shape" else max(1, n_small // 10)
+            qs = make_queries(args.config, n_src, sw, 0, sample_starts(args.config, n_src, ss, sr, 0))
+            o = oracle_lib.OracleReference(sc, mode="mapper", min_interesting_size=13)
+            cores = os.cpu_count() or 1
+            o.align(oracle_lib.QueryBatch.from_arrays(qs[0][:16], qs[1][:32], qs[2][:32], qs[3], qs[4][:16], qs[5][:16]), oracle_lib.make_params(), threads=1)  # builds the index (not timed)
+            o.require_size(args.read_len)
+            b = oracle_lib.QueryBatch.from_arrays(*qs[:6])
+            t1 = time.perf_counter()
+            w = o.align(b, oracle_lib.make_params(), threads=cores)
+            cpu_s = time.perf_counter() - t1
+            small = api.ReferenceDatabase(sc, mode="mapper", max_query_length=args.read_len, device=local_rank, min_interesting_size=13)
+            rs = small.align_arrays(*qs[:6], params)
+            small.close()
+            same = bool(np.array_equal(w.ints, rs.ints) and np.array_equal(w.dbls.view(np.int64), rs.dbls.view(np.int64)))
+            cpu = {"value": round(len(qs[0]) * qs[6] / cpu_s / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port", "seconds": round(cpu_s, 3),
+                   "sample": "%d queries of the same read model against the GRCh38-shaped reference at 1/200 scale (15 Mb, 24 contigs, N-runs, minInterestingSize 13), oracle (C++ port of the "
+                             "Java path) on every host core, index build excluded; the GPU's streams on that sample are compared with the oracle's (bit_identical)" % len(qs[0])}
+        elif extras and args.cpu_sample > 0:
             import oracle_lib
             n = min(args.cpu_sample, nq)
             o = oracle_lib.OracleReference([("ecoli_syn", ref)], mode="mapper")
@@ -263,7 +345,7 @@ def main():
         # seed-lookup micro-kernel: bulk PackedMap.get on the device, bytes = 8 per bucket-header probe + B_pos per
         # fetched position, next to the measured random-64 B-sector ceiling of this GPU
         seed = None
-        if args.seed_probes > 0:
+        if extras and args.seed_probes > 0:
             rng = np.random.default_rng(12345)
             lo, hi = info["min_interesting_size"], info["max_hashed_length"]
             used = rng.integers(lo, hi + 1, size=args.seed_probes, dtype=np.int32)
@@ -283,7 +365,10 @@ def main():
                     "with_positions": {"probes": n2, "positions_fetched": fetched, "kernel_ms": round(ms_pos, 4),
                                        "achieved_GBps": round((8.0 * n2 + pos_bytes * fetched) / (ms_pos * 1e-3) / 1e9, 2)},
                     "note": "algorithmic bytes: 8 B header per probe (+ %d B per fetched position); every probe touches one random 64 B sector, so the "
-                            "sector ceiling (%.1f G sectors/s = %.0f GB/s of sector traffic) is the bound that applies" % (pos_bytes, sectors_per_s / 1e9, sectors_per_s * 64 / 1e9)}
+                            "sector ceiling (%.1f G sectors/s = %.0f GB/s of sector traffic) is the bound that applies; THIS index (%d MB) is cache-resident: "
+                            "hbm_resident_index below is the HBM number" % (pos_bytes, sectors_per_s / 1e9, sectors_per_s * 64 / 1e9, info["index_bytes"] >> 20)}
+            if args.seed_index_mb > 0 or big:
+                seed["hbm_resident_index"] = seed_probe_hbm(api, synth, db if big else None, args.seed_index_mb, local_rank, sectors_per_s, args.seed_probes, rng)
 
         # HBM bytes per launch from the PMC passes committed with this round's profiles (same command, scripts/gpu_profile_round.sh);
         # only quoted for the workload they were collected on, with their source
@@ -291,9 +376,13 @@ def main():
         traffic_source = None
         try:
             if args.config == "1" and (args.reads, args.ref_len, args.read_len) == (1_000_000, 5_000_000, 150):
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")))
-                traffic = int(pm["hbm_bytes_per_launch"]["mean_over_the_two_launches_of_a_step"])
-                traffic_source = "profiles/r02/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, build %s)" % pm.get("build", "?")
+                rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_summary.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "pmc_summary.json")))
+                if pm.get("build") == build and int(pm.get("contexts", n_ctx)) == n_ctx:
+                    traffic = int(pm["hbm_bytes_per_launch"]["mean_over_the_two_launches_of_a_step"])
+                    traffic_source = "profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, build %s)" % (rounds[-1], pm["build"])
+                else:  # counters of another build (or another number of contexts) say nothing about this one
+                    traffic_source = "none: profiles/%s/pmc_summary.json was collected on build %s, this is %s" % (rounds[-1], pm.get("build", "?"), build)
         except Exception:
             traffic = None
 
@@ -304,7 +393,10 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": {"1": "configs[1]: %d synthetic %d bp single-end reads per GPU vs %d bp synthetic E. coli-sized reference (index replicated, reads sharded, no collective)",
                                     "2": "configs[2] shape: %d synthetic 2 x %d bp pairs (--spacing 100 50) per GPU vs %d bp synthetic E. coli-sized reference",
-                                    "4shape": "configs[4] shape: %d synthetic %d bp queries (what --split-queries-past-size 1000 makes of 10 kb reads) per GPU vs %d bp synthetic reference"}[args.config] % (nq, args.read_len, args.ref_len),
+                                    "4shape": "configs[4] shape: %d synthetic %d bp queries (what --split-queries-past-size 1000 makes of 10 kb reads) per GPU vs %d bp synthetic reference",
+                                    "3shape": "configs[3] on one GPU: %d synthetic 2 x %d bp pairs (--spacing 100 50, seed 0x5EED0003) sampled genome-wide vs the %d bp GRCh38-shaped synthetic reference (24 contigs, real chromosome lengths, 1 %% N-runs of 10 kb, seed 0x6C38)",
+                                    "4": "configs[4] on one GPU: %d queries of %d bp = 10 kb reads (5 %% substitutions + 5 %% indel events per base, seed 0x5EED0004) cut by --split-queries-past-size 1000, vs the %d bp GRCh38-shaped synthetic reference",
+                                    "4mild": "configs[4] shape on one GPU with milder reads: %d queries of %d bp = 10 kb reads (2 %% substitutions + 0.2 %% indel events per base) cut by --split-queries-past-size 1000, vs the %d bp GRCh38-shaped synthetic reference"}[args.config] % (nq, args.read_len, args.ref_len),
                        "reads_per_gpu": nq * reads_per_query, "read_len": args.read_len, "reference_len": args.ref_len, "parallelism": "reads sharded x%d" % world,
                        "aligned_reads": aligned, "index_build_s": round(index_build_s, 3), "index_bytes": info["index_bytes"],
                        "index_build": {"hashed_on": "gpu" if info["built_on_device"] else "host", "hash_s": round(info["hash_seconds"], 3),
@@ -333,6 +425,7 @@ def main():
             "golden": golden,
             "counters": counters,
             "pcie_inclusive": pcie,
+            "streamed": streamed,
             "wave_form": wave,
             "seed_probe": seed,
         }
@@ -346,6 +439,69 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return rc
+
+
+def seed_probe_hbm(api, synth, db, index_mb, device, sectors_per_s, n_probes, rng):
+    """The seed-lookup micro-kernel on an index that no cache holds (the 5 Mb workload's 47 MB index is L2 / Infinity-Cache resident): a second
+    index of `index_mb` M synthetic bases (hashed on the GPU; or the workload's own 3.1 Gb one), random (length, key) probes.  Three ways of reading the
+    rate: (a) algorithmic bytes (8 B header + B_pos per returned position) against the 8 TB/s stream peak, (b) the 64-byte sectors the probes
+    touch against the same peak, (c) probes against this GPU's measured random-64-B-sector gather rate.  `sorted`: the same probes issued in
+    (table, bucket) order - what batching a read batch's probes by address could gain at best."""
+    own = db is None
+    t0 = time.time()
+    if own:
+        db = api.ReferenceDatabase([("probe_ref", np.concatenate([synth.synthetic_reference(min(50_000_000, index_mb * 1_000_000 - o), seed=0x9B0 + o // 50_000_000)
+                                                                    for o in range(0, index_mb * 1_000_000, 50_000_000)]))], max_query_length=150, device=device)
+    build_s = time.time() - t0
+    info = db.info()
+    pb = info["position_bytes"]
+    lo, hi = info["min_interesting_size"], min(info["max_hashed_length"], 150)
+    used = rng.integers(lo, hi + 1, size=n_probes, dtype=np.int32)
+    keys = rng.integers(-2**31, 2**31 - 1, size=n_probes, dtype=np.int64).astype(np.int32)
+    out = {"index_bytes": info["index_bytes"], "reference_bases": info["total_forward_size"], "position_bytes": pb, "build_s": round(build_s, 2) if own else None, "probes": n_probes}
+
+    def measure(u, k, label):
+        db.seed_probe(u[:4096], k[:4096], 0)
+        _, _, ms_hdr = db.seed_probe(u, k, 0)
+        n2 = len(u) // 2
+        c2, _, ms_pos = db.seed_probe(u[:n2], k[:n2], 7)
+        fetched = int(np.minimum(np.maximum(c2, 0), 7).sum())
+        hdr_rate, pos_rate = len(u) / (ms_hdr * 1e-3), n2 / (ms_pos * 1e-3)
+        out[label] = {"header_only": {"probes_per_s": round(hdr_rate, 1), "algorithmic_frac_of_peak": round(8.0 * hdr_rate / 8e12, 5), "sector_traffic_frac_of_peak": round(64.0 * hdr_rate / 8e12, 4),
+                                      "frac_of_gather_ceiling": round(hdr_rate / sectors_per_s, 4)},
+                      "with_positions": {"probes_per_s": round(pos_rate, 1), "positions_per_probe": round(fetched / n2, 3),
+                                         "algorithmic_frac_of_peak": round((8.0 * n2 + pb * fetched) / (ms_pos * 1e-3) / 8e12, 5),
+                                         "sector_traffic_frac_of_peak": round(64.0 * pos_rate / 8e12, 4), "frac_of_gather_ceiling": round(pos_rate / sectors_per_s, 4)}}
+    measure(used, keys, "random_order")
+    # the same probes in (table, bucket) order: bucket = key mod capacity, non-negative (PackedMap.getPackedKey, PackedMap.java:210-215)
+    caps = np.ones(hi + 2, dtype=np.int64)
+    for L in range(lo, hi + 1):
+        caps[L] = max(1, db.table_shape(L)[0])
+    bucket = np.mod(keys.astype(np.int64), caps[used])
+    order = np.lexsort((bucket, used))
+    measure(used[order], keys[order], "sorted_by_table_and_bucket")
+    out["note"] = ("a probe moves one 64-byte sector (a bucket line) to use 8 B of header and ~%d B of positions: the algorithmic fraction is bounded by used bytes / 64 x the sector rate; "
+                   "random sectors reach ~40 %% of the stream peak on this GPU (random_64B_gather_ceiling), so north_star's 40 %% of peak in algorithmic bytes is out of reach for a "
+                   "hash probe whatever the kernel does; sorting the probes by address is the upper bound of what probe batching could add" % int(pb * out["random_order"]["with_positions"]["positions_per_probe"]))
+    if own:
+        db.close()
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N child processes of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would start them.  The parent never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
 
 
 def java_reference(ref, codes, nq, args):

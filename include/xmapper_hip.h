@@ -149,6 +149,8 @@ int xm_index_get_info(const xm_index* index, xm_index_info_t* info);
 /* inspection (parity tests): one PackedMap as (counts per bucket or -1 if overfull, concatenated encoded positions) */
 int xm_index_table_info(const xm_index* index, int32_t used_length, int32_t* capacity, int32_t* max_count_per_key, int64_t* num_stored, int64_t* num_overfull);
 int xm_index_table_dump(const xm_index* index, int32_t used_length, int32_t* counts, int64_t* positions);
+/* the PackedMap of one gapmer length: its keyCapacity and per-key limit (HashBlock_Database.java:569-577,620-665) without walking the buckets */
+int xm_index_table_shape(const xm_index* index, int32_t used_length, int32_t* capacity, int32_t* max_count_per_key);
 int64_t xm_index_dup_keys(const xm_index* index, int32_t contig, int32_t* out, int64_t cap);
 
 /* Replaces the per-read loop of AlignerWorker.process() / Api.align (AlignerWorker.java:177-231,306-644): every query is
@@ -184,10 +186,16 @@ int xm_measure_random_gather(int device, int64_t table_bytes, int64_t accesses, 
  * batch still in HBM): per forward reference position the depth and the counts of differing query bases (A, C, G, T), in integer units of
  * 1 / XM_PILEUP_UNIT read bases (a query with n alignments adds 1/n per alignment; the mates of a pair add 1/2 each where they overlap), and one
  * event per insertion / deletion block: eight int64 = contig, position (startB of the block), type (1 insertion, 2 deletion), length, query
- * ordinal (over all batches added), mate | reversed << 1, startA, weight.  Several GPUs: one pile-up per replica, summed by the host in rank order. */
+ * ordinal (over all batches added), mate | reversed << 1 | near-query-end << 2, startA, weight.  Several GPUs: one pile-up per replica, summed by the host in rank order. */
 #define XM_PILEUP_UNIT 1441440ull
 typedef struct xm_pileup xm_pileup;
 int xm_pileup_new(xm_index* index, xm_pileup** out);
+/* MatchDatabase(queryEndFraction) (Mapper.java:76,351-353,700; --distinguish-query-ends, default 0.1 in Mapper.main): set before the first add.  With a
+ * fraction > 0 the pile-up also keeps the "middle" depth - the depth from query bases that are not within that fraction of the query's length of
+ * either query end - which is what the indel thresholds of the writers look at (Mapper.java:532-542, pinned by MutationsWriter_Test.java:114-134),
+ * and events carry bit 2 of their flags word when they lie near a query end.  xm_pileup_read_middle reads it (fraction 0: equal to the depth). */
+int xm_pileup_set_query_ends(xm_pileup* pileup, double fraction);
+int xm_pileup_read_middle(xm_pileup* pileup, int32_t contig, int64_t first, int64_t n, uint64_t* depth);
 int xm_pileup_add_last(xm_pileup* pileup, int64_t* num_events);
 int xm_pileup_read(xm_pileup* pileup, int32_t contig, int64_t first, int64_t n, uint64_t* depth, uint64_t* alt /* [4][n] */);
 int64_t xm_pileup_events(xm_pileup* pileup, int64_t first, int64_t n, int64_t* out /* [8 * n] */);

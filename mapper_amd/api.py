@@ -277,6 +277,13 @@ class ReferenceDatabase:
         if self._L.xm_index_ensure_length(self._h, int(n)):
             raise RuntimeError(self._L.xm_last_error().decode())
 
+    def table_shape(self, used_length):
+        """(capacity, per-key limit) of the table of one gapmer length."""
+        cap, mx = C.c_int32(), C.c_int32()
+        if self._L.xm_index_table_shape(self._h, int(used_length), C.byref(cap), C.byref(mx)):
+            raise RuntimeError(self._L.xm_last_error().decode())
+        return cap.value, mx.value
+
     def table(self, used_length):
         cap, mx, n, o = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
         if self._L.xm_index_table_info(self._h, used_length, C.byref(cap), C.byref(mx), C.byref(n), C.byref(o)):
@@ -452,6 +459,8 @@ def device_memory(device=0):
 def divide_scratch(contexts, device, reserve=24 << 30, most=200 << 30):
     """Several contexts on one GPU: what is free now (the index is resident) minus a reserve for batches, result arenas and pile-ups, in equal
     parts; a context that would get less than 8 GiB is not worth having -> (how many of `contexts` to use, bytes each)."""
+    for c in contexts:
+        c.set_scratch(1 << 20)  # (a context that already holds scratch gives it back first: what is free is then what there is to divide)
     free, _ = device_memory(device)
     n = len(contexts)
     while n > 1 and (free - reserve) // n < (8 << 30):
@@ -459,6 +468,8 @@ def divide_scratch(contexts, device, reserve=24 << 30, most=200 << 30):
     share = max(1 << 30, min(most, (free - reserve) // max(n, 1)))
     for c in contexts[:n]:
         c.set_scratch(share)
+    for c in contexts[n:]:
+        c.set_scratch(0)
     return n, share
 
 

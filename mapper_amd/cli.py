@@ -18,8 +18,7 @@ import numpy as np
 
 from . import api, sam
 
-JAVA_HOST_ONLY = {"--out-vcf": 1, "--out-ancestor": 1,
-                  "--distinguish-query-ends": 1, "--infer-ancestors": 0, "--verify-consistent-db": 0,
+JAVA_HOST_ONLY = {"--out-vcf": 1, "--out-ancestor": 1, "--infer-ancestors": 0, "--verify-consistent-db": 0,
                   "--vcf-exclude-non-mutations": 0, "--vcf-omit-support-reads": 0}
 IGNORED = {"--verbose": 0, "-v": 0, "-vv": 0, "--verbose-alignment": 0, "--verbose-reference": 0, "--verbosity-auto": 0, "--num-threads": 1,
            "--no-infer-ancestors": 0, "--allow-duplicate-contig-names": 0, "--version": 0}
@@ -128,8 +127,27 @@ def parse_args(argv):
             o["maxNumMatches"] = int(argv[i + 1]); i += 1
         elif a == "--out-refs-map-count":  # Mapper.java:197: how many queries mapped to each combination of references
             o["out_refs_map_count"] = argv[i + 1]; i += 1
-        elif a == "--out-mutations":  # Mapper.java:187: the mutations file (mapper_amd/pileup.py; accumulated on the GPU)
+        elif a == "--out-mutations":  # Mapper.java:203-237: the mutations file (mapper_amd/pileup.py; accumulated on the GPU) and its nested thresholds
             o["out_mutations"] = argv[i + 1]; i += 1
+            f = o.setdefault("mutation_filter", {})
+            while i + 1 < len(argv):
+                sub = argv[i + 1]
+                if sub == "--snp-threshold":
+                    f["minSNPTotalDepth"], f["minSNPDepthFraction"] = float(argv[i + 2]), float(argv[i + 3])
+                elif sub == "--indel-start-threshold":
+                    f["minIndelTotalStartDepth"], f["minIndelStartDepthFraction"] = float(argv[i + 2]), float(argv[i + 3])
+                elif sub == "--indel-continue-threshold":
+                    f["minIndelContinuationTotalDepth"], f["minIndelContinuationDepthFraction"] = float(argv[i + 2]), float(argv[i + 3])
+                elif sub == "--indel-threshold":
+                    f["minIndelTotalStartDepth"] = f["minIndelContinuationTotalDepth"] = float(argv[i + 2])
+                    f["minIndelStartDepthFraction"] = f["minIndelContinuationDepthFraction"] = float(argv[i + 3])
+                else:
+                    break  # maybe this argument is a top-level argument
+                i += 3
+        elif a == "--distinguish-query-ends":  # Mapper.java:351-355
+            o["query_end_fraction"] = float(argv[i + 1]); i += 1
+            if not 0 <= o["query_end_fraction"] < 1:
+                raise UsageError("--distinguish-query-ends must be >= 0 and < 1")
         elif a == "--cache-dir":  # Mapper.java:264: keep the hashed reference between runs
             o["cache_dir"] = argv[i + 1]; i += 1
         elif a == "--batch-size":  # (not a Mapper flag) queries per GPU batch; batches are streamed (upload of the next one during the alignment of the current one)
@@ -273,7 +291,7 @@ def run(argv, out=sys.stdout):
     on_aligned = None
     if o.get("out_mutations"):  # Mapper.java:700-708: the MatchDatabase listens to every batch; here it accumulates on the GPU while the batch is resident
         from . import pileup
-        match_db = pileup.MatchDatabase(db.replicas if hasattr(db, "replicas") else db)
+        match_db = pileup.MatchDatabase(db.replicas if hasattr(db, "replicas") else db, o.get("query_end_fraction", 0.1))  # (default 0.1: Mapper.java:76)
         on_aligned = lambda replica, first_query, qs: match_db.add_last(qs, replica=replica)  # noqa: E731
     results = db.align_batches([q for q, _ in queries], params, batch_size, on_aligned=on_aligned)
     first, result, nxt = 0, None, 0
@@ -311,7 +329,10 @@ def run(argv, out=sys.stdout):
                 f.write("%s\t%d\n" % (",".join(key), count))
     if match_db is not None:  # Mapper.java:758-785
         with open(o["out_mutations"], "w") as f:
-            match_db.write_mutations(f)
+            filt = pileup.MutationDetectionParameters.defaultFilter()  # Mapper.java:56; --snp-threshold etc. override it
+            for k, v in o.get("mutation_filter", {}).items():
+                setattr(filt, k, v)
+            match_db.write_mutations(f, filt)
         match_db.close()
     n = len(queries)
     out.write("\nStatistics: \n")

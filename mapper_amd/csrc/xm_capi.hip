@@ -307,7 +307,12 @@ struct PileupView {
   unsigned long long eventCap;
   unsigned long long* eventCount;
   long long queryBase;           // index of the batch's first query among all queries added so far
+  unsigned long long* mid;       // [totalForwardSize] depth from query bases that are not near a query end (null: no query-end fraction set)
+  double endFraction;            // MatchDatabase(queryEndFraction), --distinguish-query-ends (Mapper.java:76,351-353,700)
 };
+// a query base "near the end of the query": within endFraction of the query's length of either end  [inferred: the rule lives in the un-vendored
+// MatchDatabase; pinned by MutationsWriter_Test.java:114-134 only for fraction 0.5 = every base]
+__device__ __forceinline__ bool xmNearQueryEnd(int k, int readLen, double f) { return (double)k < f * readLen || (double)k >= readLen - f * readLen; }
 __global__ void __launch_bounds__(256) xm_pileup_kernel(IndexView ix, BatchView batch, const int32_t* ints, const int64_t* intOff, PileupView pv) {
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= batch.nq) return;
@@ -353,6 +358,7 @@ __global__ void __launch_bounds__(256) xm_pileup_kernel(IndexView ix, BatchView 
               const unsigned long long wi = (pos >= ovLo && pos < ovHi) ? (sq == 0 ? w / 2 : w - w / 2) : w;
               const uint8_t r = ix.refCodes[base + pos];
               const int k = startA + i;
+              if (pv.mid && !xmNearQueryEnd(k, readLen, pv.endFraction)) atomicAdd(&pv.mid[base + pos], wi);
               const uint8_t qb = reversed ? bpComplement(read[readLen - 1 - k]) : read[k];
               atomicAdd(&pv.depth[base + pos], wi);
               if (!bpIsAmbiguous(r) && !bpIsAmbiguous(qb) && qb != r) atomicAdd(&pv.alt[(long long)encodedCharToInt(qb) * pv.total + base + pos], wi);
@@ -360,12 +366,14 @@ __global__ void __launch_bounds__(256) xm_pileup_kernel(IndexView ix, BatchView 
           } else {
             if (lenA == 0) for (int i = 0; i < lenB; i++) {  // a deletion: the read spans these reference bases
               const long long pos = startB + i;
-              atomicAdd(&pv.depth[base + pos], (pos >= ovLo && pos < ovHi) ? (sq == 0 ? w / 2 : w - w / 2) : w);
+              const unsigned long long wi = (pos >= ovLo && pos < ovHi) ? (sq == 0 ? w / 2 : w - w / 2) : w;
+              atomicAdd(&pv.depth[base + pos], wi);
+              if (pv.mid && !xmNearQueryEnd(startA, readLen, pv.endFraction)) atomicAdd(&pv.mid[base + pos], wi);  // (the gap sits in front of query base startA)
             }
             const unsigned long long at = atomicAdd(pv.eventCount, 1ull);
             if (at < pv.eventCap) {
               long long* e = pv.events + at * 8;
-              e[0] = contig; e[1] = startB; e[2] = lenA > 0 ? 1 : 2; e[3] = lenA > 0 ? lenA : lenB; e[4] = pv.queryBase + q; e[5] = mate | (reversed << 1); e[6] = startA;
+              e[0] = contig; e[1] = startB; e[2] = lenA > 0 ? 1 : 2; e[3] = lenA > 0 ? lenA : lenB; e[4] = pv.queryBase + q; e[5] = mate | (reversed << 1) | ((pv.mid && xmNearQueryEnd(startA, readLen, pv.endFraction)) ? 4 : 0); e[6] = startA;
               e[7] = (long long)((startB >= ovLo && startB < ovHi) ? (sq == 0 ? w / 2 : w - w / 2) : w);
             }
           }
@@ -904,7 +912,8 @@ struct xm_pileup {
   xm_index* index = nullptr;            // the context whose batches are added (xm_pileup_add_last needs it alive; read / events / free do not)
   std::shared_ptr<HostShare> hs;
   int device = 0;
-  DevBuf<unsigned long long> dDepth, dAlt, dEventCount;
+  DevBuf<unsigned long long> dDepth, dAlt, dEventCount, dMid;
+  double endFraction = 0;
   DevBuf<long long> dEvents;
   long long total = 0, queriesAdded = 0;
   std::vector<long long> events;  // (host) 8 per event, in the order of the calls
@@ -1009,6 +1018,10 @@ int xm_context_set_scratch(xm_index* idx, int64_t bytes) {
   if (bytes < 0) return fail("xm_context_set_scratch: negative size");
   std::lock_guard<std::mutex> lock(idx->mu);
   idx->scratchBytes = bytes;
+  if (bytes > 0 && idx->dArenas.n > (size_t)bytes && !idx->hostOnly) {  // what the context holds beyond its new limit goes back to the GPU now
+    (void)hipSetDevice(idx->device);
+    idx->dArenas.release();
+  }
   return 0;
 }
 
@@ -1110,6 +1123,14 @@ int xm_index_table_info(const xm_index* idx, int32_t L, int32_t* capacity, int32
   for (int k = 0; k < t.capacity; k++) if (h.bucketOff[(size_t)(t.offBase + k)] & XM_OVERFULL) o++;
   *numOverfull = o;
   *numStored = (int64_t)(h.bucketOff[(size_t)(t.offBase + t.capacity)] & ~XM_OVERFULL);
+  return 0;
+}
+
+int xm_index_table_shape(const xm_index* idx, int32_t L, int32_t* capacity, int32_t* maxCount) {
+  if (!idx || !capacity || !maxCount) return fail("null argument");
+  const HostIndex& h = idx->host();
+  if (L < 0 || L > h.maxHashedLength) return fail("length not hashed");
+  *capacity = h.tables[(size_t)L].capacity; *maxCount = h.tables[(size_t)L].maxCount;
   return 0;
 }
 
@@ -1844,6 +1865,35 @@ int xm_pileup_new(xm_index* idx, xm_pileup** out) {
   }
 }
 
+int xm_pileup_set_query_ends(xm_pileup* p, double fraction) {
+  if (!p) return fail("xm_pileup_set_query_ends: null argument");
+  if (!(fraction >= 0 && fraction < 1)) return fail("--distinguish-query-ends must be >= 0 and < 1");  // Mapper.java:424-425
+  if (p->queriesAdded > 0) return fail("xm_pileup_set_query_ends: alignments were already added");
+  try {
+    HIP_CHECK(hipSetDevice(p->device));
+    p->endFraction = fraction;
+    if (fraction > 0) {
+      p->dMid.ensure((size_t)p->total);
+      HIP_CHECK(hipMemset(p->dMid.p, 0, sizeof(unsigned long long) * (size_t)p->total));
+    }
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_pileup_set_query_ends: ") + e.what()); }
+}
+
+int xm_pileup_read_middle(xm_pileup* p, int32_t contig, int64_t first, int64_t n, uint64_t* depth) {
+  if (!p || !p->hs || !depth) return fail("xm_pileup_read_middle: null argument");
+  try {
+    const HostIndex& host = p->hs->host;
+    if (contig < 0 || contig >= host.numContigs() || first < 0 || n < 0 || first + n > host.contigLen[(size_t)contig]) throw std::runtime_error("range outside of the contig");
+    HIP_CHECK(hipSetDevice(p->device));
+    HIP_CHECK(hipDeviceSynchronize());
+    const size_t at = (size_t)host.contigStart[(size_t)contig] + (size_t)first;
+    // (no query-end fraction: every base is a middle base)
+    if (n) HIP_CHECK(hipMemcpy(depth, (p->endFraction > 0 ? p->dMid.p : p->dDepth.p) + at, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_pileup_read_middle: ") + e.what()); }
+}
+
 int xm_pileup_add_last(xm_pileup* p, int64_t* num_events) {
   if (!p || !p->index) return fail("xm_pileup_add_last: null argument");
   xm_index* idx = p->index;
@@ -1859,7 +1909,7 @@ int xm_pileup_add_last(xm_pileup* p, int64_t* num_events) {
       p->dEvents.ensure((size_t)cap * 8);
       HIP_CHECK(hipMemsetAsync(p->dEventCount.p, 0, sizeof(unsigned long long), s));
       BatchView bv{nq, idx->dMateCount.p, idx->dMateOffset.p, idx->dMateLength.p, idx->dCodes.p, idx->dExpected.p, idx->dDeviation.p};
-      PileupView pv{p->dDepth.p, p->dAlt.p, p->total, p->dEvents.p, cap, p->dEventCount.p, p->queriesAdded};
+      PileupView pv{p->dDepth.p, p->dAlt.p, p->total, p->dEvents.p, cap, p->dEventCount.p, p->queriesAdded, p->endFraction > 0 ? p->dMid.p : nullptr, p->endFraction};
       std::shared_lock<std::shared_mutex> tablesInUse(idx->dt->rw);
       hipLaunchKernelGGL(xm_pileup_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, idx->dt->view, bv, (const int32_t*)idx->dFinalInts.p, (const int64_t*)idx->dFinalIntOff.p, pv);
       HIP_CHECK(hipGetLastError());
@@ -1916,7 +1966,7 @@ int64_t xm_pileup_events(xm_pileup* p, int64_t first, int64_t n, int64_t* out) {
 void xm_pileup_free(xm_pileup* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
-  p->dDepth.release(); p->dAlt.release(); p->dEventCount.release(); p->dEvents.release();
+  p->dDepth.release(); p->dAlt.release(); p->dEventCount.release(); p->dEvents.release(); p->dMid.release();
   delete p;
 }
 

@@ -7,9 +7,14 @@ reference's own tests pin: src/test/java/MatchDatabase_Test.java:12-69 (every al
 1 together where they overlap) and src/test/java/MutationsWriter_Test.java:18-134 (the line format `contig, 1-based position, reference
 allele, query allele, allele depth, total depth`; a deletion is reported at its first base with the deleted bases against dashes, an insertion
 at the base before it with dashes against the inserted bases; consecutive substitutions are separate lines; the total-depth filter).
+--distinguish-query-ends (MatchDatabase(queryEndFraction), Mapper.java:76,351-353,700): "when detecting indels, only consider the middle of each query"
+(Mapper.java:532) - the indel thresholds look at the *middle* depth, the depth from query bases that are not within the fraction of the query's
+length of either query end (Mapper.java:538-542 "total (middle) depth"), and an indel near a query end does not support itself; pinned by
+MutationsWriter_Test.java:114-134 (fraction 0.5 = every base is near an end: the insertion is not reported once a middle depth of 1 is asked for).
 [unpinned]: the header lines (the reference's test strips lines that start with '#' or 'CHR'), the weight of a query with several
-alignments (taken as 1/n each), how ambiguous bases count (depth only), the order of lines at one position, and --distinguish-query-ends
-(Mapper.java:206; not implemented: asking for it is an error).
+alignments (taken as 1/n each), how ambiguous bases count (depth only), the order of lines at one position, where exactly "near the end" stops
+(here: query index k with k < f * length or k >= length - f * length), the supporting-depth fractions and the continuation thresholds
+(Mapper.java:208-230: taken as alt / total; an indel is cut where its continuation fails).
 
 The accumulation itself runs on the GPU (xm_pileup_kernel: one lane per query walks its result stream in HBM and adds to per-position
 integer counters, so the result does not depend on the order of the atomic adds); this module holds the host side."""
@@ -24,15 +29,22 @@ UNIT = 1441440  # XM_PILEUP_UNIT (include/xmapper_hip.h)
 
 
 class MutationDetectionParameters:
-    """The filters of MutationDetectionParameters that the reference's tests exercise; emptyFilter() = everything is reported."""
+    """MutationDetectionParameters [QuickVariants]: the six thresholds Mapper.main fills in (Mapper.java:208-230).  emptyFilter() = everything is
+    reported (what the reference's tests start from); defaultFilter() = the defaults --out-mutations documents (Mapper.java:534-542)."""
 
-    def __init__(self, minSNPTotalDepth=0.0, minIndelTotalStartDepth=0.0):
-        self.minSNPTotalDepth = minSNPTotalDepth
-        self.minIndelTotalStartDepth = minIndelTotalStartDepth
+    def __init__(self, minSNPTotalDepth=0.0, minSNPDepthFraction=0.0, minIndelTotalStartDepth=0.0, minIndelStartDepthFraction=0.0,
+                 minIndelContinuationTotalDepth=0.0, minIndelContinuationDepthFraction=0.0):
+        self.minSNPTotalDepth, self.minSNPDepthFraction = minSNPTotalDepth, minSNPDepthFraction
+        self.minIndelTotalStartDepth, self.minIndelStartDepthFraction = minIndelTotalStartDepth, minIndelStartDepthFraction
+        self.minIndelContinuationTotalDepth, self.minIndelContinuationDepthFraction = minIndelContinuationTotalDepth, minIndelContinuationDepthFraction
 
     @staticmethod
     def emptyFilter():
         return MutationDetectionParameters()
+
+    @staticmethod
+    def defaultFilter():
+        return MutationDetectionParameters(5.0, 0.9, 1.0, 0.8, 1.0, 0.7)
 
 
 def _number(x):
@@ -45,9 +57,8 @@ class MatchDatabase:
     each, summed on the host in replica order)."""
 
     def __init__(self, databases, query_end_fraction=0.0):
-        if query_end_fraction != 0:
-            raise NotImplementedError("--distinguish-query-ends: the rule lives in the un-vendored MatchDatabase and is pinned by one test only")
         self.dbs = list(databases) if isinstance(databases, (list, tuple)) else [databases]
+        self.query_end_fraction = float(query_end_fraction)
         self._L = _capi.lib()
         self._h = []
         for db in self.dbs:
@@ -55,6 +66,8 @@ class MatchDatabase:
             if self._L.xm_pileup_new(db._h, C.byref(h)):
                 raise RuntimeError(self._L.xm_last_error().decode())
             self._h.append(h)
+            if self._L.xm_pileup_set_query_ends(h, self.query_end_fraction):
+                raise RuntimeError(self._L.xm_last_error().decode())
         self.contigs = self.dbs[0].contigs
         self._reads = {}   # query ordinal (per replica) -> mates, kept only for queries with an insertion
         self._batches = [[] for _ in self.dbs]
@@ -90,6 +103,17 @@ class MatchDatabase:
         """AlignmentPosition.getCount() for every position of the contig."""
         return self._sum(contig)[0].astype(np.float64) / UNIT
 
+    def _middle(self, contig):
+        """The depth from query bases away from the query ends (all of it without a query-end fraction), summed over the replicas."""
+        n = len(self.contigs[contig][1])
+        mid = np.zeros(n, np.uint64)
+        for h in self._h:
+            d = np.zeros(n, np.uint64)
+            if self._L.xm_pileup_read_middle(h, contig, 0, n, d.ctypes.data):
+                raise RuntimeError(self._L.xm_last_error().decode())
+            mid += d
+        return mid
+
     def _events(self):
         """(replica, contig, startB, type, length, query ordinal, mate | reversed << 1, startA, weight) of every insertion / deletion block."""
         out = []
@@ -122,13 +146,15 @@ class MatchDatabase:
         rows = []
         indels = {}
         for r, contig, pos, kind, length, ordinal, flags, start_a, weight in self._events():
+            if flags & 4:   # near a query end: "when detecting indels, only consider the middle of each query" (Mapper.java:532)
+                continue
             ref = self.contigs[contig][1]
             if kind == 1:
                 mate = self._mate(r, ordinal, flags & 1)
                 if mate is None:
                     text = "N" * length
                 else:
-                    oriented = reverse_complement(mate) if flags >> 1 else mate
+                    oriented = reverse_complement(mate) if (flags >> 1) & 1 else mate
                     text = decode(oriented[start_a:start_a + length])
                 key = (contig, pos, 1, "-" * length, text)   # reported at the base before the insertion: 1-based position = startB
             else:
@@ -136,21 +162,34 @@ class MatchDatabase:
             indels[key] = indels.get(key, 0) + weight
         for c in range(len(self.contigs)):
             depth, alt = self._sum(c)
+            mid = self._middle(c) if indels else depth
             ref = self.contigs[c][1]
             for b, letter in enumerate("ACGT"):
                 for pos in np.nonzero(alt[b])[0]:
                     total = depth[pos] / UNIT
-                    if total < f.minSNPTotalDepth:
+                    support = alt[b][pos] / UNIT
+                    if total < f.minSNPTotalDepth or support < f.minSNPDepthFraction * total:
                         continue
-                    rows.append((c, int(pos) + 1, 0, decode(ref[pos:pos + 1]), letter, alt[b][pos] / UNIT, total))
+                    rows.append((c, int(pos) + 1, 0, decode(ref[pos:pos + 1]), letter, support, total))
             for (cc, pos1, kind, ra, qa), w in indels.items():
                 if cc != c:
                     continue
+                support = w / UNIT
                 at = min(max(pos1 - 1, 0), len(ref) - 1)
-                total = depth[at] / UNIT
-                if total < f.minIndelTotalStartDepth:
+                total = mid[at] / UNIT     # the total (middle) depth where the indel starts (Mapper.java:538-539)
+                if total < f.minIndelTotalStartDepth or support < f.minIndelStartDepthFraction * total:
                     continue
-                rows.append((c, pos1, kind, ra, qa, w / UNIT, total))
+                # continuation (Mapper.java:541-542) [inferred]: every further base of the indel is judged where it lies (a deletion's bases on the
+                # reference, an insertion's at its one position); the indel is cut in front of the first base that fails
+                n = max(len(ra), len(qa))
+                keep = 1
+                while keep < n:
+                    here = min(at + keep, len(ref) - 1) if kind == 2 else at
+                    t = mid[here] / UNIT
+                    if t < f.minIndelContinuationTotalDepth or support < f.minIndelContinuationDepthFraction * t:
+                        break
+                    keep += 1
+                rows.append((c, pos1, kind, ra[:keep], qa[:keep], support, total))
         rows.sort(key=lambda t: (t[0], t[1], t[2], t[3], t[4]))
         return [(c, pos1, ra, qa, w, total) for c, pos1, _, ra, qa, w, total in rows]
 

@@ -28,7 +28,7 @@ def build():
 def test_plain_c_program_links_every_entry_point():
     exe = build()
     out = subprocess.run([exe, "symbols"], capture_output=True, text=True)
-    assert out.returncode == 0 and out.stdout.startswith("symbols 30 stamp "), out.stdout + out.stderr
+    assert out.returncode == 0 and out.stdout.startswith("symbols 33 stamp "), out.stdout + out.stderr
 
 
 def test_error_contract_from_c():

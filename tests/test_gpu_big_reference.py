@@ -5,7 +5,7 @@ shape: tests/test_gpu_parity.py::test_grch38_regime_alignments_equal_oracle), so
   * configs[3]: 1,000,000 pairs 2 x 150 bp sampled genome-wide (seed 0x5EED0003, --spacing 100 50) come back as pairs with both mates at their origins;
   * configs[4]: 100,000 reads of 10 kb (seed 0x5EED0004) cut by --split-queries-past-size 1000 (the command line's splitter, SequenceSplitter.java:17,35-38)
     into 1,000,000 queries of 1 kb: with the error rates as stated (5 % substitutions + 5 % indel events per base: above --max-penalty, almost nothing
-    aligns) and with milder ones (2 % + 0.2 %), every section that aligns sits where it came from;
+    aligns, and what does is a short chance match) and with milder ones (2 % + 0.2 %), where the sections that align sit where they came from;
   * determinism (the same batch twice gives the same streams) and batch invariance (a query's result does not depend on the batch it travels in);
   * the index takes the paths a 5 Mb reference never takes: 64-bit position arrays, 64-byte bucket lines, tables hashed on the GPU in groups with the
     multi blocks around the N-runs from the host; the bucket-line probe and the CSR probe return the same positions.
@@ -106,12 +106,10 @@ def test_config4_long_reads_through_the_splitter(grch):
     b, a, k = split_batch(reads, 1000)
     r1 = db.align_arrays(*arrays(b), params)
     one, ctg, rev, off = first_alignment(r1)
-    q = np.nonzero(one)[0]
-    # a section that aligns at all sits on its read's contig and strand, within the drift its indels allow (a read's sections share its origin)
-    if len(q):
-        read = q // k
-        assert (ctg == contig[read]).mean() > 0.99 and (rev == strand[read]).mean() > 0.99
+    # ~15 penalty units per 100 bases against --max-penalty's 10: next to nothing aligns, and what does is a short local match whose other bases
+    # count as unaligned (0.1 each, AlignmentParameters.java:73-95), not the section's origin - so no statement about places here, only about numbers
     frac_stated = one.mean()
+    assert frac_stated < 0.01
     sl = slice(300_000, 320_000)
     sb = oracle_lib.QueryBatch.from_arrays(b.mate_count[sl], b.mate_offset[2 * sl.start:2 * sl.stop], b.mate_length[2 * sl.start:2 * sl.stop], b.codes, b.expected_inner[sl], b.deviation[sl])
     r2 = db.align_arrays(*arrays(sb), params)

@@ -13,11 +13,11 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "mutations_reference.json")))
 
 
-def build(query_texts, reference, params=None):
+def build(query_texts, reference, params=None, query_end_fraction=0.0):
     db = api.ReferenceDatabase([("ref", reference)], mode="api")
     queries = [api.Query(*[api.encode(t) for t in qt]) if isinstance(qt, (list, tuple)) else api.Query(api.encode(qt)) for qt in query_texts]
     r = db.align_batch(queries, api.AlignmentParameters(**(params or FIX["alignment_parameters"])))
-    m = pileup.MatchDatabase(db)
+    m = pileup.MatchDatabase(db, query_end_fraction)
     m.add_last(queries)
     return db, m, r
 
@@ -25,7 +25,7 @@ def build(query_texts, reference, params=None):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", FIX["mutation_cases"], ids=[c["name"] for c in FIX["mutation_cases"]])
 def test_mutations_writer_cases(case):
-    db, m, _ = build([case["query"]], case["reference"])
+    db, m, _ = build([case["query"]], case["reference"], query_end_fraction=case.get("query_end_fraction", 0.0))
     out = io.StringIO()
     m.write_mutations(out, pileup.MutationDetectionParameters(**case.get("filter", {})))
     lines = [l for l in out.getvalue().split("\n") if l and not l.startswith("#") and not l.startswith("CHR")]  # (withoutMetadataLines, MutationsWriter_Test.java:144-154)
@@ -47,12 +47,46 @@ def test_match_database_counts():
     q = api.Query(api.encode(q1), api.encode(q2), expected_inner_distance=0.0, spacing_deviation_per_unit_penalty=1.0)
     r = db.align_batch([q], api.AlignmentParameters(**dict(FIX["alignment_parameters"], MaxErrorRate=1.0)))
     comps = r.query_alignments(0)
-    if len(comps) == 1 and len(comps[0]) == 1 and len(comps[0][0].components) == 2:  # (the aligner found the pair as the reference's test builds it)
-        m = pileup.MatchDatabase(db)
-        m.add_last([q])
-        assert np.array_equal(m.depth(0), np.ones(len(ref)))
-        m.close()
+    # the aligner returns the pair as the reference's test builds it (MatchDatabase_Test.java:47-54): one alignment of two sequences at 0 and 3
+    assert len(comps) == 1 and len(comps[0]) == 1 and [sa.start_index_b() for sa in comps[0][0].components] == [c["start1"], c["start2"]]
+    m = pileup.MatchDatabase(db)
+    m.add_last([q])
+    assert np.array_equal(m.depth(0), np.ones(len(ref)))
+    m.close()
     db.close()
+
+
+@pytest.mark.gpu
+def test_query_ends_and_thresholds_on_a_synthetic_batch():
+    """--distinguish-query-ends 0.1 with the reference's default thresholds (Mapper.java:76,534-542) on a deep synthetic pile-up: the middle depth is
+    the depth minus what the first and last tenth of every read contribute (recounted on the host), indels near read ends do not count, and the
+    thresholds only ever remove lines."""
+    ref = synth.synthetic_reference(20_000, seed=91)
+    reads = synth.synthetic_single_end(ref, 3000, seed=92, indel_prob=0.3)[0]
+    queries = [api.Query(r) for r in reads]
+    db = api.ReferenceDatabase([("r", ref)])
+    res = db.align_batch(queries, api.AlignmentParameters())
+    m0 = pileup.MatchDatabase(db)
+    m0.add_last(queries)
+    m1 = pileup.MatchDatabase(db, 0.1)
+    m1.add_last(queries)
+    assert np.array_equal(m0._sum(0)[0], m1._sum(0)[0]) and np.array_equal(m0._middle(0), m0._sum(0)[0])
+    mid = np.zeros(len(ref))
+    for q in range(len(queries)):
+        for comp in res.query_alignments(q):
+            for al in comp:
+                for sa in al.components:
+                    for b in sa.sections:
+                        n = len(reads[q])
+                        ks = np.arange(b.startA, b.startA + b.lengthA) if b.lengthA == b.lengthB else np.full(b.lengthB, b.startA)
+                        inner = ~((ks < 0.1 * n) | (ks >= n - 0.1 * n))
+                        np.add.at(mid, b.startB + np.arange(len(ks))[inner], 1.0 / len(comp))
+    assert np.allclose(m1._middle(0) / pileup.UNIT, mid, atol=1e-9)
+    everything = m1.mutations(pileup.MutationDetectionParameters.emptyFilter())
+    filtered = m1.mutations(pileup.MutationDetectionParameters.defaultFilter())
+    assert 0 < len(filtered) < len(everything) and set((c, p, a, b) for c, p, a, b, _, _ in filtered) <= set((c, p, a, b) for c, p, a, b, _, _ in everything)
+    assert len([x for x in everything if "-" in x[2] + x[3]]) < len([x for x in m0.mutations() if "-" in x[2] + x[3]])  # indels near read ends are gone
+    m0.close(); m1.close(); db.close()
 
 
 @pytest.mark.gpu
@@ -119,7 +153,8 @@ def test_cli_out_mutations(tmp_path):
     outs = []
     for extra in ([], ["--devices", "0,0", "--batch-size", "128"]):
         path = tmp_path / ("mut%d.txt" % len(outs))
-        assert cli.run(["--reference", str(tmp_path / "ref.fasta"), "--queries", str(tmp_path / "reads.fastq"), "--out-mutations", str(path)] + extra, out=io.StringIO()) == 0
+        assert cli.run(["--reference", str(tmp_path / "ref.fasta"), "--queries", str(tmp_path / "reads.fastq"), "--distinguish-query-ends", "0", "--out-mutations", str(path),
+                        "--snp-threshold", "0", "0", "--indel-threshold", "0", "0"] + extra, out=io.StringIO()) == 0
         outs.append(open(path).read())
     assert outs[0] == outs[1]
     body = [l.split("\t") for l in outs[0].split("\n") if l and not l.startswith("#") and not l.startswith("CHR")]

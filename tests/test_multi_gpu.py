@@ -122,8 +122,9 @@ def test_contexts_share_one_index():
     free0, rss0 = api.device_memory(0)[0], proc.memory_info().rss
     ctx = [first] + [first.new_context() for _ in range(3)]
     free1, rss1 = api.device_memory(0)[0], proc.memory_info().rss
-    assert free0 - free1 < index_bytes // 8, "a context must not copy the tables in HBM"
-    assert rss1 - rss0 < index_bytes // 8, "a context must not copy the host tables"
+    # (three more streams and their events cost the HIP runtime some tens of MB of host memory; a copy of the tables would be 3 x 330 MB)
+    assert free0 - free1 < index_bytes // 4, "a context must not copy the tables in HBM"
+    assert rss1 - rss0 < index_bytes // 2, "a context must not copy the host tables"
     params = api.AlignmentParameters()
     reads = synth.synthetic_single_end(ref, 40_000, seed=0xC1, indel_prob=0.3)[0]
     parts = [se_batch(reads[i * 10_000:(i + 1) * 10_000]) for i in range(4)]
