@@ -388,10 +388,11 @@ __global__ void __launch_bounds__(256) xm_pileup_kernel(IndexView ix, BatchView 
 struct PassCtl {
   unsigned long long nHeavy, nHeavyLate, nScale[2], nOut[2], nPath[2];
   unsigned long long errQuery;  // smallest query index whose status is an error (~0 = none)
+  unsigned long long nConf[2];  // reads that wait for a value of the confidence table (XM_ST_NEED_CONF)
 };
 
 __global__ void __launch_bounds__(256) xm_classify_kernel(const int64_t* todo, long long nTodo, const int32_t* status, int64_t* listHeavy, int64_t* listScale, int64_t* listOut,
-                                                          int64_t* listPath, int64_t* listHeavyLate, int hintThreshold, PassCtl* ctl, int ts, int to, int tp) {
+                                                          int64_t* listPath, int64_t* listHeavyLate, int hintThreshold, PassCtl* ctl, int ts, int to, int tp, int64_t* listConf, int tc) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nTodo) return;
   int64_t q = todo ? todo[i] : (int64_t)i;
@@ -406,6 +407,7 @@ __global__ void __launch_bounds__(256) xm_classify_kernel(const int64_t* todo, l
   } else if (st == XM_ST_NEED_PATH) listPath[atomicAdd(&ctl->nPath[tp], 1ull)] = q;
   else if (st == XM_ST_OVERFLOW) listScale[atomicAdd(&ctl->nScale[ts], 1ull)] = q;
   else if (st == XM_ST_OUT_OVERFLOW) listOut[atomicAdd(&ctl->nOut[to], 1ull)] = q;
+  else if (st == XM_ST_NEED_CONF) listConf[atomicAdd(&ctl->nConf[tc], 1ull)] = q;
   else atomicMin(&ctl->errQuery, (unsigned long long)q);
 }
 
@@ -752,6 +754,7 @@ struct DeviceTables {
   DevBuf<Table> dTables;
   DevBuf<uint32_t> dBucketOff, dPositions32;
   DevBuf<uint64_t> dPositions64;
+  DevBuf<int32_t> dBaLogStep;
   DevBuf<uint32_t> dLines32;  // bucket lines (IndexView::lines32 / lines64), built on the device from the CSR tables by upload()
   DevBuf<uint64_t> dLines64;
   bool posIs64 = false;
@@ -816,6 +819,14 @@ struct DeviceTables {
     view.contigStart = dContigStart.p; view.contigLen = dContigLen.p; view.seqCumStart = dSeqCumStart.p; view.refCodes = dRefCodes.p;
     view.tables = dTables.p; view.bucketOff = dBucketOff.p; view.positions32 = dPositions32.p; view.positions64 = dPositions64.p;
     view.dupKeyStart = dDupKeyStart.p; view.dupKeys = dDupKeys.p;
+    view.conf = nullptr; view.confMask = 0; view.confMiss = nullptr;  // (per call: alignResidentLocked)
+    {
+      int32_t steps[24];
+      blockAlignerLogSteps(steps, 24);
+      dBaLogStep.ensure(24);
+      HIP_CHECK(hipMemcpy(dBaLogStep.p, steps, sizeof(steps), hipMemcpyHostToDevice));
+      view.baLogStep = dBaLogStep.p;
+    }
     uploadedLength = host.maxHashedLength;
     hs->hashedLength.store(host.maxHashedLength);
   }
@@ -862,6 +873,15 @@ struct xm_index {
   DevBuf<int32_t> dFinalInts;
   DevBuf<double> dFinalDbls;
   DevBuf<DevCounters> dCounters;
+  // confidence table (IndexView::conf): host copy, device copy, the settings it was computed for, miss list, reads that wait for it
+  std::vector<ConfEntry> confHost;
+  size_t confCount = 0;
+  double confSig[4] = {0, 0, 0, 0};   // Max_PenaltySpan, MutationPenalty, granularity, total size
+  bool confDirty = true;
+  DevBuf<ConfEntry> dConf;
+  DevBuf<uint8_t> dConfMiss;
+  DevBuf<int64_t> dListConf[2];
+  std::vector<int32_t> residentLens, stagedLens;  // distinct total query lengths of the batch (the table is seeded for them)
   int64_t residentNq = -1;   // batch kept in HBM by xm_batch_upload
   int64_t residentGen = 0, lastAlignedGen = -1;  // which resident batch the streams of the last align call belong to
   int64_t lastAlignedNq = -1;  // queries whose result streams (dFinalInts / dFinalDbls / dFinalIntOff) are still in HBM from the last align call (xm_pileup_add_last)
@@ -878,6 +898,74 @@ struct xm_index {
   int64_t stagedNq = -1;
   int stagedMaxLen = 0;
   double stagedH2dMs = 0;
+
+  static constexpr size_t kConfMissCap = 1 << 16;
+  bool confInsert(double penalty, int32_t qlen, const Params& p) {  // -> false: already there
+    uint64_t bits;
+    memcpy(&bits, &penalty, 8);
+    if ((confCount + 1) * 2 > confHost.size()) {  // grow (and rehash) at half load
+      std::vector<ConfEntry> old;
+      old.swap(confHost);
+      confHost.assign(old.empty() ? (size_t)1 << 14 : old.size() * 2, ConfEntry{0, 0, 0, 0.0});
+      for (const ConfEntry& e : old) if (e.used) { uint32_t h = confHash(e.penaltyBits, e.queryLength) & (uint32_t)(confHost.size() - 1); while (confHost[h].used) h = (h + 1) & (uint32_t)(confHost.size() - 1); confHost[h] = e; }
+    }
+    const uint32_t mask = (uint32_t)(confHost.size() - 1);
+    uint32_t h = confHash(bits, qlen) & mask;
+    while (confHost[h].used) {
+      if (confHost[h].penaltyBits == bits && confHost[h].queryLength == qlen) return false;
+      h = (h + 1) & mask;
+    }
+    const HostIndex& hst = hs->host;
+    confHost[h] = ConfEntry{bits, qlen, 1, confidenceLengthOnHost(penalty, qlen, p.Max_PenaltySpan, p.MutationPenalty, hst.dupGranularity(), hst.totalForwardSize * 2)};
+    confCount++;
+    confDirty = true;
+    return true;
+  }
+  // the table for this call: reset when the settings it depends on changed; seeded with what the batch's reads will ask for in the common case
+  // (an alignment without indels costs a whole number of substitutions: the sums 0, m, m + m, ... up to the allowed penalty), whatever else
+  // comes up (ambiguity and unaligned penalties, spacing penalties of pairs, other sums) is added after the pass that missed it
+  void confPrepare(const Params& p, hipStream_t s) {
+    const HostIndex& hst = hs->host;
+    const double sig[4] = {p.Max_PenaltySpan, p.MutationPenalty, hst.dupGranularity(), (double)(hst.totalForwardSize * 2)};
+    if (memcmp(sig, confSig, sizeof(sig)) != 0) { memcpy(confSig, sig, sizeof(sig)); confHost.clear(); confCount = 0; confDirty = true; }
+    for (int32_t len : residentLens) {
+      const double limit = (double)len * p.MaxErrorRate + p.Max_PenaltySpan + p.MutationPenalty;
+      double pen = 0;
+      for (int j = 0; j < 4096 && pen <= limit; j++) { confInsert(pen, len, p); pen += p.MutationPenalty; }
+    }
+    confUpload(s);
+    if (!dConfMiss.p) {
+      dConfMiss.ensure(sizeof(ConfMiss) + kConfMissCap * sizeof(ConfMissKey));
+      ConfMiss hdr;
+      memset(&hdr, 0, sizeof(hdr));
+      hdr.cap = kConfMissCap;
+      HIP_CHECK(hipMemcpyAsync(dConfMiss.p, &hdr, offsetof(ConfMiss, keys), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    }
+  }
+  void confUpload(hipStream_t s) {
+    if (!confDirty) return;
+    if (confHost.empty()) confHost.assign((size_t)1 << 14, ConfEntry{0, 0, 0, 0.0});
+    HIP_CHECK(hipStreamSynchronize(s));   // (no kernel of this context reads the old copy any more)
+    dConf.ensure(confHost.size());
+    HIP_CHECK(hipMemcpy(dConf.p, confHost.data(), confHost.size() * sizeof(ConfEntry), hipMemcpyHostToDevice));
+    confDirty = false;
+  }
+  // after a pass with XM_ST_NEED_CONF reads: the keys they left, evaluated and added; -> number of new entries
+  size_t confAbsorbMisses(const Params& p, hipStream_t s) {
+    ConfMiss hdr;
+    HIP_CHECK(hipMemcpyAsync(&hdr, dConfMiss.p, offsetof(ConfMiss, keys), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    const size_t n = (size_t)std::min<unsigned long long>(hdr.n, hdr.cap);
+    std::vector<ConfMissKey> keys(n);
+    if (n) HIP_CHECK(hipMemcpy(keys.data(), dConfMiss.p + offsetof(ConfMiss, keys), n * sizeof(ConfMissKey), hipMemcpyDeviceToHost));
+    const unsigned long long zero = 0;
+    HIP_CHECK(hipMemcpy(dConfMiss.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    size_t added = 0;
+    for (const ConfMissKey& k : keys) { double pen; memcpy(&pen, &k.penaltyBits, 8); if (confInsert(pen, k.queryLength, p)) added++; }
+    confUpload(s);
+    return added;
+  }
 
   void initContext() {  // stream and events of this context (the device tables exist)
     HIP_CHECK(hipSetDevice(device));
@@ -1167,19 +1255,28 @@ void xm_result_free(xm_result* r) {
 }
 
 // validation + Readable_HashBlock_Database growth + host-to-device copy of one batch; the batch stays resident in HBM
-static int validateBatch(const xm_query_batch* b, bool* anyPaired = nullptr) {  // -> longest mate
+static int validateBatch(const xm_query_batch* b, bool* anyPaired = nullptr, std::vector<int32_t>* totalLengths = nullptr) {  // -> longest mate
   const int64_t nq = b->num_queries;
   int maxLen = 1;
   if (anyPaired) *anyPaired = false;
+  std::vector<uint8_t> seen(totalLengths ? 60001 : 0, 0);   // total query lengths that occur (Query.getLength(): what the confidence table is keyed by)
   for (int64_t q = 0; q < nq; q++) {
     if (b->mate_count[q] < 1 || b->mate_count[q] > 2) throw std::runtime_error("mate_count must be 1 or 2");
     if (anyPaired && b->mate_count[q] == 2) *anyPaired = true;
+    int total = 0;
     for (int m = 0; m < b->mate_count[q]; m++) {
       int32_t len = b->mate_length[q * 2 + m];
       if (len < 1 || len > 30000) throw std::runtime_error("mate length out of range (1..30000; longer reads are split by the caller as --split-queries-past-size does)");
       if (b->mate_offset[q * 2 + m] < 0 || b->mate_offset[q * 2 + m] + len > b->codes_length) throw std::runtime_error("mate outside of codes");
       if (len > maxLen) maxLen = len;
+      total += len;
+      if (totalLengths) seen[(size_t)len] = 1;
     }
+    if (totalLengths) seen[(size_t)total] = 1;
+  }
+  if (totalLengths) {
+    totalLengths->clear();
+    for (size_t i = 0; i < seen.size(); i++) if (seen[i]) totalLengths->push_back((int32_t)i);
   }
   return maxLen;
 }
@@ -1187,7 +1284,7 @@ static int validateBatch(const xm_query_batch* b, bool* anyPaired = nullptr) {  
 static void uploadBatchLocked(xm_index* idx, const xm_query_batch* b) {
   const int64_t nq = b->num_queries;
   bool anyPaired = false;
-  const int maxLen = validateBatch(b, &anyPaired);
+  const int maxLen = validateBatch(b, &anyPaired, &idx->residentLens);
   idx->residentAnyPaired = anyPaired;
   idx->ensureTablesFor(maxLen);  // Readable_HashBlock_Database.getContainingMap growth, done before the launch
   HIP_CHECK(hipSetDevice(idx->device));
@@ -1234,7 +1331,7 @@ int xm_batch_stage(xm_index* idx, const xm_query_batch* b) {
     std::lock_guard<std::mutex> stageLock(idx->stageMu);
     const int64_t nq = b->num_queries;
     bool anyPaired = false;
-    const int maxLen = validateBatch(b, &anyPaired);
+    const int maxLen = validateBatch(b, &anyPaired, &idx->stagedLens);
     idx->stagedAnyPaired = anyPaired;
     idx->ensureTablesFor(maxLen);  // (tables that grow wait for the launches that read them: DeviceTables::rw)
     HIP_CHECK(hipSetDevice(idx->device));
@@ -1274,6 +1371,7 @@ int xm_batch_commit(xm_index* idx) {
     idx->dCodes.swapWith(idx->sCodes); idx->dExpected.swapWith(idx->sExpected); idx->dDeviation.swapWith(idx->sDeviation);
     idx->residentGen++;
     idx->residentNq = idx->stagedNq; idx->residentMaxLen = idx->stagedMaxLen; idx->residentH2dMs = idx->stagedH2dMs; idx->residentAnyPaired = idx->stagedAnyPaired;
+    idx->residentLens.swap(idx->stagedLens);
     idx->stagedNq = -1;
     return 0;
   } catch (std::exception& e) { return fail(std::string("xm_batch_commit: ") + e.what()); }
@@ -1311,7 +1409,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     hipStream_t s = idx->stream;
     // the shared tables stay as they are while this call's kernels read them (another context that grows them waits; so does this one's next growth)
     std::shared_lock<std::shared_mutex> tablesInUse(idx->dt->rw);
-    const IndexView view = idx->dt->view;
+    IndexView view = idx->dt->view;
     const int numCUs = idx->dt->numCUs;
     res->num_queries = nq;
     res->int_off = (int64_t*)g_pinned->get(sizeof(int64_t) * (size_t)(nq + 1), &box->bytesIntOff);
@@ -1332,6 +1430,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     params.UnalignedPenalty = p->UnalignedPenalty; params.AmbiguityPenalty = p->AmbiguityPenalty; params.Max_PenaltySpan = p->Max_PenaltySpan;
     params.MaxNumMatches = p->MaxNumMatches; params.StartingInsertionStartFree = 0;
 
+    idx->confPrepare(params, s);
+    view.conf = idx->dConf.p; view.confMask = (uint32_t)(idx->confHost.size() - 1); view.confMiss = (ConfMiss*)idx->dConfMiss.p;
+    idx->dListConf[0].ensure((size_t)nq); idx->dListConf[1].ensure((size_t)nq);
     idx->dStatus.ensure((size_t)nq); idx->dIntOff.ensure((size_t)nq); idx->dDblOff.ensure((size_t)nq); idx->dIntLen.ensure((size_t)nq); idx->dDblLen.ensure((size_t)nq);
     idx->dCursors.ensure(4); idx->dCounters.ensure(1); idx->dCtl.ensure(1);
     idx->dListHeavy.ensure((size_t)nq); idx->dListHeavyLate.ensure((size_t)nq);
@@ -1363,7 +1464,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const int64_t* todo = nullptr;  // device list of the current pass; null on the first pass = all reads
     long long nTodo = nq;
     unsigned long long pendingHeavy = 0, pendingScale = 0, pendingPath = 0;
-    int ts = 0, to = 0, tp = 0;  // which of the two scale / out / path lists receives new entries
+    int ts = 0, to = 0, tp = 0, tc = 0;  // which of the two scale / out / path / confidence lists receives new entries
+    unsigned long long pendingConf = 0;
+    int confRounds = 0;
     // the scratch capacities are sized for ~150-300 bp mates at scale 1; batches of longer reads start at a larger scale instead of
     // sending every read through a pass that can only overflow
     int scale = idx->residentMaxLen <= 320 ? 1 : (idx->residentMaxLen <= 1280 ? 4 : 16), overflowScale = scale;
@@ -1611,7 +1714,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,
-                         idx->dListOut[to].p, idx->dListPath[tp].p, idx->dListHeavyLate.p, (int)heavyHintThreshold, idx->dCtl.p, ts, to, tp);
+                         idx->dListOut[to].p, idx->dListPath[tp].p, idx->dListHeavyLate.p, (int)heavyHintThreshold, idx->dCtl.p, ts, to, tp, idx->dListConf[tc].p, tc);
       HIP_CHECK(hipGetLastError());
       PassCtl ctl;
       HIP_CHECK(hipMemcpyAsync(&ctl, idx->dCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, s));
@@ -1643,6 +1746,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       pendingHeavy = ctl.nHeavy + ctl.nHeavyLate;
       pendingScale = ctl.nScale[ts];
       pendingPath = ctl.nPath[tp];
+      pendingConf = ctl.nConf[tc];   // (accumulates over the passes until the list is run)
       if (ctl.nOut[to] > 0) {  // result arena too small: rerun those reads with the same settings and room to spare
         todo = idx->dListOut[to].p; nTodo = (long long)ctl.nOut[to];
         to ^= 1;
@@ -1706,6 +1810,23 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         if (regionsTotal > 0) hoMode = 2;
         if (envInt("XM_PROF_GAPPED_ONLY", 0) != 0)  // XM_PROFILE builds: the in-kernel timers of the gapped pass alone
           HIP_CHECK(hipMemsetAsync((char*)idx->dCounters.p + offsetof(DevCounters, t), 0, sizeof(((DevCounters*)nullptr)->t), s));
+        continue;
+      }
+      if (pendingScale == 0 && pendingConf > 0) {
+        // reads that met a (penalty, length) the confidence table did not hold: the host evaluates the keys they left (its libm, the oracle's)
+        // and they run again, start to finish, in a pass of their own
+        if (++confRounds > 64) throw std::runtime_error("internal error: the confidence table does not converge");
+        idx->confAbsorbMisses(params, s);
+        view.conf = idx->dConf.p; view.confMask = (uint32_t)(idx->confHost.size() - 1);
+        todo = idx->dListConf[tc].p; nTodo = (long long)pendingConf;
+        tc ^= 1;
+        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nConf[tc], 0, sizeof(unsigned long long), s));
+        rerun += nTodo;
+        regionsTotal = 0;
+        if (scale < gappedScale) scale = gappedScale;
+        if (overflowScale < scale) overflowScale = scale;
+        heavy = true;
+        defer = false; inlineRest = false;
         continue;
       }
       if (pendingScale == 0) break;

@@ -43,6 +43,8 @@ enum : int32_t {
   XM_ST_INTERNAL = 5,      // the reference would have thrown (e.g. TreeMap.subMap fromKey > toKey): whole batch fails
   XM_ST_NEED_HEAVY = 6,    // light pass only: the read needs the gapped extension chain; the full pass reruns it
   XM_ST_NEED_PATH = 7,     // gapped pass with deferred PathAligner: a search request is waiting in the read's memo slot
+  XM_ST_NEED_CONF = 11,    // quicklyConfidentInBestAlignment needs a value of the confidence table the host has not put there yet (ConfView): the
+                           // read left its key in the miss list; the host evaluates it and the read runs again  (8-10: the wave form's, xm_wave.h)
 };
 
 // ---------------------------------------------------------------- Java arithmetic
@@ -183,7 +185,44 @@ struct IndexView {
   // the buckets of a genome-like reference) still go through bucketOff + positions.  Built on the device from the CSR tables (xm_lines_kernel).
   const uint32_t* lines32;
   const uint64_t* lines64;
+  // ---- per call (set on the launch's copy of the view, not shared between contexts)
+  // Transcendentals in output-affecting decisions are evaluated on the HOST, by the libm the oracle uses (SURVEY.md section 7 hard part 4):
+  // AlignerWorker.quicklyConfidentInBestAlignment's pow / log term (AlignerWorker.java:532-549) comes from a table keyed by (penalty, query
+  // length) that the host fills (xm_confidence.h); BlockAligner's (int)Math.log(refLen / Math.log(4.0)) (BlockAligner.java:48) is a step function
+  // of refLen whose steps the host computes.
+  const struct ConfEntry* conf;   // open addressing, confMask + 1 slots
+  uint32_t confMask;
+  struct ConfMiss* confMiss;      // keys the table did not hold
+  const int32_t* baLogStep;       // [24] baLogStep[k] = smallest refLen >= 1 with (int)log(refLen / log(4.0)) >= k  (k = 1..23; INT32_MAX beyond)
 };
+struct ConfEntry { uint64_t penaltyBits; int32_t queryLength; int32_t used; double totalLengthForHighConfidence; };
+struct ConfMissKey { uint64_t penaltyBits; int32_t queryLength; int32_t pad; };
+struct ConfMiss { unsigned long long n; unsigned long long cap; ConfMissKey keys[1]; };
+XM_INL uint32_t confHash(uint64_t penaltyBits, int32_t queryLength) {
+  uint64_t x = (penaltyBits ^ (penaltyBits >> 31)) * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)queryLength * 0xC2B2AE3D27D4EB4Full;
+  return (uint32_t)(x >> 37);
+}
+// -> true and the value, or false (not in the table)
+XM_INL bool confLookup(const ConfEntry* table, uint32_t mask, double penalty, int32_t queryLength, double& value) {
+  if (!table) return false;
+  uint64_t bits;
+  __builtin_memcpy(&bits, &penalty, 8);
+  uint32_t h = confHash(bits, queryLength) & mask;
+  while (true) {
+    const ConfEntry e = table[h];
+    if (!e.used) return false;
+    if (e.penaltyBits == bits && e.queryLength == queryLength) { value = e.totalLengthForHighConfidence; return true; }
+    h = (h + 1) & mask;
+  }
+}
+// BlockAligner.java:48 (sic): (int)Math.log(refLen / Math.log(4.0)) + 1, from the host's steps
+XM_INL int32_t baNumBasesToEncodeReferencePosition(const int32_t* step, int32_t refLen) {
+  if (refLen == 0) return INT32_MIN + 1;  // log(0) = -Infinity, (int) saturates
+  if (refLen < 0) return 1;               // log of a negative number is NaN, (int)NaN = 0
+  int k = 0;
+  while (k + 1 < 24 && refLen >= step[k + 1]) k++;
+  return k + 1;
+}
 constexpr int XM_LINE_SLOTS = 7;
 constexpr int64_t XM_LINE_FLAG = 1ll << 62;  // an index "into positions" with this bit set addresses a word of the lines array instead
 // the line of bucket j (= t.offBase + k) from the CSR form; same code on the device (xm_lines_kernel) and in the host simulation

@@ -62,6 +62,7 @@ struct ExtEnv {  // everything the chain needs
   SeqView reference; // sequenceB (forward contig)
   int32_t contig;
   Matcher* slotA; Matcher* slotB; Matcher* slotT;
+  const int32_t* baLogStep; // IndexView::baLogStep (BlockAligner's log term, evaluated on the host)
   float* heavyHint;         // light pass: where a read that stops with XM_ST_NEED_HEAVY leaves its cost hint
   struct MemoHdr* memo;     // gapped pass with deferred PathAligner searches: the read's memo slot (null = searches run inline)
   int32_t* memoCursor;      // replay position in the memo log
@@ -1623,7 +1624,8 @@ XM_NOINL bool blockAlign(const ExtEnv& e, const Section& qsIn, const Section& rs
   double maxInterestingPenalty = p.MaxErrorRate * secLen(qs);
   // initialAlignments :39-96
   double maxInterestingPenaltyWholeQuery = p.MaxErrorRate * e.query.len;  // (sic) uses query.getLength()
-  int numBasesToEncodeReferencePosition = j2i(log((double)secLen(rs) / log(4.0))) + 1;  // (sic) :48
+  int numBasesToEncodeReferencePosition = e.baLogStep ? baNumBasesToEncodeReferencePosition(e.baLogStep, secLen(rs))  // (sic) :48, the host's steps
+                                                      : 3;  // (only the component test entry runs the chain without an index; it never reaches BlockAligner)
   int numHashblocks = secLen(qs) / numBasesToEncodeReferencePosition + 1;
   int targetNumHashblocksPerBlock = j2i(sqrt((double)numHashblocks)) + 1;
   int targetBlockSize = targetNumHashblocksPerBlock * numBasesToEncodeReferencePosition;

@@ -1387,15 +1387,16 @@ WV_FN bool wQuicklyConfidentInBestAlignment(WL_T L, const WEnv& e, int ai, int a
   }
   const int contig = m.c[0].contig;
   const int matchStart = wQmStartIndexB(m), matchEnd = wQmEndIndexB(m);
-  const double granularity = e.ix.dupGranularity;
   const double penalty = a->good[alIdx].totalPenalty;
-  const double numberOfMutations = (penalty + e.params.Max_PenaltySpan) / e.params.MutationPenalty;
-  const double existingMutationRate = numberOfMutations / wQmQueryTotalLength(L, m);
   if (penalty <= 0 && e.params.Max_PenaltySpan < e.params.getMinPossibleNonzeroPenalty()) return true;
-  const double probabilityMutationInSection = 1 - pow(1 - existingMutationRate, granularity);
-  const double acceptableProbability = 1.0 / (double)e.ix.totalForwardAndReverseSize;
-  const double numberOfUnmatchedBlocksForHighConfidence = log(acceptableProbability) / log(probabilityMutationInSection);
-  const double totalLengthForHighConfidence = numberOfUnmatchedBlocksForHighConfidence * granularity;
+  // the pow / log term is the host's (IndexView::conf, xm_confidence.h); a key the table does not hold yet: the read leaves the wave form and the
+  // lane-per-read pass that takes it over puts the key on the miss list
+  double totalLengthForHighConfidence = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!confLookup(e.ix.conf, e.ix.confMask, penalty, wQmQueryTotalLength(L, m), totalLengthForHighConfidence)) { { L->status = XM_ST_WAVE_FALLBACK; L->why = 19; } return false; }
+#else
+  totalLengthForHighConfidence = confidenceLengthOnHost(penalty, wQmQueryTotalLength(L, m), e.params.Max_PenaltySpan, e.params.MutationPenalty, e.ix.dupGranularity, e.ix.totalForwardAndReverseSize);
+#endif
   const double matchMiddle = (double)((matchStart + matchEnd) / 2);
   const double interestingWindow = jmaxd(totalLengthForHighConfidence, (double)((matchEnd - matchStart + 1) / 2));
   const int windowStart = j2i(matchMiddle - interestingWindow);
@@ -1540,7 +1541,9 @@ WV_FN void wAlignRead(WL_T L, const WEnv& e, const ReadIn& in, WResult& rr) {
     haveOptimisticMatch = true;
     optimisticBestAlignment = wQmaAlign(L, e, 0, optimisticBestMatch, 0);
     if (L->status) return;
-    if (wQuicklyConfidentInBestAlignment(L, e, 0, optimisticBestAlignment, optimisticBestMatch)) {
+    const bool quick = wQuicklyConfidentInBestAlignment(L, e, 0, optimisticBestAlignment, optimisticBestMatch);
+    if (L->status) return;
+    if (quick) {
       if (e.dc) e.dc->quickAccepts++;
       rr.single[0] = optimisticBestAlignment;
       return;

@@ -491,7 +491,7 @@ WV_FN bool wBlockAlign(WL_T L, const WEnv& e, const WChainCtx& cx, const Section
   const double maxInterestingPenalty = p.MaxErrorRate * secLen(qs);
   // initialAlignments :39-96
   const double maxInterestingPenaltyWholeQuery = p.MaxErrorRate * cx.qLen;  // (sic) uses query.getLength()
-  const int numBasesToEncodeReferencePosition = j2i(log((double)secLen(rs) / log(4.0))) + 1;  // (sic) :48
+  const int numBasesToEncodeReferencePosition = baNumBasesToEncodeReferencePosition(e.ix.baLogStep, secLen(rs));  // (sic) :48, the host's steps
   const int numHashblocks = secLen(qs) / numBasesToEncodeReferencePosition + 1;
   const int targetNumHashblocksPerBlock = j2i(sqrt((double)numHashblocks)) + 1;
   const int targetBlockSize = targetNumHashblocksPerBlock * numBasesToEncodeReferencePosition;

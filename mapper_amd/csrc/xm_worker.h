@@ -5,6 +5,7 @@
 // lane's scratch arena (persistent part bump-allocated from the bottom, stack-discipline temporaries above it).
 #pragma once
 #include "xm_extend.h"
+#include "xm_confidence.h"
 
 namespace xm {
 
@@ -113,6 +114,7 @@ XM_INL void makeExtEnv(ReadCtx& cx, ExtEnv& e, const SeqView& query, int contig)
   e.slotA = e.slotB = e.slotT = nullptr;
   e.memo = cx.memo; e.memoCursor = &cx.memoCursor;
   e.heavyHint = &cx.heavyHint;
+  e.baLogStep = cx.ix->baLogStep;
 }
 
 // alignMatch :412-462 (fromHashblockMatch is always true).  The matcher slots live in tmp for the duration of the call.
@@ -508,6 +510,24 @@ XM_INL double penaltyLowerBound(const ReadCtx& cx, int numMismatchedHashblocks) 
   return dmin(mutationPenalty, indelPenalty);
 }
 
+// totalLengthForHighConfidence of quicklyConfidentInBestAlignment.  On the device: from the host's table (IndexView::conf); a key the table does not
+// hold goes to the miss list and the read stops with XM_ST_NEED_CONF.  (Host simulation of the tests: evaluated in place, by the same host function.)
+XM_INL bool confidenceLength(ReadCtx& cx, double penalty, int queryTotalLength, double& value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (confLookup(cx.ix->conf, cx.ix->confMask, penalty, queryTotalLength, value)) return true;
+  ConfMiss* miss = cx.ix->confMiss;
+  if (miss) {
+    const unsigned long long at = atomicAdd(&miss->n, 1ull);
+    if (at < miss->cap) { uint64_t bits; __builtin_memcpy(&bits, &penalty, 8); miss->keys[at].penaltyBits = bits; miss->keys[at].queryLength = queryTotalLength; miss->keys[at].pad = 0; }
+  }
+  cx.status = XM_ST_NEED_CONF;
+  return false;
+#else
+  value = confidenceLengthOnHost(penalty, queryTotalLength, cx.params.Max_PenaltySpan, cx.params.MutationPenalty, cx.ix->dupGranularity, cx.ix->totalForwardAndReverseSize);
+  return true;
+#endif
+}
+
 XM_NOINL bool quicklyConfidentInBestAlignment(ReadCtx& cx, QMAligner& a, int alIdx, const QMatch& m) {  // :494-587
   if (alIdx < 0) return false;
   XM_TIC(t0);
@@ -515,15 +535,11 @@ XM_NOINL bool quicklyConfidentInBestAlignment(ReadCtx& cx, QMAligner& a, int alI
   for (int k = 0; k < al.nSeq; k++) if (saHasIndel(al.seq[k])) return false;
   int contig = m.c[0].contig;
   int matchStart = qmStartIndexB(m), matchEnd = qmEndIndexB(m);
-  double granularity = cx.ix->dupGranularity;
   double penalty = al.totalPenalty;
-  double numberOfMutations = (penalty + cx.params.Max_PenaltySpan) / cx.params.MutationPenalty;
-  double existingMutationRate = numberOfMutations / qmQueryTotalLength(cx.seed, m);
   if (penalty <= 0 && cx.params.Max_PenaltySpan < cx.params.getMinPossibleNonzeroPenalty()) return true;
-  double probabilityMutationInSection = 1 - pow(1 - existingMutationRate, granularity);
-  double acceptableProbability = 1.0 / (double)cx.ix->totalForwardAndReverseSize;
-  double numberOfUnmatchedBlocksForHighConfidence = log(acceptableProbability) / log(probabilityMutationInSection);
-  double totalLengthForHighConfidence = numberOfUnmatchedBlocksForHighConfidence * granularity;
+  // :532-540: 1 - (1 - rate)^granularity, the two logarithms and their quotient are the host's (xm_confidence.h): table lookup by (penalty, length)
+  double totalLengthForHighConfidence = 0;
+  if (!confidenceLength(cx, penalty, qmQueryTotalLength(cx.seed, m), totalLengthForHighConfidence)) return false;  // (status set: the read runs again once the host has the value)
   double matchMiddle = (double)((matchStart + matchEnd) / 2);
   double interestingWindow = jmaxd(totalLengthForHighConfidence, (double)((matchEnd - matchStart + 1) / 2));
   int windowStart = j2i(matchMiddle - interestingWindow);
@@ -694,7 +710,9 @@ XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr, bool resume = false) {
 resume_optimistic:
     st.optimisticBestAlignment = qmaAlign(cx, *aligner, st.optimisticBestMatch, 0);
     if (cx.status) return;
-    if (quicklyConfidentInBestAlignment(cx, *aligner, st.optimisticBestAlignment, st.optimisticBestMatch)) {
+    const bool quick = quicklyConfidentInBestAlignment(cx, *aligner, st.optimisticBestAlignment, st.optimisticBestMatch);
+    if (cx.status) return;  // (XM_ST_NEED_CONF: the host has a value to add to the confidence table)
+    if (quick) {
       if (cx.dc) cx.dc->quickAccepts++;
       rr.single[0] = st.optimisticBestAlignment;
       return;

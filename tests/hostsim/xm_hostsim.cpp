@@ -26,6 +26,7 @@ static void markDump() { const char* names[6] = {"chunks", "counters", "history"
 struct SimIndex {
   HostIndex host;
   IndexView view;
+  int32_t baSteps[24];
   std::vector<uint32_t> p32, l32;
   std::vector<uint64_t> l64;
   void refresh() {
@@ -38,6 +39,9 @@ struct SimIndex {
     view.contigStart = host.contigStart.data(); view.contigLen = host.contigLen.data(); view.seqCumStart = host.seqCumStart.data(); view.refCodes = host.refCodes.data();
     view.tables = host.tables.data(); view.bucketOff = host.bucketOff.data(); view.positions32 = p32.data(); view.positions64 = (const uint64_t*)host.positions.data();
     view.dupKeyStart = host.dupKeyStart.data(); view.dupKeys = host.dupKeys.data();
+    view.conf = nullptr; view.confMask = 0; view.confMiss = nullptr;   // (the host simulation evaluates the confidence term in place: xm_worker.h)
+    blockAlignerLogSteps(baSteps, 24);
+    view.baLogStep = baSteps;
     // bucket lines (IndexView::lines32 / lines64), filled by the function the device kernel uses; XMSIM_LINES=0: CSR probes only
     view.lines32 = nullptr; view.lines64 = nullptr;
     l32.clear(); l64.clear();
