@@ -368,6 +368,8 @@ def main():
                             "sector ceiling (%.1f G sectors/s = %.0f GB/s of sector traffic) is the bound that applies; THIS index (%d MB) is cache-resident: "
                             "hbm_resident_index below is the HBM number" % (pos_bytes, sectors_per_s / 1e9, sectors_per_s * 64 / 1e9, info["index_bytes"] >> 20)}
             if args.seed_index_mb > 0 or big:
+                for c_ in ctx:
+                    c_.set_scratch(1 << 20)  # (the contexts give their scratch back: the second index and its build need the room)
                 seed["hbm_resident_index"] = seed_probe_hbm(api, synth, db if big else None, args.seed_index_mb, local_rank, sectors_per_s, args.seed_probes, rng)
 
         # HBM bytes per launch from the PMC passes committed with this round's profiles (same command, scripts/gpu_profile_round.sh);

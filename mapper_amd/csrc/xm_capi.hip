@@ -83,11 +83,13 @@ __device__ unsigned long long* xm_read_times = nullptr;
 // One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed, int lanesPerWave,
                                                        uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters,
-                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync, long long firstStride, PNode* waveNodes, HandOver ho, int pairLanes) {
+                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync, long long firstStride, PNode* waveNodes, HandOver ho, int pairLanes,
+                                                       SearchPool searchPool) {
   // lanesPerWave < 64 (gapped pass): the extension chain diverges so much that a wave runs its reads nearly one after another, so
   // spreading them over more, partly filled waves shortens the critical path; the idle lanes own no scratch arena
   xmSetWaveNodes(waveNodes);
   xmSetPairMode(pairLanes);
+  xmSetSearchPool(searchPool);
   xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
   // pairLanes (gapped pass, lanesPerWave <= 32): a read is run by two adjacent lanes doing the same work (xm_extend.h, xmSetPairMode);
   // `laneInWave` below is the read's slot in the wave, `second` marks the lane that leaves atomics and result writes to its partner
@@ -220,6 +222,8 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_path_kernel(const int64_t* list, long long n, const int32_t* slotOf, uint8_t* memoBase, int scale, int lanesPerWave,
                                                       uint8_t* arenas, unsigned long long arenaBytes, unsigned long long* nextItem, DevCounters* counters) {
   // few searches: spread them over as many waves as the GPU holds (the time of a launch is its longest wave)
+  xmSetSearchPool(SearchPool{nullptr, 0, 0, 0, nullptr});
+  __syncthreads();
   const int laneInWave = (int)(threadIdx.x & 63u);
   if (laneInWave >= lanesPerWave) return;
   unsigned long long lane = ((unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (unsigned)lanesPerWave + (unsigned)laneInWave;
@@ -246,6 +250,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(i
                                                             int32_t* outInts, double* outDbls) {
   xmSetWaveNodes(waveNodes);
   xmSetPairMode(0);
+  xmSetSearchPool(SearchPool{nullptr, 0, 0, 0, nullptr});
   xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
   if (threadIdx.x != 0) return;
   DevCounters local;
@@ -860,6 +865,8 @@ struct xm_index {
   DevBuf<int32_t> dSlotOf, dRegionOf;
   DevBuf<uint8_t> dMemo;
   DevBuf<PNode> dWaveNodes;  // per wave: node payloads of its LDS-mode search
+  DevBuf<uint8_t> dSearchPool;  // buffers for the arrays of HBM-mode searches (SearchPool, xm_extend.h)
+  DevBuf<int32_t> dSearchFlags;
   // wave-per-read passes
   DevBuf<int64_t> dListWaveHeavy, dListWaveNext, dListWaveSearch[2], dListFallback;
   DevBuf<uint8_t> dWaveMemo;
@@ -1517,12 +1524,21 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // (Deferred searches replay a read from its start, which a consumed region does not allow: no hand-over then.)
     const bool pairMode = envInt("XM_PAIR_LANES", 1) != 0;
     // temporaries of a gapped-pass lane (reads that resume from a saved region): 7/12 of the arena of that scale by default (experiment knob: percent of it)
-    const long long gappedTmpPct = envKnob("XM_GAPPED_TMP_PCT", 100, 5, 100);
+    // HBM-mode searches take their arrays from a pool of the launch (SearchPool) in batches of short reads (gapped pass at scale <= 4): a lane's
+    // temporaries then hold the chain's structures only (matchers 148 KB + piece lists 23 KB + small change at scale 4; default 30 % of 7/12 of
+    // the arena = 201 KB).  Batches of long reads run every search in HBM mode: no pool, whole temporaries.
+    const bool searchPoolOn = envInt("XM_SEARCH_POOL", 1) != 0 && gappedScale <= 4;
+    const long long gappedTmpPct = envKnob("XM_GAPPED_TMP_PCT", searchPoolOn ? 30 : 100, 5, 100);
     auto gappedTmpBytes = [&](size_t arena) -> size_t { return (size_t)((arena - arenaPersistBytes(arena)) * (size_t)gappedTmpPct / 100) & ~(size_t)15; };
+    // light pass: a lane's temporaries hold the three matchers alignMatch sets aside (37 KB at scale 1; the chain that would fill them does not
+    // run there) and the joined text of overlapping mates; a read's region holds its seeding state: 49 KB single-end, 99 KB paired at scale 1
+    // (ambiguity codes add up to 20 KB per mate: such a read overflows a single-end region and is seeded again by the gapped pass)
+    const size_t lightTmpUnit = (size_t)envKnob("XM_LIGHT_TMP_KB", 48, 16, 16384) * 1024;
+    const size_t regionPersistUnit = (size_t)envKnob("XM_REGION_KB", idx->residentAnyPaired ? 120 : 72, 32, 16384) * 1024;
     const bool handOver = envInt("XM_HANDOVER", 1) != 0 && !deferSearches;
     int hoMode = handOver ? 1 : 0;   // mode of the next launch
     const int seedScale = scale;
-    const size_t regionBytes = retainedRegionBytes(arenaUnit * (size_t)seedScale);
+    const size_t regionBytes = ((regionPersistUnit * (size_t)seedScale) & ~(size_t)15) + ((sizeof(SavedRead) + 15) & ~(size_t)15);
     long long nRegions = 0;
     size_t regionsTotal = 0;         // bytes at the start of the scratch that hold saved reads (0: none alive)
     if (handOver) {
@@ -1642,7 +1658,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     while (nTodo > 0) {
       std::unique_lock<std::mutex> sizing(idx->dt->allocMu);
       size_t arenaBytes = arenaUnit * (size_t)scale;  // bytes of scratch a lane owns in this launch
-      if (hoMode == 1) arenaBytes -= arenaPersistBytes(arenaBytes);                                // temporaries only (+ one region of the pool per lane)
+      if (hoMode == 1) arenaBytes = lightTmpUnit * (size_t)scale;                                    // temporaries only (+ one region of the pool per lane)
       else if (hoMode == 2) arenaBytes = regionBytes + gappedTmpBytes(arenaBytes);  // a region for reads without saved state + temporaries
       // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped chain
       // diverges inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  The XM_* variables are experiment knobs.
@@ -1699,6 +1715,17 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       HandOver ho{hoMode, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
       const int launchedMode = hoMode;
       idx->dWaveNodes.ensure((size_t)grid * (block / 64) * XM_PAL_NODES);
+      SearchPool pool{nullptr, 0, 0, 0, nullptr};
+      if (searchPoolOn && heavy && scale == gappedScale) {
+        const Caps pc = makeCaps(scale);
+        const size_t need = (size_t)pc.maxNodes * 32 + std::max((size_t)pc.gridCap, (size_t)pc.nodeHash) * 4 + (size_t)pc.maxBuckets * 20 + (size_t)pc.bucketHash * 4 + (size_t)pc.maxNodes * 8 + 4096;
+        pool.bufBytes = (need + 4095) & ~(size_t)4095;
+        pool.n = (int32_t)std::min<long long>(envKnob("XM_SEARCH_POOL_BUFFERS", 2048, 1, 1 << 20), std::max<long long>(1, ((long long)grid * (block / 64))));
+        idx->dSearchPool.ensure((size_t)pool.n * pool.bufBytes);
+        idx->dSearchFlags.ensure((size_t)pool.n);
+        HIP_CHECK(hipMemsetAsync(idx->dSearchFlags.p, 0, sizeof(int32_t) * (size_t)pool.n, s));
+        pool.base = idx->dSearchPool.p; pool.flags = idx->dSearchFlags.p;
+      }
       idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq); idx->dListPath[tp].ensure(defer ? (size_t)nTodo : 1);
       // gapped pass with an ordered list: the first read of every lane is dealt out (kernel), the counter starts behind those items
       const long long firstStride = (heavy && !defer && heavyHintThreshold > 0 && scale == gappedScale) ? (long long)grid * (block / 64) : 0;
@@ -1710,7 +1737,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
                          laneArenas, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
                          defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
                          (heavy && !fullSync) ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, ((!heavy && lightSync) || (heavy && fullSync)) ? 1 : 0,
-                         fullSync ? 0ll : firstStride, idx->dWaveNodes.p, ho, pairLanes);
+                         fullSync ? 0ll : firstStride, idx->dWaveNodes.p, ho, pairLanes, pool);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,

@@ -393,12 +393,43 @@ XM_INL PNode* palWaveNodes();
 __shared__ int xm_pair_mode;
 XM_INL void xmSetPairMode(int on) { if (threadIdx.x == 0) xm_pair_mode = on; }  // (before the block's first barrier)
 XM_INL bool xmPairMode() { return __builtin_amdgcn_readfirstlane(xm_pair_mode) != 0; }
+// The arrays of an HBM-mode search (nodes, grid or hash, buckets, lists: 480 KB at the gapped pass's scale) are needed by under one search in a
+// hundred, so a lane does not own them: they come from a pool of the launch (xmSearchPool), claimed for the duration of one search.  A lane's
+// temporaries then hold the chain's structures only (matchers, piece lists: ~200 KB), which is what lets a context run all its lanes out of a
+// few tens of GiB of scratch.  An empty pool (or none: batches of long reads, whose searches all run in HBM mode) leaves the search in the lane's
+// temporaries as before.
+struct SearchPool { uint8_t* base; unsigned long long bufBytes; int32_t n; int32_t pad; int32_t* flags; };
+__shared__ SearchPool xm_search_pool;
+XM_INL void xmSetSearchPool(const SearchPool& p) { if (threadIdx.x == 0) xm_search_pool = p; }  // (before the block's first barrier)
+// -> slot (>= 0) and the buffer as an arena, or -1.  pair: the two lanes of a read take one buffer together (the first lane claims)
+XM_INL int xmClaimSearchBuffer(Arena& a, bool pair) {
+  const SearchPool p = xm_search_pool;
+  int slot = -1;
+  const int lane = (int)__lane_id();
+  if (p.n > 0 && !(pair && (lane & 1))) {
+    const unsigned gl = (unsigned)(((blockIdx.x * blockDim.x + threadIdx.x) >> (pair ? 1 : 0)) * 2654435761u);
+    for (int k = 0; k < 32 && slot < 0; k++) {
+      const int i = (int)((gl + (unsigned)k * 40503u) % (unsigned)p.n);
+      if (atomicCAS(&p.flags[i], 0, 1) == 0) slot = i;
+    }
+  }
+  if (pair) slot = __shfl(slot, lane & ~1);
+  if (slot >= 0) a.init(p.base + (unsigned long long)slot * p.bufBytes, (size_t)p.bufBytes);
+  return slot;
+}
+XM_INL void xmReleaseSearchBuffer(int slot, bool pair) {
+  if (slot >= 0 && !(pair && ((int)__lane_id() & 1))) atomicExch(&xm_search_pool.flags[slot], 0);
+}
 #else
 XM_INL uint8_t* palSlot() { static thread_local double slot[XM_PAL_SLOT_BYTES / 8]; return (uint8_t*)slot; }  // host simulation (tests only)
 XM_INL void xmSetWaveNodes(PNode*) {}
 XM_INL PNode* palWaveNodes();
 XM_INL void xmSetPairMode(int) {}
 XM_INL bool xmPairMode() { return false; }
+struct SearchPool { uint8_t* base; unsigned long long bufBytes; int32_t n; int32_t pad; int32_t* flags; };
+XM_INL void xmSetSearchPool(const SearchPool&) {}
+XM_INL int xmClaimSearchBuffer(Arena&, bool) { return -1; }
+XM_INL void xmReleaseSearchBuffer(int, bool) {}
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1172,6 +1203,15 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
 XM_NOINL bool pathSearchHbm(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair = false, PaResume* resume = nullptr) {
   return pathSearchT<false>(pr, tmp, caps, status, dc, outBlocks, nb, nullptr, pair, resume);
 }
+// the HBM-mode search with its arrays in a buffer of the launch's pool when there is one (else, or when the pool is empty, in the lane's temporaries)
+XM_INL bool pathSearchHbmPooled(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair, PaResume* resume = nullptr) {
+  Arena pooled;
+  const int slot = xmClaimSearchBuffer(pooled, pair);
+  if (slot < 0) return pathSearchHbm(pr, tmp, caps, status, dc, outBlocks, nb, pair, resume);
+  const bool found = pathSearchHbm(pr, pooled, caps, status, dc, outBlocks, nb, pair, resume);
+  xmReleaseSearchBuffer(slot, pair);
+  return found;
+}
 XM_NOINL bool pathSearchLds(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool* ldsOverflow, bool pair, PaResume* resume = nullptr) {
   return pathSearchT<true>(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow, pair, resume);
 }
@@ -1215,7 +1255,7 @@ XM_INL bool pathSearchSlot(const PaProblem& pr, Arena& tmp, const Caps& caps, in
   bool found = pathSearchLds(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow, pair, &rs);
   if (*ldsOverflow && rs.valid) {
     *ldsOverflow = false;
-    found = pathSearchHbm(pr, tmp, caps, status, dc, outBlocks, nb, pair, &rs);
+    found = pathSearchHbmPooled(pr, tmp, caps, status, dc, outBlocks, nb, pair, &rs);
   }
   return found;
 }
@@ -1280,7 +1320,7 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
     found = pathSearchSlot(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, false);
 #endif
     }
-    if (ldsOverflow) found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, xmPairMode());
+    if (ldsOverflow) found = pathSearchHbmPooled(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, xmPairMode());
   }
   if (!found || *e.status) return false;
   out.nb = nb;
