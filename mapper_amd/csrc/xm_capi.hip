@@ -1720,7 +1720,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         const Caps pc = makeCaps(scale);
         const size_t need = (size_t)pc.maxNodes * 32 + std::max((size_t)pc.gridCap, (size_t)pc.nodeHash) * 4 + (size_t)pc.maxBuckets * 20 + (size_t)pc.bucketHash * 4 + (size_t)pc.maxNodes * 8 + 4096;
         pool.bufBytes = (need + 4095) & ~(size_t)4095;
-        pool.n = (int32_t)std::min<long long>(envKnob("XM_SEARCH_POOL_BUFFERS", 2048, 1, 1 << 20), std::max<long long>(1, ((long long)grid * (block / 64))));
+        pool.n = (int32_t)(2 * (long long)grid * (block / 64));  // two per wave of the launch
         idx->dSearchPool.ensure((size_t)pool.n * pool.bufBytes);
         idx->dSearchFlags.ensure((size_t)pool.n);
         HIP_CHECK(hipMemsetAsync(idx->dSearchFlags.p, 0, sizeof(int32_t) * (size_t)pool.n, s));

@@ -394,10 +394,12 @@ __shared__ int xm_pair_mode;
 XM_INL void xmSetPairMode(int on) { if (threadIdx.x == 0) xm_pair_mode = on; }  // (before the block's first barrier)
 XM_INL bool xmPairMode() { return __builtin_amdgcn_readfirstlane(xm_pair_mode) != 0; }
 // The arrays of an HBM-mode search (nodes, grid or hash, buckets, lists: 480 KB at the gapped pass's scale) are needed by under one search in a
-// hundred, so a lane does not own them: they come from a pool of the launch (xmSearchPool), claimed for the duration of one search.  A lane's
-// temporaries then hold the chain's structures only (matchers, piece lists: ~200 KB), which is what lets a context run all its lanes out of a
-// few tens of GiB of scratch.  An empty pool (or none: batches of long reads, whose searches all run in HBM mode) leaves the search in the lane's
-// temporaries as before.
+// hundred, so a lane does not own them: every WAVE owns two such buffers (SearchPool: buffer 2 w and 2 w + 1 belong to wave w of the launch) that
+// its reads claim for the duration of one search.  A lane's temporaries then hold the chain's structures only (matchers, piece lists: ~200 KB),
+// which is what lets a context run all its lanes out of a few tens of GiB of scratch.  The buffers are a wave's own because memory written by one
+// CU and reused by a CU of another XCD inside one launch is not coherent (each XCD has its own write-back L2).  Both buffers taken (three reads
+// of one wave in HBM-mode searches at once), or no pool (batches of long reads, whose searches all run in HBM mode): the search stays in the
+// lane's temporaries as before.
 struct SearchPool { uint8_t* base; unsigned long long bufBytes; int32_t n; int32_t pad; int32_t* flags; };
 __shared__ SearchPool xm_search_pool;
 XM_INL void xmSetSearchPool(const SearchPool& p) { if (threadIdx.x == 0) xm_search_pool = p; }  // (before the block's first barrier)
@@ -407,10 +409,10 @@ XM_INL int xmClaimSearchBuffer(Arena& a, bool pair) {
   int slot = -1;
   const int lane = (int)__lane_id();
   if (p.n > 0 && !(pair && (lane & 1))) {
-    const unsigned gl = (unsigned)(((blockIdx.x * blockDim.x + threadIdx.x) >> (pair ? 1 : 0)) * 2654435761u);
-    for (int k = 0; k < 32 && slot < 0; k++) {
-      const int i = (int)((gl + (unsigned)k * 40503u) % (unsigned)p.n);
-      if (atomicCAS(&p.flags[i], 0, 1) == 0) slot = i;
+    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    for (int k = 0; k < 2 && slot < 0; k++) {
+      const int i = 2 * wave + k;
+      if (i < p.n && atomicCAS(&p.flags[i], 0, 1) == 0) slot = i;
     }
   }
   if (pair) slot = __shfl(slot, lane & ~1);
