@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_path_kernel(const int64_t* list, long long n, const int32_t* slotOf, uint8_t* memoBase, int scale, int lanesPerWave,
                                                       uint8_t* arenas, unsigned long long arenaBytes, unsigned long long* nextItem, DevCounters* counters) {
   // few searches: spread them over as many waves as the GPU holds (the time of a launch is its longest wave)
-  xmSetSearchPool(SearchPool{nullptr, 0, 0, 0, nullptr});
+  xmSetSearchPool(SearchPool{nullptr, 0, 0, 0});
   __syncthreads();
   const int laneInWave = (int)(threadIdx.x & 63u);
   if (laneInWave >= lanesPerWave) return;
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(i
                                                             int32_t* outInts, double* outDbls) {
   xmSetWaveNodes(waveNodes);
   xmSetPairMode(0);
-  xmSetSearchPool(SearchPool{nullptr, 0, 0, 0, nullptr});
+  xmSetSearchPool(SearchPool{nullptr, 0, 0, 0});
   xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
   if (threadIdx.x != 0) return;
   DevCounters local;
@@ -865,8 +865,7 @@ struct xm_index {
   DevBuf<int32_t> dSlotOf, dRegionOf;
   DevBuf<uint8_t> dMemo;
   DevBuf<PNode> dWaveNodes;  // per wave: node payloads of its LDS-mode search
-  DevBuf<uint8_t> dSearchPool;  // buffers for the arrays of HBM-mode searches (SearchPool, xm_extend.h)
-  DevBuf<int32_t> dSearchFlags;
+  DevBuf<uint8_t> dSearchPool;  // one buffer per wave for the arrays of HBM-mode searches (SearchPool, xm_extend.h)
   // wave-per-read passes
   DevBuf<int64_t> dListWaveHeavy, dListWaveNext, dListWaveSearch[2], dListFallback;
   DevBuf<uint8_t> dWaveMemo;
@@ -1715,16 +1714,14 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       HandOver ho{hoMode, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
       const int launchedMode = hoMode;
       idx->dWaveNodes.ensure((size_t)grid * (block / 64) * XM_PAL_NODES);
-      SearchPool pool{nullptr, 0, 0, 0, nullptr};
+      SearchPool pool{nullptr, 0, 0, 0};
       if (searchPoolOn && heavy && scale == gappedScale) {
         const Caps pc = makeCaps(scale);
         const size_t need = (size_t)pc.maxNodes * 32 + std::max((size_t)pc.gridCap, (size_t)pc.nodeHash) * 4 + (size_t)pc.maxBuckets * 20 + (size_t)pc.bucketHash * 4 + (size_t)pc.maxNodes * 8 + 4096;
         pool.bufBytes = (need + 4095) & ~(size_t)4095;
-        pool.n = (int32_t)(2 * (long long)grid * (block / 64));  // two per wave of the launch
+        pool.n = (int32_t)((long long)grid * (block / 64));  // one per wave of the launch
         idx->dSearchPool.ensure((size_t)pool.n * pool.bufBytes);
-        idx->dSearchFlags.ensure((size_t)pool.n);
-        HIP_CHECK(hipMemsetAsync(idx->dSearchFlags.p, 0, sizeof(int32_t) * (size_t)pool.n, s));
-        pool.base = idx->dSearchPool.p; pool.flags = idx->dSearchFlags.p;
+        pool.base = idx->dSearchPool.p;
       }
       idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq); idx->dListPath[tp].ensure(defer ? (size_t)nTodo : 1);
       // gapped pass with an ordered list: the first read of every lane is dealt out (kernel), the counter starts behind those items

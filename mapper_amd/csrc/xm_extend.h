@@ -394,33 +394,23 @@ __shared__ int xm_pair_mode;
 XM_INL void xmSetPairMode(int on) { if (threadIdx.x == 0) xm_pair_mode = on; }  // (before the block's first barrier)
 XM_INL bool xmPairMode() { return __builtin_amdgcn_readfirstlane(xm_pair_mode) != 0; }
 // The arrays of an HBM-mode search (nodes, grid or hash, buckets, lists: 480 KB at the gapped pass's scale) are needed by under one search in a
-// hundred, so a lane does not own them: every WAVE owns two such buffers (SearchPool: buffer 2 w and 2 w + 1 belong to wave w of the launch) that
-// its reads claim for the duration of one search.  A lane's temporaries then hold the chain's structures only (matchers, piece lists: ~200 KB),
-// which is what lets a context run all its lanes out of a few tens of GiB of scratch.  The buffers are a wave's own because memory written by one
-// CU and reused by a CU of another XCD inside one launch is not coherent (each XCD has its own write-back L2).  Both buffers taken (three reads
-// of one wave in HBM-mode searches at once), or no pool (batches of long reads, whose searches all run in HBM mode): the search stays in the
-// lane's temporaries as before.
-struct SearchPool { uint8_t* base; unsigned long long bufBytes; int32_t n; int32_t pad; int32_t* flags; };
+// hundred, so a lane does not own them: every WAVE owns one such buffer (SearchPool: buffer w belongs to wave w of the launch), used by the read
+// whose turn it is at the wave's search slot (pathAlign: HBM-mode searches take turns like the LDS-mode ones, so no claim is needed).  A lane's
+// temporaries then hold the chain's structures only (matchers, piece lists: ~200 KB), which is what lets a context run all its lanes out of a
+// few tens of GiB of scratch.  The buffer is the wave's own because memory written by one CU and reused by a CU of another XCD inside one
+// launch is not coherent (each XCD has its own write-back L2).  No pool (batches of long reads, whose searches all run in HBM mode): the
+// searches stay in the lanes' temporaries, side by side, as before.
+struct SearchPool { uint8_t* base; unsigned long long bufBytes; int32_t n; int32_t pad; };
 __shared__ SearchPool xm_search_pool;
 XM_INL void xmSetSearchPool(const SearchPool& p) { if (threadIdx.x == 0) xm_search_pool = p; }  // (before the block's first barrier)
-// -> slot (>= 0) and the buffer as an arena, or -1.  pair: the two lanes of a read take one buffer together (the first lane claims)
-XM_INL int xmClaimSearchBuffer(Arena& a, bool pair) {
+XM_INL bool xmHaveSearchPool() { return __builtin_amdgcn_readfirstlane(xm_search_pool.n) > 0; }
+// the wave's buffer as an arena (only inside a turn at the wave's slot)
+XM_INL bool xmWaveSearchBuffer(Arena& a) {
   const SearchPool p = xm_search_pool;
-  int slot = -1;
-  const int lane = (int)__lane_id();
-  if (p.n > 0 && !(pair && (lane & 1))) {
-    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    for (int k = 0; k < 2 && slot < 0; k++) {
-      const int i = 2 * wave + k;
-      if (i < p.n && atomicCAS(&p.flags[i], 0, 1) == 0) slot = i;
-    }
-  }
-  if (pair) slot = __shfl(slot, lane & ~1);
-  if (slot >= 0) a.init(p.base + (unsigned long long)slot * p.bufBytes, (size_t)p.bufBytes);
-  return slot;
-}
-XM_INL void xmReleaseSearchBuffer(int slot, bool pair) {
-  if (slot >= 0 && !(pair && ((int)__lane_id() & 1))) atomicExch(&xm_search_pool.flags[slot], 0);
+  const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  if (wave >= p.n) return false;
+  a.init(p.base + (unsigned long long)wave * p.bufBytes, (size_t)p.bufBytes);
+  return true;
 }
 #else
 XM_INL uint8_t* palSlot() { static thread_local double slot[XM_PAL_SLOT_BYTES / 8]; return (uint8_t*)slot; }  // host simulation (tests only)
@@ -428,10 +418,10 @@ XM_INL void xmSetWaveNodes(PNode*) {}
 XM_INL PNode* palWaveNodes();
 XM_INL void xmSetPairMode(int) {}
 XM_INL bool xmPairMode() { return false; }
-struct SearchPool { uint8_t* base; unsigned long long bufBytes; int32_t n; int32_t pad; int32_t* flags; };
+struct SearchPool { uint8_t* base; unsigned long long bufBytes; int32_t n; int32_t pad; };
 XM_INL void xmSetSearchPool(const SearchPool&) {}
-XM_INL int xmClaimSearchBuffer(Arena&, bool) { return -1; }
-XM_INL void xmReleaseSearchBuffer(int, bool) {}
+XM_INL bool xmHaveSearchPool() { return false; }
+XM_INL bool xmWaveSearchBuffer(Arena&) { return false; }
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1205,14 +1195,12 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
 XM_NOINL bool pathSearchHbm(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair = false, PaResume* resume = nullptr) {
   return pathSearchT<false>(pr, tmp, caps, status, dc, outBlocks, nb, nullptr, pair, resume);
 }
-// the HBM-mode search with its arrays in a buffer of the launch's pool when there is one (else, or when the pool is empty, in the lane's temporaries)
-XM_INL bool pathSearchHbmPooled(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair, PaResume* resume = nullptr) {
-  Arena pooled;
-  const int slot = xmClaimSearchBuffer(pooled, pair);
-  if (slot < 0) return pathSearchHbm(pr, tmp, caps, status, dc, outBlocks, nb, pair, resume);
-  const bool found = pathSearchHbm(pr, pooled, caps, status, dc, outBlocks, nb, pair, resume);
-  xmReleaseSearchBuffer(slot, pair);
-  return found;
+// the HBM-mode search of the read whose turn it is at the wave's slot: its arrays in the wave's buffer when the launch has a pool, else in the
+// lane's temporaries
+XM_INL bool pathSearchHbmInTurn(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair, PaResume* resume = nullptr) {
+  Arena wb;
+  if (xmWaveSearchBuffer(wb)) return pathSearchHbm(pr, wb, caps, status, dc, outBlocks, nb, pair, resume);
+  return pathSearchHbm(pr, tmp, caps, status, dc, outBlocks, nb, pair, resume);
 }
 XM_NOINL bool pathSearchLds(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool* ldsOverflow, bool pair, PaResume* resume = nullptr) {
   return pathSearchT<true>(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow, pair, resume);
@@ -1257,7 +1245,7 @@ XM_INL bool pathSearchSlot(const PaProblem& pr, Arena& tmp, const Caps& caps, in
   bool found = pathSearchLds(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow, pair, &rs);
   if (*ldsOverflow && rs.valid) {
     *ldsOverflow = false;
-    found = pathSearchHbmPooled(pr, tmp, caps, status, dc, outBlocks, nb, pair, &rs);
+    found = pathSearchHbmInTurn(pr, tmp, caps, status, dc, outBlocks, nb, pair, &rs);
   }
   return found;
 }
@@ -1322,7 +1310,20 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
     found = pathSearchSlot(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, false);
 #endif
     }
-    if (ldsOverflow) found = pathSearchHbmPooled(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, xmPairMode());
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(XM_WAVE_UNIFORM)
+    if (xmHaveSearchPool()) {
+      // the searches that could not start in the slot (texts too long for it): one after the other through the wave's buffer, like the turns above
+      unsigned long long waiting = __ballot(ldsOverflow ? 1 : 0);
+      const int lane2 = (int)__lane_id();
+      const bool pm = xmPairMode();
+      while (waiting) {
+        const int leader = pm ? ((__ffsll((long long)waiting) - 1) & ~1) : (__ffsll((long long)waiting) - 1);
+        if (ldsOverflow && (pm ? ((lane2 & ~1) == leader) : (lane2 == leader))) found = pathSearchHbmInTurn(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, pm);
+        waiting &= pm ? ~(3ull << leader) : ~(1ull << leader);
+      }
+    } else
+#endif
+    if (ldsOverflow) found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, xmPairMode());
   }
   if (!found || *e.status) return false;
   out.nb = nb;

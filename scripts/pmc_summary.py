@@ -41,8 +41,10 @@ out["_note"] = ("rocprofv3 --pmc passes over `python3 bench.py --cpu-sample 0 --
                 "scripts/pmc_summary.py), mean per launch over %s launches of each pass; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them "
                 "(narrow scattered accesses: no gfx950 wide-load correction applies); SQ_* in quad-cycles" % sorted(set(launches.values())))
 out["hbm_bytes_per_launch"] = hbm
-try:  # the build the counters belong to (bench.py quotes roofline.traffic only with its source)
-    out["build"] = json.load(open(os.path.join(root, "bench_line.json")))["build"]
+try:  # the build (and the number of contexts) the counters belong to: bench.py quotes roofline.traffic only for the same
+    line = json.load(open(os.path.join(root, "bench_line.json")))
+    out["build"] = line["build"]
+    out["contexts"] = line["contexts"]["per_gpu"]
 except Exception:  # noqa: BLE001
     out["build"] = None
 print(json.dumps(out, indent=1))
