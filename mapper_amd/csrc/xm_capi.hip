@@ -753,6 +753,7 @@ struct DeviceTables {
   std::shared_mutex rw;      // align / probe calls of any number of contexts hold it shared while their kernels read the tables; (re)upload holds it exclusive
   std::mutex allocMu;        // contexts of one GPU size and allocate their scratch one after the other (they all look at the same free memory)
   int uploadedLength = -1;   // host.maxHashedLength the device tables hold
+  std::atomic<int> contexts{0};  // handles that share these tables (contexts of this GPU): a context sizes its launches for its share of the wave slots
   DevBuf<int64_t> dContigStart, dSeqCumStart, dDupKeyStart;
   DevBuf<int32_t> dContigLen, dDupKeys;
   DevBuf<uint8_t> dRefCodes;
@@ -974,6 +975,7 @@ struct xm_index {
   }
 
   void initContext() {  // stream and events of this context (the device tables exist)
+    dt->contexts.fetch_add(1);
     HIP_CHECK(hipSetDevice(device));
     if (!stream) { HIP_CHECK(hipStreamCreate(&stream)); HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); }
   }
@@ -991,6 +993,7 @@ struct xm_index {
     }
   }
   ~xm_index() {
+    if (dt) dt->contexts.fetch_sub(1);
     if (hostOnly) return;
     (void)hipSetDevice(device);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -1491,7 +1494,12 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // scratch limit of this context: xm_context_set_scratch, else XM_SCRATCH_GIB (experiment knob), else 200 GiB
     const unsigned long long scratchWanted = idx->scratchBytes > 0 ? (unsigned long long)idx->scratchBytes : (unsigned long long)envKnob("XM_SCRATCH_GIB", 200, 1, 280) << 30;
     int scratchShift = 0;  // halved after an allocation the GPU had no room for (another process, or contexts that were given more than there is)
-    const long long lightWaves = envKnob("XM_LIGHT_WAVES", 8, 1, 16), fullWaves = envKnob("XM_FULL_WAVES", 4, 1, 16), pathWaves = envKnob("XM_PATH_WAVES", 4, 1, 16);
+    // wave slots a launch is sized for (in waves per SIMD): alone on the GPU a context fills it (4 are resident at 128 registers; the light pass asks
+    // for twice that, the second half starts as the first drains).  Contexts that share the GPU (xm_context_new) must leave each other room: a
+    // persistent launch that holds every slot keeps the next context's launch waiting until its own tail, and the contexts then run one after the
+    // other instead of side by side - three quarters each is where three contexts measured best (profiles/r02/NOTES.md 15, profiles/r03/NOTES.md)
+    const bool sharedGpu = idx->dt->contexts.load() > 1;
+    const long long lightWaves = envKnob("XM_LIGHT_WAVES", sharedGpu ? 6 : 8, 1, 16), fullWaves = envKnob("XM_FULL_WAVES", sharedGpu ? 3 : 4, 1, 16), pathWaves = envKnob("XM_PATH_WAVES", 4, 1, 16);
     const long long fullLpw = envKnob("XM_FULL_LPW", 32, 1, 64), lightLpw = envKnob("XM_LIGHT_LPW", 64, 1, 64);
     const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
     const bool fullSync = envInt("XM_FULL_SYNC", 0) != 0;  // gapped pass: the lanes of a wave take their next reads together (no taper then)
@@ -1527,7 +1535,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // temporaries then hold the chain's structures only (matchers 148 KB + piece lists 23 KB + small change at scale 4; default 30 % of 7/12 of
     // the arena = 201 KB).  Batches of long reads run every search in HBM mode: no pool, whole temporaries.
     const bool searchPoolOn = envInt("XM_SEARCH_POOL", 1) != 0 && gappedScale <= 4;
-    const long long gappedTmpPct = envKnob("XM_GAPPED_TMP_PCT", searchPoolOn ? 30 : 100, 5, 100);
+    const long long gappedTmpPct = envKnob("XM_GAPPED_TMP_PCT", searchPoolOn ? 20 : 100, 5, 100);  // (134 KB: matchers 74 KB, piece lists 23 KB, the rest small change)
     auto gappedTmpBytes = [&](size_t arena) -> size_t { return (size_t)((arena - arenaPersistBytes(arena)) * (size_t)gappedTmpPct / 100) & ~(size_t)15; };
     // light pass: a lane's temporaries hold the three matchers alignMatch sets aside (37 KB at scale 1; the chain that would fill them does not
     // run there) and the joined text of overlapping mates; a read's region holds its seeding state: 49 KB single-end, 99 KB paired at scale 1

@@ -838,7 +838,8 @@ XM_INL size_t retainedRegionBytes(size_t arenaBytes) { return arenaPersistBytes(
 XM_INL void applyChainCaps(Caps& c, int chainScale) {
   const Caps g = makeCaps(chainScale);
   c.maxNodes = g.maxNodes; c.nodeHash = g.nodeHash; c.gridCap = g.gridCap; c.maxBuckets = g.maxBuckets; c.bucketHash = g.bucketHash;
-  c.matcherEntries = g.matcherEntries; c.maxSections = g.maxSections; c.maxPieces = g.maxPieces; c.maxCountMap = g.maxCountMap;
+  // (the matcher tables of a 150 bp read's windows take ~10 KB each: half of the scale's 48 KB is room enough, and it is a third of a lane's temporaries)
+  c.matcherEntries = chainScale >= 4 ? g.matcherEntries / 2 : g.matcherEntries; c.maxSections = g.maxSections; c.maxPieces = g.maxPieces; c.maxCountMap = g.maxCountMap;
   c.maxJoined = g.maxJoined;
 }
 
