@@ -7,11 +7,12 @@ host and their ordering) over one batch of synthetic input that is already resid
 With --gpus N each rank owns one GPU, holds a replica of the index and aligns its own 1 M reads (no collective on the data
 path; scaling = weak).  Rank 0 prints ONE JSON line.
 
-The steps of a rank are dealt to --contexts contexts of its GPU (default 3: the index replicated on the GPU with xm_index_replicate,
-each context with its own resident copy of the batch, host thread, stream and share of the scratch) that align at the same time - how
-the product aligns a stream of batches (`python -m mapper_amd --contexts 3`, mapper_amd/multi.py): the wave slots one context's gapped
-pass leaves idle (its tail, the host gaps between its passes, its result copy) are filled by the others' passes, +12 % reads/s.  At
-N=1 the line also carries `single_context`: the same kernel with one launch on the GPU at a time (--contexts 1 makes that the headline).
+The steps of a rank are dealt to --contexts contexts of its GPU (default 2; xm_context_new: the contexts share the index - host tables
+and tables in HBM - and each has its own resident copy of the batch, host thread, stream and share of the scratch) that align at the
+same time - how the product aligns a stream of batches (`python -m mapper_amd --contexts N`, mapper_amd/multi.py): the wave slots one
+context's gapped pass leaves idle (its tail, the host gaps between its passes, its result copy) are filled by the other's passes,
++15-18 % reads/s (two, three and four contexts measure the same within 3 %: profiles/r03/NOTES.md).  At N=1 the line also carries
+`single_context`: the same kernel with one launch on the GPU at a time (--contexts 1 makes that the headline).
 
 The line carries `roofline` (algorithmic bytes of SURVEY.md §8(d) per second of align-kernel time, against the 8 TB/s
 HBM peak) and `cpu_baseline` (the CPU oracle, a port of the Java path, timed on this box's host cores on a bounded
@@ -49,7 +50,7 @@ def main():
                     "(pairs; 10 kb reads split at 1000 with the error rates as stated; the same with 2 %% substitutions + 0.2 %% indel events)")
     ap.add_argument("--stream-batches", type=int, default=4, help="batches of the PCIe-inclusive streamed measurement (api.align_stream: the upload of batch k+1 overlaps the alignment of batch k; 0 = skip)")
     ap.add_argument("--seed-index-mb", type=int, default=500, help="size (M bases) of the second, HBM-resident index the seed-probe leg builds so that its probes miss every cache (0 = probes on the workload's own index only)")
-    ap.add_argument("--contexts", type=int, default=3, help="contexts per GPU: the steps are dealt to this many contexts of the GPU that align their resident batches at the same time (1: one launch at a time)")
+    ap.add_argument("--contexts", type=int, default=2, help="contexts per GPU: the steps are dealt to this many contexts of the GPU (xm_context_new: they share the index) that align their resident batches at the same time (1: one launch at a time)")
     ap.add_argument("--single-context-steps", type=int, default=3, help="steps of the one-launch-at-a-time measurement beside the headline at N=1 (0 = skip)")
     ap.add_argument("--wave-steps", type=int, default=2, help="steps of the opt-in wave-per-read form (XM_WAVE=1) measured beside the headline (0 = skip)")
     args = ap.parse_args()
@@ -273,7 +274,7 @@ def main():
                         "kernel_ms_by_pass": {"light_tier": round(us[0] / args.wave_steps / 1e3, 3), "chain_tiers_with_inline_searches": round(us[1] / args.wave_steps / 1e3, 3),
                                               "search_kernel": round(us[2] / args.wave_steps / 1e3, 3), "lane_per_read_passes_for_the_rest": round(us[3] / args.wave_steps / 1e3, 3)},
                         "launches_per_step": rw.kernel_launches, "bit_identical_to_default_path": same_w,
-                        "note": "opt-in (XM_WAVE=1); not the headline: slower than the lane-per-read passes this round (profiles/r02/NOTES.md)"}
+                        "note": "opt-in (XM_WAVE=1); not the headline: slower than the lane-per-read passes (profiles/r02/NOTES.md)"}
             finally:
                 os.environ["XM_WAVE"] = "0"
 
@@ -417,9 +418,9 @@ def main():
                                  "scattered 32-64 B pieces: traffic_rate (GB/s, traffic / average launch duration) is to be read against this GPU's measured "
                                  "random-64-B-sector ceiling (seed_probe.random_64B_gather_ceiling_sectors_per_s x 64 B), not against the stream peak"},
             "contexts": {"per_gpu": n_ctx, "scratch_gib_each": round(scratch_each / 2**30, 1) if n_ctx > 1 else None,
-                         "note": "a step is one whole pass of the hot path over one resident batch; the steps are dealt to %d contexts of the GPU (index replicated with "
-                                 "xm_index_replicate, a resident copy of the batch, a host thread, a stream and a share of the scratch each) that align at the same time: the wave "
-                                 "slots one context's gapped pass leaves idle are filled by the others' passes (profiles/r02/NOTES.md 12, 14)" % n_ctx if n_ctx > 1 else "one context"},
+                         "note": "a step is one whole pass of the hot path over one resident batch; the steps are dealt to %d contexts of the GPU (xm_context_new: one index - host "
+                                 "tables and tables in HBM - shared by all; a resident copy of the batch, a host thread, a stream and a share of the scratch each) that align at the same time: "
+                                 "the wave slots one context's gapped pass leaves idle are filled by the others' passes (profiles/r02/NOTES.md 12, 14; profiles/r03/NOTES.md)" % n_ctx if n_ctx > 1 else "one context"},
             "single_context": single,
             "cpu_baseline": cpu,
             "build": build,

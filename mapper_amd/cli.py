@@ -265,11 +265,11 @@ def run(argv, out=sys.stdout):
     batch_size = o.get("batch_size") or 1_000_000
     contexts = o.get("contexts")
     if contexts is None:
-        # a job of several batches: three contexts per GPU align their batches at the same time (+12-17 % reads per second on MI355X,
-        # profiles/r02/NOTES.md 12).  Contexts share the index (xm_context_new), so a genome-sized one is no obstacle; they divide the HBM that
-        # is free once it is resident, and a GPU with room for fewer contexts uses fewer (api.divide_scratch)
+        # a job of several batches: two contexts per GPU align their batches at the same time (+15-18 % reads per second on MI355X; more
+        # contexts add nothing: profiles/r03/NOTES.md).  Contexts share the index (xm_context_new), so a genome-sized one is no obstacle; they
+        # divide the HBM that is free once it is resident, and a GPU with room for fewer contexts uses fewer (api.divide_scratch)
         n_batches = (len(queries) + batch_size - 1) // batch_size
-        contexts = 3 if devices is None and n_batches >= 3 else 1
+        contexts = 2 if devices is None and n_batches >= 2 else 1
     if contexts > 1:
         devices = [d for d in (devices or [o["device"]]) for _ in range(contexts)]
     max_query_length = max([len(s) for q, _ in queries for s in q.sequences] + [1])
