@@ -67,7 +67,9 @@ static long long envKnob(const char* name, long long dflt, long long lo, long lo
 // lane takes a fresh one.  mode 2 (gapped pass): a read with a saved region continues from it on whatever lane picks it up; the lane's
 // arena = [one region for reads without saved state | temporaries].  mode 0: plain runRead in the lane's arena.
 struct HandOver {
-  int mode;
+  int mode;                        // (3: a pass of the light pass's shape over reads the gapped pass handed back, every one with a saved region)
+  int handBack;                    // mode 2: a resumed read stops with XM_ST_NEED_LIGHT when its candidate is done
+  int lightLevel;                  // mode 3: Caps::heavyAllowed of the light pass
   int seedScale;                   // scale the regions are sized for (the light pass's)
   uint8_t* regions;
   unsigned long long regionBytes;
@@ -183,8 +185,13 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
       const int32_t rg = ho.regionOf[q];
       uint8_t* tmp = arena + ho.regionBytes;
       const size_t tmpBytes = (size_t)(arenaBytes - ho.regionBytes);
-      if (rg >= 0) runReadResumed(cx, savedReadOf(ho.regions + (unsigned long long)rg * ho.regionBytes, (size_t)ho.regionBytes), &ix, scale, tmp, tmpBytes, &local, rr, nullptr, false);
+      if (rg >= 0) runReadResumed(cx, savedReadOf(ho.regions + (unsigned long long)rg * ho.regionBytes, (size_t)ho.regionBytes), &ix, scale, tmp, tmpBytes, &local, rr, nullptr, false, 2, ho.handBack);
       else runReadRetaining(cx, &ix, params, in, ho.seedScale, arena, (size_t)ho.regionBytes, tmp, tmpBytes, &local, rr, 2, scale);
+    } else if (ho.mode == 3) {
+      // a read the gapped pass handed back: on from behind its candidate, with the light pass's capacities and temporaries (the lane's arena is all temporaries)
+      const int32_t rg = ho.regionOf[q];
+      if (rg >= 0) runReadResumed(cx, savedReadOf(ho.regions + (unsigned long long)rg * ho.regionBytes, (size_t)ho.regionBytes), &ix, ho.seedScale, arena, (size_t)arenaBytes, &local, rr, nullptr, false, ho.lightLevel, 0);
+      else cx.status = XM_ST_INTERNAL;
     } else {
       runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed, memo, deferPath != 0);
     }
@@ -394,10 +401,11 @@ struct PassCtl {
   unsigned long long nHeavy, nHeavyLate, nScale[2], nOut[2], nPath[2];
   unsigned long long errQuery;  // smallest query index whose status is an error (~0 = none)
   unsigned long long nConf[2];  // reads that wait for a value of the confidence table (XM_ST_NEED_CONF)
+  unsigned long long nLight;    // reads the gapped pass handed back (XM_ST_NEED_LIGHT)
 };
 
 __global__ void __launch_bounds__(256) xm_classify_kernel(const int64_t* todo, long long nTodo, const int32_t* status, int64_t* listHeavy, int64_t* listScale, int64_t* listOut,
-                                                          int64_t* listPath, int64_t* listHeavyLate, int hintThreshold, PassCtl* ctl, int ts, int to, int tp, int64_t* listConf, int tc) {
+                                                          int64_t* listPath, int64_t* listHeavyLate, int hintThreshold, PassCtl* ctl, int ts, int to, int tp, int64_t* listConf, int tc, int64_t* listLight) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nTodo) return;
   int64_t q = todo ? todo[i] : (int64_t)i;
@@ -413,6 +421,7 @@ __global__ void __launch_bounds__(256) xm_classify_kernel(const int64_t* todo, l
   else if (st == XM_ST_OVERFLOW) listScale[atomicAdd(&ctl->nScale[ts], 1ull)] = q;
   else if (st == XM_ST_OUT_OVERFLOW) listOut[atomicAdd(&ctl->nOut[to], 1ull)] = q;
   else if (st == XM_ST_NEED_CONF) listConf[atomicAdd(&ctl->nConf[tc], 1ull)] = q;
+  else if (st == XM_ST_NEED_LIGHT) listLight[atomicAdd(&ctl->nLight, 1ull)] = q;
   else atomicMin(&ctl->errQuery, (unsigned long long)q);
 }
 
@@ -887,7 +896,7 @@ struct xm_index {
   bool confDirty = true;
   DevBuf<ConfEntry> dConf;
   DevBuf<uint8_t> dConfMiss;
-  DevBuf<int64_t> dListConf[2];
+  DevBuf<int64_t> dListConf[2], dListLight;
   std::vector<int32_t> residentLens, stagedLens;  // distinct total query lengths of the batch (the table is seeded for them)
   int64_t residentNq = -1;   // batch kept in HBM by xm_batch_upload
   int64_t residentGen = 0, lastAlignedGen = -1;  // which resident batch the streams of the last align call belong to
@@ -1543,6 +1552,12 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const size_t lightTmpUnit = (size_t)envKnob("XM_LIGHT_TMP_KB", 48, 16, 16384) * 1024;
     const size_t regionPersistUnit = (size_t)envKnob("XM_REGION_KB", idx->residentAnyPaired ? 120 : 72, 32, 16384) * 1024;
     const bool handOver = envInt("XM_HANDOVER", 1) != 0 && !deferSearches;
+    // hand-back: a read the gapped pass resumed stops again when its candidate is through the chain; what is left of it - index walk, votes,
+    // straight alignments of further candidates - is the light pass's kind of work, which a lane of the gapped pass runs all but alone in its wave
+    // (a quarter of that pass's wave time); a pass of the light pass's shape takes those reads back, and the ones that meet another candidate
+    // for the chain go round again
+    const bool handBack = handOver && envInt("XM_HANDBACK", 1) != 0;
+    unsigned long long pendingLight = 0;
     int hoMode = handOver ? 1 : 0;   // mode of the next launch
     const int seedScale = scale;
     const size_t regionBytes = ((regionPersistUnit * (size_t)seedScale) & ~(size_t)15) + ((sizeof(SavedRead) + 15) & ~(size_t)15);
@@ -1665,7 +1680,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     while (nTodo > 0) {
       std::unique_lock<std::mutex> sizing(idx->dt->allocMu);
       size_t arenaBytes = arenaUnit * (size_t)scale;  // bytes of scratch a lane owns in this launch
-      if (hoMode == 1) arenaBytes = lightTmpUnit * (size_t)scale;                                    // temporaries only (+ one region of the pool per lane)
+      if (hoMode == 1 || hoMode == 3) arenaBytes = lightTmpUnit * (size_t)scale;                   // temporaries only (+ one region of the pool per lane / the read's own region)
       else if (hoMode == 2) arenaBytes = regionBytes + gappedTmpBytes(arenaBytes);  // a region for reads without saved state + temporaries
       // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped chain
       // diverges inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  The XM_* variables are experiment knobs.
@@ -1719,7 +1734,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       sizing.unlock();
       const int pairLanes = (heavy && lpw <= 32 && !defer && !fullSync && pairMode) ? 1 : 0;  // two lanes per read (xm_extend.h, xmSetPairMode)
       uint8_t* laneArenas = idx->dArenas.p + regionsTotal;
-      HandOver ho{hoMode, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
+      HandOver ho{hoMode, handBack ? 1 : 0, (int)lightLevel, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
+      idx->dListLight.ensure((size_t)nq);
       const int launchedMode = hoMode;
       idx->dWaveNodes.ensure((size_t)grid * (block / 64) * XM_PAL_NODES);
       SearchPool pool{nullptr, 0, 0, 0};
@@ -1746,7 +1762,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,
-                         idx->dListOut[to].p, idx->dListPath[tp].p, idx->dListHeavyLate.p, (int)heavyHintThreshold, idx->dCtl.p, ts, to, tp, idx->dListConf[tc].p, tc);
+                         idx->dListOut[to].p, idx->dListPath[tp].p, idx->dListHeavyLate.p, (int)heavyHintThreshold, idx->dCtl.p, ts, to, tp, idx->dListConf[tc].p, tc, idx->dListLight.p);
       HIP_CHECK(hipGetLastError());
       PassCtl ctl;
       HIP_CHECK(hipMemcpyAsync(&ctl, idx->dCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, s));
@@ -1757,8 +1773,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       res->counters[!heavy ? 12 : (defer ? 13 : 15)] += (int64_t)(ms * 1000.0);  // kernel microseconds: light pass / gapped chain passes / inline reruns
       launches++;
       memoFresh = false;
-      hoMode = 0;                                // (the gapped pass below switches to 2; reruns run plain)
-      if (launchedMode == 2) regionsTotal = 0;   // every saved read has been consumed
+      hoMode = 0;                                // (the gapped pass below switches to 2, the pass that takes reads back to 3; reruns run plain)
+      pendingLight = ctl.nLight;
+      // the saved reads have all been consumed once neither a handed-back read nor one that stopped in front of the chain again is waiting
+      if ((launchedMode == 2 && pendingLight == 0) || (launchedMode == 3 && ctl.nHeavy + ctl.nHeavyLate == 0)) regionsTotal = 0;
 #ifdef XM_LIGHT_ONLY
       fprintf(stderr, "[xm] light-only experiment build: pass %d %.3f ms\n", launches, ms);
       break;  // (experiment build, scripts/gpu_light_only.sh: only the first pass is meaningful)
@@ -1824,6 +1842,14 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         todo = idx->dListPath[tp].p; nTodo = nPath;
         tp ^= 1;
         HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nPath[tp], 0, sizeof(unsigned long long), s));
+        continue;
+      }
+      if (pendingLight > 0) {  // reads the gapped pass handed back: on in a pass of the light pass's shape
+        todo = idx->dListLight.p; nTodo = (long long)pendingLight;
+        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nLight, 0, sizeof(unsigned long long), s));
+        scale = seedScale;
+        heavy = false; defer = false; inlineRest = false;
+        hoMode = 3;
         continue;
       }
       if (pendingHeavy > 0) {

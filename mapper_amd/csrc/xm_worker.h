@@ -45,7 +45,9 @@ struct ReadResult {
 // A read that stops in the light pass because a candidate needs the gapped chain (XM_ST_NEED_HEAVY) is resumed in the gapped pass at
 // that candidate, with its seeding state (pyramids, votes, candidate lists, accepted alignments) as the light pass left it.
 struct AlignReadState {
-  int32_t phase;  // 0 before the first candidate, 1 aligning the optimistic best match, 3 in the main loop at filtered[i], 4 in the partially-good loop at filtered[i], 5 after them (not resumable)
+  int32_t phase;  // 0 before the first candidate, 1 aligning the optimistic best match, 3 in the main loop at filtered[i], 4 in the partially-good loop at filtered[i], 5 after them (not resumable);
+                  // 11 / 13 / 14: the qmaAlign call of phase 1 / 3 / 4 is done (its result in `al`), resume behind it (hand-back of the gapped pass)
+  int32_t al;
   int32_t optimisticBestAlignment, haveOptimisticMatch, numMismatches, candidateNumMismatches, i, queryLength;
   QMatch optimisticBestMatch;
   double bestPenalty, estimatedPenalty, maxInterestingPenalty;
@@ -663,6 +665,9 @@ XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr, bool resume = false) {
     if (st.phase == 1) goto resume_optimistic;
     if (st.phase == 3) goto resume_main;
     if (st.phase == 4) goto resume_partial;
+    if (st.phase == 11) goto resume_after_optimistic;
+    if (st.phase == 13) { al = st.al; goto resume_after_main; }
+    if (st.phase == 14) { al = st.al; goto resume_after_partial; }
     cx.status = XM_ST_INTERNAL;  // (the caller only resumes phases 1, 3 and 4)
     return;
   }
@@ -710,6 +715,9 @@ XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr, bool resume = false) {
 resume_optimistic:
     st.optimisticBestAlignment = qmaAlign(cx, *aligner, st.optimisticBestMatch, 0);
     if (cx.status) return;
+    if (cx.caps.handBack) { st.phase = 11; st.rr = rr; cx.status = XM_ST_NEED_LIGHT; return; }
+resume_after_optimistic:
+    st.phase = 2;
     const bool quick = quicklyConfidentInBestAlignment(cx, *aligner, st.optimisticBestAlignment, st.optimisticBestMatch);
     if (cx.status) return;  // (XM_ST_NEED_CONF: the host has a value to add to the confidence table)
     if (quick) {
@@ -751,6 +759,10 @@ resume_optimistic:
         if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }
 resume_main:
         al = qmaAlign(cx, *aligner, pc.filtered[st.i], 0);
+        if (cx.status) return;
+        if (cx.caps.handBack) { st.al = al; st.phase = 13; st.rr = rr; cx.status = XM_ST_NEED_LIGHT; return; }
+resume_after_main:
+        st.phase = 2;
       }
       if (cx.status) return;
       if (al >= 0) {
@@ -772,6 +784,9 @@ resume_main:
 resume_partial:
       al = qmaAlign(cx, *aligner, pc.filtered[st.i], 0);
       if (cx.status) return;
+      if (cx.caps.handBack) { st.al = al; st.phase = 14; st.rr = rr; cx.status = XM_ST_NEED_LIGHT; return; }
+resume_after_partial:
+      st.phase = 2;
       if (al >= 0) {
         double penalty = aligner->good[al].totalPenalty;
         if (st.bestPenalty > penalty) st.bestPenalty = penalty;
@@ -874,22 +889,40 @@ XM_INL void runReadRetaining(ReadCtx& cx, const IndexView* ix, const Params& par
 // gapped pass, a read the light pass handed over: the context back on this lane, pointers into the context re-seated, the chain's scratch
 // capacities of the gapped pass, temporaries in this lane's arena; then on from the candidate that needed the chain.  The saved state is
 // consumed (pyramid levels, hit lists and the aligner advance in place): a read can be resumed once.
-XM_INL void runReadResumed(ReadCtx& cx, const SavedRead* sv, const IndexView* ix, int gappedScale, void* laneArena, size_t laneArenaBytes, DevCounters* dc, ReadResult& rr,
-                           MemoHdr* memo, bool deferPath) {
+XM_INL void runReadResumed(ReadCtx& cx, SavedRead* sv, const IndexView* ix, int chainScale, void* laneArena, size_t laneArenaBytes, DevCounters* dc, ReadResult& rr,
+                           MemoHdr* memo, bool deferPath, int heavyAllowed = 2, int handBack = 0) {
+  const DevCounters before = dc ? *dc : DevCounters();
   cx = sv->cx;
   cx.ix = ix; cx.dc = dc; cx.status = XM_OK;
   cx.seed.ix = ix; cx.seed.caps = &cx.caps; cx.seed.dc = dc; cx.seed.status = &cx.status; cx.seed.listIdCounter = &cx.listIdCounter; cx.seed.mateLen = cx.in.mateLen;
   for (int m = 0; m < 2; m++) { cx.comps[m].pyr.status = &cx.status; cx.comps[m].pyr.dc = dc; }
   cx.pc.comps = cx.comps;
   cx.tmp.init(laneArena, laneArenaBytes);
-  applyChainCaps(cx.caps, gappedScale);
-  cx.caps.heavyAllowed = 2;
+  if (chainScale > 0) applyChainCaps(cx.caps, chainScale);
+  cx.caps.heavyAllowed = heavyAllowed;
+  cx.caps.handBack = handBack;
   cx.caps.deferPath = (memo && deferPath) ? 1 : 0;
   cx.memo = memo; cx.memoCursor = 0;
   if (dc) dcAccumulate(*dc, sv->partial, false);
   XM_TIC(t0);
   alignRead(cx, rr, true);
   XM_TOC(dc, T_TOTAL, t0);
+  // the read stops again - handed back by the gapped pass (XM_ST_NEED_LIGHT), or in front of another candidate's gapped chain in the pass that
+  // took it back (XM_ST_NEED_HEAVY): its context goes back into its region, with everything counted for it so far
+  const bool again = cx.status == XM_ST_NEED_LIGHT || (cx.status == XM_ST_NEED_HEAVY && (cx.ar.phase == 1 || cx.ar.phase == 3 || cx.ar.phase == 4));
+  sv->valid = 0;
+  if (again) {
+    sv->cx = cx;
+    if (dc) {
+      sv->partial = *dc;
+      dcAccumulate(sv->partial, before, true);
+      if (cx.status == XM_ST_NEED_HEAVY) {  // the stopped candidate is counted by the run that finishes it
+        sv->partial.candidatesExtended -= dc->candidatesExtended - cx.ar.candidatesAtCall;
+        sv->partial.refWindowBytes -= dc->refWindowBytes - cx.ar.refWindowBytesAtCall;
+      }
+    }
+    sv->valid = 1;
+  }
 }
 
 // Carve a lane's arena and align one read.  `arena` must be 16-byte aligned.

@@ -14,8 +14,10 @@ arrays = (np.ones(nq, np.int32), mo, ml, np.ascontiguousarray(reads.reshape(-1))
 p = api.AlignmentParameters()
 o = oracle_lib.OracleReference([("e", ref)])
 want = o.align(oracle_lib.QueryBatch.from_arrays(*arrays), oracle_lib.make_params(), threads=os.cpu_count())
-KN = ["XM_SEARCH_POOL", "XM_GAPPED_TMP_PCT", "XM_REGION_KB", "XM_LIGHT_TMP_KB", "XM_HANDOVER", "XM_PAIR_LANES"]
+KN = ["XM_HANDBACK", "XM_SEARCH_POOL", "XM_GAPPED_TMP_PCT", "XM_REGION_KB", "XM_LIGHT_TMP_KB", "XM_HANDOVER", "XM_PAIR_LANES"]
 combos = [
+    {},
+    {"XM_HANDBACK": 0},
     {"XM_SEARCH_POOL": 0, "XM_GAPPED_TMP_PCT": 100, "XM_REGION_KB": 120, "XM_LIGHT_TMP_KB": 168},   # the old sizes
     {"XM_SEARCH_POOL": 0, "XM_GAPPED_TMP_PCT": 100, "XM_REGION_KB": 120},                            # + small light temporaries
     {"XM_SEARCH_POOL": 0, "XM_GAPPED_TMP_PCT": 100},                                                 # + small regions

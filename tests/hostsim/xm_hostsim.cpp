@@ -189,31 +189,52 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       // light pass -> gapped pass hand-over (runReadRetaining / runReadResumed): the read's region outlives the light "lane"; the gapped pass
       // runs on another context object and another temporaries buffer, as it does on another lane of the GPU
       static const bool handOver = !(getenv("XMSIM_NO_HANDOVER") && atoi(getenv("XMSIM_NO_HANDOVER")) != 0);
-      const size_t lightArena = (size_t)288 * 1024, regionBytes = retainedRegionBytes(lightArena);  // the product's sizes
+      // the product's sizes: light-pass temporaries 48 KB, a read's region 72 KB (single-end) or 120 KB (paired) + its saved context
+      const size_t lightTmpBytes = (size_t)48 * 1024, regionBytes = ((size_t)(in.nMates > 1 ? 120 : 72) * 1024) + ((sizeof(SavedRead) + 15) & ~(size_t)15);
       std::vector<double> regionBuf(regionBytes / 8 + 2);
       uint8_t* region = (uint8_t*)(((uintptr_t)regionBuf.data() + 15) & ~(uintptr_t)15);
-      const SavedRead* saved = nullptr;
+      SavedRead* saved = nullptr;
+      // hand-back (XM_ST_NEED_LIGHT): the gapped "pass" stops a resumed read behind its candidate and a "pass" of the light pass's shape - another
+      // context object, small temporaries, light capacities - takes it on; a read that stops in front of the chain there goes round again
+      static const bool handBack = handOver && !(getenv("XMSIM_NO_HANDBACK") && atoi(getenv("XMSIM_NO_HANDBACK")) != 0);
+      bool takenBack = false;
+      static ReadCtx cx3;
+      std::vector<uint8_t> arena3;
       static ReadCtx cx2;
       std::vector<uint8_t> arena2;
       while (true) {
         size_t bytes = (size_t)288 * 1024 * (size_t)scale;
         ReadResult rr;
         DevCounters before = dc;
-        if (stage == 1 && saved) {
+        if (stage == 1 && saved && takenBack) {
+          const size_t lightTmp = (size_t)48 * 1024;  // the product's light-pass temporaries
+          arena3.assign(lightTmp + 64, 0xCD);
+          uint8_t* a3 = (uint8_t*)(((uintptr_t)arena3.data() + 15) & ~(uintptr_t)15);
+          runReadResumed(cx3, saved, &idx->view, 1, a3, lightTmp, &dc, rr, nullptr, false, lightLevel, 0);
+          cx.status = cx3.status;
+          takenBack = false;
+          if (cx.status == XM_ST_NEED_HEAVY) {
+            dc = before;
+            if (saved->valid) continue;                  // another candidate for the chain: the gapped "pass" again, from the region
+            saved = nullptr; stage = 2; scale = 4; continue;  // (stopped where it cannot be resumed: a plain run)
+          }
+          saved = nullptr;
+        } else if (stage == 1 && saved) {
           arena2.assign(bytes + 64, 0xAB);
           uint8_t* a2 = (uint8_t*)(((uintptr_t)arena2.data() + 15) & ~(uintptr_t)15);
           // a resume consumes the retained state (pyramid levels, hit lists and the aligner state advance in place), so it cannot be replayed:
           // handed-over reads run their searches inline, as the product does (deferral only applies to reads that re-seed)
-          runReadResumed(cx2, saved, &idx->view, scale, a2, bytes - arenaPersistBytes(bytes), &dc, rr, nullptr, false);
+          runReadResumed(cx2, saved, &idx->view, scale, a2, (size_t)((bytes - arenaPersistBytes(bytes)) / 5) & ~(size_t)15, &dc, rr, nullptr, false, 2, handBack ? 1 : 0);
           cx.status = cx2.status;
+          if (cx.status == XM_ST_NEED_LIGHT) { dc = before; takenBack = true; continue; }
           saved = nullptr;
         } else {
           arena.resize(bytes + 64);
           uint8_t* a = (uint8_t*)(((uintptr_t)arena.data() + 15) & ~(uintptr_t)15);
           if (stage == 0 && handOver) {
-            runReadRetaining(cx, &idx->view, params, in, scale, region, regionBytes, a, lightArena - arenaPersistBytes(lightArena), &dc, rr, lightLevel);
+            runReadRetaining(cx, &idx->view, params, in, scale, region, regionBytes, a, lightTmpBytes, &dc, rr, lightLevel);
             if (cx.status == XM_ST_NEED_HEAVY) {
-              const SavedRead* sv = savedReadOf(region, regionBytes);
+              SavedRead* sv = savedReadOf(region, regionBytes);
               saved = sv->valid ? sv : nullptr;
               std::vector<uint8_t>().swap(arena);  // the light lane's temporaries are gone (a stale pointer into them would be caught by the sanitizer run)
             }
