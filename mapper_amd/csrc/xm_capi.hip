@@ -1552,11 +1552,13 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const size_t lightTmpUnit = (size_t)envKnob("XM_LIGHT_TMP_KB", 48, 16, 16384) * 1024;
     const size_t regionPersistUnit = (size_t)envKnob("XM_REGION_KB", idx->residentAnyPaired ? 120 : 72, 32, 16384) * 1024;
     const bool handOver = envInt("XM_HANDOVER", 1) != 0 && !deferSearches;
-    // hand-back: a read the gapped pass resumed stops again when its candidate is through the chain; what is left of it - index walk, votes,
-    // straight alignments of further candidates - is the light pass's kind of work, which a lane of the gapped pass runs all but alone in its wave
-    // (a quarter of that pass's wave time); a pass of the light pass's shape takes those reads back, and the ones that meet another candidate
-    // for the chain go round again
-    const bool handBack = handOver && envInt("XM_HANDBACK", 1) != 0;
+    // hand-back (XM_HANDBACK=1; off: measured slower, profiles/r03/NOTES.md): a read the gapped pass resumed stops again when its candidate is
+    // through the chain; what is left of it - index walk, votes, straight alignments of further candidates - is the light pass's kind of work,
+    // which a lane of the gapped pass runs all but alone in its wave (a quarter of that pass's wave time); a pass of the light pass's shape takes
+    // those reads back, and the ones that meet another candidate for the chain go round again.  The gapped pass gets 20 % shorter, but what a
+    // read has left to do is a chain of dependent steps that takes its few milliseconds whatever runs beside it: the passes that take reads
+    // back (60 k, 415, 18 reads ...) each last as long as their slowest read, and together cost twice what the gapped pass saved.
+    const bool handBack = handOver && envInt("XM_HANDBACK", 0) != 0;
     unsigned long long pendingLight = 0;
     int hoMode = handOver ? 1 : 0;   // mode of the next launch
     const int seedScale = scale;

@@ -196,7 +196,7 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       SavedRead* saved = nullptr;
       // hand-back (XM_ST_NEED_LIGHT): the gapped "pass" stops a resumed read behind its candidate and a "pass" of the light pass's shape - another
       // context object, small temporaries, light capacities - takes it on; a read that stops in front of the chain there goes round again
-      static const bool handBack = handOver && !(getenv("XMSIM_NO_HANDBACK") && atoi(getenv("XMSIM_NO_HANDBACK")) != 0);
+      const bool handBack = handOver && getenv("XMSIM_HANDBACK") && atoi(getenv("XMSIM_HANDBACK")) != 0;  // (off by default, as in the product)
       bool takenBack = false;
       static ReadCtx cx3;
       std::vector<uint8_t> arena3;

@@ -335,3 +335,21 @@ def test_kernel_logic_reads_with_ambiguous_bases():
         want = R.align(b, o.make_params(), threads=os.cpu_count())
         got = S.align(b, o.make_params())
         assert streams_equal(got, want), first_difference(got, want, n)
+
+
+def test_hand_back_resume_points_in_the_host_simulation(monkeypatch):
+    """XM_HANDBACK (off by default in the product): the gapped pass stops a resumed read behind the candidate that needed the chain
+    (alignRead phases 11 / 13 / 14) and a pass with the light pass's capacities continues it; reads that meet another candidate for the
+    chain go round again.  Single-end reads with indels and pairs (the partially-good loop), against the oracle."""
+    monkeypatch.setenv("XMSIM_HANDBACK", "1")
+    ref = synth.synthetic_reference(200_000, seed=21)
+    R = o.OracleReference([("r", ref)])
+    S = hs.SimReference([("r", ref)])
+    p = o.make_params()
+    b = se_batch(synth.synthetic_single_end(ref, 2500, seed=22, indel_prob=0.5)[0])
+    sa, sb = R.align(b, p), S.align(b, p)
+    assert streams_equal(sa, sb), first_difference(sa, sb, b.nq)
+    m1, m2 = synth.synthetic_paired_end(ref, 1200, seed=23, indel_prob=0.4)[:2]
+    pb = pe_batch(m1, m2)
+    sa, sb = R.align(pb, p), S.align(pb, p)
+    assert streams_equal(sa, sb), first_difference(sa, sb, pb.nq)

@@ -96,6 +96,11 @@ PASS_SHAPES = [
     {"XM_PAIR_LANES": "0"},                                                     # one lane per read in the gapped pass
     {"XM_HANDOVER": "0", "XM_PAIR_LANES": "0", "XM_FULL_LPW": "64"},            # both off, full waves
     {"XM_GAPPED_TMP_PCT": "25", "XM_SCRATCH_GIB": "1"},                         # small temporaries (HBM-mode searches overflow into the rerun passes), tiny region pool
+    {"XM_HANDBACK": "1"},                                                       # the gapped pass hands a read back when its candidate is through the chain; passes of the light shape take them on
+    {"XM_HANDBACK": "1", "XM_PAIR_LANES": "0", "XM_SCRATCH_GIB": "2"},          # the same with one lane per read and few lanes
+    {"XM_SEARCH_POOL": "0"},                                                    # HBM-mode searches in the lanes' temporaries (no buffer per wave)
+    {"XM_SEARCH_POOL": "0", "XM_GAPPED_TMP_PCT": "20"},                         # ... and too small for them: those reads rerun
+    {"XM_REGION_KB": "40", "XM_LIGHT_TMP_KB": "24"},                            # regions and light temporaries too small for anything: every read overflows into the reruns
     {"XM_WAVE": "1"},                                                           # the wave-per-read form first (light tier, chain tiers with inline searches), lane-per-read passes for the rest
     {"XM_WAVE": "1", "XM_WAVE_TIERS": "1"},                                     # its light tier only
     {"XM_WAVE": "1", "XM_WAVE_TIERS": "2"},                                     # light + chain tier (no tier with the largest capacities)
