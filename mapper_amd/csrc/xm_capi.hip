@@ -1515,6 +1515,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const bool lightSync = envInt("XM_LIGHT_SYNC", 0) != 0;  // lanes of a light-pass wave take reads together (measured: no gain)
     const long long lightLevel = envKnob("XM_LIGHT_LEVEL", 0, 0, 2);  // what the light pass still does itself (Caps::heavyAllowed)
     const long long heavyHintThreshold = envKnob("XM_HEAVY_HINT", 0, 0, 1 << 20);  // straight-alignment penalty x 8 from which a read is put first in the gapped pass and dealt out evenly (0: no order; measured: no gain, the pass is bound by the work per wave, not by its balance)
+    if (fullSync && heavyHintThreshold > 0)  // (measured once: the launch did not end within 13 minutes; never looked into, so never run)
+      throw std::runtime_error("XM_FULL_SYNC=1 and XM_HEAVY_HINT together are not supported");
     const long long taperWaves = envKnob("XM_TAPER_PCT", 100, 0, 1000);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
     // a search round costs two launches whose time is the time of one read (a replay, a search) however few reads wait; once the
     // waiting reads no longer fill the GPU the rest is cheaper inline: one last chain pass, one read per wave
