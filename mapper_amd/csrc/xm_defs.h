@@ -252,7 +252,6 @@ struct Caps {
   int32_t deferPath;     // 1: a PathAligner search without a logged result is left as a request (XM_ST_NEED_PATH), needs a memo slot
   int32_t searchInHbmOnly;  // test entry only (xm_test_local_align): every PathAligner search in HBM mode, the LDS slot is not tried
   int32_t handBack;         // gapped pass, read resumed from its saved region: stop with XM_ST_NEED_LIGHT when the resumed candidate is done
-  int32_t batchedExplore;   // HBM-mode searches look the eight cells of an explored entry up together (xm_extend.h, exploreBatched)
   int32_t maxLevels, maxPyramidBlocks, maxHistory, maxCounters, maxPending, maxQM, maxGoodAlignments, maxBlocks,
       maxNodes, nodeHash, gridCap, maxBuckets, bucketHash, matcherEntries, maxSections, maxPieces, maxCountMap, maxJoined;
 };
@@ -263,7 +262,6 @@ XM_INL Caps makeCaps(int scale) {
   c.deferPath = 0;
   c.searchInHbmOnly = 0;
   c.handBack = 0;
-  c.batchedExplore = 1;
   c.maxLevels = 48 * scale;
   c.maxPyramidBlocks = 1536 * scale;
   c.maxHistory = 192 * scale;

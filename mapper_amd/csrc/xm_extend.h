@@ -783,40 +783,6 @@ struct PathAlignerT {
       XM_PA_TOC(tCompute, t0);
     }
   }
-  // explore :722-729 for the HBM-mode search: the three updates of an explored entry look at eight distinct cells - (x, y) and its seven
-  // neighbours towards the goal and back - whose lookups do not depend on each other.  In HBM mode every lookup is a trip to memory (cell ->
-  // node index, then the node's payload), and update by update that is six dependent trips per entry; here the eight cells are looked up
-  // together, then the eight payloads, and the third update takes its left and upper neighbours from what the first two decided (a node they put
-  // is the latest node of its cell).  Same nodes in the same order as update(x+d, y); update(x, y+d); update(x+d, y+d).
-  XM_INL void exploreBatched(int x, int y) {
-    const int d = stepDelta;
-    const int cx[8] = {x, x + d, x, x + d, x + d, x, x - d, x - d};
-    const int cy[8] = {y, y, y + d, y + d, y - d, y - d, y + d, y};
-    int idx[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) idx[k] = findNode(cx[k], cy[k]);
-    PNode n[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) n[k] = nodes[idx[k] >= 0 ? idx[k] : 0];
-    UpdateOut a, b, c;
-    a.put = 0; b.put = 0; c.put = 0;
-    const bool in1 = x + d > 0 && x + d <= textALength && y > 0 && y <= textBLength;
-    const bool in2 = x > 0 && x <= textALength && y + d > 0 && y + d <= textBLength;
-    const bool in3 = x + d > 0 && x + d <= textALength && y + d > 0 && y + d <= textBLength;
-    if (in1) computeFromNodes(x + d, y, idx[1], idx[0], idx[4], idx[5], n[1], n[0], n[4], n[5], -1, a);   // left (x, y), up (x+d, y-d), diagonal (x, y-d)
-    if (in2) computeFromNodes(x, y + d, idx[2], idx[6], idx[0], idx[7], n[2], n[6], n[0], n[7], -1, b);   // left (x-d, y+d), up (x, y), diagonal (x-d, y)
-    if (a.put) putNode(a.x, a.y, a.pen, a.insX, a.insY, (uint8_t)a.fl);
-    if (b.put) putNode(b.x, b.y, b.pen, b.insX, b.insY, (uint8_t)b.fl);
-    if (in3 && !overflow) {
-      // left neighbour (x, y+d): the node the second update put, else what was there; upper neighbour (x+d, y): likewise from the first
-      PNode nl = n[2], nu = n[1];
-      int il = idx[2], iu = idx[1];
-      if (b.put) { nl.pen = b.pen; nl.insX = b.insX; nl.insY = b.insY; nl.fl = (uint8_t)b.fl; il = 0; }
-      if (a.put) { nu.pen = a.pen; nu.insX = a.insX; nu.insY = a.insY; nu.fl = (uint8_t)a.fl; iu = 0; }
-      computeFromNodes(x + d, y + d, idx[3], il, iu, idx[0], n[3], nl, nu, n[0], -1, c);
-      if (c.put) putNode(c.x, c.y, c.pen, c.insX, c.insY, (uint8_t)c.fl);
-    }
-  }
   XM_INL bool chooseSearchReverse() const {  // :17-53
     int sumMis = 0, numMis = 0, sumMatch = 0, numMatch = 0;
     int offset = predictedBestOffset;
@@ -1090,9 +1056,6 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
           *ldsOverflow = true;
           return false;
         }
-      }
-      if constexpr (!LDS) {
-        if (caps.batchedExplore) { pa.exploreBatched(x, y); if (pa.overflow) return leave(false); li = pa.listNext(li); continue; }
       }
 #if defined(__HIP_DEVICE_COMPILE__)
       if (pair) {
