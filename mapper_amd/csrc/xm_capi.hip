@@ -1508,8 +1508,12 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // persistent launch that holds every slot keeps the next context's launch waiting until its own tail, and the contexts then run one after the
     // other instead of side by side - three quarters each is where three contexts measured best (profiles/r02/NOTES.md 15, profiles/r03/NOTES.md)
     const bool sharedGpu = idx->dt->contexts.load() > 1;
-    const long long lightWaves = envKnob("XM_LIGHT_WAVES", sharedGpu ? 6 : 8, 1, 16), fullWaves = envKnob("XM_FULL_WAVES", sharedGpu ? 3 : 4, 1, 16), pathWaves = envKnob("XM_PATH_WAVES", 4, 1, 16);
-    const long long fullLpw = envKnob("XM_FULL_LPW", 32, 1, 64), lightLpw = envKnob("XM_LIGHT_LPW", 64, 1, 64);
+    // Batches of long reads (gapped pass beyond scale 4: every read goes through the chain, and its searches - thousands of nodes each, all in HBM mode -
+    // are most of its time): the lanes of a wave run their searches one after the other, so 8 reads per wave on twice as many waves instead of 32
+    // (1 kb queries: 382 ms -> 265-280 ms per 150 k; 4 to 8 reads per wave and 8 to 16 waves per SIMD worth of lanes measure the same, profiles/r03/NOTES.md 13)
+    const bool longReads = gappedScale > 4;
+    const long long lightWaves = envKnob("XM_LIGHT_WAVES", sharedGpu ? 6 : 8, 1, 16), fullWaves = envKnob("XM_FULL_WAVES", longReads ? 8 : (sharedGpu ? 3 : 4), 1, 16), pathWaves = envKnob("XM_PATH_WAVES", 4, 1, 16);
+    const long long fullLpw = envKnob("XM_FULL_LPW", longReads ? 8 : 32, 1, 64), lightLpw = envKnob("XM_LIGHT_LPW", 64, 1, 64);
     const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
     const bool fullSync = envInt("XM_FULL_SYNC", 0) != 0;  // gapped pass: the lanes of a wave take their next reads together (no taper then)
     const bool lightSync = envInt("XM_LIGHT_SYNC", 0) != 0;  // lanes of a light-pass wave take reads together (measured: no gain)

@@ -1291,7 +1291,10 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
     pr.qs = qs; pr.rs = rs; pr.params = p;
     pr.confident = an.confidentAboutBestOffset; pr.maxInsExt = an.maxInsertionExtensionPenalty; pr.maxDelExt = an.maxDeletionExtensionPenalty;
     pr.predictedBestOffset = an.predictedBestOffset;
-    bool ldsOverflow = e.caps->searchInHbmOnly != 0;  // (test entry only: straight to the HBM-mode search)
+#ifndef XM_HBM_ONLY_FROM
+#define XM_HBM_ONLY_FROM (1 << 30)  // experiment define: chain scale from which the slot is not tried (all searches of the wave at once, in HBM mode)
+#endif
+    bool ldsOverflow = e.caps->searchInHbmOnly != 0 || e.caps->scale >= XM_HBM_ONLY_FROM;  // (test entry: straight to the HBM-mode search)
     if (!ldsOverflow) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(XM_WAVE_UNIFORM)
     // wave-per-read kernels (xm_wave_kernel.hip): every lane of the wave is on the same search with the same values, so the wave's slot
