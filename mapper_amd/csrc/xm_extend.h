@@ -1291,10 +1291,13 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
     pr.qs = qs; pr.rs = rs; pr.params = p;
     pr.confident = an.confidentAboutBestOffset; pr.maxInsExt = an.maxInsertionExtensionPenalty; pr.maxDelExt = an.maxDeletionExtensionPenalty;
     pr.predictedBestOffset = an.predictedBestOffset;
+    // chains of long reads (scale 16 and up: mates over 320 bases, and the reruns of reads that outgrew scale 4): their searches outgrow the slot
+    // (hundreds to thousands of entries), so the turn at it only adds the take-over; they start in HBM mode, side by side where lanes arrive together
+    // (1 kb queries with 3 % substitutions, half of them with an indel: 3 738 -> 3 294 ms per 200 k; profiles/r03/NOTES.md 13).  XM_HBM_ONLY_FROM: experiment define
 #ifndef XM_HBM_ONLY_FROM
-#define XM_HBM_ONLY_FROM (1 << 30)  // experiment define: chain scale from which the slot is not tried (all searches of the wave at once, in HBM mode)
+#define XM_HBM_ONLY_FROM 16
 #endif
-    bool ldsOverflow = e.caps->searchInHbmOnly != 0 || e.caps->scale >= XM_HBM_ONLY_FROM;  // (test entry: straight to the HBM-mode search)
+    bool ldsOverflow = e.caps->searchInHbmOnly != 0 || e.caps->scale >= XM_HBM_ONLY_FROM;  // (searchInHbmOnly: the test entry)
     if (!ldsOverflow) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(XM_WAVE_UNIFORM)
     // wave-per-read kernels (xm_wave_kernel.hip): every lane of the wave is on the same search with the same values, so the wave's slot
