@@ -144,6 +144,24 @@ def test_long_reads_on_gpu():
         db.close()
 
 
+@pytest.mark.parametrize("env", [{"XM_FULL_WAVES": "1"}, {"XM_FULL_WAVES": "1", "XM_FULL_LPW": "32"}, {"XM_FULL_WAVES": "1", "XM_FULL_LPW": "16", "XM_PAIR_LANES": "0"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_long_reads_sharing_waves_on_gpu(env, monkeypatch):
+    """Enough 1,000 bp queries that the gapped pass puts several of them on every wave (its launch shape for long reads: 8 per wave; here 9 000 reads on
+    1 024 waves, and the shapes of the short-read pass beside it): the searches of a wave's reads - HBM mode from the start at this chain scale - and
+    the two lanes of a read must not disturb each other."""
+    ref = synth.synthetic_reference(400_000, seed=41)
+    reads = synth.synthetic_single_end(ref, 9000, read_len=1000, sub_rate=0.02, indel_prob=0.3, seed=42)[0]
+    b = se_batch(reads)
+    want = o.OracleReference([("r", ref)]).align(b, o.make_params(), threads=os.cpu_count())
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    db = api.ReferenceDatabase([("r", ref)], max_query_length=1000)
+    got, _ = gpu_align(db, b)
+    assert streams_equal(got, want), first_difference(got, want, len(reads))
+    db.close()
+
+
 def test_random_configurations_on_gpu():
     """Differential fuzz (scripts/gpu_fuzz.py): random references (repeats, ambiguity codes), read lengths 36-301, single / paired mixes, ambiguity in
     reads and random alignment parameters; every batch must equal the oracle bit for bit."""
