@@ -1551,7 +1551,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // the arena = 201 KB).  Batches of long reads run every search in HBM mode: no pool, whole temporaries.
     const bool searchPoolOn = envInt("XM_SEARCH_POOL", 1) != 0 && gappedScale <= 4;
     const long long gappedTmpPct = envKnob("XM_GAPPED_TMP_PCT", searchPoolOn ? 20 : 100, 5, 100);  // (134 KB: matchers 74 KB, piece lists 23 KB, the rest small change)
-    auto gappedTmpBytes = [&](size_t arena) -> size_t { return (size_t)((arena - arenaPersistBytes(arena)) * (size_t)gappedTmpPct / 100) & ~(size_t)15; };
+    // (+ the node arrays of a long-read chain: applyChainCaps)
+    auto gappedTmpBytes = [&](size_t arena) -> size_t { return ((size_t)((arena - arenaPersistBytes(arena)) * (size_t)gappedTmpPct / 100) & ~(size_t)15) + chainExtraTmpBytes(gappedScale); };
     // light pass: a lane's temporaries hold the three matchers alignMatch sets aside (37 KB at scale 1; the chain that would fill them does not
     // run there) and the joined text of overlapping mates; a read's region holds its seeding state: 49 KB single-end, 99 KB paired at scale 1
     // (ambiguity codes add up to 20 KB per mate: such a read overflows a single-end region and is seeded again by the gapped pass)
@@ -1702,6 +1703,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       else if (regionsTotal > 0) lanes = std::min(lanes, (long long)((idx->dArenas.n - regionsTotal) / arenaBytes));  // (sized below, before the pool was filled)
       else lanes = std::min(lanes, (long long)(budget / arenaBytes));
       if (lanes > nTodo) lanes = nTodo;
+      // long reads, scratch for fewer lanes than asked for: fewer reads per wave before fewer waves than the GPU holds at a time (4 per SIMD) - a wave's
+      // reads wait for each other's searches, an empty wave slot does nothing
+      if (heavy && longReads && lpw > 1 && lanes / lpw < (long long)numCUs * 16) lpw = (int)std::max(1ll, lanes / ((long long)numCUs * 16));
       long long nWaves = (lanes + lpw - 1) / lpw;
       if (nWaves < 1) nWaves = 1;
       if (hoMode != 1 && regionsTotal > 0) {  // the scratch cannot grow now: whole waves (and whole blocks of four) that fit behind the pool

@@ -266,7 +266,7 @@ XM_INL Caps makeCaps(int scale) {
   c.maxPyramidBlocks = 1536 * scale;
   c.maxHistory = 192 * scale;
   c.maxCounters = 96 * scale;
-  c.maxPending = 64 * scale;
+  c.maxPending = 128 * scale;  // (blocks put aside until the path is exhausted: 1 kb reads that align nowhere need 257-320 at scale 4)
   c.maxQM = 64 * scale;
   c.maxGoodAlignments = 16 * scale;
   c.maxBlocks = 16 * scale;

@@ -850,11 +850,27 @@ XM_INL size_t retainedRegionBytes(size_t arenaBytes) { return arenaPersistBytes(
 
 // what the extension chain allocates in the temporaries follows the scale of the pass that runs the chain; what lives in the read's
 // persistent arena (maxBlocks included: the accepted alignments are stored there) keeps the sizes of the scale the read was seeded with
+// Chains of long reads (scale 16 and up: mates over 320 bases): XM_LONG_CHAIN_NODES times the search nodes of the scale, twice its matcher sections and
+// its matcher tables whole.  A read that outgrows a capacity of the gapped pass is run again from its start at four times the scratch in a pass of its own,
+// one read per wave, that lasts as long as its slowest read (0.7 s and 3.2 s behind gapped passes of 4.2 s and 7.8 s per 100 k 1 kb pieces of 10 kb reads);
+// what those reads outgrew was the 640 sections of a matcher (windows of over 5 000 bases) and, fewer, the 24 576 nodes of a search
+// (profiles/r03/NOTES.md 19).  chainExtraTmpBytes: what this adds to a lane's temporaries.
+#ifndef XM_LONG_CHAIN_NODES
+#define XM_LONG_CHAIN_NODES 4
+#endif
+XM_INL size_t chainExtraTmpBytes(int chainScale) {
+  if (chainScale < 16) return 0;
+  const Caps g = makeCaps(chainScale);
+  return ((size_t)(XM_LONG_CHAIN_NODES - 1) * ((size_t)g.maxNodes * (sizeof(PNode) + 8) + (size_t)g.nodeHash * 4)  // nodes + list entries, cell hash
+          + 3 * ((size_t)g.maxSections + (size_t)g.matcherEntries) + 4095) & ~(size_t)4095;                       // three matchers: sections, the other half of the tables
+}
 XM_INL void applyChainCaps(Caps& c, int chainScale) {
   const Caps g = makeCaps(chainScale);
   c.maxNodes = g.maxNodes; c.nodeHash = g.nodeHash; c.gridCap = g.gridCap; c.maxBuckets = g.maxBuckets; c.bucketHash = g.bucketHash;
+  if (chainScale >= 16) { c.maxNodes *= XM_LONG_CHAIN_NODES; c.nodeHash *= XM_LONG_CHAIN_NODES; }
   // (the matcher tables of a 150 bp read's windows take ~10 KB each: half of the scale's 48 KB is room enough, and it is a third of a lane's temporaries)
-  c.matcherEntries = chainScale >= 4 ? g.matcherEntries / 2 : g.matcherEntries; c.maxSections = g.maxSections; c.maxPieces = g.maxPieces; c.maxCountMap = g.maxCountMap;
+  c.matcherEntries = (chainScale >= 4 && chainScale < 16) ? g.matcherEntries / 2 : g.matcherEntries; c.maxSections = chainScale >= 16 ? 2 * g.maxSections : g.maxSections;
+  c.maxPieces = g.maxPieces; c.maxCountMap = g.maxCountMap;
   c.maxJoined = g.maxJoined;
 }
 

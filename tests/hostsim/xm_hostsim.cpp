@@ -179,7 +179,12 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       // deferred PathAligner searches (chain pass -> search "kernel" -> replay ...); scratch overflow -> inline reruns at 16x, 64x...
       // XMSIM_INLINE=1: plain inline run at scale 1, 4, 16... (the first implementation's sequence)
       static const bool inlineOnly = getenv("XMSIM_INLINE") && atoi(getenv("XMSIM_INLINE")) != 0;
-      int scale = 1;
+      // (the product sizes a batch by its longest mate: scratch scale 1 up to 320 bases, 4 up to 1280, 16 beyond, the gapped pass at four times that;
+      // here every read by its own longest mate)
+      int longestMate = 0;
+      for (int m = 0; m < in.nMates; m++) longestMate = std::max(longestMate, (int)in.mateLen[m]);
+      const int seedScale = longestMate <= 320 ? 1 : (longestMate <= 1280 ? 4 : 16);
+      int scale = seedScale;
       int stage = inlineOnly ? 2 : 0;  // 0 light, 1 deferred gapped, 2 inline
       std::vector<double> memoBuf(XM_MEMO_SLOT_BYTES / 8 + 2);
       MemoHdr* memo = (MemoHdr*)(((uintptr_t)memoBuf.data() + 15) & ~(uintptr_t)15);
@@ -190,7 +195,13 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       // runs on another context object and another temporaries buffer, as it does on another lane of the GPU
       static const bool handOver = !(getenv("XMSIM_NO_HANDOVER") && atoi(getenv("XMSIM_NO_HANDOVER")) != 0);
       // the product's sizes: light-pass temporaries 48 KB, a read's region 72 KB (single-end) or 120 KB (paired) + its saved context
-      const size_t lightTmpBytes = (size_t)48 * 1024, regionBytes = ((size_t)(in.nMates > 1 ? 120 : 72) * 1024) + ((sizeof(SavedRead) + 15) & ~(size_t)15);
+      const size_t lightTmpBytes = (size_t)48 * 1024 * (size_t)seedScale, regionBytes = ((size_t)(in.nMates > 1 ? 120 : 72) * 1024 * (size_t)seedScale) + ((sizeof(SavedRead) + 15) & ~(size_t)15);
+      // temporaries of a gapped-pass lane: a fifth of 7/12 of the arena for short reads (their HBM-mode searches use the wave's buffer), all of it + the
+      // node arrays of a long-read chain for long ones (xm_capi.hip, gappedTmpBytes)
+      auto gappedTmp = [&](size_t bytes, int chainScale) -> size_t {
+        const size_t whole = bytes - arenaPersistBytes(bytes);
+        return ((seedScale == 1 ? whole / 5 : whole) & ~(size_t)15) + chainExtraTmpBytes(chainScale);
+      };
       std::vector<double> regionBuf(regionBytes / 8 + 2);
       uint8_t* region = (uint8_t*)(((uintptr_t)regionBuf.data() + 15) & ~(uintptr_t)15);
       SavedRead* saved = nullptr;
@@ -210,26 +221,26 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
           const size_t lightTmp = (size_t)48 * 1024;  // the product's light-pass temporaries
           arena3.assign(lightTmp + 64, 0xCD);
           uint8_t* a3 = (uint8_t*)(((uintptr_t)arena3.data() + 15) & ~(uintptr_t)15);
-          runReadResumed(cx3, saved, &idx->view, 1, a3, lightTmp, &dc, rr, nullptr, false, lightLevel, 0);
+          runReadResumed(cx3, saved, &idx->view, seedScale, a3, lightTmp * (size_t)seedScale, &dc, rr, nullptr, false, lightLevel, 0);
           cx.status = cx3.status;
           takenBack = false;
           if (cx.status == XM_ST_NEED_HEAVY) {
             dc = before;
             if (saved->valid) continue;                  // another candidate for the chain: the gapped "pass" again, from the region
-            saved = nullptr; stage = 2; scale = 4; continue;  // (stopped where it cannot be resumed: a plain run)
+            saved = nullptr; stage = 2; scale = seedScale * 4; continue;  // (stopped where it cannot be resumed: a plain run)
           }
           saved = nullptr;
         } else if (stage == 1 && saved) {
-          arena2.assign(bytes + 64, 0xAB);
+          arena2.assign(bytes + chainExtraTmpBytes(scale) + 64, 0xAB);
           uint8_t* a2 = (uint8_t*)(((uintptr_t)arena2.data() + 15) & ~(uintptr_t)15);
           // a resume consumes the retained state (pyramid levels, hit lists and the aligner state advance in place), so it cannot be replayed:
           // handed-over reads run their searches inline, as the product does (deferral only applies to reads that re-seed)
-          runReadResumed(cx2, saved, &idx->view, scale, a2, (size_t)((bytes - arenaPersistBytes(bytes)) / 5) & ~(size_t)15, &dc, rr, nullptr, false, 2, handBack ? 1 : 0);
+          runReadResumed(cx2, saved, &idx->view, scale, a2, gappedTmp(bytes, scale), &dc, rr, nullptr, false, 2, handBack ? 1 : 0);
           cx.status = cx2.status;
           if (cx.status == XM_ST_NEED_LIGHT) { dc = before; takenBack = true; continue; }
           saved = nullptr;
         } else {
-          arena.resize(bytes + 64);
+          arena.resize(bytes + chainExtraTmpBytes(scale) + 64);
           uint8_t* a = (uint8_t*)(((uintptr_t)arena.data() + 15) & ~(uintptr_t)15);
           if (stage == 0 && handOver) {
             runReadRetaining(cx, &idx->view, params, in, scale, region, regionBytes, a, lightTmpBytes, &dc, rr, lightLevel);
@@ -240,11 +251,11 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
             }
           } else if (stage == 1 && handOver) {
             // gapped pass, read without saved state (stopped where it cannot be resumed): seeded again in a region of light-pass size
-            runReadRetaining(cx, &idx->view, params, in, 1, region, regionBytes, a, bytes - arenaPersistBytes(bytes), &dc, rr, 2, scale);
+            runReadRetaining(cx, &idx->view, params, in, seedScale, region, regionBytes, a, ((bytes - arenaPersistBytes(bytes)) & ~(size_t)15) + chainExtraTmpBytes(scale), &dc, rr, 2, scale);
           } else {
             runRead(cx, &idx->view, params, in, scale, a, bytes, &dc, rr, stage != 0 ? 2 : lightLevel, stage == 1 ? memo : nullptr, rounds < deferRounds);
           }
-          if (cx.status == XM_ST_NEED_HEAVY && stage == 0) { dc = before; stage = 1; scale = 4; memoInit(memo); continue; }
+          if (cx.status == XM_ST_NEED_HEAVY && stage == 0) { dc = before; stage = 1; scale = seedScale * 4; memoInit(memo); continue; }
           if (cx.status == XM_ST_NEED_PATH && stage == 1) {
             dc = before;
             if (!memo->hasRequest) throw std::runtime_error("NEED_PATH without a request");
@@ -259,7 +270,7 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
         if (cx.status == XM_ST_OVERFLOW) {
           dc = before; rerun++;
           saved = nullptr;
-          if (stage == 0) { stage = 2; scale = 4; } else { stage = 2; scale *= 4; }
+          if (stage == 0) { stage = 2; scale = seedScale * 4; } else { stage = 2; scale *= 4; }
           if (scale > 4096) throw std::runtime_error("scratch scale limit");
           continue;
         }

@@ -277,6 +277,27 @@ def test_kernel_logic_paired_end_synthetic():
     assert streams_equal(sa, sb), first_difference(sa, sb, len(m1))
 
 
+@pytest.mark.parametrize("sub,indel,most_reruns", [(0.02, 0.002, 1), (0.05, 0.05, 1)], ids=["mild", "as_stated"])
+def test_kernel_logic_long_reads_in_the_product_pass_sequence(sub, indel, most_reruns):
+    """1 kb pieces of 10 kb reads (BASELINE.json configs[4], cut as the command line cuts them) through the pass sequence the product runs for a batch
+    of long reads - light pass at scale 4, gapped chain at 16 with the long-read capacities (applyChainCaps) on temporaries of the product's size -
+    against the oracle; and nearly all of them without outgrowing a capacity (a read that does is run again from its start, in a pass that lasts
+    as long as its slowest read: with the capacities of round 2 every one of the as-stated reads and 1-2 % of the mild ones did)."""
+    from mapper_amd import cli
+    ref = synth.synthetic_reference(1_000_000, seed=0xEC011)
+    n_reads = 8
+    starts = (synth.splitmix64(0x5EED0004, n_reads) % np.uint64(len(ref) - 12_600)).astype(np.int64)
+    strand = (synth.splitmix64(0x5EED0004 ^ 0x57A, n_reads) >> np.uint64(63)).astype(np.uint8)
+    reads = synth.synthetic_long_reads(ref, starts, 10_000, seed=0x5EED0004, sub_rate=sub, indel_rate=indel, strand=strand)
+    b = o.QueryBatch([([r[a_:b_].copy()], 0.0, 1.0) for r in reads for a_, b_ in cli.split_sections(10_000, 1000)])
+    R = o.OracleReference([("r", ref)])
+    S = hs.SimReference([("r", ref)])
+    p = o.make_params()
+    sa, sb = R.align(b, p, threads=os.cpu_count()), S.align(b, p)
+    assert streams_equal(sa, sb), first_difference(sa, sb, b.nq)
+    assert sb.counters[11] <= most_reruns, "reads run again at a larger scale: %d of %d" % (sb.counters[11], b.nq)
+
+
 def test_kernel_logic_edge_cases():
     """ragged / tiny / unalignable reads, reads hanging over contig ends, repeats, multi-contig reference, long reads."""
     rng = np.random.default_rng(3)
