@@ -1512,7 +1512,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // are most of its time): the lanes of a wave run their searches one after the other, so 8 reads per wave on twice as many waves instead of 32
     // (1 kb queries: 382 ms -> 265-280 ms per 150 k; 4 to 8 reads per wave and 8 to 16 waves per SIMD worth of lanes measure the same, profiles/r03/NOTES.md 13)
     const bool longReads = gappedScale > 4;
-    const long long lightWaves = envKnob("XM_LIGHT_WAVES", sharedGpu ? 6 : 8, 1, 16), fullWaves = envKnob("XM_FULL_WAVES", longReads ? 8 : (sharedGpu ? 3 : 4), 1, 16), pathWaves = envKnob("XM_PATH_WAVES", 4, 1, 16);
+    // (long reads: every lane of the light pass holds a region of 288 KiB, and every read goes on to the gapped pass, whose lanes are 6.7 MB each:
+    // two waves per SIMD worth of light lanes leave the scratch to those)
+    const long long lightWaves = envKnob("XM_LIGHT_WAVES", longReads ? 2 : (sharedGpu ? 6 : 8), 1, 16), fullWaves = envKnob("XM_FULL_WAVES", longReads ? 8 : (sharedGpu ? 3 : 4), 1, 16), pathWaves = envKnob("XM_PATH_WAVES", 4, 1, 16);
     const long long fullLpw = envKnob("XM_FULL_LPW", longReads ? 8 : 32, 1, 64), lightLpw = envKnob("XM_LIGHT_LPW", 64, 1, 64);
     const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
     const bool fullSync = envInt("XM_FULL_SYNC", 0) != 0;  // gapped pass: the lanes of a wave take their next reads together (no taper then)
@@ -1705,7 +1707,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       if (lanes > nTodo) lanes = nTodo;
       // long reads, scratch for fewer lanes than asked for: fewer reads per wave before fewer waves than the GPU holds at a time (4 per SIMD) - a wave's
       // reads wait for each other's searches, an empty wave slot does nothing
-      if (heavy && longReads && lpw > 1 && lanes / lpw < (long long)numCUs * 16) lpw = (int)std::max(1ll, lanes / ((long long)numCUs * 16));
+      // (contexts that share the GPU share its wave slots)
+      const long long slotsHeld = (long long)numCUs * 16 / std::max(1, idx->dt->contexts.load());
+      if (heavy && longReads && lpw > 1 && lanes / lpw < slotsHeld) lpw = (int)std::max(1ll, lanes / slotsHeld);
       long long nWaves = (lanes + lpw - 1) / lpw;
       if (nWaves < 1) nWaves = 1;
       if (hoMode != 1 && regionsTotal > 0) {  // the scratch cannot grow now: whole waves (and whole blocks of four) that fit behind the pool
@@ -1725,7 +1729,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         // (a lane takes a fresh region only before it fetches another read, and only nTodo - lanes reads are fetched by lanes that already had one)
         // (+ some slack: lanes that see a few reads left all take a region, but only some of them get a read)
         long long extra = nTodo > lanes ? (long long)nTodo - lanes + std::min(lanes, 4096ll) : 0;
-        extra = std::min(extra, (long long)(budget * 2 / 5 / regionBytes) - lanes);
+        // (long reads: a fifth - their seeding is 4 % of their time, and a gapped-pass lane of theirs is 6.7 MB: the scratch is worth more as lanes)
+        extra = std::min(extra, (long long)(budget * (longReads ? 1 : 2) / 5 / regionBytes) - lanes);
         extra = std::min(extra, ((long long)budget - lanes * (long long)(arenaBytes + regionBytes)) / (long long)regionBytes);
         if (extra < 0) extra = 0;
         nRegions = lanes + extra;

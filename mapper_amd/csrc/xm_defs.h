@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <math.h>
+#include <stdlib.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>

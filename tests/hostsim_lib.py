@@ -14,10 +14,14 @@ OUT = os.path.join(ROOT, "tests", "_build", "libxm_hostsim.so")
 
 def build():
     deps = [SRC] + [os.path.join(ROOT, "mapper_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "mapper_amd", "csrc")) if f.endswith(".h")]
-    if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
-        os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
-                               "-o", OUT, SRC])
+    import fcntl
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    with open(OUT + ".lock", "w") as lock:  # (pytest-xdist workers build side by side)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
+            subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+                                   "-o", OUT + ".tmp", SRC])
+            os.replace(OUT + ".tmp", OUT)
     return OUT
 
 
