@@ -12,8 +12,6 @@ timeout 900 python3 bench.py > $O/bench_full.log 2>&1
 tail -n 1 $O/bench_full.log > $O/bench_line.json
 timeout 600 python3 bench.py --config 2 --seed-probes 0 --steps 9 --stream-batches 10 2> $O/bench_config2.err | tail -n 1 > $O/bench_config2.json
 timeout 600 python3 bench.py --config 4shape --seed-probes 0 --steps 6 2> $O/bench_config4shape.err | tail -n 1 > $O/bench_config4shape.json
-# (the same with round 2's launch shape of the gapped pass, for the comparison in NOTES.md)
-XM_FULL_LPW=32 XM_FULL_WAVES=3 timeout 600 python3 bench.py --config 4shape --seed-probes 0 --steps 6 --cpu-sample 0 --single-context-steps 0 2> /dev/null | tail -n 1 > $O/bench_config4shape_32x3.json
 cd /tmp && export TMPDIR=/tmp
 Q="--cpu-sample 0 --seed-probes 0 --wave-steps 0 --single-context-steps 0 --stream-batches 0"
 # (the profiled command is the headline measurement alone: the default contexts and steps, without the extra measurements of the bench line)
