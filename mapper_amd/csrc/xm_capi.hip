@@ -1520,7 +1520,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const bool fullSync = envInt("XM_FULL_SYNC", 0) != 0;  // gapped pass: the lanes of a wave take their next reads together (no taper then)
     const bool lightSync = envInt("XM_LIGHT_SYNC", 0) != 0;  // lanes of a light-pass wave take reads together (measured: no gain)
     const long long lightLevel = envKnob("XM_LIGHT_LEVEL", 0, 0, 2);  // what the light pass still does itself (Caps::heavyAllowed)
-    const long long heavyHintThreshold = envKnob("XM_HEAVY_HINT", 0, 0, 1 << 20);  // straight-alignment penalty x 8 from which a read is put first in the gapped pass and dealt out evenly (0: no order; measured: no gain, the pass is bound by the work per wave, not by its balance)
+    // straight-alignment penalty x 8 from which a read is put first in the gapped pass and dealt out evenly (0: no order).  Batches of single reads of up to 320
+    // bases: 8 penalty units - the reads with an indel (they mismatch on one whole side of it), whose searches are the long ones of the pass: started first
+    // they do not end it (gapped pass 70.0 / 70.5 -> 65.2 / 64.8 ms per 1 M reads, same box; with 4 units 75 ms; pairs 146 -> 152-154 ms: not for them)
+    const long long heavyHintThreshold = envKnob("XM_HEAVY_HINT", (idx->residentAnyPaired || longReads || fullSync) ? 0 : 64, 0, 1 << 20);
     if (fullSync && heavyHintThreshold > 0)  // (measured once: the launch did not end within 13 minutes; never looked into, so never run)
       throw std::runtime_error("XM_FULL_SYNC=1 and XM_HEAVY_HINT together are not supported");
     const long long taperWaves = envKnob("XM_TAPER_PCT", 100, 0, 1000);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
