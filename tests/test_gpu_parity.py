@@ -91,7 +91,9 @@ PASS_SHAPES = [
     {"XM_LIGHT_LEVEL": "1"},                                                    # light pass keeps the hash-block analysis
     {"XM_TAPER_PCT": "0", "XM_FULL_LPW": "64"},                                 # no end-of-list taper, full waves in the gapped pass
     {"XM_LIGHT_WAVES": "2", "XM_FULL_WAVES": "1", "XM_SCRATCH_GIB": "2"},       # few lanes: every lane aligns many reads in turn
-    {"XM_HEAVY_HINT": "64", "XM_LIGHT_SYNC": "1"},                              # gapped pass ordered by the cost hint and dealt out; wave-synchronous light batches
+    {"XM_HEAVY_HINT": "64", "XM_LIGHT_SYNC": "1"},                              # gapped pass ordered by the cost hint and dealt out (the default for single reads; here for the pairs too); wave-synchronous light batches
+    {"XM_HEAVY_HINT": "0"},                                                     # gapped pass in list order for the single reads as well
+    {"XM_HEAVY_HINT": "16", "XM_FULL_LPW": "8", "XM_FULL_WAVES": "2"},          # nearly every read of the gapped pass "heavy", few lanes
     {"XM_HANDOVER": "0"},                                                       # gapped pass seeds its reads again (no saved regions)
     {"XM_PAIR_LANES": "0"},                                                     # one lane per read in the gapped pass
     {"XM_HANDOVER": "0", "XM_PAIR_LANES": "0", "XM_FULL_LPW": "64"},            # both off, full waves
