@@ -211,6 +211,12 @@ int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_pa
                         int32_t reference_length, double max_ins_ext, double max_del_ext, int32_t block_cap, int32_t* blocks, int32_t* num_blocks, double* penalties,
                         int64_t* nodes_put);
 
+/* DIAGNOSTIC entry (not part of the drop-in boundary): the phase timers of the wave scheduler kernel of the gapped pass since the last call, in
+ * shader-clock ticks of wave time; all zero unless the library was built with -DXM_PROFILE.  out[0] whole loop, [1] chain phases that start a read,
+ * [2] chain phases that replay, [3] search phases, [4] searches in the big buffer, [5] loop iterations, [6] searches, [7] ticks x lanes searching,
+ * [8] ticks x lanes in a chain phase. */
+int xm_debug_sched_profile(uint64_t* out16, int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif

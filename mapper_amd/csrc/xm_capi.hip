@@ -8,8 +8,10 @@
 // Reads whose fixed-capacity scratch overflowed are rerun by a second launch with a 4x larger scale (never on the CPU).
 #include "../../include/xmapper_hip.h"
 #include "xm_worker.h"
+#include "xm_sched.h"
 #include "xm_index_host.h"
 #include "xm_kernel_args.h"
+#include "xm_kernel_common.h"
 #include <hip/hip_runtime.h>
 #include <string>
 #include <vector>
@@ -37,14 +39,6 @@ int fail(const std::string& msg) { g_error = msg; return 1; }
     if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e));      \
   } while (0)
 
-__device__ __forceinline__ void addCounters(DevCounters* g, const DevCounters& l) {
-  atomicAdd(&g->reads, l.reads); atomicAdd(&g->headerProbes, l.headerProbes); atomicAdd(&g->bucketFetches, l.bucketFetches);
-  atomicAdd(&g->hitsFetched, l.hitsFetched); atomicAdd(&g->candidatesExtended, l.candidatesExtended); atomicAdd(&g->pathAlignerCalls, l.pathAlignerCalls);
-  atomicAdd(&g->pathAlignerNodes, l.pathAlignerNodes); atomicAdd(&g->quickAccepts, l.quickAccepts); atomicAdd(&g->alignmentsOut, l.alignmentsOut);
-  atomicAdd(&g->refWindowBytes, l.refWindowBytes); atomicAdd(&g->readBytes, l.readBytes);
-  for (int i = 0; i < 16; i++) if (l.t[i]) atomicAdd(&g->t[i], l.t[i]);
-}
-
 static long long envInt(const char* name, long long dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoll(v) : dflt;
@@ -61,22 +55,6 @@ static long long envKnob(const char* name, long long dflt, long long lo, long lo
 #ifndef XM_WAVES_PER_SIMD
 #define XM_WAVES_PER_SIMD 4  // 128 registers per lane: the path is latency-bound, four waves per SIMD hide more of it than the spills cost
 #endif
-
-// Light pass -> gapped pass hand-over (xm_worker.h, SavedRead).  mode 1 (light pass): a read's persistent arena is a region of the pool
-// below, the lane's arena holds the temporaries only; a read that stops in front of the gapped chain keeps its region (regionOf[q]) and the
-// lane takes a fresh one.  mode 2 (gapped pass): a read with a saved region continues from it on whatever lane picks it up; the lane's
-// arena = [one region for reads without saved state | temporaries].  mode 0: plain runRead in the lane's arena.
-struct HandOver {
-  int mode;                        // (3: a pass of the light pass's shape over reads the gapped pass handed back, every one with a saved region)
-  int handBack;                    // mode 2: a resumed read stops with XM_ST_NEED_LIGHT when its candidate is done
-  int lightLevel;                  // mode 3: Caps::heavyAllowed of the light pass
-  int seedScale;                   // scale the regions are sized for (the light pass's)
-  uint8_t* regions;
-  unsigned long long regionBytes;
-  long long nRegions;
-  int32_t* regionOf;               // per read: region that holds its SavedRead, -1 = none
-  unsigned long long* cursor;      // next unused region
-};
 
 #ifdef XM_READ_TIMES
 // diagnostic builds (-DXM_READ_TIMES, XM_READ_TIMES_FILE=path): shader-clock ticks the last pass spent on every read, written to the file
@@ -201,26 +179,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
 #endif
     if (st != XM_OK) local = before;  // work of a read that is rerun by a later pass is counted there
     if (second) continue;             // (pair mode: the first lane of the read publishes)
-    if (st == XM_OK) {
-      int64_t ni, nd;
-      resultSize(rr, ni, nd);
-      unsigned long long io = atomicAdd(&out.cursor[0], (unsigned long long)ni);
-      unsigned long long dofs = atomicAdd(&out.cursor[1], (unsigned long long)nd);
-      if (io + (unsigned long long)ni > out.intCap || dofs + (unsigned long long)nd > out.dblCap) {
-        st = XM_ST_OUT_OVERFLOW;
-      } else {
-        OutWriter w;
-        w.ints = out.ints + io; w.dbls = out.dbls + dofs; w.ni = 0; w.nd = 0;
-        resultWrite(rr, w, &local);
-        out.intOff[q] = (int64_t)io; out.dblOff[q] = (int64_t)dofs; out.intLen[q] = (int32_t)ni; out.dblLen[q] = (int32_t)nd;
-      }
-    }
-    if (st == XM_ST_NEED_HEAVY) {  // bits 8..15: cost hint (penalty x 8, capped) for the order of the gapped pass
-      float h = cx.heavyHint * 8.0f;
-      int hi = h > 255.0f ? 255 : (h > 0.0f ? (int)h : 0);
-      st |= hi << 8;
-    }
-    out.status[q] = st;
+    publishRead(out, q, rr, cx, local);
   }
   if (!second) addCounters(counters, local);
 }
@@ -282,6 +241,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(i
     slots[i].tableCap = caps.matcherEntries;
     slots[i].maxSections = caps.maxSections;
     slots[i].nSections = 0;
+    slots[i].presentMask = 0;
     slots[i].sectionLength = 0;
   }
   e.slotA = &slots[0]; e.slotB = &slots[1]; e.slotT = &slots[2];
@@ -1571,6 +1531,17 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // read has left to do is a chain of dependent steps that takes its few milliseconds whatever runs beside it: the passes that take reads
     // back (60 k, 415, 18 reads ...) each last as long as their slowest read, and together cost twice what the gapped pass saved.
     const bool handBack = handOver && envInt("XM_HANDBACK", 0) != 0;
+    // the gapped pass of batches of short reads as a wave-level scheduler (xm_sched_kernel, xm_sched.h): chain phases and search phases that the lanes of a
+    // wave execute together.  A lane's scratch there: region | chain temporaries | its own search arrays | memo.  XM_SCHED=0: the lane-per-read gapped pass
+    const bool schedOn = handOver && !handBack && !longReads && envInt("XM_SCHED", 0) != 0;
+    const long long schedLpw = envKnob("XM_SCHED_LPW", 32, 1, 64), schedQuantum = envKnob("XM_SCHED_QUANTUM", 128, 1, 1 << 30), schedGate = envKnob("XM_SCHED_GATE", 8, 1, 64);
+    SchedLayout schedLay{0, 0, 0};
+    if (schedOn) {
+      Caps c = makeCaps(scale);
+      applyChainCaps(c, gappedScale);
+      schedLay.searchBytes = schedSearchArenaBytes(c);
+      schedLay.memoBytes = (unsigned long long)envKnob("XM_SCHED_MEMO_KB", 8, 2, 1024) * 1024;
+    }
     unsigned long long pendingLight = 0;
     int hoMode = handOver ? 1 : 0;   // mode of the next launch
     const int seedScale = scale;
@@ -1695,12 +1666,14 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       std::unique_lock<std::mutex> sizing(idx->dt->allocMu);
       size_t arenaBytes = arenaUnit * (size_t)scale;  // bytes of scratch a lane owns in this launch
       if (hoMode == 1 || hoMode == 3) arenaBytes = lightTmpUnit * (size_t)scale;                   // temporaries only (+ one region of the pool per lane / the read's own region)
-      else if (hoMode == 2) arenaBytes = regionBytes + gappedTmpBytes(arenaBytes);  // a region for reads without saved state + temporaries
+      const bool schedPass = schedOn && heavy && hoMode == 2 && scale == gappedScale;
+      if (schedPass) schedLay.tmpBytes = gappedTmpBytes(arenaBytes);
+      if (hoMode == 2) arenaBytes = regionBytes + gappedTmpBytes(arenaBytes) + (schedPass ? (size_t)(schedLay.searchBytes + schedLay.memoBytes) : 0);  // a region for reads without saved state + temporaries
       // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped chain
       // diverges inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  The XM_* variables are experiment knobs.
       // a pass over few reads spreads them over all the wave slots of the GPU (the time of a launch is its longest wave)
       const long long waveSlots = (long long)numCUs * 4 * (heavy ? fullWaves : lightWaves);
-      int lpw = (int)(heavy ? fullLpw : lightLpw);  // active lanes per wave
+      int lpw = (int)(schedPass ? schedLpw : (heavy ? fullLpw : lightLpw));  // active lanes per wave
       if (heavy) lpw = (int)std::max(1ll, std::min((long long)lpw, (nTodo + waveSlots - 1) / waveSlots));
       long long lanes = waveSlots * lpw;
       const unsigned long long budget = scratchBudget();
@@ -1738,8 +1711,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         if (extra < 0) extra = 0;
         nRegions = lanes + extra;
         regionsTotal = (size_t)nRegions * regionBytes;
-        const size_t gappedArena = arenaUnit * (size_t)gappedScale, gappedLane = regionBytes + gappedTmpBytes(gappedArena);
-        long long gappedLanes = std::min((long long)nq, (long long)numCUs * 4 * fullWaves * fullLpw);
+        const size_t gappedArena = arenaUnit * (size_t)gappedScale, gappedLane = regionBytes + gappedTmpBytes(gappedArena) + (schedOn ? (size_t)(schedLay.searchBytes + schedLay.memoBytes) : 0);
+        long long gappedLanes = std::min((long long)nq, (long long)numCUs * 4 * fullWaves * (schedOn ? schedLpw : fullLpw));
         gappedLanes = std::min(gappedLanes, std::max(1ll, ((long long)budget - (long long)regionsTotal) / (long long)gappedLane));
         size_t behind = std::max((size_t)lanes * arenaBytes, (size_t)gappedLanes * gappedLane);
         behind = std::max(behind, gappedArena);  // (a rerun after a full result arena runs plain, at least one lane of it)
@@ -1752,7 +1725,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         if (!allocScratch((size_t)lanes * arenaBytes)) continue;
       }
       sizing.unlock();
-      const int pairLanes = (heavy && lpw <= 32 && !defer && !fullSync && pairMode) ? 1 : 0;  // two lanes per read (xm_extend.h, xmSetPairMode)
+      const int pairLanes = (heavy && !schedPass && lpw <= 32 && !defer && !fullSync && pairMode) ? 1 : 0;  // two lanes per read (xm_extend.h, xmSetPairMode)
       uint8_t* laneArenas = idx->dArenas.p + regionsTotal;
       HandOver ho{hoMode, handBack ? 1 : 0, (int)lightLevel, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
       idx->dListLight.ensure((size_t)nq);
@@ -1769,11 +1742,17 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       }
       idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq); idx->dListPath[tp].ensure(defer ? (size_t)nTodo : 1);
       // gapped pass with an ordered list: the first read of every lane is dealt out (kernel), the counter starts behind those items
-      const long long firstStride = (heavy && !defer && heavyHintThreshold > 0 && scale == gappedScale) ? (long long)grid * (block / 64) : 0;
-      const unsigned long long firstItem = (unsigned long long)std::min((long long)nTodo, firstStride * lpw);
+      const long long firstStride = (heavy && !schedPass && !defer && heavyHintThreshold > 0 && scale == gappedScale) ? (long long)grid * (block / 64) : 0;
+      const unsigned long long firstItem = (unsigned long long)std::min((long long)nTodo, (schedPass ? (long long)grid * (block / 64) : firstStride) * lpw);  // (the scheduler kernel deals every lane's first read)
       HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 2, &firstItem, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
       HIP_CHECK(hipEventRecord(e0, s));
+      if (schedPass) {
+        SchedLaunch sl{grid, block, view, params, bv, todo, nTodo, scale, lpw, (int)schedQuantum, (int)schedGate, laneArenas, (unsigned long long)arenaBytes, schedLay, ov, idx->dCursors.p + 2, idx->dCounters.p, idx->dWaveNodes.p, ho, pool};
+        const int rc = xmSchedLaunch(sl, (void*)s);
+        if (rc != 0) throw std::runtime_error(std::string("scheduler kernel launch: ") + hipGetErrorString((hipError_t)rc));
+      }
+      else
       hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
                          laneArenas, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
                          defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
@@ -2167,6 +2146,14 @@ void xm_pileup_free(xm_pileup* p) {
   (void)hipSetDevice(p->device);
   p->dDepth.release(); p->dAlt.release(); p->dEventCount.release(); p->dEvents.release(); p->dMid.release();
   delete p;
+}
+
+int xm_debug_sched_profile(uint64_t* out16, int32_t reset) {
+  if (!out16) return fail("xm_debug_sched_profile: null argument");
+  unsigned long long t[16];
+  if (xmSchedProfile(t, reset) != 0) return fail("xm_debug_sched_profile: cannot read the timers");
+  for (int i = 0; i < 16; i++) out16[i] = (uint64_t)t[i];
+  return 0;
 }
 
 // Test-only entry (tests/test_gpu_kat.py): see xm_test_local_kernel above and xm_test_wave_search_kernel (xm_wave_kernel.hip).

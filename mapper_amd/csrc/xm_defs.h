@@ -139,6 +139,24 @@ XM_INL int seqMatchRunBack(const SeqView& a, int ai, const SeqView& b, int bi, i
   return k;
 }
 
+// Per byte of eight 4-bit codes: bit 7 set where the code is NOT exactly one of A C G T (Basepairs.isAmbiguous: its bit count is not 1)
+XM_INL uint64_t seqAmbiguousBytes(uint64_t x) {
+  x &= 0x0F0F0F0F0F0F0F0Full;
+  const uint64_t pairs = (x & 0x0505050505050505ull) + ((x >> 1) & 0x0505050505050505ull);       // bit counts of the two 2-bit halves
+  const uint64_t pop = (pairs & 0x0303030303030303ull) + ((pairs >> 2) & 0x0303030303030303ull);  // per byte: 0..4
+  const uint64_t bad = pop ^ 0x0101010101010101ull;                                                // per byte: 0 iff exactly one bit
+  return (bad + 0x7F7F7F7F7F7F7F7Full) & 0x8080808080808080ull;                                    // (bytes are < 8: no carry between bytes)
+}
+// Per byte: bit 7 set where the byte of t (all bytes < 128) is zero
+XM_INL uint64_t seqZeroBytes(uint64_t t) { return ~(t + 0x7F7F7F7F7F7F7F7Full) & 0x8080808080808080ull; }
+// how many of s.at(start) .. s.at(end - 1) are ambiguous codes; eight per load
+XM_INL int seqCountAmbiguous(const SeqView& s, int start, int end) {
+  int n = 0, i = start;
+  for (; i + 8 <= end && i + 8 <= s.len && i >= 0; i += 8) n += __builtin_popcountll(seqAmbiguousBytes(seqWord8(s, i)));
+  for (; i < end; i++) if (__builtin_popcount(s.at(i) & 15) != 1) n++;
+  return n;
+}
+
 // ---------------------------------------------------------------- AlignmentParameters (M/AlignmentParameters.java:8-35)
 struct Params {
   double MutationPenalty, InsertionStart_Penalty, InsertionExtension_Penalty, DeletionStart_Penalty, DeletionExtension_Penalty,

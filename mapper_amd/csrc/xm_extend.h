@@ -40,6 +40,7 @@ XM_INL int secLen(const Section& s) { return s.end - s.start; }
 struct Matcher {  // HashBlock_Matcher
   int32_t referenceStart, referenceLength, blockLength, sectionLength, maxSectionIndex, numPossibilities, maxPossibility;
   int32_t nSections;   // locations.size()
+  uint64_t presentMask; // bit i = present[i] for i < 64: which sections exist is asked for every lookup, and from a register it costs no trip to memory
   uint8_t* present;    // [maxSections] 0 = "null" entry
   int16_t* tables;     // [nSections][numPossibilities], value = position - referenceStart, or -1 / -2
   int32_t tableCap, maxSections;
@@ -81,12 +82,18 @@ struct MemoHdr {
   int32_t qsStart, qsEnd, rsStart, rsEnd, referenceLen, predictedBestOffset, confident, pad;
   double maxInsExt, maxDelExt;
   Params params;
+  // in-lane form (textCap == 0; the wave scheduler of the gapped pass, xm_sched.h): the read stays on its lane while its search runs, so the request
+  // addresses the two texts where they are (the mate in the batch, or the joined mates in the lane's temporaries; the forward contig) instead of copying them
+  const uint8_t* qBase; const uint8_t* rBase;
+  int32_t qLen, qRc;
+  int64_t pad2;
 };
+static_assert(sizeof(MemoHdr) % 16 == 0, "the log behind the header holds 16-byte aligned blocks");
 struct MemoEntry {  // followed by nb ABlocks
   int32_t type, ok, nb, contig, referenceReversed, seqAId, aux, bytes;
   double totalPenalty, alignedPenalty;
 };
-enum { MEMO_MATCH = 1, MEMO_PIECE = 2, MEMO_PATH = 3 };
+enum { MEMO_MATCH = 1, MEMO_PIECE = 2, MEMO_PATH = 3, MEMO_ANALYSIS = 4 };
 constexpr int XM_MEMO_SLOT_BYTES = 8192, XM_MEMO_TEXT_BYTES = 1024;
 XM_INL uint8_t* memoTexts(MemoHdr* m) { return (uint8_t*)(m + 1); }
 XM_INL uint8_t* memoLog(MemoHdr* m) { return memoTexts(m) + m->textCap; }
@@ -94,6 +101,14 @@ XM_INL void memoInit(MemoHdr* m) {
   m->logBytes = 0; m->hasRequest = 0; m->textCap = XM_MEMO_TEXT_BYTES;
   m->logCap = XM_MEMO_SLOT_BYTES - (int)sizeof(MemoHdr) - XM_MEMO_TEXT_BYTES;
 }
+// a memo of `slotBytes` whose requests carry no texts (in-lane form)
+XM_INL void memoInitInLane(MemoHdr* m, int slotBytes) {
+  m->logBytes = 0; m->hasRequest = 0; m->textCap = 0;
+  m->logCap = slotBytes - (int)sizeof(MemoHdr);
+}
+XM_INL bool memoInLane(const MemoHdr* m) { return m && m->textCap == 0; }
+// a new candidate starts (alignRead): nothing logged for the previous one is looked at again
+XM_INL void memoRestart(MemoHdr* m, int32_t& cursor) { m->logBytes = 0; m->hasRequest = 0; cursor = 0; }
 XM_INL int memoPeek(MemoHdr* m, int cursor) {
   if (cursor >= m->logBytes) return 0;
   return ((const MemoEntry*)(memoLog(m) + cursor))->type;
@@ -126,11 +141,45 @@ XM_INL bool memoPut(MemoHdr* m, int32_t& cursor, int start, int type, bool ok, c
   return true;
 }
 
+// In-lane form only: the outcome of a hash-block analysis (HashBlock_Aligner.analyzePenalty) is logged too, so that a replay does not walk the query
+// over the matcher tables again (a fifth of the chain's time).  One MemoEntry + 16 bytes: minPossiblePenalty and maxInsertionExtensionPenalty in the
+// entry's two doubles, maxDeletionExtensionPenalty behind it; the offset and its count in contig / referenceReversed; ok = the analysis made
+// the matcher of its store slot the analysis' own (an.matcher).  The matchers themselves stay where they are between a read's chain phases.
+struct MemoAnalysisTail { double maxDeletionExtensionPenalty; int64_t pad; };
+XM_INL bool memoPutAnalysis(MemoHdr* m, int32_t& cursor, double minPossible, double maxIns, double maxDel, int offset, int count, bool setMatcher) {
+  const int bytes = (int)sizeof(MemoEntry) + (int)sizeof(MemoAnalysisTail);
+  const int start = cursor;
+  if (start + bytes > m->logCap) return false;
+  MemoEntry* en = (MemoEntry*)(memoLog(m) + start);
+  MemoEntry h;
+  h.type = MEMO_ANALYSIS; h.ok = setMatcher ? 1 : 0; h.nb = 0; h.contig = offset; h.referenceReversed = count; h.seqAId = 0; h.aux = 0; h.bytes = bytes;
+  h.totalPenalty = minPossible; h.alignedPenalty = maxIns;
+  *en = h;
+  MemoAnalysisTail t; t.maxDeletionExtensionPenalty = maxDel; t.pad = 0;
+  *(MemoAnalysisTail*)(en + 1) = t;
+  m->logBytes = start + bytes;
+  cursor = m->logBytes;
+  return true;
+}
+
 // ---------------------------------------------------------------- penalties (M/AlignmentParameters.java)
 XM_INL double blockPenalty(const SeqView& q, const SeqView& r, const Params& p, const ABlock& b) {  // :106-126
   double penalty = 0;
   if (b.lenA == b.lenB) {
-    for (int i = 0; i < b.lenA; i++) penalty += p.getPenalty(q.at(b.startA + i), r.at(b.startB + i));
+    // Eight positions per pair of loads (a byte-by-byte loop waits for memory once per base).  A position whose two codes are the same single base
+    // adds getPenalty = AmbiguityPenalty * 0 = +0.0, which leaves the sum as it is; only the others are added, in order.
+    int i = 0;
+    while (i + 8 <= b.lenA && b.startA + i >= 0 && b.startB + i >= 0 && b.startA + i + 8 <= q.len && b.startB + i + 8 <= r.len) {
+      const uint64_t wa = seqWord8(q, b.startA + i), wb = seqWord8(r, b.startB + i);
+      uint64_t todo = seqZeroBytes(wa & wb) | seqAmbiguousBytes(wa | wb);
+      while (todo) {
+        const int k = __builtin_ctzll(todo) >> 3;
+        penalty += p.getPenalty((uint8_t)(wa >> (8 * k)), (uint8_t)(wb >> (8 * k)));
+        todo &= todo - 1;
+      }
+      i += 8;
+    }
+    for (; i < b.lenA; i++) penalty += p.getPenalty(q.at(b.startA + i), r.at(b.startB + i));
   } else if (b.lenA > 0) {
     penalty += p.InsertionStart_Penalty;
     penalty += p.InsertionExtension_Penalty * b.lenA;
@@ -184,6 +233,7 @@ XM_INL void matcherInit(Matcher& m, const ExtEnv& e, const Section& referenceSec
   m.numPossibilities = 1 << (2 * m.blockLength);
   m.maxPossibility = m.numPossibilities - 1;
   m.nSections = 0;
+  m.presentMask = 0;
 }
 XM_INL int matcherEncodeBlock(const Matcher& m, const SeqView& s, int index) {  // :79-91
   if (index + m.blockLength > s.len) return M_UNKNOWN;
@@ -250,10 +300,11 @@ XM_NOINL void matcherIndexSection(const Matcher m, const SeqView ref, int sectio
 }
 // getSection :203-215; returns -1 for a "null" entry (a section skipped by an earlier jump), else the section slot
 XM_INL int matcherGetSection(Matcher& m, const SeqView& ref, int index, bool& overflow, DevCounters* dc) {
-  if (m.nSections > index) return m.present[index] ? index : -1;
+  if (m.nSections > index) return (index < 64 ? ((m.presentMask >> index) & 1) != 0 : m.present[index] != 0) ? index : -1;
   if (index >= m.maxSections || (long long)(index + 1) * m.numPossibilities > m.tableCap) { overflow = true; return -1; }
   while (m.nSections <= index) m.present[m.nSections++] = 0;
   m.present[index] = 1;
+  if (index < 64) m.presentMask |= 1ull << index;
   matcherIndexSection(m, ref, index, m.tables + (size_t)index * m.numPossibilities, dc);
   return index;
 }
@@ -285,6 +336,16 @@ XM_INL int matcherLookup(Matcher& m, const SeqView& query, const SeqView& ref, i
   int matched = M_NO_MATCHES;
   int minSectionIndex = imax(0, matcherSectionIndex(m, minReferenceIndex));
   int maxSection = imin(m.maxSectionIndex, matcherSectionIndex(m, maxReferenceIndex));
+  // the table entries of the (up to four) sections that exist already: read together, before the loop that looks at them one after the other
+  int16_t ahead[4] = {0, 0, 0, 0};
+  bool haveAhead[4] = {false, false, false, false};
+  if (m.sectionLength >= 3) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int si = minSectionIndex + k;
+      if (si <= maxSection && si < m.nSections && si < 64 && ((m.presentMask >> si) & 1)) { ahead[k] = m.tables[(size_t)si * m.numPossibilities + encoded]; haveAhead[k] = true; }
+    }
+  }
   for (int sectionIndex = minSectionIndex; sectionIndex <= maxSection; sectionIndex++) {
     int slot = matcherGetSection(m, ref, sectionIndex, overflow, dc);
     if (overflow) return M_UNKNOWN;
@@ -299,7 +360,8 @@ XM_INL int matcherLookup(Matcher& m, const SeqView& query, const SeqView& ref, i
         }
       }
     } else if (slot >= 0) {
-      int16_t v = m.tables[(size_t)slot * m.numPossibilities + encoded];
+      const int k = sectionIndex - minSectionIndex;
+      int16_t v = (k < 4 && haveAhead[k]) ? ahead[k] : m.tables[(size_t)slot * m.numPossibilities + encoded];
       lookedUp = v >= 0 ? (int)v + m.referenceStart : (int)v;
     } else {
       return M_UNKNOWN;
@@ -1270,6 +1332,16 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
     if (st) { *e.status = st; return false; }
   } else if (e.memo && e.caps->deferPath) {
     MemoHdr* const m = e.memo;
+    if (m->textCap == 0) {  // in-lane form: the texts stay where they are
+      m->qsStart = qs.start; m->qsEnd = qs.end; m->rsStart = rs.start; m->rsEnd = rs.end; m->referenceLen = e.reference.len;
+      m->predictedBestOffset = an.predictedBestOffset; m->confident = an.confidentAboutBestOffset ? 1 : 0; m->pad = 0;
+      m->maxInsExt = an.maxInsertionExtensionPenalty; m->maxDelExt = an.maxDeletionExtensionPenalty;
+      m->params = p;
+      m->qBase = e.query.base; m->qLen = e.query.len; m->qRc = e.query.rc; m->rBase = e.reference.base;
+      m->hasRequest = 1;
+      *e.status = XM_ST_NEED_PATH;
+      return false;
+    }
     {
       const int la = secLen(qs), lb = secLen(rs);
       if (la < 0 || lb < 0 || la + lb > m->textCap) { *e.status = XM_ST_OVERFLOW; return false; }  // rerun with inline searches
@@ -1457,6 +1529,18 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qsIn,
   PenaltyAnalysis result;
   result.minPossiblePenalty = 0; result.maxInsertionExtensionPenalty = 0; result.maxDeletionExtensionPenalty = 0;
   result.offsetWithMostHashblockMatches = 0; result.numHashBlockMatchesWithBestOffset = 0;
+  const bool logIt = memoInLane(e.memo);
+  if (logIt && memoPeek(e.memo, *e.memoCursor) == MEMO_ANALYSIS) {  // replay: the analysis ran in an earlier chain phase of this read
+    const MemoEntry* en = (const MemoEntry*)(memoLog(e.memo) + *e.memoCursor);
+    const MemoEntry h = *en;
+    const MemoAnalysisTail t = *(const MemoAnalysisTail*)(en + 1);
+    result.minPossiblePenalty = h.totalPenalty; result.maxInsertionExtensionPenalty = h.alignedPenalty; result.maxDeletionExtensionPenalty = t.maxDeletionExtensionPenalty;
+    result.offsetWithMostHashblockMatches = h.contig; result.numHashBlockMatchesWithBestOffset = h.referenceReversed;
+    if (h.ok && !an.matcher) an.matcher = storeSlot;
+    *e.memoCursor += h.bytes;
+    return result;
+  }
+  const bool hadMatcher = an.matcher != nullptr;
   Matcher* matcher = an.matcher;
   const SeqView query = e.query, reference = e.reference;  // register-resident copies
   DevCounters* const dc = e.dc;
@@ -1544,7 +1628,7 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qsIn,
       if (overflow) break;
     }
   }
-  matcher->nSections = mm.nSections;  // write back the only scalar that changes
+  matcher->nSections = mm.nSections; matcher->presentMask = mm.presentMask;  // write back the scalars that change
   if (overflow) *e.status = XM_ST_OVERFLOW;
   if (*e.status) { tmp.used = mark; return result; }
   int mostPopularOffset = counts.mostPopularKey;
@@ -1568,6 +1652,9 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qsIn,
   if (mostPopularOffset_count < 1) mostPopularOffset = an.predictedBestOffset;
   result.offsetWithMostHashblockMatches = mostPopularOffset;
   result.numHashBlockMatchesWithBestOffset = mostPopularOffset_count;
+  if (logIt && !memoPutAnalysis(e.memo, *e.memoCursor, result.minPossiblePenalty, result.maxInsertionExtensionPenalty, result.maxDeletionExtensionPenalty,
+                                result.offsetWithMostHashblockMatches, result.numHashBlockMatchesWithBestOffset, !hadMatcher && an.matcher != nullptr))
+    *e.status = XM_ST_OVERFLOW;
   return result;
 }
 
@@ -1815,8 +1902,7 @@ struct NextHashBlock1 {
       return false;
     }
     // SkipHighAmbiguity_Aligner :13-28
-    int numAmbiguities = 0;
-    for (int i = rs.start; i < rs.end; i++) if (bpIsAmbiguous(e.reference.at(i))) numAmbiguities++;
+    const int numAmbiguities = seqCountAmbiguous(e.reference, rs.start, rs.end);
     if (numAmbiguities >= secLen(rs) / 4) return false;
     return hashBlockAlign(e, qs, rs, p, an, out, e.slotA, NextBlock());
   }

@@ -146,12 +146,19 @@ XM_NOINL bool qmaAlignMatchBody(ReadCtx& cx, const SeqView& seqA, int contig, in
   makeExtEnv(cx, e, seqA, contig);
   Matcher* slots = arenaArray<Matcher>(cx.tmp, 3);
   if (cx.tmp.overflow) { cx.status = XM_ST_OVERFLOW; cx.tmp.used = mark; return false; }
+  // (in-lane memo with something logged behind the cursor: this call is being replayed by a later chain phase of the read - the matchers are
+  // as that phase left them in the lane's temporaries, and the analyses that filled them are taken from the log)
+  const bool replayed = memoInLane(cx.memo) && memoPeek(cx.memo, cx.memoCursor) != 0;
   for (int i = 0; i < 3; i++) {
-    slots[i].present = arenaArray<uint8_t>(cx.tmp, cx.caps.maxSections);
-    slots[i].tables = arenaArray<int16_t>(cx.tmp, cx.caps.matcherEntries);
+    uint8_t* const present = arenaArray<uint8_t>(cx.tmp, cx.caps.maxSections);
+    int16_t* const tables = arenaArray<int16_t>(cx.tmp, cx.caps.matcherEntries);
+    if (replayed) continue;
+    slots[i].present = present;
+    slots[i].tables = tables;
     slots[i].tableCap = cx.caps.matcherEntries;
     slots[i].maxSections = cx.caps.maxSections;
     slots[i].nSections = 0;
+    slots[i].presentMask = 0;
     slots[i].sectionLength = 0;
   }
   if (cx.tmp.overflow) { cx.status = XM_ST_OVERFLOW; cx.tmp.used = mark; return false; }
@@ -711,8 +718,9 @@ XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr, bool resume = false) {
     st.haveOptimisticMatch = 1;
     st.phase = 1;
     st.rr = rr;
-    if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }
+    if (memoInLane(cx.memo)) memoRestart(cx.memo, cx.memoCursor);
 resume_optimistic:
+    if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }  // (behind the label: a resumed run counts into another lane's counters)
     st.optimisticBestAlignment = qmaAlign(cx, *aligner, st.optimisticBestMatch, 0);
     if (cx.status) return;
     if (cx.caps.handBack) { st.phase = 11; st.rr = rr; cx.status = XM_ST_NEED_LIGHT; return; }
@@ -756,8 +764,9 @@ resume_after_optimistic:
       } else {
         st.phase = 3;
         st.rr = rr;
-        if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }
+        if (memoInLane(cx.memo)) memoRestart(cx.memo, cx.memoCursor);
 resume_main:
+        if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }
         al = qmaAlign(cx, *aligner, pc.filtered[st.i], 0);
         if (cx.status) return;
         if (cx.caps.handBack) { st.al = al; st.phase = 13; st.rr = rr; cx.status = XM_ST_NEED_LIGHT; return; }
@@ -780,8 +789,9 @@ resume_after_main:
     for (st.i = 0; st.i < pc.nFiltered; st.i++) {
       st.phase = 4;
       st.rr = rr;
-      if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }
+      if (memoInLane(cx.memo)) memoRestart(cx.memo, cx.memoCursor);
 resume_partial:
+      if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }
       al = qmaAlign(cx, *aligner, pc.filtered[st.i], 0);
       if (cx.status) return;
       if (cx.caps.handBack) { st.al = al; st.phase = 14; st.rr = rr; cx.status = XM_ST_NEED_LIGHT; return; }
@@ -794,6 +804,8 @@ resume_after_partial:
     }
   }
   st.phase = 5;
+  // (the wave scheduler continues a read at phases 1, 3 and 4 only: from here on - getUnpairedAlignments - searches run inline, nothing is logged)
+  if (memoInLane(cx.memo)) { cx.memo = nullptr; cx.caps.deferPath = 0; }
   qmaGetBestAlignments(*aligner);
   {
     int numBest = aligner->nBest;
@@ -878,10 +890,10 @@ XM_INL void applyChainCaps(Caps& c, int chainScale) {
 // that stops in front of the gapped chain leaves a SavedRead at the tail of the region.  Gapped pass, read without saved state
 // (heavyAllowed 2, chainScale = the gapped scale): seeded at `scale`, chain scratch of the gapped pass.
 XM_INL void runReadRetaining(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* region, size_t regionBytes, void* laneArena, size_t laneArenaBytes,
-                             DevCounters* dc, ReadResult& rr, int heavyAllowed, int chainScale = 0) {
-  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed; cx.caps.deferPath = 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
+                             DevCounters* dc, ReadResult& rr, int heavyAllowed, int chainScale = 0, MemoHdr* memo = nullptr, bool deferPath = false) {
+  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed; cx.caps.deferPath = (memo && deferPath) ? 1 : 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
   if (chainScale > 0 && chainScale != scale) applyChainCaps(cx.caps, chainScale);
-  cx.memo = nullptr; cx.memoCursor = 0; cx.heavyHint = 0;
+  cx.memo = memo; cx.memoCursor = 0; cx.heavyHint = 0;
   cx.params.StartingInsertionStartFree = 0;
   cx.persist.init(region, retainedPersistBytes(regionBytes));
   cx.tmp.init(laneArena, laneArenaBytes);

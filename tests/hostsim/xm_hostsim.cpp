@@ -6,6 +6,7 @@
 // or loaded by libxmapper_hip.so / the mapper_amd package, which has no CPU path.
 #include "../../include/xmapper_hip.h"
 #include "../../mapper_amd/csrc/xm_worker.h"
+#include "../../mapper_amd/csrc/xm_sched.h"
 #include "../../mapper_amd/csrc/xm_wave.h"
 #include "../../mapper_amd/csrc/xm_index_host.h"
 #include <cstdlib>
@@ -21,6 +22,7 @@ static int g_waveMode = -1;  // -1: from XMSIM_WAVE (default 0)
 static long long g_waveStatus[16];
 static long long g_waveWhy[64];
 static long long g_markHist[6][128];  // high-water marks of the wave form per read: chunks, counters, history, pending, query matches, alignments
+static long long g_schedSearches = 0, g_schedBig = 0;  // searches the scheduler path ran; of them in the big buffer
 static void markDump() { const char* names[6] = {"chunks", "counters", "history", "pending", "qmatches", "alignments"}; for (int k = 0; k < 6; k++) { fprintf(stderr, "[wave marks] %s:", names[k]); for (int i = 0; i < 128; i++) if (g_markHist[k][i]) fprintf(stderr, " %d:%lld", i, g_markHist[k][i]); fprintf(stderr, "\n"); } }
 
 struct SimIndex {
@@ -208,6 +210,8 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       // hand-back (XM_ST_NEED_LIGHT): the gapped "pass" stops a resumed read behind its candidate and a "pass" of the light pass's shape - another
       // context object, small temporaries, light capacities - takes it on; a read that stops in front of the chain there goes round again
       const bool handBack = handOver && getenv("XMSIM_HANDBACK") && atoi(getenv("XMSIM_HANDBACK")) != 0;  // (off by default, as in the product)
+      // XMSIM_SCHED=1: the gapped pass of batches of short reads as the wave scheduler runs it (the product's XM_SCHED=1)
+      const bool sched = handOver && seedScale == 1 && getenv("XMSIM_SCHED") && atoi(getenv("XMSIM_SCHED")) != 0;
       bool takenBack = false;
       static ReadCtx cx3;
       std::vector<uint8_t> arena3;
@@ -229,6 +233,38 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
             if (saved->valid) continue;                  // another candidate for the chain: the gapped "pass" again, from the region
             saved = nullptr; stage = 2; scale = seedScale * 4; continue;  // (stopped where it cannot be resumed: a plain run)
           }
+          saved = nullptr;
+        } else if (stage == 1 && saved && sched && !handBack) {
+          // the gapped pass as the wave scheduler runs it (xm_sched.h, xm_sched_kernel): chain phase until the read is finished or parked at a search,
+          // search phase (the lane's own arrays; the big buffer when it outgrows them), replay from the candidate, ... - on another context object
+          arena2.assign(bytes + chainExtraTmpBytes(scale) + 64, 0xAB);
+          uint8_t* a2 = (uint8_t*)(((uintptr_t)arena2.data() + 15) & ~(uintptr_t)15);
+          const size_t tmpBytes = gappedTmp(bytes, scale);
+          memoInitInLane(memo, XM_MEMO_SLOT_BYTES);
+          runReadResumed(cx2, saved, &idx->view, scale, a2, tmpBytes, &dc, rr, memo, true, 2, 0);
+          int phases = 0;
+          while (schedParked(cx2)) {
+            if (!memo->hasRequest) throw std::runtime_error("NEED_PATH without a request");
+            const size_t sbytes = schedSearchArenaBytes(cx2.caps);
+            std::vector<double> sbuf(sbytes / 8 + 2, 0.0);
+            void* sarena = (void*)(((uintptr_t)sbuf.data() + 15) & ~(uintptr_t)15);
+            memset(sarena, 0xC7, sbytes);
+            schedSearchBegin(memo, sarena, cx2.caps);
+            bool big = false;
+            static const int quantum = getenv("XMSIM_SCHED_QUANTUM") ? atoi(getenv("XMSIM_SCHED_QUANTUM")) : 64;  // (the kernel's searches run a number of steps at a time)
+            while (!schedSearchRun(memo, sarena, quantum, &dc, &big)) { }
+            if (big) {
+              std::vector<double> bbuf(((size_t)288 * 1024 * (size_t)scale) / 8 + 2, 0.0);
+              Arena bigArena;
+              bigArena.init((void*)(((uintptr_t)bbuf.data() + 15) & ~(uintptr_t)15), (size_t)288 * 1024 * (size_t)scale);
+              schedSearchBig(memo, bigArena, cx2.caps, &dc);
+              g_schedBig++;
+            }
+            g_schedSearches++;
+            schedReplay(cx2, rr);
+            if (++phases > 100000) throw std::runtime_error("scheduler phases do not end");
+          }
+          cx.status = cx2.status;
           saved = nullptr;
         } else if (stage == 1 && saved) {
           arena2.assign(bytes + chainExtraTmpBytes(scale) + 64, 0xAB);
@@ -305,6 +341,8 @@ void xmsim_set_wave_mode(int mode) { g_waveMode = mode; }
 // how the wave form left the reads of all calls so far, by status (0 = finished there)
 void xmsim_wave_status_counts(long long* out, int reset) { for (int i = 0; i < 16; i++) { out[i] = g_waveStatus[i]; if (reset) g_waveStatus[i] = 0; } }
 void xmsim_wave_why_counts(long long* out) { for (int i = 0; i < 64; i++) out[i] = g_waveWhy[i]; }
+
+void xmsim_sched_counts(long long* out, int reset) { out[0] = g_schedSearches; out[1] = g_schedBig; if (reset) g_schedSearches = g_schedBig = 0; }
 
 void xmsim_result_free(xm_result* r) {
   if (!r) return;

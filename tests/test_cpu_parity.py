@@ -374,3 +374,35 @@ def test_hand_back_resume_points_in_the_host_simulation(monkeypatch):
     pb = pe_batch(m1, m2)
     sa, sb = R.align(pb, p), S.align(pb, p)
     assert streams_equal(sa, sb), first_difference(sa, sb, pb.nq)
+
+
+@pytest.mark.parametrize("quantum", ["1", "7", "100000"])
+def test_wave_scheduler_path_in_the_host_simulation(quantum, monkeypatch):
+    """XM_SCHED=1 (xm_sched.h, xm_wsearch.h): the gapped pass as chain phases and search phases - a read parks at a PathAligner search with the
+    request in its memo, the search runs in the lane's own arrays (suspended every `quantum` explored entries, as the kernel's rounds do), the read
+    re-enters alignRead at its candidate and replays from the log of its finished calls (searches, pieces, alignMatch calls, hash-block analyses;
+    the matchers stay in the temporaries).  Single-end reads with indels, pairs, reads with ambiguity codes: streams and work counters against the oracle."""
+    monkeypatch.setenv("XMSIM_SCHED", "1")
+    monkeypatch.setenv("XMSIM_SCHED_QUANTUM", quantum)
+    import ctypes as C
+    ref = synth.synthetic_reference(200_000, seed=31)
+    R = o.OracleReference([("r", ref)])
+    S = hs.SimReference([("r", ref)])
+    p = o.make_params()
+    counts = (C.c_longlong * 2)()
+    hs.lib().xmsim_sched_counts(counts, 1)
+    b = se_batch(synth.synthetic_single_end(ref, 2500, seed=32, indel_prob=0.5)[0])
+    sa, sb = R.align(b, p), S.align(b, p)
+    assert streams_equal(sa, sb), first_difference(sa, sb, b.nq)
+    # candidates extended, PathAligner calls, nodes put (the oracle's counters have one field more in front of them than the device's layout)
+    assert list(sa.counters[5:8]) == list(sb.counters[4:7])
+    m1, m2 = synth.synthetic_paired_end(ref, 1200, seed=33, indel_prob=0.4)[:2]
+    pb = pe_batch(m1, m2)
+    sa, sb = R.align(pb, p), S.align(pb, p)
+    assert streams_equal(sa, sb), first_difference(sa, sb, pb.nq)
+    reads = sprinkle_ambiguity(synth.synthetic_single_end(ref, 1500, seed=34, indel_prob=0.3)[0])
+    ab = se_batch(reads)
+    sa, sb = R.align(ab, p, threads=os.cpu_count()), S.align(ab, p)
+    assert streams_equal(sa, sb), first_difference(sa, sb, ab.nq)
+    hs.lib().xmsim_sched_counts(counts, 0)
+    assert counts[0] > 1000, "the scheduler path ran %d searches" % counts[0]

@@ -103,6 +103,11 @@ PASS_SHAPES = [
     {"XM_SEARCH_POOL": "0"},                                                    # HBM-mode searches in the lanes' temporaries (no buffer per wave)
     {"XM_SEARCH_POOL": "0", "XM_GAPPED_TMP_PCT": "20"},                         # ... and too small for them: those reads rerun
     {"XM_REGION_KB": "40", "XM_LIGHT_TMP_KB": "24"},                            # regions and light temporaries too small for anything: every read overflows into the reruns
+    {"XM_SCHED": "1"},                                                          # the gapped pass as the wave scheduler (chain phases / search phases, xm_sched_kernel)
+    {"XM_SCHED": "1", "XM_SCHED_QUANTUM": "1", "XM_SCHED_GATE": "1"},           # ... every search suspended after each explored entry, chain phases as soon as a lane is ready
+    {"XM_SCHED": "1", "XM_SCHED_LPW": "64", "XM_SCHED_GATE": "32", "XM_SCHED_QUANTUM": "1000000"},  # ... full waves, searches run to their end
+    {"XM_SCHED": "1", "XM_SCHED_LPW": "3", "XM_FULL_WAVES": "1", "XM_SCRATCH_GIB": "2"},  # ... few lanes: every lane takes many reads in turn
+    {"XM_SCHED": "1", "XM_SCHED_MEMO_KB": "2"},                                  # ... memos too small for some reads: those run again in the lane-per-read passes
     {"XM_WAVE": "1"},                                                           # the wave-per-read form first (light tier, chain tiers with inline searches), lane-per-read passes for the rest
     {"XM_WAVE": "1", "XM_WAVE_TIERS": "1"},                                     # its light tier only
     {"XM_WAVE": "1", "XM_WAVE_TIERS": "2"},                                     # light + chain tier (no tier with the largest capacities)
