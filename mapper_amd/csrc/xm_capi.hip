@@ -836,6 +836,8 @@ struct xm_index {
   DevBuf<uint8_t> dMemo;
   DevBuf<PNode> dWaveNodes;  // per wave: node payloads of its LDS-mode search
   DevBuf<uint8_t> dSearchPool;  // one buffer per wave for the arrays of HBM-mode searches (SearchPool, xm_extend.h)
+  DevBuf<uint8_t> dBigSets;     // scheduler kernel, batches of long reads: the pool of large search sets (BigSetPool)
+  DevBuf<int32_t> dBigSetOwner;
   // wave-per-read passes
   DevBuf<int64_t> dListWaveHeavy, dListWaveNext, dListWaveSearch[2], dListFallback;
   DevBuf<uint8_t> dWaveMemo;
@@ -1533,15 +1535,27 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const bool handBack = handOver && envInt("XM_HANDBACK", 0) != 0;
     // the gapped pass of batches of short reads as a wave-level scheduler (xm_sched_kernel, xm_sched.h): chain phases and search phases that the lanes of a
     // wave execute together.  A lane's scratch there: region | chain temporaries | its own search arrays | memo.  XM_SCHED=0: the lane-per-read gapped pass
-    const bool schedOn = handOver && !handBack && !longReads && envInt("XM_SCHED", 0) != 0;
-    const long long schedLpw = envKnob("XM_SCHED_LPW", 32, 1, 64), schedQuantum = envKnob("XM_SCHED_QUANTUM", 128, 1, 1 << 30), schedGate = envKnob("XM_SCHED_GATE", 8, 1, 64);
+    // XM_SCHED=1: batches of short reads; XM_SCHED_LONG=1: batches of long reads (their searches - thousands of entries each - are most of their time)
+    const bool schedOn = handOver && !handBack && (longReads ? envInt("XM_SCHED_LONG", 0) != 0 : envInt("XM_SCHED", 0) != 0);
+    const bool schedSplit = schedOn && !longReads && envInt("XM_SCHED", 0) == 2;
+    long long gappedFront = 0;  // reads at the front of the gapped pass's list (the ones that look expensive)
+    const long long schedLpw = envKnob("XM_SCHED_LPW", longReads ? 8 : 32, 1, 64), schedQuantum = envKnob("XM_SCHED_QUANTUM", 128, 1, 1 << 30), schedGate = envKnob("XM_SCHED_GATE", longReads ? 2 : 8, 1, 64);
     SchedLayout schedLay{0, 0, 0};
+    BigSetPool bigSets{nullptr, 0, nullptr, 0, 0};
     if (schedOn) {
       Caps c = makeCaps(scale);
       applyChainCaps(c, gappedScale);
       schedLay.searchBytes = schedSearchArenaBytes(c);
-      schedLay.memoBytes = (unsigned long long)envKnob("XM_SCHED_MEMO_KB", 8, 2, 1024) * 1024;
+      schedLay.memoBytes = (unsigned long long)envKnob("XM_SCHED_MEMO_KB", longReads ? 4 * gappedScale : 8, 2, 4096) * 1024;
     }
+    // (the chain temporaries of a scheduler lane: no arrays for searches in them - batches of long reads keep the matchers' share of what applyChainCaps adds)
+    auto schedTmpBytes = [&](size_t arena) -> size_t {
+      if (!longReads) return gappedTmpBytes(arena);
+      const Caps g = makeCaps(gappedScale);
+      const size_t searchArrays = (size_t)g.maxNodes * (sizeof(PNode) + 8) + (size_t)std::max(g.gridCap, g.nodeHash) * 4 + (size_t)g.maxBuckets * 20 + (size_t)g.bucketHash * 4;
+      const size_t whole = ((size_t)((arena - arenaPersistBytes(arena)) * (size_t)gappedTmpPct / 100) & ~(size_t)15);
+      return (whole > searchArrays + (256u << 10) ? whole - searchArrays : whole) + chainExtraMatcherBytes(gappedScale);
+    };
     unsigned long long pendingLight = 0;
     int hoMode = handOver ? 1 : 0;   // mode of the next launch
     const int seedScale = scale;
@@ -1667,8 +1681,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       size_t arenaBytes = arenaUnit * (size_t)scale;  // bytes of scratch a lane owns in this launch
       if (hoMode == 1 || hoMode == 3) arenaBytes = lightTmpUnit * (size_t)scale;                   // temporaries only (+ one region of the pool per lane / the read's own region)
       const bool schedPass = schedOn && heavy && hoMode == 2 && scale == gappedScale;
-      if (schedPass) schedLay.tmpBytes = gappedTmpBytes(arenaBytes);
-      if (hoMode == 2) arenaBytes = regionBytes + gappedTmpBytes(arenaBytes) + (schedPass ? (size_t)(schedLay.searchBytes + schedLay.memoBytes) : 0);  // a region for reads without saved state + temporaries
+      if (schedPass) schedLay.tmpBytes = schedTmpBytes(arenaBytes);
+      if (hoMode == 2) arenaBytes = schedPass ? regionBytes + (size_t)(schedLay.tmpBytes + schedLay.searchBytes + schedLay.memoBytes) : regionBytes + gappedTmpBytes(arenaBytes);  // a region for reads without saved state + temporaries
       // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped chain
       // diverges inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  The XM_* variables are experiment knobs.
       // a pass over few reads spreads them over all the wave slots of the GPU (the time of a launch is its longest wave)
@@ -1676,7 +1690,27 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       int lpw = (int)(schedPass ? schedLpw : (heavy ? fullLpw : lightLpw));  // active lanes per wave
       if (heavy) lpw = (int)std::max(1ll, std::min((long long)lpw, (nTodo + waveSlots - 1) / waveSlots));
       long long lanes = waveSlots * lpw;
-      const unsigned long long budget = scratchBudget();
+      // scheduler kernel, batches of long reads: the pool of large search sets comes out of the context's scratch before the lanes are counted (a quarter of it:
+      // a lane then owns ~2 MB instead of ~7, and the reads in flight are what a batch of long reads is short of)
+      if (schedOn && longReads && hoMode == 1 && bigSets.nPerGroup == 0) {
+        Caps c = makeCaps(seedScale);
+        applyChainCaps(c, gappedScale);
+        bigSets.bufBytes = (schedBigSetBytes(c) + 4095) & ~(size_t)4095;
+        const unsigned long long share = scratchBudget() * (unsigned long long)envKnob("XM_SCHED_BIGSET_PCT", 25, 1, 90) / 100;
+        long long perGroup = (long long)(share / bigSets.bufBytes / 8);
+        while (perGroup >= 1 && !idx->dBigSets.tryEnsure((size_t)perGroup * 8 * bigSets.bufBytes)) perGroup /= 2;
+        if (perGroup >= 1) {
+          bigSets.nPerGroup = (int32_t)std::min<long long>(perGroup, 1 << 20);
+          bigSets.base = idx->dBigSets.p;
+          idx->dBigSetOwner.ensure((size_t)bigSets.nPerGroup * 8);
+          bigSets.owner = idx->dBigSetOwner.p;
+        }
+      }
+      unsigned long long budget = scratchBudget();
+      if (bigSets.nPerGroup > 0) {  // (the pool counts against the context's scratch limit)
+        const unsigned long long lim = scratchWanted >> scratchShift, used = (unsigned long long)bigSets.nPerGroup * 8 * bigSets.bufBytes;
+        budget = std::min(budget, lim > used + (64ull << 20) ? lim - used : (64ull << 20));
+      }
       if (hoMode == 1) lanes = std::min(lanes, (long long)(budget / (arenaBytes + regionBytes)));
       else if (regionsTotal > 0) lanes = std::min(lanes, (long long)((idx->dArenas.n - regionsTotal) / arenaBytes));  // (sized below, before the pool was filled)
       else lanes = std::min(lanes, (long long)(budget / arenaBytes));
@@ -1711,7 +1745,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         if (extra < 0) extra = 0;
         nRegions = lanes + extra;
         regionsTotal = (size_t)nRegions * regionBytes;
-        const size_t gappedArena = arenaUnit * (size_t)gappedScale, gappedLane = regionBytes + gappedTmpBytes(gappedArena) + (schedOn ? (size_t)(schedLay.searchBytes + schedLay.memoBytes) : 0);
+        const size_t gappedArena = arenaUnit * (size_t)gappedScale, gappedLane = schedOn ? regionBytes + schedTmpBytes(gappedArena) + (size_t)(schedLay.searchBytes + schedLay.memoBytes) : regionBytes + gappedTmpBytes(gappedArena);
         long long gappedLanes = std::min((long long)nq, (long long)numCUs * 4 * fullWaves * (schedOn ? schedLpw : fullLpw));
         gappedLanes = std::min(gappedLanes, std::max(1ll, ((long long)budget - (long long)regionsTotal) / (long long)gappedLane));
         size_t behind = std::max((size_t)lanes * arenaBytes, (size_t)gappedLanes * gappedLane);
@@ -1746,9 +1780,36 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       const unsigned long long firstItem = (unsigned long long)std::min((long long)nTodo, (schedPass ? (long long)grid * (block / 64) : firstStride) * lpw);  // (the scheduler kernel deals every lane's first read)
       HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 2, &firstItem, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
-      HIP_CHECK(hipEventRecord(e0, s));
-      if (schedPass) {
-        SchedLaunch sl{grid, block, view, params, bv, todo, nTodo, scale, lpw, (int)schedQuantum, (int)schedGate, laneArenas, (unsigned long long)arenaBytes, schedLay, ov, idx->dCursors.p + 2, idx->dCounters.p, idx->dWaveNodes.p, ho, pool};
+      if (!(schedPass && schedSplit && gappedFront > 0 && gappedFront < nTodo)) HIP_CHECK(hipEventRecord(e0, s));
+      if (schedPass && schedSplit && gappedFront > 0 && gappedFront < nTodo) {
+        // XM_SCHED=2 (experiment): the reads at the front of the list - the ones with an indel, whose time is mostly searches - through the scheduler
+        // kernel, the others - mismatches only: their time is the chain, which the lane-per-read kernel runs with its lanes in step - through that one
+        const long long nFrontReads = gappedFront;
+        const unsigned long long firstA = (unsigned long long)std::min(nFrontReads, (long long)grid * (block / 64) * lpw), zero = 0;
+        HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 2, &firstA, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 3, &zero, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipEventRecord(e0, s));
+        SchedLaunch sl{grid, block, view, params, bv, todo, nFrontReads, scale, lpw, (int)schedQuantum, (int)schedGate, laneArenas, (unsigned long long)arenaBytes, schedLay, ov, idx->dCursors.p + 2, idx->dCounters.p, idx->dWaveNodes.p, ho, pool, bigSets};
+        const int rc = xmSchedLaunch(sl, (void*)s);
+        if (rc != 0) throw std::runtime_error(std::string("scheduler kernel launch: ") + hipGetErrorString((hipError_t)rc));
+        hipEvent_t em;
+        HIP_CHECK(hipEventCreate(&em));
+        HIP_CHECK(hipEventRecord(em, s));
+        const int lpwB = (int)fullLpw;
+        hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, view, params, bv, todo + nFrontReads, nTodo - nFrontReads, scale, 2, lpwB,
+                           laneArenas, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 3, idx->dCounters.p, (uint8_t*)nullptr, idx->dSlotOf.p, 0, 0,
+                           (long long)((double)nWaves * taperWaves / 100.0), 0, 0ll, idx->dWaveNodes.p, ho, (lpwB <= 32 && pairMode) ? 1 : 0, pool);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(e1, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        float msA = 0, msB = 0;
+        HIP_CHECK(hipEventElapsedTime(&msA, e0, em)); HIP_CHECK(hipEventElapsedTime(&msB, em, e1));
+        HIP_CHECK(hipEventDestroy(em));
+        if (envInt("XM_TRACE_PASSES", 0) != 0) fprintf(stderr, "[xm] split gapped pass: scheduler kernel over %lld reads %.3f ms, lane-per-read kernel over %lld reads %.3f ms\n", nFrontReads, msA, nTodo - nFrontReads, msB);
+      }
+      else if (schedPass) {
+        if (bigSets.nPerGroup > 0) HIP_CHECK(hipMemsetAsync(bigSets.owner, 0, sizeof(int32_t) * (size_t)bigSets.nPerGroup * 8, s));
+        SchedLaunch sl{grid, block, view, params, bv, todo, nTodo, scale, lpw, (int)schedQuantum, (int)schedGate, laneArenas, (unsigned long long)arenaBytes, schedLay, ov, idx->dCursors.p + 2, idx->dCounters.p, idx->dWaveNodes.p, ho, pool, bigSets};
         const int rc = xmSchedLaunch(sl, (void*)s);
         if (rc != 0) throw std::runtime_error(std::string("scheduler kernel launch: ") + hipGetErrorString((hipError_t)rc));
       }
@@ -1858,6 +1919,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
                            (long long)ctl.nHeavyLate, idx->dSlotOf.p);
         HIP_CHECK(hipGetLastError());
         todo = idx->dListHeavy.p; nTodo = (long long)pendingHeavy;
+        gappedFront = (long long)ctl.nHeavy;
         HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nHeavy, 0, 2 * sizeof(unsigned long long), s));  // nHeavy, nHeavyLate (a gapped pass never adds to these lists)
         scale = gappedScale;
         if (overflowScale < gappedScale) overflowScale = gappedScale;

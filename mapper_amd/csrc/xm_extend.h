@@ -1328,6 +1328,10 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
   if (e.memo && memoPeek(e.memo, *e.memoCursor) == MEMO_PATH) {
     int32_t st = 0;
     found = memoTake(e.memo, *e.memoCursor, out, &st);
+#if defined(XM_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    // (profile builds, in-lane form: t[12] = wave time from the start of a replaying chain phase to the point where the replay has caught up)
+    if (memoInLane(e.memo) && e.memo->pad2 != 0 && *e.memoCursor >= e.memo->logBytes) { XM_TIC(now_); unsigned long long t0_ = (unsigned long long)e.memo->pad2; XM_TOC(e.dc, 12, t0_); (void)now_; e.memo->pad2 = 0; }
+#endif
     nb = out.nb;
     if (st) { *e.status = st; return false; }
   } else if (e.memo && e.caps->deferPath) {

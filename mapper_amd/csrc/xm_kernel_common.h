@@ -25,6 +25,10 @@ struct HandOver {
 
 // A lane's scratch in the scheduler kernel: [region for a read that comes without saved state | chain temporaries | search arrays | memo]
 struct SchedLayout { unsigned long long tmpBytes, searchBytes, memoBytes; };
+// Large search sets of a launch (batches of long reads): buffers of bufBytes each, in eight groups of nPerGroup - a buffer is only ever used by
+// workgroups of ONE XCD (group = HW_REG_XCC_ID of the workgroup), because memory written through one XCD's L2 and reused through another's inside a
+// launch is not coherent (its write-backs can land on the new user's data).  owner[i]: 0 free, 1 taken.  n = 0: no pool.
+struct BigSetPool { uint8_t* base; unsigned long long bufBytes; int32_t* owner; int32_t nPerGroup, pad; };
 struct SchedLaunch {
   int grid, block;
   IndexView ix; Params params; BatchView batch;
@@ -37,6 +41,7 @@ struct SchedLaunch {
   PNode* waveNodes;
   HandOver ho;
   SearchPool searchPool;
+  BigSetPool bigSets;
 };
 int xmSchedLaunch(const SchedLaunch& a, void* stream);  // xm_sched_kernel.hip; returns hipError_t as int
 int xmSchedProfile(unsigned long long* out16, int reset);  // XM_PROFILE builds: the scheduler kernel's phase timers

@@ -17,15 +17,20 @@
 
 namespace xm {
 
-// A lane's own search arrays (xm_wsearch.h) hold the searches of 150 bp reads and pairs (under one in a hundred outgrows 1008 nodes, fewer 2048); what
-// outgrows them runs in the wave's big buffer (SearchPool), one search at a time, in the lane-per-read form.
-XM_INL size_t schedSearchArenaBytes(const Caps& chain) { return wsArenaBytes(chain.maxBlocks); }
+// A lane's own search arrays (xm_wsearch.h): the small set holds the searches of 150 bp reads and pairs (under one in a hundred outgrows 1008 nodes, fewer
+// 2048) and of the pieces BlockAligner cuts; what outgrows it starts over in a large set - a buffer of the launch's pool (batches of long reads: the chain's
+// capacities; the lanes do not own one each: a lane's scratch is what limits the reads in flight there) - or runs in the wave's big buffer (SearchPool),
+// one search at a time, in the lane-per-read form.
+XM_INL size_t schedSearchArenaBytes(const Caps& chain) { return wsSmallSizes(chain.maxBlocks).bytes; }
 
 // chain phase, a read that was parked at a search: back into alignRead at the candidate it stopped in (cx.ar.phase 1, 3 or 4)
 XM_INL void schedReplay(ReadCtx& cx, ReadResult& rr) {
   cx.status = XM_OK;
   cx.memoCursor = 0;
   cx.tmp.used = 0; cx.tmp.overflow = false;
+#if defined(XM_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+  if (cx.memo) cx.memo->pad2 = (int64_t)clock64();
+#endif
   alignRead(cx, rr, true);
 }
 // after a chain phase: is the read parked at a search?  (Its candidate is counted by the run that finishes it.)
@@ -59,16 +64,24 @@ XM_INL void schedLogResult(MemoHdr* m, bool found, ABlock* blocks, int nb, int32
 XM_INL void schedSearchBegin(MemoHdr* m, void* searchArena, const Caps& caps) {
   PaProblem pr;
   schedRequest(m, pr);
-  wsBegin((uint8_t*)searchArena, pr, caps.maxBlocks);
+  wsBegin((uint8_t*)searchArena, pr, wsSmallSizes(caps.maxBlocks));
 }
-XM_INL bool schedSearchRun(MemoHdr* m, void* searchArena, int maxSteps, DevCounters* dc, bool* big) {
-  *big = false;
-  if (!wsRun((uint8_t*)searchArena, maxSteps)) return false;
+// -> 0: suspended (more steps to go); 1: over, outcome logged; 2: it outgrew the small set (nothing logged, nothing counted): the caller gives it a large
+// set (schedSearchRestartBig) or runs it in the lane-per-read form (schedSearchBig); 3: it outgrew the large set too (the read runs again with more scratch)
+XM_INL int schedSearchRun(MemoHdr* m, void* searchArena, int maxSteps, DevCounters* dc) {
+  if (!wsRun((uint8_t*)searchArena, maxSteps)) return 0;
   const WSearch* const S = (const WSearch*)searchArena;
-  if (S->status == XM_ST_OVERFLOW) { *big = true; return true; }
+  if (S->status == XM_ST_OVERFLOW) return S->z.maxNodes <= WS_SMALL_NODES ? 2 : 3;
   if (dc) { dc->pathAlignerCalls++; dc->pathAlignerNodes += S->nodesPut; }
-  schedLogResult(m, S->found != 0, (ABlock*)((uint8_t*)searchArena + WS_OFF_BLOCKS), S->nb, S->status);
-  return true;
+  schedLogResult(m, S->found != 0, (ABlock*)((uint8_t*)searchArena + S->z.offBlocks), S->nb, S->status);
+  return 1;
+}
+// the search that outgrew the small set, once more from the start in a large set (batches of long reads: a buffer of the launch's pool, sized for the chain's capacities)
+XM_INL size_t schedBigSetBytes(const Caps& caps) { return wsSizes(caps.maxNodes, caps.maxBuckets, caps.maxBlocks).bytes; }
+XM_INL void schedSearchRestartBig(MemoHdr* m, void* bigArena, const Caps& caps) {
+  PaProblem pr;
+  schedRequest(m, pr);
+  wsBegin((uint8_t*)bigArena, pr, wsSizes(caps.maxNodes, caps.maxBuckets, caps.maxBlocks));
 }
 // ... with the chain's full capacities in `big` (the wave's buffer, or a host buffer in the simulation); an overflow there is the read's
 XM_INL void schedSearchBig(MemoHdr* m, Arena& big, const Caps& caps, DevCounters* dc) {

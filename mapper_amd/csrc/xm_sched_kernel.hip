@@ -26,13 +26,29 @@ __device__ unsigned long long xm_sched_prof[16];
 #define SP_ADD(slot, v) do { } while (0)
 #endif
 
+// a large search set of the workgroup's XCD, or -1 (none free right now: the search stays parked and asks again in the next round)
+__device__ __forceinline__ int bigSetAcquire(const BigSetPool& p, uint32_t seed) {
+  if (p.nPerGroup <= 0) return -1;
+  const int group = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;  // HW_REG_XCC_ID, bits 3:0
+  const int base = group * p.nPerGroup;
+  for (int i = 0; i < 16; i++) {
+    const int j = base + (int)((seed + (uint32_t)i * 2654435761u) % (uint32_t)p.nPerGroup);
+    if (atomicCAS(&p.owner[j], 0, 1) == 0) return j;
+  }
+  return -1;
+}
+__device__ __forceinline__ void bigSetRelease(const BigSetPool& p, int idx) {
+  __threadfence();
+  atomicExch(&p.owner[idx], 0);
+}
+
 // The gapped pass as a wave-level scheduler (xm_sched.h): every lane holds one read; the lanes of a wave advance their chains together (chain
 // phase) until each read is finished or parked at a PathAligner search, then the parked lanes run their searches together (search phase), and so
 // on; a lane whose read is finished takes the next one of the list.  A lane's scratch: [region for a read that comes without saved state |
 // chain temporaries | search arrays | memo].
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_sched_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int lanesPerWave, int quantum, int gate,
                                                        uint8_t* arenas, unsigned long long arenaBytes, SchedLayout lay, OutView out, unsigned long long* nextItem, DevCounters* counters,
-                                                       PNode* waveNodes, HandOver ho, SearchPool searchPool) {
+                                                       PNode* waveNodes, HandOver ho, SearchPool searchPool, BigSetPool bigSets) {
   xmSetWaveNodes(waveNodes);
   xmSetPairMode(0);
   xmSetSearchPool(searchPool);
@@ -49,6 +65,9 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_sched_kernel(IndexV
   DevCounters before = local;
   ReadCtx cx;
   ReadResult rr;
+  uint8_t* curSearch = searchArena;  // the arrays of the lane's search: its own small set, or a large set of the launch's pool
+  int bigIdx = -1;                   // the pool buffer the lane holds (-1: none), wantBig: its search outgrew the small set and waits for one
+  bool wantBig = false;
   int state = 0;  // 0: no read, 1: chain work, 2: parked at a search
   bool fresh = false, drained = false, dealt = true;
   const long long nWaves = (long long)gridDim.x * (blockDim.x >> 6), waveIndex = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -104,6 +123,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_sched_kernel(IndexV
 #endif
       if (schedParked(cx)) {
         state = 2;
+        curSearch = searchArena; wantBig = false;
         schedSearchBegin(memo, searchArena, cx.caps);
       } else {
         if (cx.status != XM_OK) local = before;  // work of a read that is rerun by a later pass is counted there
@@ -120,13 +140,20 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_sched_kernel(IndexV
 #endif
       // (every search of the wave gets `quantum` explored entries per round: a search of thousands of entries does not keep the lanes whose
       // searches took a hundred from their chains)
-      bool big = false;
-      const bool over = schedSearchRun(memo, searchArena, quantum, &local, &big);
-      const bool done = !big;
+      if (wantBig) {
+        bigIdx = bigSetAcquire(bigSets, (uint32_t)lane * 40503u + (uint32_t)q);
+        if (bigIdx >= 0) { wantBig = false; curSearch = bigSets.base + (unsigned long long)bigIdx * bigSets.bufBytes; schedSearchRestartBig(memo, curSearch, cx.caps); }
+      }
+      int how = wantBig ? 0 : schedSearchRun(memo, curSearch, quantum, &local);
+      if (how == 2 && bigSets.nPerGroup > 0) { wantBig = true; how = 0; }  // (a large set: asked for at the start of the next round)
+      if (how == 3) { schedLogResult(memo, false, nullptr, 0, XM_ST_OVERFLOW); how = 1; }
+      if (how != 0 && bigIdx >= 0) { bigSetRelease(bigSets, bigIdx); bigIdx = -1; curSearch = searchArena; }
+      const bool over = how != 0;
+      const bool done = how != 2;
 #if defined(XM_PROFILE)
       { const unsigned long long dt = clock64() - tSearch; SP_ADD(3, dt); SP_ADD(7, dt * (unsigned long long)nSearch); }
       {  // entries explored in this round: the most by one lane (= the round's length) and by all lanes together
-        const int mySteps = ((const WSearch*)searchArena)->lastSteps;
+        const int mySteps = ((const WSearch*)curSearch)->lastSteps;
         unsigned long long m = __ballot(1);
         int mx = 0; long long sum = 0;
         while (m) { const int l = __ffsll((long long)m) - 1; const int v = __shfl(mySteps, l); mx = v > mx ? v : mx; sum += v; m &= m - 1; }
@@ -140,7 +167,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_sched_kernel(IndexV
         if (!done && laneInWave == leader) {
           Arena wb;
           if (xmWaveSearchBuffer(wb)) schedSearchBig(memo, wb, cx.caps, &local);
-          else schedLogResult(memo, false, nullptr, 0, XM_ST_OVERFLOW);
+          else schedLogResult(memo, false, nullptr, 0, XM_ST_OVERFLOW);  // (no buffer: the read runs again in a pass with more scratch)
         }
         waiting &= waiting - 1;
       }
@@ -177,7 +204,7 @@ int xmSchedProfile(unsigned long long* out16, int reset) {
 
 int xmSchedLaunch(const SchedLaunch& a, void* stream) {
   hipLaunchKernelGGL(xm_sched_kernel, dim3(a.grid), dim3(a.block), 0, (hipStream_t)stream, a.ix, a.params, a.batch, a.todo, a.nTodo, a.scale, a.lanesPerWave, a.quantum, a.gate, a.arenas, a.arenaBytes, a.lay, a.out,
-                     a.nextItem, a.counters, a.waveNodes, a.ho, a.searchPool);
+                     a.nextItem, a.counters, a.waveNodes, a.ho, a.searchPool, a.bigSets);
   return (int)hipGetLastError();
 }
 

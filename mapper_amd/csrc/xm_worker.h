@@ -876,6 +876,12 @@ XM_INL size_t chainExtraTmpBytes(int chainScale) {
   return ((size_t)(XM_LONG_CHAIN_NODES - 1) * ((size_t)g.maxNodes * (sizeof(PNode) + 8) + (size_t)g.nodeHash * 4)  // nodes + list entries, cell hash
           + 3 * ((size_t)g.maxSections + (size_t)g.matcherEntries) + 4095) & ~(size_t)4095;                       // three matchers: sections, the other half of the tables
 }
+// the matcher part of chainExtraTmpBytes (what a lane of the scheduler kernel adds: its searches have their own arrays)
+XM_INL size_t chainExtraMatcherBytes(int chainScale) {
+  if (chainScale < 16) return 0;
+  const Caps g = makeCaps(chainScale);
+  return (3 * ((size_t)g.maxSections + (size_t)g.matcherEntries) + 4095) & ~(size_t)4095;
+}
 XM_INL void applyChainCaps(Caps& c, int chainScale) {
   const Caps g = makeCaps(chainScale);
   c.maxNodes = g.maxNodes; c.nodeHash = g.nodeHash; c.gridCap = g.gridCap; c.maxBuckets = g.maxBuckets; c.bucketHash = g.bucketHash;

@@ -52,22 +52,51 @@ struct alignas(8) WList { uint32_t xy; int32_t next; };
 struct alignas(16) WBkt { double key; int32_t tail, pad; };
 struct alignas(16) WLive { double key; int32_t slot, head; };  // a live bucket: its key, its slot in the key table, its first list entry
 
-constexpr int WS_MAX_NODES = 2048, WS_MAX_CELLS = 1536, WS_MAX_BUCKETS = 256;
-constexpr int WS_CELL_SLOTS = 2048, WS_CELL_SHIFT = 21, WS_BKT_SLOTS = 512;
-constexpr size_t WS_OFF_CELLBITS = 512;  // (the WSearch header lives in front)
-constexpr size_t WS_OFF_BKTBITS = WS_OFF_CELLBITS + WS_CELL_SLOTS / 8;
-constexpr size_t WS_OFF_CELLS = 1024;
-constexpr size_t WS_OFF_LIST = WS_OFF_CELLS + (size_t)WS_CELL_SLOTS * sizeof(WCell);
-constexpr size_t WS_OFF_BKT = WS_OFF_LIST + (size_t)WS_MAX_NODES * sizeof(WList);
-constexpr size_t WS_OFF_LIVE = WS_OFF_BKT + (size_t)WS_BKT_SLOTS * sizeof(WBkt);
-constexpr size_t WS_OFF_BLOCKS = WS_OFF_LIVE + (size_t)(WS_MAX_BUCKETS + 8) * sizeof(WLive);  // result blocks (caps.maxBlocks of them)
-static_assert(WS_OFF_BKTBITS + WS_BKT_SLOTS / 8 <= WS_OFF_CELLS, "the bit maps must fit in front of the cells");
-XM_INL size_t wsArenaBytes(int maxBlocks) { return (WS_OFF_BLOCKS + (size_t)maxBlocks * sizeof(ABlock) + 255) & ~(size_t)255; }
+// Capacities of a search's tables, chosen when it begins: the small set holds the searches of 150 bp reads and of the pieces BlockAligner cuts
+// (2048 nodes on 1536 cells, 256 keys: 90 KB, of which a search of 300 entries touches a tenth); batches of long reads give their lanes a second,
+// large set (the chain's capacities: tens of thousands of nodes) that a search starts over in when it outgrows the small one.
+struct WSizes {
+  int32_t maxNodes, maxCells, maxBuckets;
+  int32_t cellSlots, cellShift, bktSlots;       // powers of two; slot of a cell = hash >> cellShift
+  uint32_t offCellBits, offBktBits, offCells, offList, offBkt, offLive, offBlocks, bytes;
+};
+constexpr uint32_t WS_OFF_TABLES = 512;  // (the WSearch header lives in front)
+XM_INL int wsLog2Ceil(long long v) { int k = 0; while ((1ll << k) < v) k++; return k; }
+XM_INL WSizes wsSizes(int maxNodes, int maxBuckets, int maxBlocks) {
+  WSizes z;
+  z.maxNodes = maxNodes;
+  z.maxCells = maxNodes - maxNodes / 4;
+  z.maxBuckets = maxBuckets;
+  const int cl = wsLog2Ceil((long long)z.maxCells + z.maxCells / 3);  // load <= 3/4
+  z.cellSlots = 1 << cl; z.cellShift = 32 - cl;
+  z.bktSlots = 1 << wsLog2Ceil(2ll * maxBuckets);
+  uint32_t o = WS_OFF_TABLES;
+  z.offCellBits = o; o += (uint32_t)z.cellSlots / 8;
+  z.offBktBits = o; o += (uint32_t)z.bktSlots / 8;
+  o = (o + 63u) & ~63u;
+  z.offCells = o; o += (uint32_t)z.cellSlots * 32u;
+  z.offList = o; o += (uint32_t)z.maxNodes * 8u;
+  z.offBkt = o; o += (uint32_t)z.bktSlots * 16u;
+  z.offLive = o; o += (uint32_t)(z.maxBuckets + 8) * 16u;
+  z.offBlocks = o; o += (uint32_t)maxBlocks * (uint32_t)sizeof(ABlock);
+  z.bytes = (o + 255u) & ~255u;
+  return z;
+}
+constexpr int WS_SMALL_NODES = 2048, WS_SMALL_BUCKETS = 256;
+XM_INL WSizes wsSmallSizes(int maxBlocks) { return wsSizes(WS_SMALL_NODES, WS_SMALL_BUCKETS, maxBlocks); }
+// bytes of a lane's search arena: the small set, or - bigNodes > 0 - the large one (the small set's tables lie inside it)
+XM_INL size_t wsArenaBytes(int maxBlocks, int bigNodes = 0, int bigBuckets = 0) {
+  const WSizes sm = wsSmallSizes(maxBlocks);
+  if (bigNodes <= WS_SMALL_NODES) return sm.bytes;
+  const WSizes bg = wsSizes(bigNodes, bigBuckets, maxBlocks);
+  return bg.bytes > sm.bytes ? bg.bytes : sm.bytes;
+}
 
 // The search's state between two runs of wsRun.  (While it runs, the scalars are in registers.)
 struct WSearch {
   // the problem
   PaProblem pr;
+  WSizes z;
   int32_t maxBlocks;
   int32_t startIndexA, startIndexB, textALength, textBLength, diagonal, stepDelta, startX, startY, goalX, goalY, gridW, gridH;
   int32_t searchReverse, mayExtend;
@@ -81,22 +110,23 @@ struct WSearch {
   int32_t done, found, status, nb;
   int32_t lastSteps, pad;  // entries explored by the last wsRun (diagnostics)
 };
-static_assert(sizeof(WSearch) <= WS_OFF_CELLBITS, "the header must fit in front of the tables");
+static_assert(sizeof(WSearch) <= WS_OFF_TABLES, "the header must fit in front of the tables");
 
-XM_INL uint32_t wsCellHash(uint32_t key) { return (key * 2654435761u) >> WS_CELL_SHIFT; }
+XM_INL uint32_t wsCellHash(uint32_t key) { return key * 2654435761u; }  // (the top bits are the slot)
 XM_INL uint32_t wsKeyHash(double key) {
   uint64_t kb;
   __builtin_memcpy(&kb, &key, 8);
-  return (uint32_t)((kb ^ (kb >> 29)) * 0x9E3779B97F4A7C15ull >> 32) & (uint32_t)(WS_BKT_SLOTS - 1);
+  return (uint32_t)((kb ^ (kb >> 29)) * 0x9E3779B97F4A7C15ull >> 32);
 }
 
 // The running search: WSearch's scalars + the table pointers in locals (every method force-inlined into wsRun).
 struct WRun {
   uint8_t* arena;
-  WCell* cells; uint32_t* cellBits;
+  WCell* cells; uint32_t* cellBits; uint32_t cellShift, cellMask;
   WList* list;
-  WBkt* bkt; uint32_t* bktBits;
+  WBkt* bkt; uint32_t* bktBits; uint32_t bktMask;
   WLive* live;
+  int32_t maxNodes, maxCells, maxBuckets;
   const uint8_t* qBase; int32_t qLen; bool qRc; const uint8_t* rBase;
   Params P;
   bool confident; double maxInsExt, maxDelExt;
@@ -112,12 +142,13 @@ struct WRun {
 
   static constexpr double disallowed = 1000000.0;
 
-  XM_INL void bind(uint8_t* a) {
+  XM_INL void bind(uint8_t* a, const WSizes& z) {
     arena = a;
-    cells = (WCell*)(a + WS_OFF_CELLS); cellBits = (uint32_t*)(a + WS_OFF_CELLBITS);
-    list = (WList*)(a + WS_OFF_LIST);
-    bkt = (WBkt*)(a + WS_OFF_BKT); bktBits = (uint32_t*)(a + WS_OFF_BKTBITS);
-    live = (WLive*)(a + WS_OFF_LIVE);
+    cells = (WCell*)(a + z.offCells); cellBits = (uint32_t*)(a + z.offCellBits); cellShift = (uint32_t)z.cellShift; cellMask = (uint32_t)z.cellSlots - 1u;
+    list = (WList*)(a + z.offList);
+    bkt = (WBkt*)(a + z.offBkt); bktBits = (uint32_t*)(a + z.offBktBits); bktMask = (uint32_t)z.bktSlots - 1u;
+    live = (WLive*)(a + z.offLive);
+    maxNodes = z.maxNodes; maxCells = z.maxCells; maxBuckets = z.maxBuckets;
   }
   XM_INL uint8_t charA(int i) const {
     XM_GLOBAL(const uint8_t)* const g = (XM_GLOBAL(const uint8_t)*)qBase;
@@ -130,7 +161,7 @@ struct WRun {
   // A lookup in two halves: the first probe's loads (bit-map word and cell: issued for all the cells an update looks at before any is waited
   // for), then the walk to the cell's slot, or to the empty slot that ends its run (-1 - slot), which only goes on when the first probe collided.
   XM_INL void probeIssue(int x, int y, uint32_t& h, uint32_t& bw, WCell& c) const {
-    h = wsCellHash(((uint32_t)x << 16) | (uint32_t)y);
+    h = wsCellHash(((uint32_t)x << 16) | (uint32_t)y) >> cellShift;
     bw = cellBits[h >> 5];
     c = cells[h];
   }
@@ -138,7 +169,7 @@ struct WRun {
     while (true) {
       if (!((bw >> (h & 31u)) & 1u)) return -1 - (int)h;
       if (c.x == (uint16_t)x && c.y == (uint16_t)y) return (int)h;
-      h = (h + 1) & (uint32_t)(WS_CELL_SLOTS - 1);
+      h = (h + 1) & cellMask;
       bw = cellBits[h >> 5];
       c = cells[h];
     }
@@ -179,7 +210,7 @@ struct WRun {
   XM_INL void putNode(int x, int y, double pen, double insX, double insY, uint8_t fl, int cellSlot) {
     double est = estimateOverallPenalty(x, y, pen, insX, insY, fl);
     if (est < activePenalty) est = activePenalty;
-    if (nNodes >= WS_MAX_NODES || (x | y) < 0 || x > 65535 || y > 65535) { overflow = true; return; }
+    if (nNodes >= maxNodes || (x | y) < 0 || x > 65535 || y > 65535) { overflow = true; return; }
     const int idx = nNodes;
     int slot, tail;
     if (actSlot >= 0 && est == activePenalty) {
@@ -188,21 +219,21 @@ struct WRun {
       tail = actTail;
     } else if (lastSlot >= 0 && est == lastKey) { slot = lastSlot; tail = lastTail; }
     else {
-      uint32_t h = wsKeyHash(est);
+      uint32_t h = wsKeyHash(est) & bktMask;
       uint32_t bw = bktBits[h >> 5];
       WBkt b = bkt[h];
       bool have = false;
       while (true) {
         if (!((bw >> (h & 31u)) & 1u)) break;
         if (b.key == est) { have = true; break; }
-        h = (h + 1) & (uint32_t)(WS_BKT_SLOTS - 1);
+        h = (h + 1) & bktMask;
         bw = bktBits[h >> 5];
         b = bkt[h];
       }
       slot = (int)h;
       tail = have ? b.tail : -1;
       if (!have) {  // prioritizedNodes.put(key, new list) + priorities.add(key)
-        if (nBuckets >= WS_MAX_BUCKETS) { overflow = true; return; }
+        if (nBuckets >= maxBuckets) { overflow = true; return; }
         nBuckets++;
         bktBits[h >> 5] = bw | (1u << (h & 31u));
         WLive L; L.key = est; L.slot = slot; L.head = idx;
@@ -222,7 +253,7 @@ struct WRun {
       WCell c;
       if (cellSlot == INT32_MIN) cellSlot = findCell(x, y, c);
       if (cellSlot < 0) {
-        if (nCells >= WS_MAX_CELLS) { overflow = true; return; }
+        if (nCells >= maxCells) { overflow = true; return; }
         nCells++;
         cellSlot = -1 - cellSlot;
         cellBits[cellSlot >> 5] |= 1u << (cellSlot & 31);
@@ -310,11 +341,13 @@ struct WRun {
 };
 
 // PathAligner.align's set-up (:55-140): the problem into the arena's header, the bit maps cleared, the start nodes put
-XM_NOINL void wsBegin(uint8_t* arena, const PaProblem& prIn, int maxBlocks) {
+XM_NOINL void wsBegin(uint8_t* arena, const PaProblem& prIn, const WSizes& zIn) {
   WSearch* const S = (WSearch*)arena;
   const PaProblem pr = prIn;
+  const WSizes z = zIn;
   S->pr = pr;
-  S->maxBlocks = maxBlocks;
+  S->z = z;
+  S->maxBlocks = (int32_t)((z.bytes - z.offBlocks) / sizeof(ABlock));
   S->done = 0; S->found = 0; S->status = XM_OK; S->nb = 0;
   S->nodesPut = 0; S->lastSteps = 0;
   const Section qs = pr.qs, rs = pr.rs;
@@ -325,7 +358,7 @@ XM_NOINL void wsBegin(uint8_t* arena, const PaProblem& prIn, int maxBlocks) {
   S->maxInterestingPenalty = secLen(qs) * params.MaxErrorRate;
   if (S->textALength < 0 || S->textBLength < 0 || S->textALength + 2 > 32000 || S->textBLength + 2 > 32000) { S->status = XM_ST_OVERFLOW; S->done = 1; return; }
   WRun w;
-  w.bind(arena);
+  w.bind(arena, z);
   w.qBase = pr.qBase; w.qLen = pr.qLen; w.qRc = pr.qRc; w.rBase = pr.rBase;
   w.P = params;
   w.confident = pr.confident; w.maxInsExt = pr.maxInsExt; w.maxDelExt = pr.maxDelExt;
@@ -367,11 +400,12 @@ XM_NOINL void wsBegin(uint8_t* arena, const PaProblem& prIn, int maxBlocks) {
   w.nNodes = 0; w.nCells = 0; w.nBuckets = 0; w.nLive = 0; w.curPos = -1;
   w.activePenalty = 0; w.nodesPut = 0; w.overflow = false;
   w.actSlot = -1; w.actTail = -1; w.lastSlot = -1; w.lastTail = -1; w.lastKey = 0; w.firstAppendToActive = -1;
-  {  // the two bit maps: 320 bytes
+  {  // the two bit maps (320 bytes for the small set)
     struct alignas(16) Z { uint32_t w[4]; };
-    Z z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
-    Z* const bits = (Z*)(arena + WS_OFF_CELLBITS);
-    for (int i = 0; i < (int)((WS_CELL_SLOTS + WS_BKT_SLOTS) / 8 / 16); i++) bits[i] = z;
+    Z zero; zero.w[0] = zero.w[1] = zero.w[2] = zero.w[3] = 0;
+    Z* const bits = (Z*)(arena + z.offCellBits);
+    const int n = (z.cellSlots + z.bktSlots) / 8 / 16;
+    for (int i = 0; i < n; i++) bits[i] = zero;
   }
   const double disallowed = WRun::disallowed;
   if (w.textBLength >= w.textALength) {
@@ -402,7 +436,8 @@ XM_NOINL bool wsRun(uint8_t* arena, int maxSteps) {
   WS_ACC_DECL;
   WS_TIC(tR);
   WRun w;
-  w.bind(arena);
+  const WSizes z = S->z;
+  w.bind(arena, z);
   {
     const PaProblem pr = S->pr;
     w.qBase = pr.qBase; w.qLen = pr.qLen; w.qRc = pr.qRc; w.rBase = pr.rBase;
@@ -487,7 +522,7 @@ XM_NOINL bool wsRun(uint8_t* arena, int maxSteps) {
   if (fail) { S->found = 0; return true; }
   // traceback :195-264
   const Params params = w.P;
-  ABlock* const outBlocks = (ABlock*)(arena + WS_OFF_BLOCKS);
+  ABlock* const outBlocks = (ABlock*)(arena + z.offBlocks);
   const int maxBlocks = S->maxBlocks;
   int i = lastX, j = lastY;
   int nb = 0;

@@ -22,7 +22,7 @@ static int g_waveMode = -1;  // -1: from XMSIM_WAVE (default 0)
 static long long g_waveStatus[16];
 static long long g_waveWhy[64];
 static long long g_markHist[6][128];  // high-water marks of the wave form per read: chunks, counters, history, pending, query matches, alignments
-static long long g_schedSearches = 0, g_schedBig = 0;  // searches the scheduler path ran; of them in the big buffer
+static long long g_schedSearches = 0, g_schedBig = 0, g_schedBigSet = 0;  // searches the scheduler path ran; of them in the lane-per-read form in the big buffer, in a large set
 static void markDump() { const char* names[6] = {"chunks", "counters", "history", "pending", "qmatches", "alignments"}; for (int k = 0; k < 6; k++) { fprintf(stderr, "[wave marks] %s:", names[k]); for (int i = 0; i < 128; i++) if (g_markHist[k][i]) fprintf(stderr, " %d:%lld", i, g_markHist[k][i]); fprintf(stderr, "\n"); } }
 
 struct SimIndex {
@@ -211,7 +211,9 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       // context object, small temporaries, light capacities - takes it on; a read that stops in front of the chain there goes round again
       const bool handBack = handOver && getenv("XMSIM_HANDBACK") && atoi(getenv("XMSIM_HANDBACK")) != 0;  // (off by default, as in the product)
       // XMSIM_SCHED=1: the gapped pass of batches of short reads as the wave scheduler runs it (the product's XM_SCHED=1)
-      const bool sched = handOver && seedScale == 1 && getenv("XMSIM_SCHED") && atoi(getenv("XMSIM_SCHED")) != 0;
+      // XMSIM_SCHED_LONG=1: the same for batches of long reads (the product's XM_SCHED_LONG=1): their lanes have a second, large set of search arrays
+      const bool sched = handOver && (seedScale == 1 ? (getenv("XMSIM_SCHED") && atoi(getenv("XMSIM_SCHED")) != 0) : (getenv("XMSIM_SCHED_LONG") && atoi(getenv("XMSIM_SCHED_LONG")) != 0));
+      const bool schedBigSet = seedScale > 1;
       bool takenBack = false;
       static ReadCtx cx3;
       std::vector<uint8_t> arena3;
@@ -240,7 +242,10 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
           arena2.assign(bytes + chainExtraTmpBytes(scale) + 64, 0xAB);
           uint8_t* a2 = (uint8_t*)(((uintptr_t)arena2.data() + 15) & ~(uintptr_t)15);
           const size_t tmpBytes = gappedTmp(bytes, scale);
-          memoInitInLane(memo, XM_MEMO_SLOT_BYTES);
+          const int memoBytes = schedBigSet ? 4 * scale * 1024 : XM_MEMO_SLOT_BYTES;  // (the product's XM_SCHED_MEMO_KB defaults)
+          std::vector<double> schedMemoBuf((size_t)memoBytes / 8 + 2);
+          memo = (MemoHdr*)(((uintptr_t)schedMemoBuf.data() + 15) & ~(uintptr_t)15);
+          memoInitInLane(memo, memoBytes);
           runReadResumed(cx2, saved, &idx->view, scale, a2, tmpBytes, &dc, rr, memo, true, 2, 0);
           int phases = 0;
           while (schedParked(cx2)) {
@@ -250,10 +255,21 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
             void* sarena = (void*)(((uintptr_t)sbuf.data() + 15) & ~(uintptr_t)15);
             memset(sarena, 0xC7, sbytes);
             schedSearchBegin(memo, sarena, cx2.caps);
-            bool big = false;
             static const int quantum = getenv("XMSIM_SCHED_QUANTUM") ? atoi(getenv("XMSIM_SCHED_QUANTUM")) : 64;  // (the kernel's searches run a number of steps at a time)
-            while (!schedSearchRun(memo, sarena, quantum, &dc, &big)) { }
-            if (big) {
+            int how;
+            while ((how = schedSearchRun(memo, sarena, quantum, &dc)) == 0) { }
+            std::vector<double> bigBuf;
+            if (how == 2 && schedBigSet) {  // a large set from the launch's pool
+              const size_t bb = schedBigSetBytes(cx2.caps);
+              bigBuf.assign(bb / 8 + 2, 0.0);
+              void* barena = (void*)(((uintptr_t)bigBuf.data() + 15) & ~(uintptr_t)15);
+              memset(barena, 0xC7, bb);
+              schedSearchRestartBig(memo, barena, cx2.caps);
+              while ((how = schedSearchRun(memo, barena, quantum, &dc)) == 0) { }
+              g_schedBigSet++;
+            }
+            if (how == 3) schedLogResult(memo, false, nullptr, 0, XM_ST_OVERFLOW);
+            if (how == 2) {
               std::vector<double> bbuf(((size_t)288 * 1024 * (size_t)scale) / 8 + 2, 0.0);
               Arena bigArena;
               bigArena.init((void*)(((uintptr_t)bbuf.data() + 15) & ~(uintptr_t)15), (size_t)288 * 1024 * (size_t)scale);
@@ -342,7 +358,7 @@ void xmsim_set_wave_mode(int mode) { g_waveMode = mode; }
 void xmsim_wave_status_counts(long long* out, int reset) { for (int i = 0; i < 16; i++) { out[i] = g_waveStatus[i]; if (reset) g_waveStatus[i] = 0; } }
 void xmsim_wave_why_counts(long long* out) { for (int i = 0; i < 64; i++) out[i] = g_waveWhy[i]; }
 
-void xmsim_sched_counts(long long* out, int reset) { out[0] = g_schedSearches; out[1] = g_schedBig; if (reset) g_schedSearches = g_schedBig = 0; }
+void xmsim_sched_counts(long long* out, int reset) { out[0] = g_schedSearches; out[1] = g_schedBig; out[2] = g_schedBigSet; if (reset) g_schedSearches = g_schedBig = g_schedBigSet = 0; }
 
 void xmsim_result_free(xm_result* r) {
   if (!r) return;

@@ -389,7 +389,7 @@ def test_wave_scheduler_path_in_the_host_simulation(quantum, monkeypatch):
     R = o.OracleReference([("r", ref)])
     S = hs.SimReference([("r", ref)])
     p = o.make_params()
-    counts = (C.c_longlong * 2)()
+    counts = (C.c_longlong * 4)()
     hs.lib().xmsim_sched_counts(counts, 1)
     b = se_batch(synth.synthetic_single_end(ref, 2500, seed=32, indel_prob=0.5)[0])
     sa, sb = R.align(b, p), S.align(b, p)

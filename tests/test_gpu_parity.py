@@ -108,6 +108,7 @@ PASS_SHAPES = [
     {"XM_SCHED": "1", "XM_SCHED_LPW": "64", "XM_SCHED_GATE": "32", "XM_SCHED_QUANTUM": "1000000"},  # ... full waves, searches run to their end
     {"XM_SCHED": "1", "XM_SCHED_LPW": "3", "XM_FULL_WAVES": "1", "XM_SCRATCH_GIB": "2"},  # ... few lanes: every lane takes many reads in turn
     {"XM_SCHED": "1", "XM_SCHED_MEMO_KB": "2"},                                  # ... memos too small for some reads: those run again in the lane-per-read passes
+    {"XM_SCHED": "2"},                                                          # ... the reads that look expensive through the scheduler kernel, the others through the lane-per-read kernel
     {"XM_WAVE": "1"},                                                           # the wave-per-read form first (light tier, chain tiers with inline searches), lane-per-read passes for the rest
     {"XM_WAVE": "1", "XM_WAVE_TIERS": "1"},                                     # its light tier only
     {"XM_WAVE": "1", "XM_WAVE_TIERS": "2"},                                     # light + chain tier (no tier with the largest capacities)
@@ -151,12 +152,16 @@ def test_long_reads_on_gpu():
         db.close()
 
 
-@pytest.mark.parametrize("env", [{"XM_FULL_WAVES": "1"}, {"XM_FULL_WAVES": "1", "XM_FULL_LPW": "32"}, {"XM_FULL_WAVES": "1", "XM_FULL_LPW": "16", "XM_PAIR_LANES": "0"}],
+@pytest.mark.parametrize("env", [{"XM_FULL_WAVES": "1"}, {"XM_FULL_WAVES": "1", "XM_FULL_LPW": "32"}, {"XM_FULL_WAVES": "1", "XM_FULL_LPW": "16", "XM_PAIR_LANES": "0"},
+                                 {"XM_SCHED_LONG": "1"}, {"XM_SCHED_LONG": "1", "XM_SCHED_LPW": "32", "XM_SCHED_QUANTUM": "16", "XM_FULL_WAVES": "1"},
+                                 {"XM_SCHED_LONG": "1", "XM_SCHED_BIGSET_PCT": "1", "XM_SCRATCH_GIB": "4"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_long_reads_sharing_waves_on_gpu(env, monkeypatch):
     """Enough 1,000 bp queries that the gapped pass puts several of them on every wave (its launch shape for long reads: 8 per wave; here 9 000 reads on
     1 024 waves, and the shapes of the short-read pass beside it): the searches of a wave's reads - HBM mode from the start at this chain scale - and
-    the two lanes of a read must not disturb each other."""
+    the two lanes of a read must not disturb each other.  XM_SCHED_LONG=1: the gapped pass as the wave scheduler (xm_sched_kernel) - searches side by side in the
+    lanes' small sets, the ones that outgrow them in large sets of the launch's pool (one group of buffers per XCD; the last shape: a pool of a few buffers, so that
+    searches wait for one)."""
     ref = synth.synthetic_reference(400_000, seed=41)
     reads = synth.synthetic_single_end(ref, 9000, read_len=1000, sub_rate=0.02, indel_prob=0.3, seed=42)[0]
     b = se_batch(reads)
