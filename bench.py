@@ -43,13 +43,16 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a one-GPU box)")
     ap.add_argument("--force-device", type=int, default=-1, help="testing: every rank uses this GPU instead of its LOCAL_RANK")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads of the same workload timed on the host cores (0 = skip); default: the whole batch (about a second on the GPU box's 256 cores)")
-    ap.add_argument("--config", default="1", choices=["1", "2", "4shape", "3shape", "4", "4mild"],
+    ap.add_argument("--config", default="1", choices=["1", "1rep", "2", "4shape", "3shape", "4", "4mild"],
                     help="1: BASELINE.json configs[1] (single-end 150 bp, the headline); 2: configs[2] shape (2x150 bp pairs, --spacing 100 50); "
                     "4shape: the 1,000 bp queries --split-queries-past-size 1000 makes of configs[4]'s reads, against the same 5 Mb reference; "
                     "3shape / 4 / 4mild: configs[3] / configs[4] on ONE GPU against the 3.1 Gb GRCh38-shaped reference of SURVEY.md section 8(d) "
                     "(pairs; 10 kb reads split at 1000 with the error rates as stated; the same with 2 %% substitutions + 0.2 %% indel events)")
     ap.add_argument("--stream-batches", type=int, default=4, help="batches of the PCIe-inclusive streamed measurement (api.align_stream: the upload of batch k+1 overlaps the alignment of batch k; 0 = skip)")
     ap.add_argument("--seed-index-mb", type=int, default=500, help="size (M bases) of the second, HBM-resident index the seed-probe leg builds so that its probes miss every cache (0 = probes on the workload's own index only)")
+    ap.add_argument("--big-scale", type=float, default=1.0, help="testing: the GRCh38-shaped reference of --config 3shape / 4 / 4mild at this fraction of its size (1.0 = the 3.1 Gb of SURVEY.md section 8(d))")
+    ap.add_argument("--share-dir", default=None, help="--gpus N with --config 3shape / 4 / 4mild: where rank 0 leaves the synthetic reference (memory-mapped by the other ranks) and the index "
+                    "it built (xm_index_save; the other ranks xm_index_load it): one generation and one hashing per node instead of N (default: a directory under the system's temporary directory named after MASTER_PORT)")
     ap.add_argument("--contexts", type=int, default=2, help="contexts per GPU: the steps are dealt to this many contexts of the GPU (xm_context_new: they share the index) that align their resident batches at the same time (1: one launch at a time)")
     ap.add_argument("--single-context-steps", type=int, default=3, help="steps of the one-launch-at-a-time measurement beside the headline at N=1 (0 = skip)")
     ap.add_argument("--wave-steps", type=int, default=2, help="steps of the opt-in wave-per-read form (XM_WAVE=1) measured beside the headline (0 = skip)")
@@ -84,11 +87,37 @@ def main():
 
     big = args.config in ("3shape", "4", "4mild")   # the 3.1 Gb GRCh38-shaped reference of SURVEY.md section 8(d), on one GPU
     build_kw = {}
+    share = None
+    if big and world > 1:
+        # N ranks on one node: ONE generation of the 3 GB reference and ONE hashing of it (rank 0); the other ranks map the reference and load the index
+        # (HashBlock_Database.java:477-487 / DirCache.java:19-60: the reference's workers share one database; Mapper.java:1026-1040)
+        import tempfile
+        share = args.share_dir or os.path.join(tempfile.gettempdir(), "xm_bench_share_%s" % os.environ.get("MASTER_PORT", "0"))
+        os.makedirs(share, exist_ok=True)
     if big:
-        grch = synth.grch38_shaped_reference()
-        contigs, whole, gstarts, gruns = grch
+        if share is None or rank == 0:
+            contigs, whole, gstarts, gruns = synth.grch38_shaped_reference(scale=args.big_scale)
+            if share is not None:
+                np.save(os.path.join(share, "whole.tmp.npy"), whole)
+                os.replace(os.path.join(share, "whole.tmp.npy"), os.path.join(share, "whole.npy"))
+                np.savez(os.path.join(share, "layout.npz"), starts=gstarts, n_runs=np.array([len(r_) for r_ in gruns]), runs=np.concatenate(gruns) if len(gruns) else np.zeros(0, np.int64))
+        if share is not None:
+            dist.barrier()
+            if rank != 0:
+                whole = np.load(os.path.join(share, "whole.npy"), mmap_mode="r")
+                lay = np.load(os.path.join(share, "layout.npz"))
+                gstarts = lay["starts"]
+                cuts = np.concatenate([[0], np.cumsum(lay["n_runs"])])
+                gruns = [lay["runs"][cuts[c_]:cuts[c_ + 1]] for c_ in range(len(lay["n_runs"]))]
+                contigs = [(synth.GRCH38_NAMES[c_], whole[gstarts[c_]:gstarts[c_ + 1]]) for c_ in range(len(gstarts) - 1)]
         ref = whole
         args.ref_len = int(len(whole))
+    elif args.config == "1rep":
+        # configs[1]'s reads against a reference with the structure i.i.d. ACGT lacks (segmental duplications at 90-99.5 % identity, tandem repeats, a 28-mer
+        # whose buckets overflow): the branch a real genome sends reads into - no early accept in a duplicated window, every candidate enumerated
+        rep_stats = {}
+        ref = synth.repeat_rich_reference(args.ref_len, stats=rep_stats)
+        contigs = [("ecoli_rep", ref)]
     else:
         ref = synth.synthetic_reference(args.ref_len, seed=0xEC011)
         contigs = [("ecoli_syn", ref)]
@@ -175,7 +204,17 @@ def main():
         return time.perf_counter() - t_start, state["kernel_ms"], state["launches"], state["d2h_ms"], state["pass_us"], state["last"]
 
     t0 = time.time()
-    db = api.ReferenceDatabase(contigs, mode="mapper", max_query_length=args.read_len, device=local_rank)
+    if share is not None:
+        index_file = os.path.join(share, "index.xmidx")
+        if rank == 0:
+            db = api.ReferenceDatabase(contigs, mode="mapper", max_query_length=args.read_len, device=local_rank)
+            db.save(index_file + ".tmp")
+            os.replace(index_file + ".tmp", index_file)
+        dist.barrier()
+        if rank != 0:
+            db = api.ReferenceDatabase.load(index_file, device=local_rank, max_query_length=args.read_len)
+    else:
+        db = api.ReferenceDatabase(contigs, mode="mapper", max_query_length=args.read_len, device=local_rank)
     index_build_s = time.time() - t0
     # One context at a time first (at N=1, when the headline uses several): the kernel's own numbers, one launch on the GPU at a time
     single = None
@@ -395,13 +434,17 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": {"1": "configs[1]: %d synthetic %d bp single-end reads per GPU vs %d bp synthetic E. coli-sized reference (index replicated, reads sharded, no collective)",
+                                    "1rep": "configs[1]'s reads on a repeat-rich reference: %d synthetic %d bp single-end reads per GPU vs %d bp synthetic reference with segmental duplications (90-99.5 %% identity), tandem repeats and an overfull-bucket 28-mer (synth.repeat_rich_reference)",
                                     "2": "configs[2] shape: %d synthetic 2 x %d bp pairs (--spacing 100 50) per GPU vs %d bp synthetic E. coli-sized reference",
                                     "4shape": "configs[4] shape: %d synthetic %d bp queries (what --split-queries-past-size 1000 makes of 10 kb reads) per GPU vs %d bp synthetic reference",
                                     "3shape": "configs[3] on one GPU: %d synthetic 2 x %d bp pairs (--spacing 100 50, seed 0x5EED0003) sampled genome-wide vs the %d bp GRCh38-shaped synthetic reference (24 contigs, real chromosome lengths, 1 %% N-runs of 10 kb, seed 0x6C38)",
                                     "4": "configs[4] on one GPU: %d queries of %d bp = 10 kb reads (5 %% substitutions + 5 %% indel events per base, seed 0x5EED0004) cut by --split-queries-past-size 1000, vs the %d bp GRCh38-shaped synthetic reference",
                                     "4mild": "configs[4] shape on one GPU with milder reads: %d queries of %d bp = 10 kb reads (2 %% substitutions + 0.2 %% indel events per base) cut by --split-queries-past-size 1000, vs the %d bp GRCh38-shaped synthetic reference"}[args.config] % (nq, args.read_len, args.ref_len),
                        "reads_per_gpu": nq * reads_per_query, "read_len": args.read_len, "reference_len": args.ref_len, "parallelism": "reads sharded x%d" % world,
-                       "aligned_reads": aligned, "index_build_s": round(index_build_s, 3), "index_bytes": info["index_bytes"],
+                       "aligned_reads": aligned, "quick_accept_fraction": round(int(c[7]) / max(1, nq), 4), "candidates_extended_per_query": round(int(c[4]) / max(1, nq), 3),
+                       "header_probes_per_query": round(int(c[1]) / max(1, nq), 2),
+                       "reference_repeats": rep_stats if args.config == "1rep" else None,
+                       "index_build_s": round(index_build_s, 3), "index_bytes": info["index_bytes"],
                        "index_build": {"hashed_on": "gpu" if info["built_on_device"] else "host", "hash_s": round(info["hash_seconds"], 3),
                                        "duplication_map_s": round(info["duplication_seconds"], 3)}},
             "roofline": {"bound": "hbm", "kernel": "xm_align_kernel", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",

@@ -456,16 +456,18 @@ def device_memory(device=0):
     return f.value, t.value
 
 
-def divide_scratch(contexts, device, reserve=24 << 30, most=200 << 30):
-    """Several contexts on one GPU: what is free now (the index is resident) minus a reserve for batches, result arenas and pile-ups, in equal
+def divide_scratch(contexts, device, reserve=24 << 30, most=200 << 30, per_context_extra=0):
+    """Several contexts on one GPU: what is free now (the index is resident) minus a reserve for batches and result arenas and minus what every
+    context will allocate beside its scratch (per_context_extra: a pile-up of 40-48 bytes per reference base with --out-mutations), in equal
     parts; a context that would get less than 8 GiB is not worth having -> (how many of `contexts` to use, bytes each)."""
     for c in contexts:
         c.set_scratch(1 << 20)  # (a context that already holds scratch gives it back first: what is free is then what there is to divide)
     free, _ = device_memory(device)
+    reserve = min(int(reserve), int(free) // 4)  # (a small or busy GPU: the reserve is a share of what there is, not a fixed claim)
     n = len(contexts)
-    while n > 1 and (free - reserve) // n < (8 << 30):
+    while n > 1 and (free - reserve - n * per_context_extra) // n < (8 << 30):
         n -= 1
-    share = max(1 << 30, min(most, (free - reserve) // max(n, 1)))
+    share = max(256 << 20, min(most, (free - reserve - n * per_context_extra) // max(n, 1)))
     for c in contexts[:n]:
         c.set_scratch(share)
     for c in contexts[n:]:

@@ -275,7 +275,11 @@ def run(argv, out=sys.stdout):
     max_query_length = max([len(s) for q, _ in queries for s in q.sequences] + [1])
     if devices and len(devices) > 1:
         from . import multi
-        db = multi.MultiGpuDatabase(ordered, devices, mode="mapper", enable_gapmers=o["enable_gapmers"], max_query_length=max_query_length, cache_dir=o.get("cache_dir"))
+        # (--out-mutations: every context accumulates its own pile-up on its GPU - depth 8 B, four alternative counts 32 B and, with a query-end fraction, the
+        # middle depth 8 B per reference base: 149 GB for a 3.1 Gb reference - so the contexts of a GPU are counted with it: api.divide_scratch)
+        pile_up = (48 if o.get("query_end_fraction", 0.1) > 0 else 40) * sum(len(t) for _, t in ordered) + (64 << 20) if o.get("out_mutations") else 0
+        db = multi.MultiGpuDatabase(ordered, devices, mode="mapper", enable_gapmers=o["enable_gapmers"], max_query_length=max_query_length, cache_dir=o.get("cache_dir"),
+                                    per_context_extra=pile_up)
     else:
         db = api.ReferenceDatabase(ordered, mode="mapper", enable_gapmers=o["enable_gapmers"], device=devices[0] if devices else o["device"],
                                    max_query_length=max_query_length, cache_dir=o.get("cache_dir"))

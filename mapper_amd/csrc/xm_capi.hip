@@ -721,7 +721,7 @@ struct DeviceTables {
   int device = 0;
   std::shared_mutex rw;      // align / probe calls of any number of contexts hold it shared while their kernels read the tables; (re)upload holds it exclusive
   std::mutex allocMu;        // contexts of one GPU size and allocate their scratch one after the other (they all look at the same free memory)
-  int uploadedLength = -1;   // host.maxHashedLength the device tables hold
+  std::atomic<int> uploadedLength{-1};   // host.maxHashedLength the device tables hold (written under hs->mu + rw, read without them by ensureTablesFor's first test)
   std::atomic<int> contexts{0};  // handles that share these tables (contexts of this GPU): a context sizes its launches for its share of the wave slots
   DevBuf<int64_t> dContigStart, dSeqCumStart, dDupKeyStart;
   DevBuf<int32_t> dContigLen, dDupKeys;
@@ -1169,6 +1169,7 @@ void xm_index_free(xm_index* idx) { delete idx; }
 
 int xm_index_get_info(const xm_index* idx, xm_index_info_t* info) {
   if (!idx || !info) return fail("null argument");
+  std::lock_guard<std::mutex> hostLock(idx->hs->mu);  // (another context's batch may be growing the shared host tables)
   const HostIndex& h = idx->host();
   info->num_contigs = h.numContigs(); info->min_interesting_size = h.minInterestingSize; info->max_hashed_length = h.maxHashedLength;
   info->enable_gapmers = h.enableGapmers; info->dup_window = h.dupWindow; info->position_bytes = (idx->hostOnly ? h.seqCumStart.back() > 0xFFFFFFFFll : idx->dt->posIs64) ? 8 : 4;
@@ -1183,6 +1184,7 @@ int xm_index_get_info(const xm_index* idx, xm_index_info_t* info) {
 
 int xm_index_table_info(const xm_index* idx, int32_t L, int32_t* capacity, int32_t* maxCount, int64_t* numStored, int64_t* numOverfull) {
   if (!idx) return fail("null index");
+  std::lock_guard<std::mutex> hostLock(idx->hs->mu);  // (another context's batch may be growing the shared host tables)
   const HostIndex& h = idx->host();
   if (L < 0 || L > h.maxHashedLength) return fail("length not hashed");
   const Table& t = h.tables[(size_t)L];
@@ -1196,6 +1198,7 @@ int xm_index_table_info(const xm_index* idx, int32_t L, int32_t* capacity, int32
 
 int xm_index_table_shape(const xm_index* idx, int32_t L, int32_t* capacity, int32_t* maxCount) {
   if (!idx || !capacity || !maxCount) return fail("null argument");
+  std::lock_guard<std::mutex> hostLock(idx->hs->mu);  // (another context's batch may be growing the shared host tables)
   const HostIndex& h = idx->host();
   if (L < 0 || L > h.maxHashedLength) return fail("length not hashed");
   *capacity = h.tables[(size_t)L].capacity; *maxCount = h.tables[(size_t)L].maxCount;
@@ -1204,6 +1207,7 @@ int xm_index_table_shape(const xm_index* idx, int32_t L, int32_t* capacity, int3
 
 int xm_index_table_dump(const xm_index* idx, int32_t L, int32_t* counts, int64_t* positionsOut) {
   if (!idx) return fail("null index");
+  std::lock_guard<std::mutex> hostLock(idx->hs->mu);  // (another context's batch may be growing the shared host tables)
   const HostIndex& h = idx->host();
   if (L < 0 || L > h.maxHashedLength) return fail("length not hashed");
   const Table& t = h.tables[(size_t)L];
@@ -1220,6 +1224,7 @@ int xm_index_table_dump(const xm_index* idx, int32_t L, int32_t* counts, int64_t
 
 int64_t xm_index_dup_keys(const xm_index* idx, int32_t contig, int32_t* out, int64_t cap) {
   if (!idx || contig < 0 || contig >= idx->host().numContigs()) return -1;
+  std::lock_guard<std::mutex> hostLock(idx->hs->mu);  // (another context's batch may be growing the shared host tables)
   const HostIndex& h = idx->host();
   int64_t a = h.dupKeyStart[(size_t)contig], b = h.dupKeyStart[(size_t)contig + 1];
   for (int64_t i = a; i < b && i - a < cap; i++) out[i - a] = h.dupKeys[(size_t)i];
@@ -1539,6 +1544,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const bool schedOn = handOver && !handBack && (longReads ? envInt("XM_SCHED_LONG", 0) != 0 : envInt("XM_SCHED", 0) != 0);
     const bool schedSplit = schedOn && !longReads && envInt("XM_SCHED", 0) == 2;
     long long gappedFront = 0;  // reads at the front of the gapped pass's list (the ones that look expensive)
+    bool orderedList = false;   // the next launch's list is the gapped pass's ordered one (expensive-looking reads first): only that list is dealt out lane-major
     const long long schedLpw = envKnob("XM_SCHED_LPW", longReads ? 8 : 32, 1, 64), schedQuantum = envKnob("XM_SCHED_QUANTUM", 128, 1, 1 << 30), schedGate = envKnob("XM_SCHED_GATE", longReads ? 2 : 8, 1, 64);
     SchedLayout schedLay{0, 0, 0};
     BigSetPool bigSets{nullptr, 0, nullptr, 0, 0};
@@ -1776,7 +1782,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       }
       idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq); idx->dListPath[tp].ensure(defer ? (size_t)nTodo : 1);
       // gapped pass with an ordered list: the first read of every lane is dealt out (kernel), the counter starts behind those items
-      const long long firstStride = (heavy && !schedPass && !defer && heavyHintThreshold > 0 && scale == gappedScale) ? (long long)grid * (block / 64) : 0;
+      const long long firstStride = (heavy && orderedList && !schedPass && !defer && heavyHintThreshold > 0 && scale == gappedScale) ? (long long)grid * (block / 64) : 0;
       const unsigned long long firstItem = (unsigned long long)std::min((long long)nTodo, (schedPass ? (long long)grid * (block / 64) : firstStride) * lpw);  // (the scheduler kernel deals every lane's first read)
       HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 2, &firstItem, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
@@ -1795,7 +1801,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         hipEvent_t em;
         HIP_CHECK(hipEventCreate(&em));
         HIP_CHECK(hipEventRecord(em, s));
-        const int lpwB = (int)fullLpw;
+        const int lpwB = (int)std::min<long long>(fullLpw, lpw);  // (the lanes' arenas are laid out for `lpw` lanes per wave)
         hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, view, params, bv, todo + nFrontReads, nTodo - nFrontReads, scale, 2, lpwB,
                            laneArenas, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 3, idx->dCounters.p, (uint8_t*)nullptr, idx->dSlotOf.p, 0, 0,
                            (long long)((double)nWaves * taperWaves / 100.0), 0, 0ll, idx->dWaveNodes.p, ho, (lpwB <= 32 && pairMode) ? 1 : 0, pool);
@@ -1833,6 +1839,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       res->counters[!heavy ? 12 : (defer ? 13 : 15)] += (int64_t)(ms * 1000.0);  // kernel microseconds: light pass / gapped chain passes / inline reruns
       launches++;
       memoFresh = false;
+      orderedList = false;
       hoMode = 0;                                // (the gapped pass below switches to 2, the pass that takes reads back to 3; reruns run plain)
       pendingLight = ctl.nLight;
       // the saved reads have all been consumed once neither a handed-back read nor one that stopped in front of the chain again is waiting
@@ -1920,6 +1927,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         HIP_CHECK(hipGetLastError());
         todo = idx->dListHeavy.p; nTodo = (long long)pendingHeavy;
         gappedFront = (long long)ctl.nHeavy;
+        orderedList = true;
         HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nHeavy, 0, 2 * sizeof(unsigned long long), s));  // nHeavy, nHeavyLate (a gapped pass never adds to these lists)
         scale = gappedScale;
         if (overflowScale < gappedScale) overflowScale = gappedScale;

@@ -303,6 +303,9 @@ XM_INL Caps makeCaps(int scale) {
 }
 
 // ---------------------------------------------------------------- bump arena
+#if defined(XM_ARENA_TRACE) && !defined(__HIPCC__)
+void xm_arena_trace(const void* base, size_t offset, size_t bytes);  // host simulation only (tests/hostsim): which structure lies where in an arena
+#endif
 struct Arena {
   uint8_t* base;
   size_t size, used;
@@ -312,6 +315,9 @@ struct Arena {
     size_t a = (used + 15) & ~(size_t)15;
     if (a + bytes > size) { overflow = true; return (void*)base; }  // caller checks `overflow` before use
     used = a + bytes;
+#if defined(XM_ARENA_TRACE) && !defined(__HIPCC__)
+    xm_arena_trace(base, a, bytes);
+#endif
     return base + a;
   }
 };

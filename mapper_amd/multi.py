@@ -23,6 +23,8 @@ class MultiGpuDatabase:
         if not devices:
             raise ValueError("at least one device")
         kw.pop("device", None)
+        # what every context will allocate beside its scratch (the command line's --out-mutations: one pile-up per context, 40-48 bytes per reference base)
+        per_context_extra = kw.pop("per_context_extra", 0)
         self.devices = [int(d) for d in devices]
         # contexts of one GPU (a repeated ordinal) share the index's tables in its HBM (xm_context_new: no copy) and divide what is free after the
         # index is resident as their scratch (api.divide_scratch; a GPU with room for fewer contexts than asked uses fewer).  Three contexts
@@ -40,7 +42,7 @@ class MultiGpuDatabase:
         keep = []
         for d in by_device:
             mine = [r for r, dd in zip(self.replicas, self.devices) if dd == d]
-            n = api.divide_scratch(mine, d)[0] if len(mine) > 1 else 1
+            n = api.divide_scratch(mine, d, per_context_extra=int(per_context_extra))[0] if len(mine) > 1 else 1
             keep += mine[:n]
             for r in mine[n:]:
                 r.close()

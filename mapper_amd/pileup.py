@@ -34,9 +34,13 @@ class MutationDetectionParameters:
 
     def __init__(self, minSNPTotalDepth=0.0, minSNPDepthFraction=0.0, minIndelTotalStartDepth=0.0, minIndelStartDepthFraction=0.0,
                  minIndelContinuationTotalDepth=0.0, minIndelContinuationDepthFraction=0.0):
-        self.minSNPTotalDepth, self.minSNPDepthFraction = minSNPTotalDepth, minSNPDepthFraction
-        self.minIndelTotalStartDepth, self.minIndelStartDepthFraction = minIndelTotalStartDepth, minIndelStartDepthFraction
-        self.minIndelContinuationTotalDepth, self.minIndelContinuationDepthFraction = minIndelContinuationTotalDepth, minIndelContinuationDepthFraction
+        # Mapper.main narrows every threshold to float - (float)Double.parseDouble(...), Mapper.java:203-230 - so they are kept as float32 values here and
+        # the products with the depths are taken in float32 too (_below): 0.7 of a depth of 10 is 7.0 in float and 7.000000000000001 in double, and an
+        # allele seen 7 times must not be dropped by the latter.  [inferred: the fields of MutationDetectionParameters live in QuickVariants]
+        f32 = lambda x: float(np.float32(x))  # noqa: E731
+        self.minSNPTotalDepth, self.minSNPDepthFraction = f32(minSNPTotalDepth), f32(minSNPDepthFraction)
+        self.minIndelTotalStartDepth, self.minIndelStartDepthFraction = f32(minIndelTotalStartDepth), f32(minIndelStartDepthFraction)
+        self.minIndelContinuationTotalDepth, self.minIndelContinuationDepthFraction = f32(minIndelContinuationTotalDepth), f32(minIndelContinuationDepthFraction)
 
     @staticmethod
     def emptyFilter():
@@ -45,6 +49,11 @@ class MutationDetectionParameters:
     @staticmethod
     def defaultFilter():
         return MutationDetectionParameters(5.0, 0.9, 1.0, 0.8, 1.0, 0.7)
+
+
+def _below(support, fraction, total):
+    """support < fraction * total in float arithmetic (the thresholds are floats in the reference: Mapper.java:203-230)."""
+    return bool(np.float32(support) < np.float32(fraction) * np.float32(total))
 
 
 def _number(x):
@@ -168,7 +177,7 @@ class MatchDatabase:
                 for pos in np.nonzero(alt[b])[0]:
                     total = depth[pos] / UNIT
                     support = alt[b][pos] / UNIT
-                    if total < f.minSNPTotalDepth or support < f.minSNPDepthFraction * total:
+                    if total < f.minSNPTotalDepth or _below(support, f.minSNPDepthFraction, total):
                         continue
                     rows.append((c, int(pos) + 1, 0, decode(ref[pos:pos + 1]), letter, support, total))
             for (cc, pos1, kind, ra, qa), w in indels.items():
@@ -177,7 +186,7 @@ class MatchDatabase:
                 support = w / UNIT
                 at = min(max(pos1 - 1, 0), len(ref) - 1)
                 total = mid[at] / UNIT     # the total (middle) depth where the indel starts (Mapper.java:538-539)
-                if total < f.minIndelTotalStartDepth or support < f.minIndelStartDepthFraction * total:
+                if total < f.minIndelTotalStartDepth or _below(support, f.minIndelStartDepthFraction, total):
                     continue
                 # continuation (Mapper.java:541-542) [inferred]: every further base of the indel is judged where it lies (a deletion's bases on the
                 # reference, an insertion's at its one position); the indel is cut in front of the first base that fails
@@ -186,7 +195,7 @@ class MatchDatabase:
                 while keep < n:
                     here = min(at + keep, len(ref) - 1) if kind == 2 else at
                     t = mid[here] / UNIT
-                    if t < f.minIndelContinuationTotalDepth or support < f.minIndelContinuationDepthFraction * t:
+                    if t < f.minIndelContinuationTotalDepth or _below(support, f.minIndelContinuationDepthFraction, t):
                         break
                     keep += 1
                 rows.append((c, pos1, kind, ra[:keep], qa[:keep], support, total))

@@ -251,3 +251,66 @@ def synthetic_long_reads(whole, gstarts, read_len=10_000, seed=0x5EED0004, sub_r
         rev = strand.astype(bool)
         out[rev] = _COMP[out[rev][:, ::-1]]
     return out
+
+
+# ---------------------------------------------------------------- a repeat-rich reference (round 4)
+def repeat_rich_reference(length=5_000_000, seed=0x4E9EA7, n_segdups=100, n_tandem=220, n_hot=240, stats=None):
+    """A reference with the structure a real genome has and i.i.d. ACGT lacks: the branch of the path that a duplicated window sends a read into
+    (no early accept - AlignerWorker.java:494-587 via Readable_DuplicationDetector.java:28-47 -, every candidate enumerated, overfull buckets skipped -
+    HashBlock_Database.java:569-577).  On an i.i.d. background:
+      * segmental duplications: n_segdups source segments of 1-20 kb, each copied to 1-3 other places at 90-99.5 % identity (substitutions), a third of the
+        copies reverse-complemented;
+      * tandem repeats: n_tandem loci of a 2-60 bp unit repeated 5-50 times, 2 % of the unit copies carrying a substitution;
+      * one 28-mer planted at n_hot places (its buckets overflow max(L^2, 5) entries and are marked overfull).
+    Pure function of the arguments.  stats (a dict, optional) receives the bases written by each kind and the fraction of positions that lie in a
+    segment present at least twice."""
+    ref = synthetic_reference(length, seed=seed).copy()
+    covered = np.zeros(length, dtype=bool)
+    r = splitmix64(seed ^ 0xD0B1E, 16 * (n_segdups + n_tandem + n_hot) + 64)
+    k = 0
+
+    def nxt():
+        nonlocal k
+        v = int(r[k]); k += 1
+        return v
+    dup_bases = 0
+    for _ in range(n_segdups):
+        seg_len = 1000 + nxt() % 19001
+        src = nxt() % (length - seg_len)
+        copies = 1 + nxt() % 3
+        covered[src:src + seg_len] = True
+        for _c in range(copies):
+            dst = nxt() % (length - seg_len)
+            ident_ppm = 900_000 + nxt() % 95_001          # 90 % .. 99.5 %
+            rc = (nxt() % 3) == 0
+            seg = ref[src:src + seg_len].copy()
+            rs = splitmix64(np.uint64(nxt() & 0x7FFFFFFFFFFFFFFF), seg_len)
+            do_sub = (rs >> np.uint64(44)).astype(np.int64) < (1_000_000 - ident_ppm) * (1 << 20) // 1_000_000
+            which = ((rs & np.uint64(0xFFFF)) % np.uint64(3)).astype(np.int64) + 1
+            seg = np.where(do_sub, _CODES[(np.log2(seg).astype(np.int64) + which) & 3], seg)
+            if rc:
+                seg = _COMP[seg[::-1]]
+            ref[dst:dst + seg_len] = seg
+            covered[dst:dst + seg_len] = True
+            dup_bases += seg_len
+    tandem_bases = 0
+    for _ in range(n_tandem):
+        unit = 2 + nxt() % 59
+        reps = 5 + nxt() % 46
+        at = nxt() % (length - unit * reps)
+        u = _CODES[(splitmix64(np.uint64(nxt() & 0x7FFFFFFFFFFFFFFF), unit) >> np.uint64(62)).astype(np.int64)]
+        t = np.tile(u, reps)
+        rs = splitmix64(np.uint64(nxt() & 0x7FFFFFFFFFFFFFFF), len(t))
+        do_sub = (rs >> np.uint64(44)).astype(np.int64) < (1 << 20) // 50
+        which = ((rs & np.uint64(0xFFFF)) % np.uint64(3)).astype(np.int64) + 1
+        t = np.where(do_sub, _CODES[(np.log2(t).astype(np.int64) + which) & 3], t)
+        ref[at:at + len(t)] = t
+        covered[at:at + len(t)] = True
+        tandem_bases += len(t)
+    hot = _CODES[(splitmix64(np.uint64(seed ^ 0x407), 28) >> np.uint64(62)).astype(np.int64)]
+    for _ in range(n_hot):
+        at = nxt() % (length - 28)
+        ref[at:at + 28] = hot
+    if stats is not None:
+        stats.update(segdup_copy_bases=int(dup_bases), tandem_bases=int(tandem_bases), hot_kmer_copies=int(n_hot), fraction_in_repeats=float(covered.mean()))
+    return ref

@@ -17,6 +17,14 @@
 
 using namespace xm;
 
+// XM_ARENA_TRACE builds (scripts/light_pass_footprint.py): the allocations of the arenas, in order
+#if defined(XM_ARENA_TRACE)
+struct ArenaAlloc { const void* base; size_t offset, bytes; };
+static std::vector<ArenaAlloc> g_allocs;
+static bool g_traceOn = false;
+namespace xm { void xm_arena_trace(const void* base, size_t offset, size_t bytes) { if (g_traceOn) g_allocs.push_back(ArenaAlloc{base, offset, bytes}); } }
+#endif
+
 static thread_local std::string g_err;
 static int g_waveMode = -1;  // -1: from XMSIM_WAVE (default 0)
 static long long g_waveStatus[16];
@@ -357,6 +365,59 @@ void xmsim_set_wave_mode(int mode) { g_waveMode = mode; }
 // how the wave form left the reads of all calls so far, by status (0 = finished there)
 void xmsim_wave_status_counts(long long* out, int reset) { for (int i = 0; i < 16; i++) { out[i] = g_waveStatus[i]; if (reset) g_waveStatus[i] = 0; } }
 void xmsim_wave_why_counts(long long* out) { for (int i = 0; i < 64; i++) out[i] = g_waveWhy[i]; }
+
+#if defined(XM_ARENA_TRACE)
+// The light pass's footprint in a lane's scratch, structure by structure: every read of the batch through runReadRetaining at the light pass's
+// settings (scale 1, region + 48 KB of temporaries, heavyAllowed 0) over memory filled with a pattern; per allocation of the two arenas (in
+// allocation order: the order is the same for every single-end read without ambiguity codes) the bytes that no longer hold the pattern.
+// out[3 * i + 0] = arena (0 region, 1 temporaries), [1] = capacity in bytes, [2] = bytes written, summed over the reads; returns the number of rows.
+int64_t xmsim_light_footprint(void* idxp, const xm_params* p, const xm_query_batch* b, int64_t* out, int64_t capRows, int64_t* readsDone) {
+  SimIndex* idx = (SimIndex*)idxp;
+  Params params;
+  params.MutationPenalty = p->MutationPenalty; params.InsertionStart_Penalty = p->InsertionStart_Penalty; params.InsertionExtension_Penalty = p->InsertionExtension_Penalty;
+  params.DeletionStart_Penalty = p->DeletionStart_Penalty; params.DeletionExtension_Penalty = p->DeletionExtension_Penalty; params.MaxErrorRate = p->MaxErrorRate;
+  params.UnalignedPenalty = p->UnalignedPenalty; params.AmbiguityPenalty = p->AmbiguityPenalty; params.Max_PenaltySpan = p->Max_PenaltySpan;
+  params.MaxNumMatches = p->MaxNumMatches; params.StartingInsertionStartFree = 0;
+  {
+    int maxLen = 1;
+    for (int64_t q = 0; q < b->num_queries; q++) for (int m = 0; m < b->mate_count[q]; m++) if (b->mate_length[q * 2 + m] > maxLen) maxLen = b->mate_length[q * 2 + m];
+    if (maxLen > idx->host.maxHashedLength) { idx->host.ensureLength(maxLen); idx->refresh(); }
+  }
+  const size_t regionBytes = (size_t)72 * 1024 + ((sizeof(SavedRead) + 15) & ~(size_t)15), tmpBytes = (size_t)48 * 1024;
+  std::vector<uint8_t> region(regionBytes + 64), tmp(tmpBytes + 64);
+  uint8_t* rg = (uint8_t*)(((uintptr_t)region.data() + 15) & ~(uintptr_t)15);
+  uint8_t* tp = (uint8_t*)(((uintptr_t)tmp.data() + 15) & ~(uintptr_t)15);
+  static ReadCtx cx;
+  int64_t rows = 0;
+  *readsDone = 0;
+  for (int64_t q = 0; q < b->num_queries; q++) {
+    if (b->mate_count[q] != 1) continue;
+    ReadIn in;
+    in.nMates = 1;
+    for (int m = 0; m < 2; m++) { in.mate[m] = b->codes + b->mate_offset[q * 2 + m]; in.mateLen[m] = m < 1 ? b->mate_length[q * 2 + m] : 0; }
+    in.expectedInner = 0.0; in.deviation = 1.0;
+    memset(rg, 0xCD, regionBytes); memset(tp, 0xCD, tmpBytes);
+    g_allocs.clear();
+    g_traceOn = true;
+    DevCounters dc; memset(&dc, 0, sizeof(dc));
+    ReadResult rr;
+    runReadRetaining(cx, &idx->view, params, in, 1, rg, regionBytes, tp, tmpBytes, &dc, rr, 0);
+    g_traceOn = false;
+    if ((int64_t)g_allocs.size() > capRows) return -1;
+    if ((int64_t)g_allocs.size() > rows) { for (int64_t i = rows; i < (int64_t)g_allocs.size(); i++) { out[3 * i] = 0; out[3 * i + 1] = 0; out[3 * i + 2] = 0; } rows = (int64_t)g_allocs.size(); }
+    for (size_t i = 0; i < g_allocs.size(); i++) {
+      const ArenaAlloc& a = g_allocs[i];
+      const uint8_t* base = (const uint8_t*)a.base;
+      const int arena = base == rg ? 0 : 1;
+      int64_t dirty = 0;
+      for (size_t k = 0; k < a.bytes; k++) if (base[a.offset + k] != 0xCD) dirty++;
+      out[3 * i] = arena; if ((int64_t)a.bytes > out[3 * i + 1]) out[3 * i + 1] = (int64_t)a.bytes; out[3 * i + 2] += dirty;
+    }
+    (*readsDone)++;
+  }
+  return rows;
+}
+#endif
 
 void xmsim_sched_counts(long long* out, int reset) { out[0] = g_schedSearches; out[1] = g_schedBig; out[2] = g_schedBigSet; if (reset) g_schedSearches = g_schedBig = g_schedBigSet = 0; }
 

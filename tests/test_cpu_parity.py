@@ -406,3 +406,31 @@ def test_wave_scheduler_path_in_the_host_simulation(quantum, monkeypatch):
     assert streams_equal(sa, sb), first_difference(sa, sb, ab.nq)
     hs.lib().xmsim_sched_counts(counts, 0)
     assert counts[0] > 1000, "the scheduler path ran %d searches" % counts[0]
+
+
+def test_kernel_logic_on_a_repeat_rich_reference(monkeypatch):
+    """synth.repeat_rich_reference (segmental duplications at 90-99.5 % identity, tandem repeats, a 28-mer whose buckets overflow): the branch of the
+    path a real genome sends reads into - a read in a duplicated window gets no early accept (Readable_DuplicationDetector.java:28-47 via
+    AlignerWorker.java:494-587), its candidates are all enumerated, overfull buckets are skipped (HashBlock_Database.java:569-577).  Index tables and
+    duplication keys against the oracle's, then reads and pairs: streams and work counters, lane-per-read sequence and the scheduler path."""
+    st = {}
+    ref = synth.repeat_rich_reference(600_000, n_segdups=14, n_tandem=30, n_hot=40, stats=st)
+    assert st["fraction_in_repeats"] >= 0.3
+    R = o.OracleReference([("rep", ref)])
+    S = hs.SimReference([("rep", ref)])
+    p = o.make_params()
+    b = se_batch(synth.synthetic_single_end(ref, 3000, seed=91)[0])
+    want = R.align(b, p, threads=os.cpu_count())
+    m1, m2 = synth.synthetic_paired_end(ref, 1000, seed=92)[:2]
+    pb = pe_batch(m1, m2)
+    wantp = R.align(pb, p, threads=os.cpu_count())
+    quick = want.counters[8] / b.nq
+    assert 0.2 < quick < 0.85, "quick accepts on the repeat-rich reference: %.3f of the reads (i.i.d. reference: 0.94)" % quick
+    assert want.counters[5] > 1.5 * b.nq, "candidates extended per read: %.2f" % (want.counters[5] / b.nq)
+    for sched in ("0", "1"):
+        monkeypatch.setenv("XMSIM_SCHED", sched)
+        got = S.align(b, p)
+        assert streams_equal(got, want), first_difference(got, want, b.nq)
+        assert list(want.counters[5:9]) == list(got.counters[4:8])  # candidates extended, PathAligner calls, nodes put, quick accepts
+        gotp = S.align(pb, p)
+        assert streams_equal(gotp, wantp), first_difference(gotp, wantp, pb.nq)

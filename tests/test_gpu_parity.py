@@ -474,3 +474,33 @@ def test_grch38_regime_alignments_equal_oracle():
         assert [int(x) for x in got.counters[:8]] == [wc[0], wc[1] + wc[2], wc[2], wc[3], wc[5], wc[6], wc[7], wc[8]], name
     assert R.index_info()[0] == 13
     db.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"XM_SCHED": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_repeat_rich_reference_equals_oracle(env, monkeypatch):
+    """configs[1]'s and configs[2]'s read models on synth.repeat_rich_reference (5 Mb: segmental duplications at 90-99.5 % identity, tandem repeats, a 28-mer
+    whose buckets overflow - over 30 % of the positions in a segment present at least twice): 100,000 reads and 50,000 pairs, result streams bit for bit and
+    work counters equal to the oracle's.  This is the branch a real genome sends reads into and i.i.d. ACGT does not: no early accept in a duplicated window
+    (Readable_DuplicationDetector.java:28-47, AlignerWorker.java:494-587), every candidate enumerated, overfull buckets skipped (HashBlock_Database.java:569-577);
+    the duplication map itself is built from these buckets (DuplicationDetector.java:129-250)."""
+    st = {}
+    ref = synth.repeat_rich_reference(5_000_000, stats=st)
+    assert st["fraction_in_repeats"] >= 0.3
+    R = o.OracleReference([("rep", ref)])
+    reads = synth.synthetic_single_end(ref, 100_000, seed=0x5EED0001)[0]
+    b = se_batch(reads)
+    m1, m2 = synth.synthetic_paired_end(ref, 50_000, seed=0x5EED0002)[:2]
+    pb = pe_batch(m1, m2, 100.0, 50.0)
+    want, wantp = R.align(b, o.make_params(), threads=os.cpu_count()), R.align(pb, o.make_params(), threads=os.cpu_count())
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    db = api.ReferenceDatabase([("rep", ref)])
+    for name, batch, w, n in (("reads", b, want, 100_000), ("pairs", pb, wantp, 50_000)):
+        got, _ = gpu_align(db, batch)
+        assert streams_equal(got, w), first_difference(got, w, n)
+        wc = [int(x) for x in w.counters[:9]]
+        assert [int(x) for x in got.counters[:8]] == [wc[0], wc[1] + wc[2], wc[2], wc[3], wc[5], wc[6], wc[7], wc[8]], name
+    quick = want.counters[8] / 100_000
+    assert quick < 0.85, "quick accepts: %.3f of the reads (i.i.d. reference: 0.94)" % quick
+    db.close()

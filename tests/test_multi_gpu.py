@@ -170,3 +170,31 @@ def test_contexts_share_one_index():
     last = ctx[1].align_arrays(*arrays[1], params)
     assert streams_equal(last, want[1])
     ctx[1].close(); ctx[3].close()
+
+
+def test_contexts_of_a_gpu_are_counted_with_their_pile_ups(monkeypatch):
+    """api.divide_scratch: what every context allocates beside its scratch (--out-mutations: one pile-up per context, 40-48 bytes per reference base) comes
+    out of the free HBM before the contexts are counted - two contexts on a 3.1 Gb reference would ask for 2 x 149 GB of pile-up - and the reserve is a
+    share of what is free on a small or busy GPU, not a fixed claim."""
+    class Ctx:
+        def __init__(self):
+            self.scratch = None
+
+        def set_scratch(self, n):
+            self.scratch = n
+    GiB = 1 << 30
+    monkeypatch.setattr(api, "device_memory", lambda d: (250 * GiB, 288 * GiB))
+    a, b = Ctx(), Ctx()
+    n, share = api.divide_scratch([a, b], 0)
+    assert n == 2 and share == (250 - 24) * GiB // 2 and a.scratch == share and b.scratch == share
+    pile_up = 48 * 3_088_269_832 + (64 << 20)
+    a, b = Ctx(), Ctx()
+    n, share = api.divide_scratch([a, b], 0, per_context_extra=pile_up)
+    assert n == 1 and b.scratch == 0 and share == min(200 * GiB, 250 * GiB - 24 * GiB - pile_up)
+    a, b = Ctx(), Ctx()
+    n, share = api.divide_scratch([a, b], 0, per_context_extra=48 * 500_000_000)
+    assert n == 2 and share == (250 * GiB - 24 * GiB - 2 * 48 * 500_000_000) // 2
+    monkeypatch.setattr(api, "device_memory", lambda d: (10 * GiB, 288 * GiB))
+    a, b = Ctx(), Ctx()
+    n, share = api.divide_scratch([a, b], 0)
+    assert n == 1 and share == 10 * GiB - (10 * GiB) // 4
