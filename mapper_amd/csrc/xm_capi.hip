@@ -1415,6 +1415,11 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     params.UnalignedPenalty = p->UnalignedPenalty; params.AmbiguityPenalty = p->AmbiguityPenalty; params.Max_PenaltySpan = p->Max_PenaltySpan;
     params.MaxNumMatches = p->MaxNumMatches; params.StartingInsertionStartFree = 0;
 
+    {  // XM_WSEARCH_FROM (experiment knob): the chain scale from which searches that start in HBM mode run in the form of xm_wsearch.h (default 16)
+      const int from = (int)envKnob("XM_WSEARCH_FROM", 16, 1, 0x7fffffff);
+      HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(xm_wide_search_from), &from, sizeof(from), 0, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    }
     idx->confPrepare(params, s);
     view.conf = idx->dConf.p; view.confMask = (uint32_t)(idx->confHost.size() - 1); view.confMiss = (ConfMiss*)idx->dConfMiss.p;
     idx->dListConf[0].ensure((size_t)nq); idx->dListConf[1].ensure((size_t)nq);
@@ -1773,9 +1778,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       idx->dWaveNodes.ensure((size_t)grid * (block / 64) * XM_PAL_NODES);
       SearchPool pool{nullptr, 0, 0, 0};
       if (searchPoolOn && heavy && scale == gappedScale) {
-        const Caps pc = makeCaps(scale);
-        const size_t need = (size_t)pc.maxNodes * 32 + std::max((size_t)pc.gridCap, (size_t)pc.nodeHash) * 4 + (size_t)pc.maxBuckets * 20 + (size_t)pc.bucketHash * 4 + (size_t)pc.maxNodes * 8 + 4096;
-        pool.bufBytes = (need + 4095) & ~(size_t)4095;
+        pool.bufBytes = searchPoolBytes(makeCaps(scale));
         pool.n = (int32_t)((long long)grid * (block / 64));  // one per wave of the launch
         idx->dSearchPool.ensure((size_t)pool.n * pool.bufBytes);
         pool.base = idx->dSearchPool.p;

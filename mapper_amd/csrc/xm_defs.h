@@ -25,11 +25,13 @@
 #define XM_NOINL_LINKAGE  // (a second translation unit of the library that includes these headers makes the out-of-line functions inline)
 #endif
 #define XM_NOINL XM_NOINL_LINKAGE __host__ __device__ __noinline__
+#define XM_NOINL_DECL XM_NOINL_LINKAGE __host__ __device__
 #else
 #define XM_HD
 #define XM_GLOBAL(T) T
 #define XM_INL inline
 #define XM_NOINL
+#define XM_NOINL_DECL
 #endif
 
 namespace xm {
@@ -286,8 +288,8 @@ XM_INL Caps makeCaps(int scale) {
   c.maxHistory = 192 * scale;
   c.maxCounters = 96 * scale;
   c.maxPending = 128 * scale;  // (blocks put aside until the path is exhausted: 1 kb reads that align nowhere need 257-320 at scale 4)
-  c.maxQM = 64 * scale;
-  c.maxGoodAlignments = 16 * scale;
+  c.maxQM = 128 * scale;            // (reads in repeats: a tandem repeat of 50 copies offers a read that many places; 64 and 16 sent ~70 reads per million
+  c.maxGoodAlignments = 32 * scale;  // of the repeat-rich workload into the pass behind the gapped pass, which lasts as long as its slowest read: profiles/r04/NOTES.md)
   c.maxBlocks = 16 * scale;
   c.maxNodes = 1536 * scale;
   c.nodeHash = 4096 * scale;  // power of two >= 2 * maxNodes

@@ -1266,9 +1266,24 @@ XM_NOINL bool pathSearchHbm(const PaProblem& pr, Arena& tmp, const Caps& caps, i
 }
 // the HBM-mode search of the read whose turn it is at the wave's slot: its arrays in the wave's buffer when the launch has a pool, else in the
 // lane's temporaries
+// The wave's buffer is sized for XM_POOL_NODE_FACTOR times the node capacities of the pass's scale (searchPoolCaps; the host sizes it with the same
+// function): the searches that need it are few, but on a reference with repeats some of them put eight thousand nodes and more, and a read whose search
+// outgrows the pass's capacities is run again from its start, alone on a wave, in a pass that lasts as long as the slowest such read (profiles/r04/NOTES.md).
+constexpr int XM_POOL_NODE_FACTOR = 4;
+XM_INL Caps searchPoolCaps(const Caps& caps) {
+  Caps c = caps;
+  c.maxNodes = caps.maxNodes * XM_POOL_NODE_FACTOR; c.nodeHash = caps.nodeHash * XM_POOL_NODE_FACTOR;
+  c.maxBuckets = caps.maxBuckets * 2; c.bucketHash = caps.bucketHash * 2;
+  return c;
+}
+XM_INL size_t searchPoolBytes(const Caps& passCaps) {
+  const Caps c = searchPoolCaps(passCaps);
+  const size_t cells = (size_t)(c.gridCap > c.nodeHash ? c.gridCap : c.nodeHash);
+  return ((size_t)c.maxNodes * 32 + cells * 4 + (size_t)c.maxBuckets * 20 + (size_t)c.bucketHash * 4 + (size_t)c.maxNodes * 8 + (size_t)c.maxBlocks * 16 * 4 + 4096 + 4095) & ~(size_t)4095;
+}
 XM_INL bool pathSearchHbmInTurn(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair, PaResume* resume = nullptr) {
   Arena wb;
-  if (xmWaveSearchBuffer(wb)) return pathSearchHbm(pr, wb, caps, status, dc, outBlocks, nb, pair, resume);
+  if (xmWaveSearchBuffer(wb)) return pathSearchHbm(pr, wb, searchPoolCaps(caps), status, dc, outBlocks, nb, pair, resume);
   return pathSearchHbm(pr, tmp, caps, status, dc, outBlocks, nb, pair, resume);
 }
 XM_NOINL bool pathSearchLds(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool* ldsOverflow, bool pair, PaResume* resume = nullptr) {
@@ -1317,6 +1332,23 @@ XM_INL bool pathSearchSlot(const PaProblem& pr, Arena& tmp, const Caps& caps, in
     found = pathSearchHbmInTurn(pr, tmp, caps, status, dc, outBlocks, nb, pair, &rs);
   }
   return found;
+}
+
+// The search in the form of xm_wsearch.h (lane-private tables built for few dependent trips to memory: four per explored entry against about
+// thirteen of PathAlignerT<false>), run from start to end in the lane's temporaries: what a chain whose searches start in HBM mode (scale 16 and up: long
+// reads, and the reruns of reads that outgrew scale 4 - a handful of reads whose searches put tens of thousands of nodes and whose pass lasts as long
+// as the slowest of them) uses instead of pathSearchHbm.  xm_wide_search_from: the chain scale from which it does (XM_WSEARCH_FROM; 0x7fffffff: never).
+XM_NOINL_DECL bool pathSearchW(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb);
+#if defined(__HIPCC__)
+__device__ int xm_wide_search_from = 16;
+#endif
+XM_INL int wideSearchFrom() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return xm_wide_search_from;
+#else
+  static const int v = getenv("XMSIM_WSEARCH_FROM") ? atoi(getenv("XMSIM_WSEARCH_FROM")) : 16;
+  return v;
+#endif
 }
 
 // PathAligner.align.  Inline mode: LDS-mode search first (the lanes of the wave that arrive here together take the wave's slot
@@ -1412,7 +1444,10 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
       }
     } else
 #endif
-    if (ldsOverflow) found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, xmPairMode());
+    if (ldsOverflow) {
+      if (e.caps->scale >= wideSearchFrom() && !e.caps->searchInHbmOnly) found = pathSearchW(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb);
+      else found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, xmPairMode());
+    }
   }
   if (!found || *e.status) return false;
   out.nb = nb;
@@ -1919,3 +1954,5 @@ XM_NOINL bool outerChain(const ExtEnv& e, const Section& qs, const Section& rs, 
 }
 
 }  // namespace xm
+
+#include "xm_wsearch.h"

@@ -92,7 +92,7 @@ XM_INL void schedSearchBig(MemoHdr* m, Arena& big, const Caps& caps, DevCounters
   int32_t st = big.overflow ? (int32_t)XM_ST_OVERFLOW : (int32_t)XM_OK;
   int32_t nb = 0;
   bool found = false;
-  if (!st) found = pathSearchHbm(pr, big, caps, &st, dc, blocks, nb);
+  if (!st) found = pathSearchHbm(pr, big, searchPoolCaps(caps), &st, dc, blocks, nb);  // (the wave's buffer: sized for searchPoolCaps)
   schedLogResult(m, found, blocks, nb, st);
   big.used = mark;
 }

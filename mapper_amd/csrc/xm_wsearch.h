@@ -19,7 +19,7 @@
 // a number of steps at a time.
 // Exactly the reference's search: one bucket per exact double key with insertion order preserved, stale re-exploration, == tie-breaks; the nodes it
 // puts are counted and compared with the oracle's (DevCounters::pathAlignerNodes).  What does not fit (more than 2048 nodes, 1536 cells or 256
-// keys; coordinates beyond 16 bits) reports XM_ST_OVERFLOW and is run by the lane-per-read form in the wave's big buffer.
+// keys; coordinates beyond an int16) reports XM_ST_OVERFLOW and is run by the lane-per-read form in the wave's big buffer.
 #pragma once
 #include "xm_extend.h"
 
@@ -57,7 +57,7 @@ struct alignas(16) WLive { double key; int32_t slot, head; };  // a live bucket:
 // large set (the chain's capacities: tens of thousands of nodes) that a search starts over in when it outgrows the small one.
 struct WSizes {
   int32_t maxNodes, maxCells, maxBuckets;
-  int32_t cellSlots, cellShift, bktSlots;       // powers of two; slot of a cell = hash >> cellShift
+  int32_t cellSlots, cellShift, bktSlots;       // cellSlots: a multiple of 128, slot of a cell = (hash x cellSlots) >> 32; bktSlots: a power of two
   uint32_t offCellBits, offBktBits, offCells, offList, offBkt, offLive, offBlocks, bytes;
 };
 constexpr uint32_t WS_OFF_TABLES = 512;  // (the WSearch header lives in front)
@@ -67,9 +67,9 @@ XM_INL WSizes wsSizes(int maxNodes, int maxBuckets, int maxBlocks) {
   z.maxNodes = maxNodes;
   z.maxCells = maxNodes - maxNodes / 4;
   z.maxBuckets = maxBuckets;
-  const int cl = wsLog2Ceil((long long)z.maxCells + z.maxCells / 3);  // load <= 3/4
-  z.cellSlots = 1 << cl; z.cellShift = 32 - cl;
-  z.bktSlots = 1 << wsLog2Ceil(2ll * maxBuckets);
+  z.cellSlots = (z.maxCells + z.maxCells / 3 + 255) & ~127;  // load <= 3/4; a multiple of 128: the bit map is cleared in 16-byte words (slot = hash x slots >> 32)
+  z.cellShift = 0;
+  z.bktSlots = 1 << wsLog2Ceil(2ll * (maxBuckets < 64 ? 64 : maxBuckets));
   uint32_t o = WS_OFF_TABLES;
   z.offCellBits = o; o += (uint32_t)z.cellSlots / 8;
   z.offBktBits = o; o += (uint32_t)z.bktSlots / 8;
@@ -122,7 +122,7 @@ XM_INL uint32_t wsKeyHash(double key) {
 // The running search: WSearch's scalars + the table pointers in locals (every method force-inlined into wsRun).
 struct WRun {
   uint8_t* arena;
-  WCell* cells; uint32_t* cellBits; uint32_t cellShift, cellMask;
+  WCell* cells; uint32_t* cellBits; uint32_t cellSlots;
   WList* list;
   WBkt* bkt; uint32_t* bktBits; uint32_t bktMask;
   WLive* live;
@@ -144,7 +144,7 @@ struct WRun {
 
   XM_INL void bind(uint8_t* a, const WSizes& z) {
     arena = a;
-    cells = (WCell*)(a + z.offCells); cellBits = (uint32_t*)(a + z.offCellBits); cellShift = (uint32_t)z.cellShift; cellMask = (uint32_t)z.cellSlots - 1u;
+    cells = (WCell*)(a + z.offCells); cellBits = (uint32_t*)(a + z.offCellBits); cellSlots = (uint32_t)z.cellSlots;
     list = (WList*)(a + z.offList);
     bkt = (WBkt*)(a + z.offBkt); bktBits = (uint32_t*)(a + z.offBktBits); bktMask = (uint32_t)z.bktSlots - 1u;
     live = (WLive*)(a + z.offLive);
@@ -161,7 +161,7 @@ struct WRun {
   // A lookup in two halves: the first probe's loads (bit-map word and cell: issued for all the cells an update looks at before any is waited
   // for), then the walk to the cell's slot, or to the empty slot that ends its run (-1 - slot), which only goes on when the first probe collided.
   XM_INL void probeIssue(int x, int y, uint32_t& h, uint32_t& bw, WCell& c) const {
-    h = wsCellHash(((uint32_t)x << 16) | (uint32_t)y) >> cellShift;
+    h = (uint32_t)(((uint64_t)wsCellHash(((uint32_t)x << 16) | (uint32_t)y) * cellSlots) >> 32);
     bw = cellBits[h >> 5];
     c = cells[h];
   }
@@ -169,7 +169,7 @@ struct WRun {
     while (true) {
       if (!((bw >> (h & 31u)) & 1u)) return -1 - (int)h;
       if (c.x == (uint16_t)x && c.y == (uint16_t)y) return (int)h;
-      h = (h + 1) & cellMask;
+      h = h + 1 == cellSlots ? 0u : h + 1;
       bw = cellBits[h >> 5];
       c = cells[h];
     }
@@ -210,7 +210,7 @@ struct WRun {
   XM_INL void putNode(int x, int y, double pen, double insX, double insY, uint8_t fl, int cellSlot) {
     double est = estimateOverallPenalty(x, y, pen, insX, insY, fl);
     if (est < activePenalty) est = activePenalty;
-    if (nNodes >= maxNodes || (x | y) < 0 || x > 65535 || y > 65535) { overflow = true; return; }
+    if (nNodes >= maxNodes || x < -32768 || x > 32767 || y < -32768 || y > 32767) { overflow = true; return; }  // (a list entry packs x and y as two int16: start nodes left of / above the grid have negative coordinates)
     const int idx = nNodes;
     int slot, tail;
     if (actSlot >= 0 && est == activePenalty) {
@@ -241,7 +241,7 @@ struct WRun {
       }
     }
     nNodes++;
-    WList e; e.xy = ((uint32_t)x << 16) | (uint32_t)y; e.next = -1;
+    WList e; e.xy = ((uint32_t)(uint16_t)(int16_t)x << 16) | (uint32_t)(uint16_t)(int16_t)y; e.next = -1;
     list[idx] = e;
     if (tail >= 0) list[tail].next = idx;
     WBkt nb; nb.key = est; nb.tail = idx; nb.pad = 0;
@@ -249,7 +249,7 @@ struct WRun {
     if (slot == actSlot) { actTail = idx; if (firstAppendToActive < 0) firstAppendToActive = idx; }
     else { lastSlot = slot; lastTail = idx; lastKey = est; }
     // saveNode :523-539 (a cell outside the grid is never looked at)
-    if (x < textALength + 2 && y < textBLength + 2) {
+    if (x >= 0 && y >= 0 && x < textALength + 2 && y < textBLength + 2) {
       WCell c;
       if (cellSlot == INT32_MIN) cellSlot = findCell(x, y, c);
       if (cellSlot < 0) {
@@ -496,7 +496,7 @@ XM_NOINL bool wsRun(uint8_t* arena, int maxSteps) {
     if (steps >= maxSteps) break;  // suspended in front of entry li
     WS_TOC(7, tR);
     const WList e = w.list[li];
-    const int x = (int)(e.xy >> 16), y = (int)(e.xy & 0xFFFFu);
+    const int x = (int)(int16_t)(uint16_t)(e.xy >> 16), y = (int)(int16_t)(uint16_t)(e.xy & 0xFFFFu);
     WS_TOC(1, tR);
     if (w.activePenalty > maxInterestingPenalty + 0.000001) { fail = true; break; }
     if (x == goalX) { haveLast = true; lastX = x; lastY = y; break; }
@@ -606,4 +606,28 @@ XM_NOINL bool wsRun(uint8_t* arena, int maxSteps) {
   return true;
 }
 
+// pathSearchW (declared in xm_extend.h): the whole search in the caller's temporaries, with the chain's capacities
+XM_NOINL bool pathSearchW(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb) {
+  const size_t mark = tmp.used;
+  const WSizes z = wsSizes(caps.maxNodes, caps.maxBuckets, caps.maxBlocks);
+  uint8_t* const a = (uint8_t*)tmp.alloc(z.bytes);
+  nb = 0;
+  if (tmp.overflow) { *status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
+  wsBegin(a, pr, z);
+  wsRun(a, 0x7FFFFFFF);
+  const WSearch* const S = (const WSearch*)a;
+  if (dc) { dc->pathAlignerCalls++; dc->pathAlignerNodes += S->nodesPut; }
+  bool found = false;
+  if (S->status != XM_OK) *status = S->status;
+  else if (S->found) {
+    found = true;
+    nb = S->nb;
+    const ABlock* const b = (const ABlock*)(a + z.offBlocks);
+    for (int i = 0; i < nb; i++) outBlocks[i] = b[i];
+  }
+  tmp.used = mark;
+  return found;
+}
+
 }  // namespace xm
+

@@ -278,9 +278,10 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
             }
             if (how == 3) schedLogResult(memo, false, nullptr, 0, XM_ST_OVERFLOW);
             if (how == 2) {
-              std::vector<double> bbuf(((size_t)288 * 1024 * (size_t)scale) / 8 + 2, 0.0);
+              const size_t poolBytes = searchPoolBytes(makeCaps(scale)) + (size_t)cx2.caps.maxBlocks * sizeof(ABlock) + 64;  // (the product's buffer per wave)
+              std::vector<double> bbuf(poolBytes / 8 + 2, 0.0);
               Arena bigArena;
-              bigArena.init((void*)(((uintptr_t)bbuf.data() + 15) & ~(uintptr_t)15), (size_t)288 * 1024 * (size_t)scale);
+              bigArena.init((void*)(((uintptr_t)bbuf.data() + 15) & ~(uintptr_t)15), poolBytes);
               schedSearchBig(memo, bigArena, cx2.caps, &dc);
               g_schedBig++;
             }
