@@ -288,8 +288,10 @@ XM_INL Caps makeCaps(int scale) {
   c.maxHistory = 192 * scale;
   c.maxCounters = 96 * scale;
   c.maxPending = 128 * scale;  // (blocks put aside until the path is exhausted: 1 kb reads that align nowhere need 257-320 at scale 4)
-  c.maxQM = 128 * scale;            // (reads in repeats: a tandem repeat of 50 copies offers a read that many places; 64 and 16 sent ~70 reads per million
-  c.maxGoodAlignments = 32 * scale;  // of the repeat-rich workload into the pass behind the gapped pass, which lasts as long as its slowest read: profiles/r04/NOTES.md)
+  c.maxQM = 64 * scale;
+  c.maxGoodAlignments = 32 * scale;  // (reads in repeats: a tandem repeat offers a read dozens of places; room for 16 sent ~50 reads per million of the repeat-rich workload
+                                     // into the pass behind the gapped pass, which lasts as long as its slowest read: profiles/r04/NOTES.md.  The seeding state of a pair
+                                     // with ambiguity codes and the two aligners of getUnpairedAlignments must still fit a region: qmaInit's pool, the sub-aligners' half)
   c.maxBlocks = 16 * scale;
   c.maxNodes = 1536 * scale;
   c.nodeHash = 4096 * scale;  // power of two >= 2 * maxNodes

@@ -27,7 +27,7 @@ struct QMAligner {  // QueryMatch_Aligner
   int32_t nMates;        // 1 or 2 (query.getNumSequences())
   int32_t queryLength;   // query.getLength()
   double expectedInner, deviation;
-  QAl* good; int32_t nGood;     // blocks of accepted alignments live compactly in blockPool
+  QAl* good; int32_t nGood, goodCap;  // blocks of accepted alignments live compactly in blockPool
   QAl cand;                      // the candidate doAlign is building (blocks: candBlocks[k], capacity caps.maxBlocks)
   ABlock* blockPool; int32_t poolUsed, poolCap;
   double bestPenalty;
@@ -88,7 +88,9 @@ XM_INL double divideRoundUp(double a, double b) {  // M/QueryMatch_Aligner.java:
   return r;
 }
 
-XM_INL void qmaInit(ReadCtx& cx, QMAligner& a, int nMates, int queryLength) {
+// goodCap: room for that many accepted alignments (the read's aligner: caps.maxGoodAlignments; the two aligners of getUnpairedAlignments half of it - the
+// seeding state of a pair must still fit the region beside them)
+XM_INL void qmaInit(ReadCtx& cx, QMAligner& a, int nMates, int queryLength, int goodCap) {
   a.parameters = cx.params;
   a.nMates = nMates;
   a.queryLength = queryLength;
@@ -97,9 +99,11 @@ XM_INL void qmaInit(ReadCtx& cx, QMAligner& a, int nMates, int queryLength) {
   a.nGood = 0;
   a.nBest = 0;
   a.bestPenalty = (double)INT32_MAX;
-  int n = cx.caps.maxGoodAlignments;
+  const int n = goodCap;
+  a.goodCap = n;
   a.good = arenaArray<QAl>(cx.persist, n);
-  a.poolCap = 12 * n + 4 * cx.caps.maxBlocks;
+  a.poolCap = 6 * n + 4 * cx.caps.maxBlocks;  // (blocks of the accepted alignments: most have one to three per mate; the read's aligner had room for 16 alignments and 12 blocks
+                                              // each - the same pool now serves 32 alignments, and what the aligners of a pair with ambiguity codes take together has not grown)
   a.poolUsed = 0;
   a.blockPool = arenaArray<ABlock>(cx.persist, (size_t)a.poolCap);
   ABlock* candBlocks = arenaArray<ABlock>(cx.persist, (size_t)2 * cx.caps.maxBlocks);
@@ -278,7 +282,7 @@ XM_NOINL bool qmaExtract(ReadCtx& cx, const Params& p, const SeqAl& joined, int 
 XM_NOINL bool qmaDoAlign(ReadCtx& cx, QMAligner& a, const QMatch& match, double extraSpacing) {
   const SeedEnv& se = cx.seed;
   if (cx.dc) cx.dc->candidatesExtended++;
-  if (a.nGood >= cx.caps.maxGoodAlignments) { cx.status = XM_ST_OVERFLOW; return false; }
+  if (a.nGood >= a.goodCap) { cx.status = XM_ST_OVERFLOW; return false; }
   QAl& res = a.cand;
   size_t mark = cx.tmp.used;
   double innerDistance = (match.n < 2 ? 0 : qmTotalDistanceBetweenComponents(se, match)) + extraSpacing;
@@ -634,7 +638,7 @@ XM_NOINL void getUnpairedAlignments(ReadCtx& cx, ReadResult& rr) {
     if (cx.status) return;
     QMAligner* sub = arenaArray<QMAligner>(cx.persist, 1);
     if (cx.persist.overflow) { cx.status = XM_ST_OVERFLOW; return; }
-    qmaInit(cx, *sub, 1, len);
+    qmaInit(cx, *sub, 1, len, cx.caps.maxGoodAlignments / 2);
     if (cx.status) return;
     rr.aligner[sequenceIndex] = sub;
     for (int i = 0; i < locs.n; i++) {
@@ -710,7 +714,7 @@ XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr, bool resume = false) {
   st.numMismatches = 0;
   pcOptimisticGetBestMatches(pc, se);
   if (cx.status) return;
-  qmaInit(cx, *aligner, in.nMates, st.queryLength);
+  qmaInit(cx, *aligner, in.nMates, st.queryLength, cx.caps.maxGoodAlignments);
   if (cx.status) return;
   rr.aligner[0] = aligner;
   if (pc.nFiltered == 1) {

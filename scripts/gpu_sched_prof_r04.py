@@ -38,5 +38,15 @@ print("gapped-pass Mticks", {n: round(x / 1e6, 1) for n, x in zip(names, r.prof)
 s = {n: int(out[i]) for i, n in enumerate(snames)}
 print("scheduler Mticks", {n: round(v / 1e6, 1) for n, v in s.items()}, flush=True)
 print("search rounds: explored entries %d, sum over rounds of the longest lane %d -> %.0f ticks of wave time per round-step, %.0f per explored entry" % (s["round_sum_steps"], s["round_max_steps"], s["search"] / max(1, s["round_max_steps"]), s["search"] / max(1, s["round_sum_steps"])), flush=True)
+import json
+if os.environ.get("XM_PROFILE_JSON"):
+    json.dump({"workload": "configs[%s], %d queries, one context, gapped pass only (XM_PROF_GAPPED_ONLY=1), library built with -DXM_PROFILE=2" % (cfg, nq), "XM_SCHED": os.environ.get("XM_SCHED", "0"),
+               "unit": "shader-clock ticks of wave time (the lowest active lane of a wave counts), summed over the waves of the launch",
+               "kernel_ms_profile_build": r.kernel_ms, "pathaligner_calls_nodes": [int(x) for x in r.counters[5:7]],
+               "gapped_pass_phases": {n: int(x) for n, x in zip(names, r.prof)}, "scheduler": s,
+               "mean_lanes_searching_at_the_start_of_a_search_phase": (s["search_lane_ticks"] / s["search"]) if s["search"] else None,
+               "mean_lanes_stepping_per_lock_step_step": (s["round_sum_steps"] / s["round_max_steps"]) if s["round_max_steps"] else None,
+               "mean_lanes_with_chain_work_in_a_chain_phase": (s["chain_lane_ticks"] / max(1, s["chain_fresh"] + s["chain_replay"])) if s["search"] else None},
+              open(os.environ["XM_PROFILE_JSON"], "w"), indent=1)
 if s["search"]:
     print("mean lanes searching in a search phase: %.2f; mean lanes with chain work in a chain phase: %.2f" % (s["search_lane_ticks"] / s["search"], s["chain_lane_ticks"] / max(1, s["chain_fresh"] + s["chain_replay"])), flush=True)

@@ -14,11 +14,12 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+suffix = sys.argv[2] if len(sys.argv) > 2 else ""   # pass directories pmcF<suffix>, pmcW<suffix>, pmcS<suffix> (e.g. _config2: the passes over bench.py --config 2)
 acc = defaultdict(lambda: defaultdict(list))   # pass -> counter -> values
 grids = set()
 rows = []
 for d in ("pmcF", "pmcW", "pmcS"):
-    path = os.path.join(root, d, "pmc_counter_collection.csv")
+    path = os.path.join(root, d + suffix, "pmc_counter_collection.csv")
     if not os.path.exists(path):
         continue
     for r in csv.DictReader(open(path)):
@@ -42,7 +43,7 @@ out["_note"] = ("rocprofv3 --pmc passes over `python3 bench.py --cpu-sample 0 --
                 "(narrow scattered accesses: no gfx950 wide-load correction applies); SQ_* in quad-cycles" % sorted(set(launches.values())))
 out["hbm_bytes_per_launch"] = hbm
 try:  # the build (and the number of contexts) the counters belong to: bench.py quotes roofline.traffic only for the same
-    line = json.load(open(os.path.join(root, "bench_line.json")))
+    line = json.load(open(os.path.join(root, "bench_line.json" if not suffix else "bench%s.json" % suffix)))
     out["build"] = line["build"]
     out["contexts"] = line["contexts"]["per_gpu"]
 except Exception:  # noqa: BLE001
