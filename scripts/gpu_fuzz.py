@@ -10,7 +10,8 @@ from mapper_amd import api, synth
 
 
 
-def run(rounds=24, seed=2026, max_queries=4000):
+def run(rounds=24, seed=2026, max_queries=4000, backend="gpu"):
+  """backend "gpu": libxmapper_hip.so; "sim": the kernel sources in the host simulation of the tests (tests/hostsim), for the CPU-only tier."""
   rng = np.random.default_rng(seed)
   bad = 0
   for it in range(rounds):
@@ -42,9 +43,15 @@ def run(rounds=24, seed=2026, max_queries=4000):
           queries += [([r], 0.0, 1.0) for r in extra]
       b = o.QueryBatch(queries)
       mode = "api" if it % 7 == 3 else "mapper"
-      db = api.ReferenceDatabase([("r%d" % it, ref)], mode=mode, max_query_length=L)
       t = time.time()
-      r = db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, api.AlignmentParameters(**params))
+      if backend == "sim":
+          import hostsim_lib
+          db = hostsim_lib.SimReference([("r%d" % it, ref)], mode=mode)
+          r = db.align(b, o.make_params(params))
+          r.kernel_ms = 0.0
+      else:
+          db = api.ReferenceDatabase([("r%d" % it, ref)], mode=mode, max_query_length=L)
+          r = db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, api.AlignmentParameters(**params))
       want = o.OracleReference([("r%d" % it, ref)], mode=mode).align(b, o.make_params(params), threads=os.cpu_count())
       same = np.array_equal(want.ints, r.ints) and np.array_equal(want.dbls.view(np.int64), r.dbls.view(np.int64)) and np.array_equal(want.int_off, r.int_off)
       aligned = int(sum(1 for q in range(len(queries)) if r.ints[r.int_off[q] + 1] > 0))
@@ -56,7 +63,8 @@ def run(rounds=24, seed=2026, max_queries=4000):
               a0, a1 = want.int_off[q], want.int_off[q + 1]
               if a1 - a0 != r.int_off[q + 1] - r.int_off[q] or not np.array_equal(want.ints[a0:a1], r.ints[r.int_off[q]:r.int_off[q + 1]]):
                   print("  first differing query", q, "params", params); break
-      db.close()
+      if backend != "sim":
+          db.close()
   print("fuzz done, differing batches:", bad)
   return bad
 

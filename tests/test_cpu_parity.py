@@ -434,3 +434,16 @@ def test_kernel_logic_on_a_repeat_rich_reference(monkeypatch):
         assert list(want.counters[5:9]) == list(got.counters[4:8])  # candidates extended, PathAligner calls, nodes put, quick accepts
         gotp = S.align(pb, p)
         assert streams_equal(gotp, wantp), first_difference(gotp, wantp, pb.nq)
+
+
+@pytest.mark.parametrize("sched", ["0", "1"])
+def test_kernel_logic_random_configurations(sched, monkeypatch):
+    """The differential fuzz of the GPU tier (scripts/gpu_fuzz.py: random references with repeats and ambiguity codes, read lengths 36-301, single / paired
+    mixes, random alignment parameters) through the host simulation: every batch must equal the oracle bit for bit.  Round 3 of this seed is a batch of pairs
+    sampled from a reference with ambiguity codes that reach getUnpairedAlignments: the seeding state of both mates, their possibilities and three aligners in
+    one region - the case that decides how much room the aligners may take (xm_worker.h, qmaInit)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import gpu_fuzz
+    monkeypatch.setenv("XMSIM_SCHED", sched)
+    assert gpu_fuzz.run(rounds=6, seed=77, max_queries=1500, backend="sim") == 0
