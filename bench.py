@@ -425,6 +425,16 @@ def main():
                     traffic_source = "profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, build %s)" % (rounds[-1], pm["build"])
                 else:  # counters of another build (or another number of contexts) say nothing about this one
                     traffic_source = "none: profiles/%s/pmc_summary.json was collected on build %s, this is %s" % (rounds[-1], pm.get("build", "?"), build)
+            elif args.config in ("2", "4shape") and (args.reads, args.ref_len) == (1_000_000, 5_000_000):
+                name = "pmc_config%s.json" % args.config
+                rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, name)))
+                pm = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], name)))
+                if pm.get("build") == build:
+                    gs = [g for g in pm["launches_by_grid"] if g["launches_profiled"] > 0]
+                    traffic = int(sum(g["hbm_bytes_per_launch"] * g["launches_profiled"] for g in gs) / sum(g["launches_profiled"] for g in gs))  # mean over the launches of a step
+                    traffic_source = "profiles/%s/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload by launch grid, build %s; mean over the launches)" % (rounds[-1], name, pm["build"])
+                else:
+                    traffic_source = "none: profiles/%s/%s was collected on build %s, this is %s" % (rounds[-1], name, pm.get("build", "?"), build)
         except Exception:
             traffic = None
 
