@@ -22,4 +22,4 @@ timeout 900 python scripts/gpu_rep_r04.py 1000000 "XM_SCHED=0,XM_SCHED=1,XM_WSEA
 echo "# scripts/gpu_diag_r04.py (configs[1], the lane-per-read passes twice, then the scheduler twice: same streams, same counters)"
 timeout 600 python scripts/gpu_diag_r04.py 0 0 1 1 2>&1 | grep -v "^\[xm\]"
 } > $O/repeat_rich.log 2>&1
-tail -3 $O/sched_sweeps.log $O/long_reads.log $O/repeat_rich.log
+for f in sched_sweeps long_reads repeat_rich; do tail -n 3 $O/$f.log; done
