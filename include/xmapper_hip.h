@@ -204,8 +204,8 @@ void xm_pileup_free(xm_pileup* pileup);
 /* TEST-ONLY entry (tests/test_gpu_kat.py; not part of the drop-in boundary): the reference's component-level known-answer tests run by the
  * device code of the align kernels over two given texts.  chain 0 = PathAligner alone (PathAligner_Test.java:10-39): mode 0 the lane-per-read
  * search in the wave's LDS slot, 1 the same search in HBM mode, 2 the wave-cooperative search with the search kernel's capacities, 3 with the
- * capacities of the chain tiers' inline searches.  chain 1 = HashBlock_Aligner -> StraightAligner -> PathAligner_Runner
- * (HashBlockAligner_Test.java:10-48): mode 0 searches slot-first as in the kernel, 1 all searches in HBM mode.
+ * capacities of the chain tiers' inline searches, 4 the lane-private form of the search (xm_wsearch.h: the wave scheduler's, and the chains of long reads).  chain 1 = HashBlock_Aligner -> StraightAligner -> PathAligner_Runner
+ * (HashBlockAligner_Test.java:10-48): mode 0 searches slot-first as in the kernel, 1 all searches in HBM mode, 4 all in the lane-private form.
  * Returns 0 with blocks[4 * num_blocks] = (startA, startB, lengthA, lengthB) and penalties[2] = (total, aligned); 1 = no alignment (null); -1 = error. */
 int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_params* params, const uint8_t* query, int32_t query_length, const uint8_t* reference,
                         int32_t reference_length, double max_ins_ext, double max_del_ext, int32_t block_cap, int32_t* blocks, int32_t* num_blocks, double* penalties,

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <string>
 #include <vector>
+#include <unordered_set>
 #include <mutex>
 #include <shared_mutex>
 #include <memory>
@@ -209,8 +210,8 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_path_kernel(const i
 
 // Test entry (xm_test_local_align): the reference's component-level known-answer tests (PathAligner_Test.java:10-39: PathAligner alone;
 // HashBlockAligner_Test.java:10-48: HashBlock_Aligner -> StraightAligner -> PathAligner_Runner) over two given texts, run by the code the align
-// kernel runs.  chain 0: one search, in the wave's LDS slot (mode 0) or in HBM mode (mode 1); chain 1: hashBlockAlign with the searches
-// slot-first as in the kernel (mode 0) or all in HBM mode (mode 1).  One lane works; out: found, nb, status, nodes, blocks; penalties.
+// kernel runs.  chain 0: one search, in the wave's LDS slot (mode 0), in HBM mode (mode 1) or in the lane-private form (mode 4); chain 1: hashBlockAlign with the searches
+// slot-first as in the kernel (mode 0), all in HBM mode (mode 1) or all in the lane-private form of xm_wsearch.h (mode 4).  One lane works; out: found, nb, status, nodes, blocks; penalties.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(int chain, int mode, Params params, const uint8_t* query, int queryLength, const uint8_t* reference, int referenceLength,
                                                             double maxIns, double maxDel, int scale, uint8_t* arena, unsigned long long arenaBytes, PNode* waveNodes, int blockCap,
                                                             int32_t* outInts, double* outDbls) {
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(i
   DevCounters local;
   memset(&local, 0, sizeof(local));
   Caps caps = makeCaps(scale);
-  caps.searchInHbmOnly = mode == 1 ? 1 : 0;
+  caps.searchInHbmOnly = mode == 1 ? 1 : (mode == 4 ? 2 : 0);
   Arena tmp;
   tmp.init(arena, (size_t)arenaBytes);
   int32_t status = XM_OK;
@@ -878,6 +879,8 @@ struct xm_index {
   double stagedH2dMs = 0;
 
   static constexpr size_t kConfMissCap = 1 << 16;
+  std::unordered_set<int32_t> confSeeded;  // query lengths whose whole-substitution sums are in the table
+  double confSeedRate = -1;               // (... for this MaxErrorRate)
   bool confInsert(double penalty, int32_t qlen, const Params& p) {  // -> false: already there
     uint64_t bits;
     memcpy(&bits, &penalty, 8);
@@ -905,11 +908,20 @@ struct xm_index {
   void confPrepare(const Params& p, hipStream_t s) {
     const HostIndex& hst = hs->host;
     const double sig[4] = {p.Max_PenaltySpan, p.MutationPenalty, hst.dupGranularity(), (double)(hst.totalForwardSize * 2)};
-    if (memcmp(sig, confSig, sizeof(sig)) != 0) { memcpy(confSig, sig, sizeof(sig)); confHost.clear(); confCount = 0; confDirty = true; }
+    if (memcmp(sig, confSig, sizeof(sig)) != 0) { memcpy(confSig, sig, sizeof(sig)); confHost.clear(); confCount = 0; confDirty = true; confSeeded.clear(); }
+    if (confSeedRate != p.MaxErrorRate) { confSeedRate = p.MaxErrorRate; confSeeded.clear(); }
+    // a length is seeded once; a call seeds a bounded number of entries (fixed-length batches: a few dozen; a batch of unsplit long reads has thousands
+    // of distinct lengths with thousands of sums each, of which the reads ask for a few: what is not seeded comes in through the miss path)
+    long long budget = envKnob("XM_CONF_SEED", 1 << 18, 0, 1 << 26);  // (0: nothing seeded, every key through the miss path - the tests run that)
     for (int32_t len : residentLens) {
+      if (confSeeded.count(len)) continue;
       const double limit = (double)len * p.MaxErrorRate + p.Max_PenaltySpan + p.MutationPenalty;
+      const double steps = p.MutationPenalty > 0 ? std::min(4096.0, std::floor(limit / p.MutationPenalty) + 2) : 1;
+      if (steps > (double)budget) continue;
+      budget -= (long long)steps;
       double pen = 0;
-      for (int j = 0; j < 4096 && pen <= limit; j++) { confInsert(pen, len, p); pen += p.MutationPenalty; }
+      for (int j = 0; j < (int)steps && pen <= limit; j++) { confInsert(pen, len, p); pen += p.MutationPenalty; }
+      confSeeded.insert(len);
     }
     confUpload(s);
     if (!dConfMiss.p) {
@@ -1945,7 +1957,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       if (pendingScale == 0 && pendingConf > 0) {
         // reads that met a (penalty, length) the confidence table did not hold: the host evaluates the keys they left (its libm, the oracle's)
         // and they run again, start to finish, in a pass of their own
-        if (++confRounds > 64) throw std::runtime_error("internal error: the confidence table does not converge");
+        if (++confRounds > 1024) throw std::runtime_error("internal error: the confidence table does not converge");
         idx->confAbsorbMisses(params, s);
         view.conf = idx->dConf.p; view.confMask = (uint32_t)(idx->confHost.size() - 1);
         todo = idx->dListConf[tc].p; nTodo = (long long)pendingConf;
@@ -2233,8 +2245,8 @@ int xm_debug_sched_profile(uint64_t* out16, int32_t reset) {
 int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_params* p, const uint8_t* query, int32_t query_length, const uint8_t* reference, int32_t reference_length,
                         double max_ins_ext, double max_del_ext, int32_t block_cap, int32_t* blocks, int32_t* num_blocks, double* penalties, int64_t* nodes_put) {
   if (!p || !query || !reference || !blocks || !num_blocks || !penalties) { fail("xm_test_local_align: null argument"); return -1; }
-  if (chain < 0 || chain > 1 || mode < 0 || mode > 3 || (chain == 1 && mode > 1) || query_length < 1 || reference_length < 1 || query_length > 30000 || reference_length > 100000 || block_cap < 1)
-  { fail("xm_test_local_align: bad arguments (chain 0: modes 0 LDS slot, 1 HBM, 2 wave search with the search kernel's capacities, 3 with the inline capacities; chain 1: modes 0, 1)"); return -1; }
+  if (chain < 0 || chain > 1 || mode < 0 || mode > 4 || (chain == 1 && (mode == 2 || mode == 3)) || query_length < 1 || reference_length < 1 || query_length > 30000 || reference_length > 100000 || block_cap < 1)
+  { fail("xm_test_local_align: bad arguments (chain 0: modes 0 LDS slot, 1 HBM, 2 wave search with the search kernel's capacities, 3 with the inline capacities, 4 lane-private form; chain 1: modes 0, 1, 4)"); return -1; }
   try {
     if (device >= 0) HIP_CHECK(hipSetDevice(device));
     Params params;
@@ -2258,7 +2270,7 @@ int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_pa
     HIP_CHECK(hipMemcpy(dr.p, reference, (size_t)reference_length, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemset(dInts.p, 0, sizeof(int32_t) * (4 + 4 * (size_t)cap)));
     HIP_CHECK(hipMemset(dDbls.p, 0, sizeof(double) * 2));
-    if (mode >= 2) {
+    if (mode == 2 || mode == 3) {
       TestSearch t;
       memset(&t, 0, sizeof(t));
       t.big = mode == 2 ? 1 : 0;
@@ -2289,7 +2301,7 @@ int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_pa
     HIP_CHECK(hipMemcpy(ints.data(), dInts.p, sizeof(int32_t) * ints.size(), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(dbls, dDbls.p, sizeof(dbls), hipMemcpyDeviceToHost));
     if (nodes_put) *nodes_put = ints[3];
-    const int ok = mode >= 2 ? ints[0] : (ints[2] != XM_OK ? -1 : ints[0]);
+    const int ok = (mode == 2 || mode == 3) ? ints[0] : (ints[2] != XM_OK ? -1 : ints[0]);
     if (ok < 0) { fail("xm_test_local_align: the search failed with status " + std::to_string(ints[2])); return -1; }
     if (ok == 0) { *num_blocks = 0; return 1; }
     if (ints[1] > cap) { fail("xm_test_local_align: more blocks than block_cap"); return -1; }

@@ -1405,7 +1405,7 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
 #ifndef XM_HBM_ONLY_FROM
 #define XM_HBM_ONLY_FROM 16
 #endif
-    bool ldsOverflow = e.caps->searchInHbmOnly != 0 || e.caps->scale >= XM_HBM_ONLY_FROM;  // (searchInHbmOnly: the test entry)
+    bool ldsOverflow = e.caps->searchInHbmOnly != 0 || e.caps->scale >= XM_HBM_ONLY_FROM;  // (searchInHbmOnly: the test entry; 2 = in the form of xm_wsearch.h)
     if (!ldsOverflow) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(XM_WAVE_UNIFORM)
     // wave-per-read kernels (xm_wave_kernel.hip): every lane of the wave is on the same search with the same values, so the wave's slot
@@ -1445,7 +1445,7 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
     } else
 #endif
     if (ldsOverflow) {
-      if (e.caps->scale >= wideSearchFrom() && !e.caps->searchInHbmOnly) found = pathSearchW(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb);
+      if ((e.caps->scale >= wideSearchFrom() && !e.caps->searchInHbmOnly) || e.caps->searchInHbmOnly == 2) found = pathSearchW(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb);
       else found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, xmPairMode());
     }
   }

@@ -35,6 +35,16 @@ def se_batch(reads):
     return oracle_lib.QueryBatch.from_arrays(mc, mo, ml, np.ascontiguousarray(reads.reshape(-1)), np.zeros(nq), np.ones(nq))
 
 
+def ragged_se_batch(reads):
+    """single reads of different lengths (a list of code arrays)"""
+    nq = len(reads)
+    lens = np.array([len(r) for r in reads], np.int64)
+    mc = np.ones(nq, np.int32)
+    mo = np.zeros(2 * nq, np.int64); mo[0::2] = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    ml = np.zeros(2 * nq, np.int32); ml[0::2] = lens
+    return oracle_lib.QueryBatch.from_arrays(mc, mo, ml, np.ascontiguousarray(np.concatenate(reads)), np.zeros(nq), np.ones(nq))
+
+
 def pe_batch(m1, m2, expected=100.0, dev=50.0):
     nq, L = m1.shape
     codes = np.ascontiguousarray(np.concatenate([m1, m2], axis=1).reshape(-1))

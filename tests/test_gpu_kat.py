@@ -1,7 +1,7 @@
 """GPU tier of the reference's component-level known-answer tests (tests/golden/kat_reference.json "local_cases"): the three
 PathAligner_Test triples (T/PathAligner_Test.java:10-39) and the four HashBlockAligner_Test triples (T/HashBlockAligner_Test.java:10-48)
 through the DEVICE code of the align kernels - the lane-per-read search in the wave's LDS slot and in HBM mode, the wave-cooperative
-search with both capacity sets, and hashBlockAlign with its searches slot-first and HBM-only - via the test-only entry xm_test_local_align.
+search with both capacity sets, the lane-private form of xm_wsearch.h, and hashBlockAlign with its searches slot-first, HBM-only and lane-private - via the test-only entry xm_test_local_align.
 Asserted: aligned text A, aligned text B and the penalty, exactly as the JUnit tests assert them."""
 import ctypes as C
 import numpy as np
@@ -11,8 +11,8 @@ import oracle_lib as o
 from helpers import KAT
 from mapper_amd import api, _capi
 
-CASES = [(c, m) for c in KAT["local_cases"] for m in ((0, 1, 2, 3) if c["chain"] == 0 else (0, 1))]
-MODE_NAMES = {0: "lds-slot", 1: "hbm", 2: "wave-search", 3: "wave-search-inline-capacities"}
+CASES = [(c, m) for c in KAT["local_cases"] for m in ((0, 1, 2, 3, 4) if c["chain"] == 0 else (0, 1, 4))]
+MODE_NAMES = {0: "lds-slot", 1: "hbm", 2: "wave-search", 3: "wave-search-inline-capacities", 4: "lane-private"}
 
 
 def local_align(chain, mode, query, reference, params, max_ins, max_del):
@@ -53,7 +53,7 @@ def test_local_aligner_cases_on_the_gpu(case, mode):
 
 @pytest.mark.gpu
 def test_search_forms_put_the_same_nodes():
-    """The four forms of the search are the same best-first search: they put the same number of nodes (PathAligner.java:446-473) on every
+    """The five forms of the search are the same best-first search: they put the same number of nodes (PathAligner.java:446-473) on every
     PathAligner case, and on random texts with an indel they agree on blocks, penalty and node count."""
     rng = np.random.default_rng(7)
     cases = [(c["query"], c["reference"], c["params"], c["penalty"]) for c in KAT["local_cases"] if c["chain"] == 0]
@@ -65,8 +65,8 @@ def test_search_forms_put_the_same_nodes():
         q = ref[2:cut] + ref[cut + int(rng.integers(1, 4)):n]
         cases.append((q, ref, base, 8.0))
     for q, r, prm, pen in cases:
-        res = [local_align(0, m, q, r, prm, pen, pen) for m in (0, 1, 2, 3)]
+        res = [local_align(0, m, q, r, prm, pen, pen) for m in (0, 1, 2, 3, 4)]
         assert all((x is None) == (res[0] is None) for x in res)
         if res[0] is not None:
             assert all(x[:3] == res[0][:3] for x in res), (q, r, res)
-            assert res[2][3] == res[3][3] and res[0][3] == res[1][3] == res[2][3], (q, r, [x[3] for x in res])
+            assert res[2][3] == res[3][3] and res[0][3] == res[1][3] == res[2][3] == res[4][3], (q, r, [x[3] for x in res])

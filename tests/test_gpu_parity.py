@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as o
-from helpers import KAT, streams_equal, first_difference, se_batch, pe_batch, check_align_case, sam_text, sprinkle_ambiguity, ambiguous_reference
+from helpers import KAT, streams_equal, first_difference, se_batch, ragged_se_batch, pe_batch, check_align_case, sam_text, sprinkle_ambiguity, ambiguous_reference
 from mapper_amd import api, synth
 
 pytestmark = pytest.mark.gpu
@@ -171,6 +171,28 @@ def test_long_reads_sharing_waves_on_gpu(env, monkeypatch):
     db = api.ReferenceDatabase([("r", ref)], max_query_length=1000)
     got, _ = gpu_align(db, b)
     assert streams_equal(got, want), first_difference(got, want, len(reads))
+    db.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"XM_CONF_SEED": "0"}, {"XM_CONF_SEED": "300"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_many_read_lengths_one_batch_on_gpu(env, monkeypatch):
+    """A batch in which every read has its own length (36 ... 700: several hundred distinct (penalty, length) families for the confidence-length table the
+    host keeps for the kernels, xm_capi.hip confPrepare) - with the table seeded as in the product, not seeded at all (every key comes in through the reads that
+    missed it and run again), and seeded for a few lengths only; then the same lengths again in a second batch (nothing left to seed).  The oracle's streams."""
+    ref = synth.synthetic_reference(300_000, seed=51)
+    rng = np.random.default_rng(52)
+    lens = rng.permutation(np.arange(36, 700))[:420]
+    reads = []
+    for i, L in enumerate(lens):
+        reads.append(synth.synthetic_single_end(ref, 1, read_len=int(L), sub_rate=0.02, indel_prob=0.3, seed=1000 + i)[0][0])
+    b = ragged_se_batch(reads)
+    want = o.OracleReference([("r", ref)]).align(b, o.make_params(), threads=os.cpu_count())
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    db = api.ReferenceDatabase([("r", ref)], max_query_length=700)
+    for _ in range(2):
+        got, _ = gpu_align(db, b)
+        assert streams_equal(got, want), first_difference(got, want, len(reads))
     db.close()
 
 
