@@ -11,7 +11,8 @@ The steps of a rank are dealt to --contexts contexts of its GPU (default 2; xm_c
 and tables in HBM - and each has its own resident copy of the batch, host thread, stream and share of the scratch) that align at the
 same time - how the product aligns a stream of batches (`python -m mapper_amd --contexts N`, mapper_amd/multi.py): the wave slots one
 context's gapped pass leaves idle (its tail, the host gaps between its passes, its result copy) are filled by the other's passes,
-+15-18 % reads/s (two, three and four contexts measure the same within 3 %: profiles/r03/NOTES.md).  At N=1 the line also carries
++15-18 % reads/s (configs[1]: three and four contexts measure the same or less; a workload whose passes end in a long tail - --config 1rep -
+gains up to five contexts, given hardware queues for them: GPU_MAX_HW_QUEUES, profiles/r04/NOTES.md 13).  At N=1 the line also carries
 `single_context`: the same kernel with one launch on the GPU at a time (--contexts 1 makes that the headline).
 
 The line carries `roofline` (algorithmic bytes of SURVEY.md §8(d) per second of align-kernel time, against the 8 TB/s
@@ -23,6 +24,9 @@ import json
 import os
 import sys
 import time
+
+# (before anything initialises the HIP runtime: contexts beyond two need hardware queues of their own, mapper_amd/_capi.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -53,7 +57,7 @@ def main():
     ap.add_argument("--big-scale", type=float, default=1.0, help="testing: the GRCh38-shaped reference of --config 3shape / 4 / 4mild at this fraction of its size (1.0 = the 3.1 Gb of SURVEY.md section 8(d))")
     ap.add_argument("--share-dir", default=None, help="--gpus N with --config 3shape / 4 / 4mild: where rank 0 leaves the synthetic reference (memory-mapped by the other ranks) and the index "
                     "it built (xm_index_save; the other ranks xm_index_load it): one generation and one hashing per node instead of N (default: a directory under the system's temporary directory named after MASTER_PORT)")
-    ap.add_argument("--contexts", type=int, default=2, help="contexts per GPU: the steps are dealt to this many contexts of the GPU (xm_context_new: they share the index) that align their resident batches at the same time (1: one launch at a time)")
+    ap.add_argument("--contexts", type=int, default=None, help="contexts per GPU (default 2; --config 1rep: 4): the steps are dealt to this many contexts of the GPU (xm_context_new: they share the index) that align their resident batches at the same time (1: one launch at a time)")
     ap.add_argument("--single-context-steps", type=int, default=3, help="steps of the one-launch-at-a-time measurement beside the headline at N=1 (0 = skip)")
     ap.add_argument("--wave-steps", type=int, default=2, help="steps of the opt-in wave-per-read form (XM_WAVE=1) measured beside the headline (0 = skip)")
     args = ap.parse_args()
@@ -218,6 +222,9 @@ def main():
     index_build_s = time.time() - t0
     # One context at a time first (at N=1, when the headline uses several): the kernel's own numbers, one launch on the GPU at a time
     single = None
+    if args.contexts is None:
+        # a pass of the repeat-rich workload ends with a long tail of few heavy reads (a quarter of its wave slots busy on average): more contexts fill it
+        args.contexts = 4 if args.config == "1rep" else 2
     n_ctx = max(1, args.contexts)
     scratch_each = None
     if n_ctx > 1 and world == 1 and args.single_context_steps > 0:

@@ -94,6 +94,10 @@ def lib():
             # (and a half-built library must never be picked up silently); __graft_entry__.build() or `make -C mapper_amd/csrc` builds it
             raise ImportError("%s is missing: build it first (python -c 'import __graft_entry__ as g; g.build()' or make -j8 -C mapper_amd/csrc); "
                               "mapper_amd has no CPU fallback" % path)
+        # The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4); every context has a compute and a copy stream, so with
+        # more than two contexts launches of different contexts would share a queue and run one after the other (repeat-rich reads, four contexts: 1.5 -> 2.2 M
+        # reads/s with 8 queues, profiles/r04/NOTES.md 13).  Read when the runtime initialises: only a default, and without effect in a process that already has.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = C.CDLL(path)  # (XM_LIB_PATH: A/B experiments with another build of the same library)
         L.xm_last_error.restype = C.c_char_p
         L.xm_build_stamp.restype = C.c_char_p

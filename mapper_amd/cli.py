@@ -265,8 +265,9 @@ def run(argv, out=sys.stdout):
     batch_size = o.get("batch_size") or 1_000_000
     contexts = o.get("contexts")
     if contexts is None:
-        # a job of several batches: two contexts per GPU align their batches at the same time (+15-18 % reads per second on MI355X; more
-        # contexts add nothing: profiles/r03/NOTES.md).  Contexts share the index (xm_context_new), so a genome-sized one is no obstacle; they
+        # a job of several batches: two contexts per GPU align their batches at the same time (+15-18 % reads per second on MI355X; on reads
+        # from i.i.d. references more contexts add nothing, profiles/r03/NOTES.md; on a repeat-rich reference, whose passes end with a long tail of
+        # few heavy reads, `--contexts 4` gives 1.45x over two, profiles/r04/NOTES.md 13).  Contexts share the index (xm_context_new), so a genome-sized one is no obstacle; they
         # divide the HBM that is free once it is resident, and a GPU with room for fewer contexts uses fewer (api.divide_scratch)
         n_batches = (len(queries) + batch_size - 1) // batch_size
         contexts = 2 if devices is None and n_batches >= 2 else 1

@@ -19,6 +19,7 @@ fi
 if [ $WHAT = all ] || [ $WHAT = prof ]; then
 export XM_LIB_PATH=$R/mapper_amd/_lib_prof/libxmapper_hip.so
 for m in 1 0; do XM_SCHED=$m XM_PROFILE_JSON=$O/sched_profile_$m.json timeout 600 python3 scripts/gpu_sched_prof_r04.py 1 > $O/sched_prof_$m.log 2>&1; done
+XM_TRACE_PASSES=1 XM_PROFILE_JSON=$O/sched_profile_rep.json timeout 600 python3 scripts/gpu_sched_prof_r04.py rep > $O/sched_prof_rep.log 2>&1
 unset XM_LIB_PATH
 fi
 if [ $WHAT = all ] || [ $WHAT = pmc ]; then
@@ -34,8 +35,8 @@ for c in 2 4shape; do
 done
 cd $R
 python3 scripts/pmc_summary.py $O > $O/pmc_summary.json
-python3 scripts/pmc_summary.py $O _config2 > $O/pmc_config2.json
-python3 scripts/pmc_summary.py $O _config4shape > $O/pmc_config4shape.json
+python3 scripts/pmc_by_grid.py $O _config2 > $O/pmc_config2.json
+python3 scripts/pmc_by_grid.py $O _config4shape > $O/pmc_config4shape.json
 fi
 ls $O | head -60
 cut -c1-1200 $O/bench_line.json

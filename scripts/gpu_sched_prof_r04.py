@@ -1,12 +1,12 @@
 """GPU experiment (round 4): the scheduler kernel's phase timers (a library built with -DXM_PROFILE=2: XM_LIB_PATH) on the bench batch.
-usage: gpu_sched_prof_r04.py [config 1|2] [nq]"""
+usage: gpu_sched_prof_r04.py [config 1|2|rep] [nq]   (rep: configs[1]'s reads on synth.repeat_rich_reference)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mapper_amd import api, synth, _capi
 cfg = sys.argv[1] if len(sys.argv) > 1 else "1"
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
-ref = synth.synthetic_reference(5_000_000, seed=0xEC011)
+ref = synth.repeat_rich_reference(5_000_000) if cfg == "rep" else synth.synthetic_reference(5_000_000, seed=0xEC011)
 if cfg == "2":
     m1, m2 = synth.synthetic_paired_end(ref, nq, read_len=150, seed=0x5EED0002)[:2]
     L = 150
