@@ -447,3 +447,15 @@ def test_kernel_logic_random_configurations(sched, monkeypatch):
     import gpu_fuzz
     monkeypatch.setenv("XMSIM_SCHED", sched)
     assert gpu_fuzz.run(rounds=6, seed=77, max_queries=1500, backend="sim") == 0
+
+
+@pytest.mark.parametrize("sched", ["0", "1"])
+def test_kernel_logic_random_shapes(sched, monkeypatch):
+    """The second flavour of the fuzz (gpu_fuzz.run_shapes): several contigs with reads across their ends, a length per read inside one batch (long reads among
+    them: chains at the long-read scales), mates of unequal length, pairs and single reads mixed - through the host simulation, equal to the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import gpu_fuzz
+    monkeypatch.setenv("XMSIM_SCHED", sched)
+    monkeypatch.setenv("XMSIM_SCHED_LONG", sched)
+    assert gpu_fuzz.run_shapes(rounds=3, seed=99, max_queries=700, backend="sim") == 0

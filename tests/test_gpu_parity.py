@@ -204,6 +204,17 @@ def test_random_configurations_on_gpu():
     assert gpu_fuzz.run(rounds=8, seed=77, max_queries=1500) == 0
 
 
+@pytest.mark.parametrize("env", [{}, {"XM_SCHED": "1", "XM_SCHED_LONG": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_random_shapes_on_gpu(env, monkeypatch):
+    """Second flavour of the fuzz (gpu_fuzz.run_shapes): several contigs with reads across their ends, a length per read inside one batch (36 ... 450; every third
+    round 300 ... 1 600: chains at the long-read scales, searches in the form of xm_wsearch.h), mates of unequal length, pairs and single reads mixed."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gpu_fuzz
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    assert gpu_fuzz.run_shapes(rounds=9, seed=99, max_queries=1500) == 0
+
+
 def test_edge_cases_on_gpu():
     rng = np.random.default_rng(3)
     c0 = synth.synthetic_reference(60_000, seed=11)
