@@ -174,6 +174,8 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
     } else {
       runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed, memo, deferPath != 0);
     }
+    XM_PAIR_CHECK(0, cx.status);
+    XM_PAIR_CHECK(1, ((long long)rr.nComponents << 40) ^ ((long long)rr.single[0] << 20) ^ (long long)rr.empty[0] ^ ((long long)local.pathAlignerNodes << 4));
     int32_t st = cx.status;
 #ifdef XM_READ_TIMES
     if (xm_read_times && !second) xm_read_times[q] = clock64() - readT0;
@@ -1866,6 +1868,15 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       const bool tracePasses = envInt("XM_TRACE_PASSES", 0) != 0;
       if (tracePasses) fprintf(stderr, "[xm] pass %d: %s reads %lld scale %d lpw %d waves %lld: %.3f ms -> heavy %llu path %llu scale %llu out %llu\n", launches, !heavy ? "light" : (defer ? "chain" : "inline"),
                                nTodo, scale, lpw, nWaves, ms, ctl.nHeavy, ctl.nPath[tp], ctl.nScale[ts], ctl.nOut[to]);
+#ifdef XM_PROFILE
+      if (tracePasses && heavy) {  // reads of a wave that stood at a PathAligner call together, this pass
+        unsigned long long a[16] = {0}, z[16] = {0};
+        HIP_CHECK(hipMemcpyFromSymbol(a, HIP_SYMBOL(xm_arrive_prof), sizeof(a)));
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(xm_arrive_prof), z, sizeof(z)));
+        fprintf(stderr, "[xm] pass %d: pair checks (status, result, search problem, search outcome): %llu %llu %llu %llu\n", launches, a[4], a[5], a[6], a[7]);
+        fprintf(stderr, "[xm] pass %d: PathAligner arrivals %llu with %llu reads (%.2f per arrival); arrivals of four reads or more: %llu with %llu reads\n", launches, a[0], a[1], a[0] ? (double)a[1] / (double)a[0] : 0.0, a[2], a[3]);
+      }
+#endif
       if (ctl.errQuery != ~0ull) {
         int32_t code = 0;
         HIP_CHECK(hipMemcpy(&code, idx->dStatus.p + ctl.errQuery, sizeof(code), hipMemcpyDeviceToHost));

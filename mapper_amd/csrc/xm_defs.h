@@ -322,6 +322,9 @@ struct Arena {
 #if defined(XM_ARENA_TRACE) && !defined(__HIPCC__)
     xm_arena_trace(base, a, bytes);
 #endif
+#ifdef XM_ARENA_POISON  // diagnostic builds: whatever is allocated starts as garbage (nothing may read arena memory it has not written)
+    for (size_t i_ = 0; i_ < bytes; i_++) base[a + i_] = 0xA5;
+#endif
     return base + a;
   }
 };

@@ -1342,6 +1342,17 @@ XM_NOINL_DECL bool pathSearchW(const PaProblem& pr, Arena& tmp, const Caps& caps
 #if defined(__HIPCC__)
 __device__ int xm_wide_search_from = 16;
 #endif
+#if defined(__HIPCC__) && defined(XM_PROFILE)
+// profile builds: how many reads of a wave stand at a PathAligner call together ([0] arrivals, [1] reads in them, [2] arrivals of four reads or more, [3] reads in those)
+__device__ unsigned long long xm_arrive_prof[16];
+// (diagnostic) pair mode: the two lanes of a read must hold the same value wherever they stand together; [4 + k]: times they did not at check point k
+#define XM_PAIR_CHECK(k, v) do { if (xmPairMode()) { const long long v_ = (long long)(v); const int lo_ = __shfl_xor((int)v_, 1), hi_ = __shfl_xor((int)(v_ >> 32), 1); \
+  if (lo_ != (int)v_ || hi_ != (int)(v_ >> 32)) atomicAdd(&xm_arrive_prof[4 + (k)], 1ull); } } while (0)
+#endif
+#if !(defined(__HIP_DEVICE_COMPILE__) && defined(XM_PROFILE))
+#undef XM_PAIR_CHECK
+#define XM_PAIR_CHECK(k, v) do { } while (0)
+#endif
 XM_INL int wideSearchFrom() {
 #if defined(__HIP_DEVICE_COMPILE__)
   return xm_wide_search_from;
@@ -1405,6 +1416,7 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
 #ifndef XM_HBM_ONLY_FROM
 #define XM_HBM_ONLY_FROM 16
 #endif
+    XM_PAIR_CHECK(2, ((long long)qs.start << 32) ^ (long long)rs.start ^ ((long long)qs.end << 16) ^ ((long long)rs.end << 48));
     bool ldsOverflow = e.caps->searchInHbmOnly != 0 || e.caps->scale >= XM_HBM_ONLY_FROM;  // (searchInHbmOnly: the test entry; 2 = in the form of xm_wsearch.h)
     if (!ldsOverflow) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(XM_WAVE_UNIFORM)
@@ -1414,6 +1426,13 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
 #elif defined(__HIP_DEVICE_COMPILE__)
     unsigned long long pending = __ballot(1);
     const int lane = (int)__lane_id();
+#ifdef XM_PROFILE
+    if (lane == __ffsll((long long)pending) - 1) {
+      const unsigned long long reads = (unsigned long long)(xmPairMode() ? (__popcll(pending) + 1) / 2 : __popcll(pending));
+      atomicAdd(&xm_arrive_prof[0], 1ull); atomicAdd(&xm_arrive_prof[1], reads);
+      if (reads >= 4) { atomicAdd(&xm_arrive_prof[2], 1ull); atomicAdd(&xm_arrive_prof[3], reads); }
+    }
+#endif
     if (xmPairMode()) {  // the two lanes of a read take the slot together
       while (pending) {
         const int leader = (__ffsll((long long)pending) - 1) & ~1;
@@ -1449,6 +1468,7 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
       else found = pathSearchHbm(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, xmPairMode());
     }
   }
+  XM_PAIR_CHECK(3, ((long long)(found ? 1 : 0) << 40) ^ ((long long)*e.status << 20) ^ (long long)nb);
   if (!found || *e.status) return false;
   out.nb = nb;
   finishSeqAl(e, p, out, e.query.rc != 0);

@@ -14,7 +14,7 @@ timeout 900 python3 bench.py > $O/bench_full.log 2>&1
 tail -n 1 $O/bench_full.log > $O/bench_line.json
 timeout 600 python3 bench.py --config 2 --seed-probes 0 --steps 9 --stream-batches 10 2> $O/bench_config2.err | tail -n 1 > $O/bench_config2.json
 timeout 600 python3 bench.py --config 4shape --seed-probes 0 --steps 6 2> $O/bench_config4shape.err | tail -n 1 > $O/bench_config4shape.json
-timeout 900 python3 bench.py --config 1rep --seed-probes 0 --steps 6 --wave-steps 0 2> $O/bench_config1rep.err | tail -n 1 > $O/bench_config1rep.json
+timeout 900 python3 bench.py --config 1rep --seed-probes 0 --steps 12 --wave-steps 0 2> $O/bench_config1rep.err | tail -n 1 > $O/bench_config1rep.json
 fi
 if [ $WHAT = all ] || [ $WHAT = prof ]; then
 export XM_LIB_PATH=$R/mapper_amd/_lib_prof/libxmapper_hip.so
