@@ -13,16 +13,20 @@ OUT = os.path.join(ROOT, "tests", "_build", "libxm_hostsim.so")
 
 
 def build():
+    """XMSIM_POISON=1 (read when the library is first loaded): the variant built with -DXM_ARENA_POISON - every arena allocation starts as garbage, so a structure
+    that is read before it is written (on the GPU: a result that depends on which read used the lane before) shows up as a difference from the oracle."""
+    poison = os.environ.get("XMSIM_POISON") == "1"
+    out = OUT.replace(".so", "_poison.so") if poison else OUT
     deps = [SRC] + [os.path.join(ROOT, "mapper_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "mapper_amd", "csrc")) if f.endswith(".h")]
     import fcntl
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    with open(OUT + ".lock", "w") as lock:  # (pytest-xdist workers build side by side)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out + ".lock", "w") as lock:  # (pytest-xdist workers build side by side)
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
-            subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
-                                   "-o", OUT + ".tmp", SRC])
-            os.replace(OUT + ".tmp", OUT)
-    return OUT
+        if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+            subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"] +
+                                  (["-DXM_ARENA_POISON"] if poison else []) + ["-o", out + ".tmp", SRC])
+            os.replace(out + ".tmp", out)
+    return out
 
 
 _lib = None

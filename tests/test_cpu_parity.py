@@ -459,3 +459,35 @@ def test_kernel_logic_random_shapes(sched, monkeypatch):
     monkeypatch.setenv("XMSIM_SCHED", sched)
     monkeypatch.setenv("XMSIM_SCHED_LONG", sched)
     assert gpu_fuzz.run_shapes(rounds=3, seed=99, max_queries=700, backend="sim") == 0
+
+
+def test_kernel_logic_reads_no_arena_memory_it_has_not_written():
+    """The host simulation built with -DXM_ARENA_POISON (every arena allocation filled with 0xA5 first: hostsim_lib.build, XMSIM_POISON=1) on reads, pairs and long
+    reads, lane-per-read passes and the wave scheduler: equal to the oracle, i.e. no structure in a lane's region or temporaries is read before it is written - on the
+    GPU, where a lane's arena holds what the lane's previous read left, such a read would make a result depend on the lane's history (profiles/r04/NOTES.md 14)."""
+    import subprocess, sys
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import oracle_lib as o, hostsim_lib
+from helpers import se_batch, pe_batch, streams_equal
+from mapper_amd import synth
+assert hostsim_lib.build().endswith("_poison.so")
+ref = synth.synthetic_reference(400_000, seed=0xEC011)
+R = o.OracleReference([("e", ref)])
+for sched in ("0", "1"):
+    os.environ["XMSIM_SCHED"] = sched; os.environ["XMSIM_SCHED_LONG"] = sched
+    S = hostsim_lib.SimReference([("e", ref)])
+    b = se_batch(synth.synthetic_single_end(ref, 4000, read_len=150, seed=11, sub_rate=0.02, indel_prob=0.4)[0])
+    assert streams_equal(S.align(b, o.make_params()), R.align(b, o.make_params(), threads=8))
+    m1, m2 = synth.synthetic_paired_end(ref, 1500, read_len=150, seed=12, sub_rate=0.02, indel_prob=0.3)[:2]
+    pb = pe_batch(m1, m2)
+    assert streams_equal(S.align(pb, o.make_params()), R.align(pb, o.make_params(), threads=8))
+    lb = se_batch(synth.synthetic_single_end(ref, 120, read_len=1000, seed=13, sub_rate=0.02, indel_prob=0.5)[0])
+    assert streams_equal(S.align(lb, o.make_params()), R.align(lb, o.make_params(), threads=8))
+print("poison ok")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, XMSIM_POISON="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "poison ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
