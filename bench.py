@@ -7,7 +7,7 @@ host and their ordering) over one batch of synthetic input that is already resid
 With --gpus N each rank owns one GPU, holds a replica of the index and aligns its own 1 M reads (no collective on the data
 path; scaling = weak).  Rank 0 prints ONE JSON line.
 
-The steps of a rank are dealt to --contexts contexts of its GPU (default 2; xm_context_new: the contexts share the index - host tables
+The steps of a rank are dealt to --contexts contexts of its GPU (default 3 for this config; xm_context_new: the contexts share the index - host tables
 and tables in HBM - and each has its own resident copy of the batch, host thread, stream and share of the scratch) that align at the
 same time - how the product aligns a stream of batches (`python -m mapper_amd --contexts N`, mapper_amd/multi.py): the wave slots one
 context's gapped pass leaves idle (its tail, the host gaps between its passes, its result copy) are filled by the other's passes,
@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--big-scale", type=float, default=1.0, help="testing: the GRCh38-shaped reference of --config 3shape / 4 / 4mild at this fraction of its size (1.0 = the 3.1 Gb of SURVEY.md section 8(d))")
     ap.add_argument("--share-dir", default=None, help="--gpus N with --config 3shape / 4 / 4mild: where rank 0 leaves the synthetic reference (memory-mapped by the other ranks) and the index "
                     "it built (xm_index_save; the other ranks xm_index_load it): one generation and one hashing per node instead of N (default: a directory under the system's temporary directory named after MASTER_PORT)")
-    ap.add_argument("--contexts", type=int, default=None, help="contexts per GPU (default 2; --config 1rep: 4): the steps are dealt to this many contexts of the GPU (xm_context_new: they share the index) that align their resident batches at the same time (1: one launch at a time)")
+    ap.add_argument("--contexts", type=int, default=None, help="contexts per GPU (default: --config 1 three, --config 1rep four, the others two): the steps are dealt to this many contexts of the GPU (xm_context_new: they share the index) that align their resident batches at the same time (1: one launch at a time)")
     ap.add_argument("--single-context-steps", type=int, default=3, help="steps of the one-launch-at-a-time measurement beside the headline at N=1 (0 = skip)")
     ap.add_argument("--wave-steps", type=int, default=2, help="steps of the opt-in wave-per-read form (XM_WAVE=1) measured beside the headline (0 = skip)")
     args = ap.parse_args()
@@ -224,7 +224,9 @@ def main():
     single = None
     if args.contexts is None:
         # a pass of the repeat-rich workload ends with a long tail of few heavy reads (a quarter of its wave slots busy on average): more contexts fill it
-        args.contexts = 4 if args.config == "1rep" else 2
+        # configs[1]: three contexts, each sized for a third of the GPU's wave slots, overlap best (14.1-14.3 M reads/s against 13.1-13.2 with two); pairs and long
+        # reads are within 2 % from two to four (profiles/r04/NOTES.md 13, 15)
+        args.contexts = 4 if args.config == "1rep" else (3 if args.config == "1" else 2)
     n_ctx = max(1, args.contexts)
     scratch_each = None
     if n_ctx > 1 and world == 1 and args.single_context_steps > 0:

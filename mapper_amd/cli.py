@@ -271,6 +271,10 @@ def run(argv, out=sys.stdout):
         # divide the HBM that is free once it is resident, and a GPU with room for fewer contexts uses fewer (api.divide_scratch)
         n_batches = (len(queries) + batch_size - 1) // batch_size
         contexts = 2 if devices is None and n_batches >= 2 else 1
+        # single reads of up to 320 bases in three batches or more: three contexts, each sized for a third of the GPU's wave slots, overlap best (+7 % over
+        # two, profiles/r04/NOTES.md 15; pairs and long reads are within 2 % from two to four contexts)
+        if contexts == 2 and n_batches >= 3 and all(len(q.sequences) == 1 for q, _ in queries) and max(len(s) for q, _ in queries for s in q.sequences) <= 320:
+            contexts = 3
     if contexts > 1:
         devices = [d for d in (devices or [o["device"]]) for _ in range(contexts)]
     max_query_length = max([len(s) for q, _ in queries for s in q.sequences] + [1])

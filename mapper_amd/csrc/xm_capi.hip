@@ -1492,15 +1492,18 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // wave slots a launch is sized for (in waves per SIMD): alone on the GPU a context fills it (4 are resident at 128 registers; the light pass asks
     // for twice that, the second half starts as the first drains).  Contexts that share the GPU (xm_context_new) must leave each other room: a
     // persistent launch that holds every slot keeps the next context's launch waiting until its own tail, and the contexts then run one after the
-    // other instead of side by side - three quarters each is where three contexts measured best (profiles/r02/NOTES.md 15, profiles/r03/NOTES.md)
-    const bool sharedGpu = idx->dt->contexts.load() > 1;
+    // other instead of side by side.  Together the contexts of a GPU ask for 12 waves per SIMD worth of light lanes and 6 of gapped lanes: two contexts 6 / 3
+    // each (round 3), three 4 / 2 - 14.1-14.3 M reads/s against 13.1-13.2 with two, once the runtime has hardware queues for three contexts' streams
+    // (GPU_MAX_HW_QUEUES, mapper_amd/_capi.py); with 6 / 3 each three contexts measured 12.3-12.7, four with 3 / 1 13.5 (profiles/r04/NOTES.md 15)
+    const int gpuContexts = idx->dt->contexts.load();
+    const bool sharedGpu = gpuContexts > 1;
     // Batches of long reads (gapped pass beyond scale 4: every read goes through the chain, and its searches - thousands of nodes each, all in HBM mode -
     // are most of its time): the lanes of a wave run their searches one after the other, so 8 reads per wave on twice as many waves instead of 32
     // (1 kb queries: 382 ms -> 265-280 ms per 150 k; 4 to 8 reads per wave and 8 to 16 waves per SIMD worth of lanes measure the same, profiles/r03/NOTES.md 13)
     const bool longReads = gappedScale > 4;
     // (long reads: every lane of the light pass holds a region of 288 KiB, and every read goes on to the gapped pass, whose lanes are 6.7 MB each:
     // two waves per SIMD worth of light lanes leave the scratch to those)
-    const long long lightWaves = envKnob("XM_LIGHT_WAVES", longReads ? 2 : (sharedGpu ? 6 : 8), 1, 16), fullWaves = envKnob("XM_FULL_WAVES", longReads ? 8 : (sharedGpu ? 3 : 4), 1, 16), pathWaves = envKnob("XM_PATH_WAVES", 4, 1, 16);
+    const long long lightWaves = envKnob("XM_LIGHT_WAVES", longReads ? 2 : (sharedGpu ? std::max(2, 12 / gpuContexts) : 8), 1, 16), fullWaves = envKnob("XM_FULL_WAVES", longReads ? 8 : (sharedGpu ? std::max(1, 6 / gpuContexts) : 4), 1, 16), pathWaves = envKnob("XM_PATH_WAVES", 4, 1, 16);
     const long long fullLpw = envKnob("XM_FULL_LPW", longReads ? 8 : 32, 1, 64), lightLpw = envKnob("XM_LIGHT_LPW", 64, 1, 64);
     const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
     const bool fullSync = envInt("XM_FULL_SYNC", 0) != 0;  // gapped pass: the lanes of a wave take their next reads together (no taper then)

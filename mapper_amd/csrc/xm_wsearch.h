@@ -32,19 +32,19 @@ __device__ unsigned long long xm_ws_prof[8];
 #endif
 #if defined(XM_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 // (accumulated in the lane's registers while it is the wave's lowest active lane; wsRun adds them to the global counters when it returns)
-#define WS_TIC(var) unsigned long long var = clock64()
-#define WS_TOC(slot, var) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long n_ = clock64(); if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) wsAcc[slot] += n_ - var; var = n_; } while (0)
-#define WS_ACC_DECL unsigned long long wsAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define WSP_TIC(var) unsigned long long var = clock64()
+#define WSP_TOC(slot, var) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long n_ = clock64(); if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) wsAcc[slot] += n_ - var; var = n_; } while (0)
+#define WSP_ACC_DECL unsigned long long wsAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define WS_ACC_PARAM , unsigned long long* wsAcc
 #define WS_ACC_ARG , wsAcc
-#define WS_ACC_FLUSH do { for (int i_ = 0; i_ < 8; i_++) if (wsAcc[i_]) atomicAdd(&xm_ws_prof[i_], wsAcc[i_]); } while (0)
+#define WSP_ACC_FLUSH do { for (int i_ = 0; i_ < 8; i_++) if (wsAcc[i_]) atomicAdd(&xm_ws_prof[i_], wsAcc[i_]); } while (0)
 #else
-#define WS_TIC(var) do { } while (0)
-#define WS_TOC(slot, var) do { } while (0)
-#define WS_ACC_DECL do { } while (0)
+#define WSP_TIC(var) do { } while (0)
+#define WSP_TOC(slot, var) do { } while (0)
+#define WSP_ACC_DECL do { } while (0)
 #define WS_ACC_PARAM
 #define WS_ACC_ARG
-#define WS_ACC_FLUSH do { } while (0)
+#define WSP_ACC_FLUSH do { } while (0)
 #endif
 
 struct alignas(16) WCell { double pen, insX, insY; uint16_t x, y; uint8_t fl, pad0; uint16_t pad; };  // 32 bytes = two 16-byte loads
@@ -268,7 +268,7 @@ struct WRun {
     if (x <= 0 || x > textALength) return;
     if (y <= 0 || y > textBLength) return;
     // the four lookups (independent loads) and the six bases the three transitions can look at, together
-    WS_TIC(tU);
+    WSP_TIC(tU);
     WCell nE, nL, nU, nD;
     const int ia = x - 1, ib = y - 1;
     const uint8_t a0 = charA(ia), b0 = charB(ib);
@@ -279,7 +279,7 @@ struct WRun {
     const int sE = probeResolve(x, y, hE, wE, nE);
     const bool left = probeResolve(x - stepDelta, y, hL, wL, nL) >= 0, up = probeResolve(x, y - stepDelta, hU, wU, nU) >= 0, diag = probeResolve(x - stepDelta, y - stepDelta, hD, wD, nD) >= 0;
     const bool existing = sE >= 0;
-    WS_TOC(2, tU);
+    WSP_TOC(2, tU);
     double insertXPenalty = disallowed, insertYPenalty = disallowed, overlayPenalty = disallowed;
     if (diag) overlayPenalty = nD.pen + P.getPenalty(a0, b0);
     if (left) {
@@ -331,11 +331,11 @@ struct WRun {
         else fl = nU.fl;
         if (iabs(signedDist(x, y)) == 0) fl |= 1; else fl |= 2;
       }
-      WS_TOC(3, tU);
+      WSP_TOC(3, tU);
       putNode(x, y, bestPenalty, insertXPenalty, insertYPenalty, fl, sE);
-      WS_TOC(4, tU);
+      WSP_TOC(4, tU);
     } else {
-      WS_TOC(3, tU);
+      WSP_TOC(3, tU);
     }
   }
 };
@@ -433,8 +433,8 @@ XM_NOINL void wsBegin(uint8_t* arena, const PaProblem& prIn, const WSizes& zIn) 
 XM_NOINL bool wsRun(uint8_t* arena, int maxSteps) {
   WSearch* const S = (WSearch*)arena;
   if (S->done) return true;
-  WS_ACC_DECL;
-  WS_TIC(tR);
+  WSP_ACC_DECL;
+  WSP_TIC(tR);
   WRun w;
   const WSizes z = S->z;
   w.bind(arena, z);
@@ -456,7 +456,7 @@ XM_NOINL bool wsRun(uint8_t* arena, int maxSteps) {
   bool haveLast = false, fail = false;
   int lastX = 0, lastY = 0;
   int32_t status = XM_OK;
-  WS_TOC(5, tR);
+  WSP_TOC(5, tR);
   // ONE loop whose every iteration explores one entry (and, in front of it, takes the next bucket when the previous one is exhausted): the searches
   // of a wave run side by side, and a loop nest - buckets outside, their entries inside - would keep the lanes whose bucket is exhausted waiting for
   // the lane with the longest one.
@@ -491,13 +491,13 @@ XM_NOINL bool wsRun(uint8_t* arena, int maxSteps) {
       li = best.head;
       w.actSlot = best.slot; w.actTail = -2;
       if (w.lastSlot == best.slot) { w.actTail = w.lastTail; w.lastSlot = -1; }
-      WS_TOC(0, tR);
+      WSP_TOC(0, tR);
     }
     if (steps >= maxSteps) break;  // suspended in front of entry li
-    WS_TOC(7, tR);
+    WSP_TOC(7, tR);
     const WList e = w.list[li];
     const int x = (int)(int16_t)(uint16_t)(e.xy >> 16), y = (int)(int16_t)(uint16_t)(e.xy & 0xFFFFu);
-    WS_TOC(1, tR);
+    WSP_TOC(1, tR);
     if (w.activePenalty > maxInterestingPenalty + 0.000001) { fail = true; break; }
     if (x == goalX) { haveLast = true; lastX = x; lastY = y; break; }
     w.firstAppendToActive = -1;
@@ -508,14 +508,14 @@ XM_NOINL bool wsRun(uint8_t* arena, int maxSteps) {
     // the entry's successor: what it had when it was read, or - it was the tail then - this step's first put into the active bucket
     li = e.next >= 0 ? e.next : w.firstAppendToActive;
     steps++;
-    WS_TOC(7, tR);
+    WSP_TOC(7, tR);
   }
-  WS_TOC(7, tR);
+  WSP_TOC(7, tR);
   S->nNodes = w.nNodes; S->nCells = w.nCells; S->nBuckets = w.nBuckets; S->nLive = w.nLive;
   S->curPos = w.curPos; S->curSlot = w.actSlot; S->li = li; S->activePenalty = w.activePenalty; S->nodesPut = w.nodesPut;
   S->lastSteps = steps;
-  WS_TOC(5, tR);
-  WS_ACC_FLUSH;
+  WSP_TOC(5, tR);
+  WSP_ACC_FLUSH;
   if (!fail && !haveLast) return false;  // suspended
   S->done = 1;
   S->status = status;
