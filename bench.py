@@ -470,13 +470,14 @@ def main():
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_step": int(alg_bytes), "bytes_per_read": round(alg_bytes / nq, 1),
                          "concurrent_launches": n_ctx, "frac_of_all_concurrent_launches": round(alg_bytes * args.steps / elapsed / 1e9 / 8000.0, 6),
+                         "frac_one_launch_at_a_time": None if not single else round(alg_bytes / (single["kernel_ms_per_step"] * 1e-3) / 1e9 / 8000.0, 6),
                          "kernel_ms_per_step": round(kernel_ms / args.steps, 3), "launches_per_step": launches / args.steps,
                          "result_d2h_ms_per_step": round(d2h_ms / args.steps, 3),
                          "kernel_ms_by_pass": {"light_pass": round(pass_us[0] / args.steps / 1e3, 3), "gapped_and_rerun_passes": round(pass_us[3] / args.steps / 1e3, 3)},
                          "traffic_rate": None if traffic is None else round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1),
                          "note": "achieved/peak/frac: algorithmic bytes of one launch over that launch's duration, against the 8 TB/s stream peak; with several contexts "
                                  "the launches of the contexts share the GPU, so a launch lasts longer than it would alone (single_context has the kernel's numbers with one "
-                                 "launch at a time) and frac_of_all_concurrent_launches is the algorithmic rate of the GPU as a whole.  traffic (PMC) is per-lane scratch in HBM, touched in "
+                                 "launch at a time; frac_one_launch_at_a_time is this fraction from that leg) and frac_of_all_concurrent_launches is the algorithmic rate of the GPU as a whole.  traffic (PMC) is per-lane scratch in HBM, touched in "
                                  "scattered 32-64 B pieces: traffic_rate (GB/s, traffic / average launch duration) is to be read against this GPU's measured "
                                  "random-64-B-sector ceiling (seed_probe.random_64B_gather_ceiling_sectors_per_s x 64 B), not against the stream peak"},
             "contexts": {"per_gpu": n_ctx, "scratch_gib_each": round(scratch_each / 2**30, 1) if n_ctx > 1 else None,
