@@ -1885,7 +1885,6 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         HIP_CHECK(hipMemcpy(&code, idx->dStatus.p + ctl.errQuery, sizeof(code), hipMemcpyDeviceToHost));
         code &= 0xFF;
         std::string q = std::to_string(ctl.errQuery);
-        if (code == XM_ST_AMBIGUOUS) throw std::runtime_error("Failed to align query " + q + ": a mate has more than 128 ambiguous (non-ACGT) bases");
         if (code == XM_ST_NEED_GROW) throw std::runtime_error("Failed to align query " + q + ": gapmer longer than the hashed lengths");
         throw std::runtime_error("Failed to align query " + q + ": the reference implementation would have thrown here (status " + std::to_string(code) + ")");
       }

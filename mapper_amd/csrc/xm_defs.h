@@ -41,7 +41,7 @@ enum : int32_t {
   XM_OK = 0,
   XM_ST_OVERFLOW = 1,      // a fixed-capacity scratch structure overflowed: rerun this read with a larger scale
   XM_ST_OUT_OVERFLOW = 2,  // the result arena overflowed: rerun with a larger result arena
-  XM_ST_AMBIGUOUS = 3,     // a mate has more than 128 ambiguous (non-ACGT) bases: beyond what the MultiHashBlock representation here holds
+                           // (3 is not in use: reads may hold any number of ambiguous bases)
   XM_ST_NEED_GROW = 4,     // a gapmer uses more bases than the largest hashed length (host must grow the index)
   XM_ST_INTERNAL = 5,      // the reference would have thrown (e.g. TreeMap.subMap fromKey > toKey): whole batch fails
   XM_ST_NEED_HEAVY = 6,    // light pass only: the read needs the gapped extension chain; the full pass reruns it

@@ -210,45 +210,58 @@ XM_INL int withGapAndExtension(const B& b, const SeqView& seq, QBlock& out) {
 // A block that covers an ambiguous base is a list of possibilities, each either a HashBlock or "no block", under a condition
 // (position -> base).  The walk never probes such a block (HashBlockPath.skipMultiblocks) but it has to know where they are, and
 // whether one exists depends on the full expansion, so the rule is restated as written.  Only reads that contain a non-ACGT base
-// take this path; it keeps the possibilities in a pool in the lane's arena.
+// take this path.  Like the reference, it bounds the combinations per block (64) and nothing else: a mate may consist of ambiguous bases
+// only.  Everything it keeps - possibilities, conditions, the expansion's stack - is in pools of the read's arena whose capacities follow
+// the scratch scale, so a read that outgrows them is run again with more scratch like any other (XM_ST_OVERFLOW).
 constexpr uint8_t F_MULTI = 0x80;   // PBlock::flags of a stored multi block: fwd = first possibility in the pool, rev = their number
 constexpr int XM_MAX_COMBINATIONS = 64;  // HashBlock_ParentRow.maxNumCombinationsToExpand
-constexpr int XM_MAX_AMBIGUOUS = 128;    // ambiguous bases per mate this representation holds
-// SequenceCondition: a set of (position -> base) constraints.  Its only operation is intersect (:22-94): null if the two sets disagree
-// on a position, else their union (the reference returns the larger operand when one contains the other, which is the union too).
-// A position is identified by its rank among the mate's ambiguous bases, so a condition is three bit sets: which ranks are
-// constrained, and the two bits of the base (A C G T = 0 1 2 3) for each.
-struct Cond {
-  uint64_t mask[2], lo[2], hi[2];
-  XM_INL void clear() { mask[0] = mask[1] = lo[0] = lo[1] = hi[0] = hi[1] = 0; }
-  XM_INL void setOnly(int rank, int base) {
-    clear();
-    const int w = rank >> 6;
-    const uint64_t bit = 1ull << (rank & 63);
-    mask[w] = bit;
-    if (base & 1) lo[w] = bit;
-    if (base & 2) hi[w] = bit;
-  }
-};
+// SequenceCondition: (position -> base) constraints, ascending by position.  Its only operation is intersect (:27-106): null if the two
+// disagree on a position, else their union (the reference returns an operand when it contains the other, which is the union too).
+// An entry is (position << 2) | base with A C G T = 0 1 2 3; a condition is a run of entries in a pool.
+typedef uint32_t CondEnt;
 struct Poss {  // ConditionalHashBlock
   PBlock block;
-  Cond cond;
+  int32_t condOff, condLen;  // MultiStore::conds[condOff .. condOff + condLen)
+  int32_t hasBlock, pad;
+};
+struct PossView {  // a possibility as expand() reads it: of a stored multi block, of an ambiguous base (its one entry is `own`) or of a single block (no condition)
+  PBlock block;
+  const CondEnt* cond; int32_t condLen;
   int32_t hasBlock;
+  CondEnt own;
 };
-XM_INL bool condIntersect(const Cond& a, const Cond& b, Cond& out) {  // false = conflict (Java null)
-  for (int w = 0; w < 2; w++) {
-    const uint64_t common = a.mask[w] & b.mask[w];
-    if (common & ((a.lo[w] ^ b.lo[w]) | (a.hi[w] ^ b.hi[w]))) return false;
+// a.intersect(b) into out[0 .. cap): the length of the union, -1 = conflict (Java null), -2 = no room
+XM_INL int condIntersect(const CondEnt* a, int na, const CondEnt* b, int nb, CondEnt* out, int cap) {
+  int i = 0, j = 0, w = 0;
+  while (i < na || j < nb) {
+    CondEnt v;
+    if (j >= nb || (i < na && (a[i] >> 2) < (b[j] >> 2))) v = a[i++];
+    else if (i >= na || (b[j] >> 2) < (a[i] >> 2)) v = b[j++];
+    else { if (a[i] != b[j]) return -1; v = a[i]; i++; j++; }
+    if (w < cap) out[w] = v;
+    w++;
   }
-  for (int w = 0; w < 2; w++) { out.mask[w] = a.mask[w] | b.mask[w]; out.lo[w] = a.lo[w] | b.lo[w]; out.hi[w] = a.hi[w] | b.hi[w]; }
-  return true;
+  return w <= cap ? w : -2;  // (a conflict behind the point where the room ended is still reported as a conflict)
 }
+struct MFrame { int32_t j, opt, condOff, condLen, found; };  // one activation of expand(): block index, next possibility, its startingCondition in MultiStore::stack
 struct MultiStore {
-  int16_t* ambPos; int32_t nAmb;  // positions of the mate's ambiguous bases, ascending (rank = index)
-  Poss* pool; int32_t poolUsed, poolCap;
-  Poss* options;  // mergeOptions of the block being made: up to XM_MAX_COMBINATIONS + 1 from expand + one per left option
-  int32_t optionsCap;
+  Poss* pool; int32_t poolUsed, poolCap;        // possibilities of the stored multi blocks; the mergeOptions of the block being made sit behind poolUsed until they are kept or dropped
+  CondEnt* conds; int32_t condUsed, condCap;    // their conditions, same discipline
+  CondEnt* stack; int32_t stackCap;             // startingConditions of the active expand() calls, one behind the other
+  MFrame* frames; int32_t framesCap;
 };
+// Capacities at a scratch scale.  The fixed part is what the block being made can ask for whatever the scale (64 + 1 options from expand() + one per left
+// possibility, and their conditions); the part that follows the scale is what is kept.  Sized so that the two mates of a pair, both with ambiguous bases,
+// fit a read's region from scale 4 on beside the rest of the seeding state (at scale 1 a single read does).
+struct MultiCaps { int32_t pool, conds, stack, frames; };
+XM_INL MultiCaps multiCaps(int scale) {
+  MultiCaps c;
+  c.pool = 160 * scale + 2 * XM_MAX_COMBINATIONS + 8;
+  c.conds = 640 * scale + 1024;
+  c.stack = 128 * scale + 256;
+  c.frames = 8 * scale + 24;
+  return c;
+}
 
 struct Pyramid {
   SeqView seq;
@@ -279,10 +292,13 @@ struct Pyramid {
     if (level > 0) return e.rev;
     return bpPop(seq.at(e.start));
   }
-  XM_INL Poss possAt(int level, const PBlock& e, int k) const {  // getPossibilities()[k]
-    Poss p;
-    if (!(e.flags & F_MULTI)) { p.block = e; p.cond.clear(); p.hasBlock = 1; return p; }  // (this, ALWAYS), M/HashBlock.java:352-356
-    if (level > 0) return ms->pool[e.fwd + k];
+  XM_INL void possAt(int level, const PBlock& e, int k, PossView& p) const {  // getPossibilities()[k]
+    if (!(e.flags & F_MULTI)) { p.block = e; p.cond = &p.own; p.condLen = 0; p.hasBlock = 1; return; }  // (this, ALWAYS), M/HashBlock.java:352-356
+    if (level > 0) {
+      const Poss& s = ms->pool[e.fwd + k];
+      p.block = s.block; p.cond = ms->conds + s.condOff; p.condLen = s.condLen; p.hasBlock = s.hasBlock;
+      return;
+    }
     uint8_t code = seq.at(e.start);  // HashBlock_BaseRow.get: one possibility per base the code can stand for, in A C G T order
     int seen = 0;
     uint8_t option = 1;
@@ -291,42 +307,52 @@ struct Pyramid {
       if (code & o) { if (seen == k) { option = o; break; } seen++; }
     }
     p.block = level0Block(option, e.start);
-    int lo = 0, hi = ms->nAmb - 1;  // rank of this position
-    while (lo < hi) { int mid = (lo + hi) >> 1; if ((int)ms->ambPos[mid] < (int)e.start) lo = mid + 1; else hi = mid; }
-    p.cond.setOnly(lo, option == 1 ? 0 : option == 2 ? 1 : option == 4 ? 2 : 3);
+    p.own = ((CondEnt)e.start << 2) | (CondEnt)(option == 1 ? 0 : option == 2 ? 1 : option == 4 ? 2 : 3);
+    p.cond = &p.own; p.condLen = 1;
     p.hasBlock = 1;
-    return p;
+  }
+  // one more mergeOption behind the pool's kept possibilities; false = no room
+  XM_INL bool multiAddOption(int& nOpt, int& nOptCond, const PBlock& block, bool hasBlock, const CondEnt* cond, int condLen) {
+    if (ms->poolUsed + nOpt >= ms->poolCap || ms->condUsed + nOptCond + condLen > ms->condCap) return false;
+    Poss& o = ms->pool[ms->poolUsed + nOpt];
+    o.block = block; o.hasBlock = hasBlock ? 1 : 0; o.pad = 0;
+    o.condOff = ms->condUsed + nOptCond; o.condLen = condLen;
+    for (int t = 0; t < condLen; t++) ms->conds[o.condOff + t] = cond[t];
+    nOpt++; nOptCond += condLen;
+    return true;
   }
   // HashBlock_ParentRow.expand :137-191 for one left possibility; the recursion (a right possibility without a block passes the search
-  // on to the block after it) runs on an explicit stack.  false = capacity exceeded
-  XM_INL bool multiExpand(int prev, int n, const PBlock& leftBlock, const Cond& leftCond, int i, int& nOpt) {
-    struct Frame { int32_t j, opt; Cond cond; bool found; };
-    Frame st[24];
+  // on to the block after it) runs on an explicit stack in the read's arena.  false = a capacity exceeded
+  XM_INL bool multiExpand(int prev, int n, const PBlock& leftBlock, const CondEnt* leftCond, int leftCondLen, int i, int& nOpt, int& nOptCond) {
+    MFrame* const st = ms->frames;
+    CondEnt* const sc = ms->stack;
+    if (leftCondLen > ms->stackCap || ms->framesCap < 1) return false;
+    for (int t = 0; t < leftCondLen; t++) sc[t] = leftCond[t];
     int sp = 0;
-    st[0].j = i; st[0].opt = 0; st[0].cond = leftCond; st[0].found = false;
+    st[0].j = i; st[0].opt = 0; st[0].condOff = 0; st[0].condLen = leftCondLen; st[0].found = 0;
     while (sp >= 0) {
-      Frame& f = st[sp];
+      MFrame& f = st[sp];
       const int nextIdx = f.j + 1;
       if (nextIdx >= n) { sp--; continue; }
       const PBlock next = entryAt(prev, nextIdx);
       if (f.opt >= numPoss(prev, next)) { sp--; continue; }
-      const Poss ro = possAt(prev, next, f.opt);
+      PossView ro;
+      possAt(prev, next, f.opt, ro);
       f.opt++;
-      Cond ic;
-      if (!condIntersect(f.cond, ro.cond, ic)) { if (f.found) sp--; continue; }
-      f.found = true;
+      const int top = f.condOff + f.condLen;  // the intersection is written behind this call's condition: a nested call keeps it there
+      const int icLen = condIntersect(sc + f.condOff, f.condLen, ro.cond, ro.condLen, sc + top, ms->stackCap - top);
+      if (icLen == -2) return false;
+      if (icLen < 0) { if (f.found) sp--; continue; }
+      f.found = 1;
       if (nOpt > XM_MAX_COMBINATIONS) return true;  // every enclosing call returns at its next intersection without adding anything
       if (!ro.hasBlock) {
-        if (sp + 1 >= 24) return false;
+        if (sp + 1 >= ms->framesCap) return false;
         sp++;
-        st[sp].j = nextIdx; st[sp].opt = 0; st[sp].cond = ic; st[sp].found = false;
+        st[sp].j = nextIdx; st[sp].opt = 0; st[sp].condOff = top; st[sp].condLen = icLen; st[sp].found = 0;
         continue;
       }
-      if (nOpt >= ms->optionsCap) return false;
-      Poss& o = ms->options[nOpt++];
-      o.cond = ic;
-      if (shouldMergeBlocks(leftBlock, ro.block)) { o.block = mergeBlocks(leftBlock, ro.block); o.hasBlock = 1; }
-      else { o.block = leftBlock; o.hasBlock = 0; }
+      const bool merge = shouldMergeBlocks(leftBlock, ro.block);
+      if (!multiAddOption(nOpt, nOptCond, merge ? mergeBlocks(leftBlock, ro.block) : leftBlock, merge, sc + top, icLen)) return false;
     }
     return true;
   }
@@ -344,30 +370,29 @@ struct Pyramid {
         }
         continue;
       }
-      int nOpt = 0;
+      int nOpt = 0, nOptCond = 0;
       const int nl = numPoss(prev, L);
       for (int k = 0; k < nl; k++) {
-        const Poss lo = possAt(prev, L, k);
+        PossView lo;
+        possAt(prev, L, k, lo);
         if (lo.hasBlock) {
-          if (!multiExpand(prev, n, lo.block, lo.cond, i, nOpt)) { *status = XM_ST_OVERFLOW; return; }
+          if (!multiExpand(prev, n, lo.block, lo.cond, lo.condLen, i, nOpt, nOptCond)) { *status = XM_ST_OVERFLOW; return; }
         } else {
-          if (nOpt >= ms->optionsCap) { *status = XM_ST_OVERFLOW; return; }
-          Poss& o = ms->options[nOpt++];
-          o = lo;
+          if (!multiAddOption(nOpt, nOptCond, lo.block, false, lo.cond, lo.condLen)) { *status = XM_ST_OVERFLOW; return; }
         }
       }
       if (nOpt > 0 && nOpt <= XM_MAX_COMBINATIONS) {
         int minStart = -1, maxEnd = -1;
-        for (int k = 0; k < nOpt; k++) if (ms->options[k].hasBlock) {
-          const PBlock& b = ms->options[k].block;
+        for (int k = 0; k < nOpt; k++) if (ms->pool[ms->poolUsed + k].hasBlock) {
+          const PBlock& b = ms->pool[ms->poolUsed + k].block;
           if (minStart < 0 || (int)b.start < minStart) minStart = b.start;
           if ((int)b.start + b.len > maxEnd) maxEnd = (int)b.start + b.len;
         }
-        if (minStart >= 0) {  // hasNonEmpty
-          if (w >= cap || ms->poolUsed + nOpt > ms->poolCap) { *status = XM_ST_OVERFLOW; return; }
+        if (minStart >= 0) {  // hasNonEmpty: the options stay where they are
+          if (w >= cap) { *status = XM_ST_OVERFLOW; return; }
           PBlock m;
           m.start = (uint16_t)minStart; m.len = (uint16_t)(maxEnd - minStart); m.fwd = ms->poolUsed; m.rev = nOpt; m.flags = F_MULTI; m.gapDir = 0; m.extraGap = 0;
-          for (int k = 0; k < nOpt; k++) ms->pool[ms->poolUsed++] = ms->options[k];
+          ms->poolUsed += nOpt; ms->condUsed += nOptCond;
           blocks[w++] = m;
         }
       }

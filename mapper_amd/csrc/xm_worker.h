@@ -599,19 +599,20 @@ XM_INL void compInit(ReadCtx& cx, Comp& c, const SeqView& query, const SeqView& 
   if (A.overflow) { cx.status = XM_ST_OVERFLOW; return; }
   c.pyr.init(query, blocks, k.maxPyramidBlocks, ls, k.maxLevels, &cx.status);
   c.pyr.dc = cx.dc;
-  int nAmb = 0;
-  if (mateHasAmbiguousBase(query)) for (int i = 0; i < query.len; i++) if (bpIsAmbiguous(query.at(i))) nAmb++;
-  if (nAmb > 0) {  // blocks over an ambiguous base are lists of possibilities (MultiHashBlock): xm_seed.h, MultiStore
-    if (nAmb > XM_MAX_AMBIGUOUS) { cx.status = XM_ST_AMBIGUOUS; return; }
+  if (mateHasAmbiguousBase(query)) {  // blocks over an ambiguous base are lists of possibilities (MultiHashBlock): xm_seed.h, MultiStore
+    // (any number of ambiguous bases: a mate of nothing but N is walked like any other - the reference bounds the combinations per block, not the bases)
     MultiStore* ms = arenaArray<MultiStore>(A, 1);
-    int16_t* ambPos = arenaArray<int16_t>(A, (size_t)nAmb);
-    Poss* pool = arenaArray<Poss>(A, (size_t)128 * k.scale);
-    Poss* options = arenaArray<Poss>(A, 2 * XM_MAX_COMBINATIONS + 8);
+    const MultiCaps mc = multiCaps(k.scale);
+    const int poolCap = mc.pool, condCap = mc.conds, stackCap = mc.stack, framesCap = mc.frames;
+    Poss* pool = arenaArray<Poss>(A, (size_t)poolCap);
+    CondEnt* conds = arenaArray<CondEnt>(A, (size_t)condCap);
+    CondEnt* stack = arenaArray<CondEnt>(A, (size_t)stackCap);
+    MFrame* frames = arenaArray<MFrame>(A, (size_t)framesCap);
     if (A.overflow) { cx.status = XM_ST_OVERFLOW; return; }
-    int w = 0;
-    for (int i = 0; i < query.len; i++) if (bpIsAmbiguous(query.at(i))) ambPos[w++] = (int16_t)i;
-    ms->ambPos = ambPos; ms->nAmb = nAmb;
-    ms->pool = pool; ms->poolUsed = 0; ms->poolCap = 128 * k.scale; ms->options = options; ms->optionsCap = 2 * XM_MAX_COMBINATIONS + 8;
+    ms->pool = pool; ms->poolUsed = 0; ms->poolCap = poolCap;
+    ms->conds = conds; ms->condUsed = 0; ms->condCap = condCap;
+    ms->stack = stack; ms->stackCap = stackCap;
+    ms->frames = frames; ms->framesCap = framesCap;
     c.pyr.ms = ms;
   }
   pathInit(c.path);

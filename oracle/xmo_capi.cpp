@@ -558,4 +558,47 @@ int64_t xmo_pyramid_dump(const uint8_t* codes, int len, int32_t* out, int64_t ca
   return n;
 }
 
+// every block of the read-side pyramid, multi blocks included (reads with ambiguous bases): one row per possibility, 12 ints:
+//   level, block start, block end - start, number of possibilities (0: a single block), possibility index, has block, its start, length, fwd, rev,
+//   flags (as above), a hash of its condition (entries (position, base index A C G T = 0..3) in order).  Stops at the first level without blocks.
+int64_t xmo_pyramid_dump_multi(const uint8_t* codes, int len, int32_t* out, int64_t capRows) {
+  std::unique_ptr<Sequence> s(new Sequence());
+  s->codes.assign(codes, codes + len);
+  HashBlock_Pyramid pyr(s.get(), false, nullptr);
+  int64_t n = 0;
+  auto row = [&](int level, int bs, int bl, int np, int k, bool has, const HashBlock* h, const SequenceCondition* c) {
+    if (n < capRows) {
+      int32_t* o = out + n * 12;
+      o[0] = level; o[1] = bs; o[2] = bl; o[3] = np; o[4] = k; o[5] = has ? 1 : 0;
+      o[6] = has ? h->startIndex : 0; o[7] = has ? h->length : 0; o[8] = has ? h->forwardHash : 0; o[9] = has ? h->reverseHash : 0;
+      o[10] = has ? ((h->requestMergeLeft ? 1 : 0) | (h->requestMergeRight ? 2 : 0) | (h->nextRequestMergeLeft ? 4 : 0) | (h->nextRequestMergeRight ? 8 : 0)) : 0;
+      uint32_t hash = c ? (uint32_t)c->keys.size() : 0u;
+      if (c) for (size_t i = 0; i < c->keys.size(); i++) {
+        const char v = c->values[i];
+        hash = hash * 1000003u + ((uint32_t)c->keys[i] * 4u + (v == 'A' ? 0u : v == 'C' ? 1u : v == 'G' ? 2u : 3u));
+      }
+      o[11] = (int32_t)hash;
+    }
+    n++;
+  };
+  for (int level = 0;; level++) {
+    HashBlock_Row* r = pyr.get(level);
+    MultiBlockP b = r->getAfter(-1);
+    if (!b) break;
+    while (b) {
+      const HashBlock* h = b->getSingle();
+      if (h) row(level, h->startIndex, h->length, 0, 0, true, h, nullptr);
+      else {
+        const int bs = b->getStartIndex(), be = b->getEndIndex();
+        for (size_t k = 0; k < b->possibilities.size(); k++) {
+          const ConditionalHashBlock& p = b->possibilities[k];
+          row(level, bs, be - bs, (int)b->possibilities.size(), (int)k, p.hasBlock, &p.block, &p.condition);
+        }
+      }
+      b = r->getAfter(b->getStartIndex());
+    }
+  }
+  return n;
+}
+
 }  // extern "C"

@@ -101,3 +101,47 @@ def ambiguous_reference(n, seed, n_runs=6, n_codes=40):
     codes = np.array([15, 5, 10, 3, 12, 6, 9, 7, 11, 13, 14], np.uint8)
     ref[rng.integers(0, n, size=n_codes)] = codes[rng.integers(0, len(codes), size=n_codes)]
     return ref
+
+
+IUPAC_2WAY = np.array([3, 5, 9, 6, 10, 12], np.uint8)   # M R W S Y K
+IUPAC_3WAY = np.array([7, 11, 13, 14], np.uint8)        # V H D B
+
+
+def heavy_ambiguity(reads, seed=11):
+    """Copies of `reads` (code arrays [n, L]) in which read q carries ambiguity of class q mod 16: a fraction of its positions - 1 %, 10 %, 50 %, 90 %, 100 % -
+    replaced by N (classes 0-4), by two-way IUPAC codes (5-9) or by three-way codes (10-12: 10 %, 50 %, 100 %); 13: a run of N at the read's start of a
+    third to all of its length; 14: the same at its end; 15: untouched.  What real FASTQ holds (all-N reads, N tails) and what no other test reaches: the
+    reference bounds the combinations per block, not the ambiguous bases per read (HashBlock_ParentRow.java:10,109,165)."""
+    rng = np.random.default_rng(seed)
+    out = reads.copy()
+    n, L = out.shape
+    fr = [0.01, 0.1, 0.5, 0.9, 1.0]
+    for q in range(n):
+        c = q % 16
+        if c < 5:
+            out[q, rng.random(L) < fr[c]] = 15
+        elif c < 10:
+            m = rng.random(L) < fr[c - 5]
+            out[q, m] = IUPAC_2WAY[rng.integers(0, len(IUPAC_2WAY), int(m.sum()))]
+        elif c < 13:
+            m = rng.random(L) < [0.1, 0.5, 1.0][c - 10]
+            out[q, m] = IUPAC_3WAY[rng.integers(0, len(IUPAC_3WAY), int(m.sum()))]
+        elif c == 13:
+            out[q, :int(rng.integers(L // 3, L + 1))] = 15
+        elif c == 14:
+            out[q, L - int(rng.integers(L // 3, L + 1)):] = 15
+    return out
+
+
+def low_complexity_reads(n, L, seed=12):
+    """homopolymer, dinucleotide and short-period reads (code arrays [n, L]), a few with one ambiguity code in them"""
+    rng = np.random.default_rng(seed)
+    acgt = np.array([1, 2, 4, 8], np.uint8)
+    out = np.zeros((n, L), np.uint8)
+    for q in range(n):
+        period = [1, 2, 3, 5][q % 4]
+        unit = acgt[rng.integers(0, 4, period)]
+        out[q] = np.tile(unit, L // period + 1)[:L]
+        if q % 5 == 4:
+            out[q, int(rng.integers(0, L))] = [15, 5, 14][q % 3]
+    return out

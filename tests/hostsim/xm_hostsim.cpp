@@ -329,6 +329,7 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
           }
         }
         if (cx.status == XM_ST_OVERFLOW) {
+          if (getenv("XMSIM_TRACE_OVERFLOW")) fprintf(stderr, "[xmsim] query %lld overflow at stage %d scale %d: persist %zu of %zu%s, tmp %zu of %zu%s\n", (long long)q, stage, scale, cx.persist.used, cx.persist.size, cx.persist.overflow ? " (overflow)" : "", cx.tmp.used, cx.tmp.size, cx.tmp.overflow ? " (overflow)" : "");
           dc = before; rerun++;
           saved = nullptr;
           if (stage == 0) { stage = 2; scale = seedScale * 4; } else { stage = 2; scale *= 4; }
@@ -564,6 +565,56 @@ int64_t xmsim_pyramid_dump(const uint8_t* codes, int len, int32_t* out, int64_t 
         o[8] = st; o[9] = st ? g.start : 0; o[10] = st ? g.len : 0; o[11] = st ? g.used : 0; o[12] = st ? g.fwd : 0; o[13] = st ? g.rev : 0;
       }
       n++;
+    }
+  }
+  return n;
+}
+
+// the same with the multi blocks of a read with ambiguous bases, in the layout of the oracle's xmo_pyramid_dump_multi (12 ints per possibility);
+// `scale` sizes the pools as compInit does.  -1: a capacity was exceeded (on the GPU: the read runs again with more scratch)
+int64_t xmsim_pyramid_dump_multi(const uint8_t* codes, int len, int scale, int32_t* out, int64_t capRows) {
+  std::vector<PBlock> blocks((size_t)len * 64 + 64);
+  std::vector<int32_t> ls((size_t)len + 8);
+  int32_t status = 0;
+  SeqView s;
+  s.base = codes; s.len = len; s.rc = 0; s.id = 0;
+  Pyramid pyr;
+  pyr.init(s, blocks.data(), (int)blocks.size(), ls.data(), len + 4, &status);
+  MultiStore ms;
+  const MultiCaps mc = multiCaps(scale);
+  std::vector<Poss> pool((size_t)mc.pool);
+  std::vector<CondEnt> conds((size_t)mc.conds), stack((size_t)mc.stack);
+  std::vector<MFrame> frames((size_t)mc.frames);
+  ms.pool = pool.data(); ms.poolUsed = 0; ms.poolCap = (int)pool.size();
+  ms.conds = conds.data(); ms.condUsed = 0; ms.condCap = (int)conds.size();
+  ms.stack = stack.data(); ms.stackCap = (int)stack.size();
+  ms.frames = frames.data(); ms.framesCap = (int)frames.size();
+  bool amb = false;
+  for (int i = 0; i < len; i++) if (bpIsAmbiguous(codes[i])) amb = true;
+  if (amb) pyr.ms = &ms;
+  int64_t n = 0;
+  for (int level = 0;; level++) {
+    if (level > 0) { pyr.ensure(level); if (status) return -1; }
+    int cnt = pyr.count(level);
+    if (cnt == 0) break;
+    for (int i = 0; i < cnt; i++) {
+      const PBlock e = amb ? pyr.entryAt(level, i) : pyr.blockAt(level, i);
+      const bool multi = (e.flags & F_MULTI) != 0;
+      const int np = multi ? pyr.numPoss(level, e) : 1;
+      for (int k = 0; k < np; k++) {
+        PossView p;
+        pyr.possAt(level, e, k, p);
+        if (n < capRows) {
+          int32_t* o = out + n * 12;
+          o[0] = level; o[1] = e.start; o[2] = e.len; o[3] = multi ? np : 0; o[4] = k; o[5] = p.hasBlock;
+          o[6] = p.hasBlock ? p.block.start : 0; o[7] = p.hasBlock ? p.block.len : 0; o[8] = p.hasBlock ? p.block.fwd : 0; o[9] = p.hasBlock ? p.block.rev : 0;
+          o[10] = p.hasBlock ? (p.block.flags & 15) : 0;
+          uint32_t hash = multi ? (uint32_t)p.condLen : 0u;
+          if (multi) for (int t = 0; t < p.condLen; t++) hash = hash * 1000003u + ((p.cond[t] >> 2) * 4u + (p.cond[t] & 3u));
+          o[11] = (int32_t)hash;
+        }
+        n++;
+      }
     }
   }
   return n;

@@ -50,6 +50,8 @@ def lib():
         L.xmsim_dup_keys.restype = C.c_int64
         L.xmsim_pyramid_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
         L.xmsim_pyramid_dump.restype = C.c_int64
+        L.xmsim_pyramid_dump_multi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        L.xmsim_pyramid_dump_multi.restype = C.c_int64
         L.xmsim_kat_multi_contains.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.xmsim_kat_position_codec.argtypes = [C.c_int, C.c_int]
         L.xmsim_set_wave_mode.argtypes = [C.c_int]
@@ -138,6 +140,21 @@ def pyramid_dump(codes):
     n = L.xmsim_pyramid_dump(codes.ctypes.data, len(codes), out.ctypes.data, cap)
     assert 0 <= n <= cap
     return out[:n]
+
+
+def pyramid_dump_multi(codes, scale=1):
+    """the product's read-side pyramid with its multi blocks, pools sized for `scale` as compInit sizes them; None = a capacity was exceeded at that scale"""
+    L = lib()
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    cap = 4096
+    while True:
+        out = np.zeros((cap, 12), dtype=np.int32)
+        n = L.xmsim_pyramid_dump_multi(codes.ctypes.data, len(codes), scale, out.ctypes.data, cap)
+        if n < 0:
+            return None
+        if n <= cap:
+            return out[:n]
+        cap = n
 
 
 def set_wave_mode(mode):

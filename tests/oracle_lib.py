@@ -109,6 +109,8 @@ def lib():
         L.xmo_kat_db_order_independent.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int]
         L.xmo_pyramid_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
         L.xmo_pyramid_dump.restype = C.c_int64
+        L.xmo_pyramid_dump_multi.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+        L.xmo_pyramid_dump_multi.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -275,6 +277,19 @@ def pyramid_dump(codes):
     while True:
         out = np.zeros((cap, 14), dtype=np.int32)
         n = L.xmo_pyramid_dump(codes.ctypes.data, len(codes), out.ctypes.data, cap)
+        if n <= cap:
+            return out[:n]
+        cap = n
+
+
+def pyramid_dump_multi(codes):
+    """every block of the read-side pyramid, the possibilities of multi blocks included (12 ints per possibility: xmo_capi.cpp)"""
+    L = lib()
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    cap = 4096
+    while True:
+        out = np.zeros((cap, 12), dtype=np.int32)
+        n = L.xmo_pyramid_dump_multi(codes.ctypes.data, len(codes), out.ctypes.data, cap)
         if n <= cap:
             return out[:n]
         cap = n

@@ -7,7 +7,8 @@ import pytest
 
 import oracle_lib as o
 import hostsim_lib as hs
-from helpers import KAT, streams_equal, first_difference, se_batch, pe_batch, check_align_case, sprinkle_ambiguity, ambiguous_reference
+from helpers import (KAT, streams_equal, first_difference, se_batch, pe_batch, ragged_se_batch, check_align_case, sprinkle_ambiguity, ambiguous_reference,
+                     heavy_ambiguity, low_complexity_reads)
 from mapper_amd import api, synth, _capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -358,6 +359,52 @@ def test_kernel_logic_reads_with_ambiguous_bases():
         assert streams_equal(got, want), first_difference(got, want, n)
 
 
+@pytest.mark.parametrize("trial", range(6))
+def test_read_pyramid_with_any_number_of_ambiguous_bases_matches_oracle(trial):
+    """The multi blocks of a read's pyramid, possibility by possibility (block, has-block, condition), against the oracle's HashBlock_ParentRow for reads of
+    5-150 bases with 1 % ... 100 % of their positions ambiguous (N or IUPAC codes): every level, not only the ones a walk asks for.  The product's pools follow
+    the scratch scale; what a scale cannot hold must be reported (None) and fit a larger one."""
+    rng = np.random.default_rng(100 + trial)
+    codes = np.array([15, 15, 15, 5, 10, 3, 12, 7, 14, 6, 9, 11, 13], np.uint8)
+    for k in range(25):
+        L = int(rng.integers(5, 151))
+        r = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, L)]
+        m = rng.random(L) < [0.01, 0.1, 0.5, 0.9, 1.0][k % 5]
+        r[m] = 15 if k % 2 else codes[rng.integers(0, len(codes), int(m.sum()))]
+        want = o.pyramid_dump_multi(r)
+        got = None
+        for scale in (1, 4, 16, 64, 256):
+            got = hs.pyramid_dump_multi(r, scale)
+            if got is not None:
+                break
+        assert got is not None and got.shape == want.shape and np.array_equal(got, want), (trial, k, L)
+
+
+def test_kernel_logic_reads_of_mostly_ambiguous_bases():
+    """Reads the reference takes and earlier rounds of this product refused (over 128 ambiguous bases in a mate failed the batch): N and IUPAC codes at 1 % ... 100 %
+    of the positions, N runs at either end up to the whole read, single reads, pairs with one or both mates affected, reads shorter than minInterestingSize,
+    homopolymers and short-period reads - the kernel logic in the product's pass sequence against the oracle, bit for bit."""
+    ref = synth.synthetic_reference(300_000, seed=41)
+    R = o.OracleReference([("r", ref)])
+    S = hs.SimReference([("r", ref)])
+    p = o.make_params()
+    reads = heavy_ambiguity(synth.synthetic_single_end(ref, 480, seed=42)[0])
+    m1, m2 = synth.synthetic_paired_end(ref, 320, seed=43)[:2]
+    m1h, m2h = heavy_ambiguity(m1, 4), heavy_ambiguity(m2, 5)
+    m2one = m2.copy(); m2one[::2] = 15                                      # every other pair: one mate of nothing but N
+    short = [r[:int(L)] for r, L in zip(heavy_ambiguity(synth.synthetic_single_end(ref, 160, seed=44)[0], 6), np.tile([1, 2, 3, 5, 8, 11, 13, 20], 20))]
+    low = low_complexity_reads(120, 150)
+    batches = [("single", se_batch(reads)), ("pairs", pe_batch(m1h, m2h)), ("one all-N mate", pe_batch(m1, m2one)), ("short", ragged_se_batch(short)),
+               ("low complexity", se_batch(low)), ("all N", se_batch(np.full((3, 150), 15, np.uint8))),
+               ("135 N inside", se_batch(np.concatenate([reads[15:16, :10], np.full((1, 135), 15, np.uint8), reads[15:16, 145:]], axis=1)))]
+    for name, b in batches:
+        want = R.align(b, p, threads=os.cpu_count())
+        got = S.align(b, p)
+        assert streams_equal(got, want), name + ": " + str(first_difference(got, want, b.nq))
+    all_n = R.align(batches[5][1], p)
+    assert all(all_n.ints[all_n.int_off[q] + 1] == 0 for q in range(3))  # (the reference walks such a read and finds nothing)
+
+
 def test_hand_back_resume_points_in_the_host_simulation(monkeypatch):
     """XM_HANDBACK (off by default in the product): the gapped pass stops a resumed read behind the candidate that needed the chain
     (alignRead phases 11 / 13 / 14) and a pass with the light pass's capacities continues it; reads that meet another candidate for the
@@ -459,6 +506,15 @@ def test_kernel_logic_random_shapes(sched, monkeypatch):
     monkeypatch.setenv("XMSIM_SCHED", sched)
     monkeypatch.setenv("XMSIM_SCHED_LONG", sched)
     assert gpu_fuzz.run_shapes(rounds=3, seed=99, max_queries=700, backend="sim") == 0
+
+
+def test_kernel_logic_ambiguity_fuzz():
+    """The third flavour of the fuzz (gpu_fuzz.run_ambiguity: per read an ambiguous fraction from {0, 1 %, 10 %, 50 %, 90 %, 100 %} as N / IUPAC codes, N runs at the ends,
+    low-complexity and very short reads, single reads and pairs mixed) through the host simulation, equal to the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import gpu_fuzz
+    assert gpu_fuzz.run_ambiguity(rounds=5, seed=31, max_queries=300, backend="sim") == 0
 
 
 def test_kernel_logic_reads_no_arena_memory_it_has_not_written():

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 import oracle_lib as o
-from helpers import KAT, streams_equal, first_difference, se_batch, ragged_se_batch, pe_batch, check_align_case, sam_text, sprinkle_ambiguity, ambiguous_reference
+from helpers import (KAT, streams_equal, first_difference, se_batch, ragged_se_batch, pe_batch, check_align_case, sam_text, sprinkle_ambiguity, ambiguous_reference,
+                     heavy_ambiguity, low_complexity_reads)
 from mapper_amd import api, synth
 
 pytestmark = pytest.mark.gpu
@@ -263,6 +264,42 @@ def test_reads_with_ambiguous_bases_on_gpu():
     one = db.align_batch([api.Query("ACGTACGTACGTANGTACGTACGTACGTACGTACGT")], api.AlignmentParameters())  # (the first implementation refused this read)
     assert len(one.int_off) == 2
     db.close()
+
+
+def test_reads_of_mostly_ambiguous_bases_on_gpu():
+    """Any number of ambiguous bases per mate (the reference bounds the combinations per block, HashBlock_ParentRow.java:10,109,165, not the bases; rounds 1-4 of this
+    product failed the batch above 128): N and IUPAC codes at 1 % ... 100 % of a read's positions, N runs at either end up to the whole read, pairs with one or both
+    mates affected or one mate all N, reads shorter than minInterestingSize, homopolymers and short-period reads, a batch in which ordinary reads surround them -
+    bit-identical to the oracle; an all-N read comes back unaligned, and nothing fails the batch."""
+    ref = synth.synthetic_reference(300_000, seed=41)
+    R = o.OracleReference([("r", ref)])
+    db = api.ReferenceDatabase([("r", ref)])
+    plain = synth.synthetic_single_end(ref, 6000, seed=45)[0]
+    reads = heavy_ambiguity(synth.synthetic_single_end(ref, 1600, seed=42)[0])
+    m1, m2 = synth.synthetic_paired_end(ref, 800, seed=43)[:2]
+    m1h, m2h = heavy_ambiguity(m1, 4), heavy_ambiguity(m2, 5)
+    m2one = m2.copy(); m2one[::2] = 15
+    short = [r[:int(L)] for r, L in zip(heavy_ambiguity(synth.synthetic_single_end(ref, 320, seed=44)[0], 6), np.tile([1, 2, 3, 5, 8, 11, 13, 20], 40))]
+    low = low_complexity_reads(240, 150)
+    mixed = np.concatenate([plain[:3000], reads, plain[3000:]])
+    batches = [("single", se_batch(reads)), ("among ordinary reads", se_batch(mixed)), ("pairs", pe_batch(m1h, m2h)), ("one all-N mate", pe_batch(m1, m2one)),
+               ("short", ragged_se_batch(short)), ("low complexity", se_batch(low)), ("all N", se_batch(np.full((64, 150), 15, np.uint8))),
+               ("135 N inside", se_batch(np.concatenate([reads[15:16, :10], np.full((1, 135), 15, np.uint8), reads[15:16, 145:]], axis=1)))]
+    for name, b in batches:
+        got, _ = gpu_align(db, b)
+        want = R.align(b, o.make_params(), threads=os.cpu_count())
+        assert streams_equal(got, want), name + ": " + str(first_difference(got, want, b.nq))
+        if name == "all N":
+            assert all(got.ints[got.int_off[q] + 1] == 0 for q in range(b.nq))
+    db.close()
+
+
+def test_ambiguity_fuzz_on_gpu():
+    """Third flavour of the fuzz (gpu_fuzz.run_ambiguity): per read an ambiguous fraction from {0, 1 %, 10 %, 50 %, 90 %, 100 %} as N / two-way / three-way codes, N runs
+    at the ends, low-complexity and very short reads, single reads and pairs in one batch, references plain / ambiguous / with repeats."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gpu_fuzz
+    assert gpu_fuzz.run_ambiguity(rounds=12, seed=515, max_queries=400) == 0
 
 
 def test_ambiguous_reference_on_gpu():
