@@ -204,18 +204,13 @@ void xm_pileup_free(xm_pileup* pileup);
 /* TEST-ONLY entry (tests/test_gpu_kat.py; not part of the drop-in boundary): the reference's component-level known-answer tests run by the
  * device code of the align kernels over two given texts.  chain 0 = PathAligner alone (PathAligner_Test.java:10-39): mode 0 the lane-per-read
  * search in the wave's LDS slot, 1 the same search in HBM mode, 2 the wave-cooperative search with the search kernel's capacities, 3 with the
- * capacities of the chain tiers' inline searches, 4 the lane-private form of the search (xm_wsearch.h: the wave scheduler's, and the chains of long reads).  chain 1 = HashBlock_Aligner -> StraightAligner -> PathAligner_Runner
+ * capacities of the chain tiers' inline searches, 4 the lane-private form of the search (xm_wsearch.h: what the chains of long reads and the reruns use).  chain 1 = HashBlock_Aligner -> StraightAligner -> PathAligner_Runner
  * (HashBlockAligner_Test.java:10-48): mode 0 searches slot-first as in the kernel, 1 all searches in HBM mode, 4 all in the lane-private form.
  * Returns 0 with blocks[4 * num_blocks] = (startA, startB, lengthA, lengthB) and penalties[2] = (total, aligned); 1 = no alignment (null); -1 = error. */
 int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_params* params, const uint8_t* query, int32_t query_length, const uint8_t* reference,
                         int32_t reference_length, double max_ins_ext, double max_del_ext, int32_t block_cap, int32_t* blocks, int32_t* num_blocks, double* penalties,
                         int64_t* nodes_put);
 
-/* DIAGNOSTIC entry (not part of the drop-in boundary): the phase timers of the wave scheduler kernel of the gapped pass since the last call, in
- * shader-clock ticks of wave time; all zero unless the library was built with -DXM_PROFILE.  out[0] whole loop, [1] chain phases that start a read,
- * [2] chain phases that replay, [3] search phases, [4] searches in the big buffer, [5] loop iterations, [6] searches, [7] ticks x lanes searching,
- * [8] ticks x lanes in a chain phase. */
-int xm_debug_sched_profile(uint64_t* out16, int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -48,7 +48,7 @@ class XmIndexInfo(C.Structure):
 
 
 EXPORTS = ["xm_last_error", "xm_build_stamp", "xm_device_count", "xm_index_build", "xm_index_replicate", "xm_context_new", "xm_context_set_scratch", "xm_device_memory", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
-           "xm_index_table_info", "xm_index_table_shape", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe", "xm_measure_random_gather", "xm_test_local_align", "xm_pileup_new", "xm_pileup_set_query_ends", "xm_pileup_read_middle", "xm_pileup_add_last", "xm_pileup_read", "xm_pileup_events", "xm_pileup_free", "xm_debug_sched_profile"]
+           "xm_index_table_info", "xm_index_table_shape", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe", "xm_measure_random_gather", "xm_test_local_align", "xm_pileup_new", "xm_pileup_set_query_ends", "xm_pileup_read_middle", "xm_pileup_add_last", "xm_pileup_read", "xm_pileup_events", "xm_pileup_free"]
 
 
 def build_library(force=False):

@@ -8,7 +8,7 @@
 // Reads whose fixed-capacity scratch overflowed are rerun by a second launch with a 4x larger scale (never on the CPU).
 #include "../../include/xmapper_hip.h"
 #include "xm_worker.h"
-#include "xm_sched.h"
+#include "xm_wsearch.h"
 #include "xm_index_host.h"
 #include "xm_kernel_args.h"
 #include "xm_kernel_common.h"
@@ -21,6 +21,8 @@
 #include <memory>
 #include <atomic>
 #include <array>
+#include <map>
+#include <chrono>
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -64,8 +66,8 @@ __device__ unsigned long long* xm_read_times = nullptr;
 // One lane aligns one read at a time (AlignerWorker.align, M/AlignerWorker.java:256-484) and loops until the batch is drained.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed, int lanesPerWave,
                                                        uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters,
-                                                       uint8_t* memoBase, const int32_t* slotOf, int memoFresh, int deferPath, long long taperUnit, int waveSync, long long firstStride, PNode* waveNodes, HandOver ho, int pairLanes,
-                                                       SearchPool searchPool) {
+                                                       long long taperUnit, long long firstStride, PNode* waveNodes, HandOver ho, int pairLanes,
+                                                       SearchPool searchPool, PassLists lists) {
   // lanesPerWave < 64 (gapped pass): the extension chain diverges so much that a wave runs its reads nearly one after another, so
   // spreading them over more, partly filled waves shortens the critical path; the idle lanes own no scratch arena
   xmSetWaveNodes(waveNodes);
@@ -111,22 +113,10 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
         if (pairLanes) leave = __shfl(leave, physLane & ~1);
         if (leave) break;
       }
-      if (waveSync) {
-        // Light pass: the lanes of a wave take their next reads together and meet again before the following batch, so that the
-        // pyramids are built and the index is walked in step (lanes that each fetched a new read whenever they finished drifted apart,
-        // and most of the wave then executed one read at a time)
-        unsigned long long first = 0;
-        if (laneInWave == 0) first = atomicAdd(nextItem, (unsigned long long)lanesPerWave);
-        first = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)first);
-        if ((long long)first >= nTodo) break;
-        item = first + (unsigned)laneInWave;
-        if ((long long)item >= nTodo) break;  // (this was the last batch: lane 0, whose item is always inside it, fetches once more and leaves too)
-      } else {
-        item = 0;
-        if (!second) item = atomicAdd(nextItem, 1ull);
-        if (pairLanes) item = (unsigned long long)__shfl((long long)item, physLane & ~1);
-        if ((long long)item >= nTodo) break;
-      }
+      item = 0;
+      if (!second) item = atomicAdd(nextItem, 1ull);
+      if (pairLanes) item = (unsigned long long)__shfl((long long)item, physLane & ~1);
+      if ((long long)item >= nTodo) break;
     }
     int64_t q = todo ? todo[item] : (int64_t)item;
     ReadIn in;
@@ -143,9 +133,6 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
     const unsigned long long readT0 = clock64();
 #endif
     DevCounters before = local;
-    // deferred-search gapped pass (memoBase != null): the read's memo slot carries its finished calls from replay to replay
-    MemoHdr* memo = memoBase ? (MemoHdr*)(memoBase + (size_t)slotOf[q] * XM_MEMO_SLOT_BYTES) : nullptr;
-    if (memo && memoFresh) memoInit(memo);
     if (ho.mode == 1) {
       uint8_t* region = ho.regions + (unsigned long long)myRegion * ho.regionBytes;
       runReadRetaining(cx, &ix, params, in, scale, region, (size_t)ho.regionBytes, arena, (size_t)arenaBytes, &local, rr, heavyAllowed);
@@ -164,15 +151,10 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
       const int32_t rg = ho.regionOf[q];
       uint8_t* tmp = arena + ho.regionBytes;
       const size_t tmpBytes = (size_t)(arenaBytes - ho.regionBytes);
-      if (rg >= 0) runReadResumed(cx, savedReadOf(ho.regions + (unsigned long long)rg * ho.regionBytes, (size_t)ho.regionBytes), &ix, scale, tmp, tmpBytes, &local, rr, nullptr, false, 2, ho.handBack);
+      if (rg >= 0) runReadResumed(cx, savedReadOf(ho.regions + (unsigned long long)rg * ho.regionBytes, (size_t)ho.regionBytes), &ix, scale, tmp, tmpBytes, &local, rr);
       else runReadRetaining(cx, &ix, params, in, ho.seedScale, arena, (size_t)ho.regionBytes, tmp, tmpBytes, &local, rr, 2, scale);
-    } else if (ho.mode == 3) {
-      // a read the gapped pass handed back: on from behind its candidate, with the light pass's capacities and temporaries (the lane's arena is all temporaries)
-      const int32_t rg = ho.regionOf[q];
-      if (rg >= 0) runReadResumed(cx, savedReadOf(ho.regions + (unsigned long long)rg * ho.regionBytes, (size_t)ho.regionBytes), &ix, ho.seedScale, arena, (size_t)arenaBytes, &local, rr, nullptr, false, ho.lightLevel, 0);
-      else cx.status = XM_ST_INTERNAL;
     } else {
-      runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed, memo, deferPath != 0);
+      runRead(cx, &ix, params, in, scale, arena, (size_t)arenaBytes, &local, rr, heavyAllowed);
     }
     XM_PAIR_CHECK(0, cx.status);
     XM_PAIR_CHECK(1, ((long long)rr.nComponents << 40) ^ ((long long)rr.single[0] << 20) ^ (long long)rr.empty[0] ^ ((long long)local.pathAlignerNodes << 4));
@@ -182,32 +164,9 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
 #endif
     if (st != XM_OK) local = before;  // work of a read that is rerun by a later pass is counted there
     if (second) continue;             // (pair mode: the first lane of the read publishes)
-    publishRead(out, q, rr, cx, local);
+    publishRead(out, q, rr, cx, local, lists);
   }
   if (!second) addCounters(counters, local);
-}
-
-// Every PathAligner search the gapped pass left waiting (MemoHdr, xm_extend.h): one request per lane, every lane in the same code.
-__global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_path_kernel(const int64_t* list, long long n, const int32_t* slotOf, uint8_t* memoBase, int scale, int lanesPerWave,
-                                                      uint8_t* arenas, unsigned long long arenaBytes, unsigned long long* nextItem, DevCounters* counters) {
-  // few searches: spread them over as many waves as the GPU holds (the time of a launch is its longest wave)
-  xmSetSearchPool(SearchPool{nullptr, 0, 0, 0});
-  __syncthreads();
-  const int laneInWave = (int)(threadIdx.x & 63u);
-  if (laneInWave >= lanesPerWave) return;
-  unsigned long long lane = ((unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (unsigned)lanesPerWave + (unsigned)laneInWave;
-  DevCounters local;
-  memset(&local, 0, sizeof(local));
-  const Caps caps = makeCaps(scale);
-  while (true) {
-    unsigned long long item = atomicAdd(nextItem, 1ull);
-    if ((long long)item >= n) break;
-    MemoHdr* memo = (MemoHdr*)(memoBase + (size_t)slotOf[list[item]] * XM_MEMO_SLOT_BYTES);
-    Arena tmp;
-    tmp.init(arenas + lane * arenaBytes, (size_t)arenaBytes);
-    memoRunPath(memo, tmp, caps, &local);
-  }
-  addCounters(counters, local);
 }
 
 // Test entry (xm_test_local_align): the reference's component-level known-answer tests (PathAligner_Test.java:10-39: PathAligner alone;
@@ -230,13 +189,12 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(i
   tmp.init(arena, (size_t)arenaBytes);
   int32_t status = XM_OK;
   float hint = 0;
-  int32_t memoCursor = 0;
   ExtEnv e;
   e.caps = &caps; e.dc = &local; e.status = &status; e.tmp = &tmp;
   e.query.base = query; e.query.len = queryLength; e.query.rc = 0; e.query.id = 0;
   e.reference.base = reference; e.reference.len = referenceLength; e.reference.rc = 0; e.reference.id = 0;
   e.contig = 0;
-  e.memo = nullptr; e.memoCursor = &memoCursor; e.heavyHint = &hint;
+  e.heavyHint = &hint;
   Matcher* slots = arenaArray<Matcher>(tmp, 3);
   for (int i = 0; i < 3; i++) {
     slots[i].present = arenaArray<uint8_t>(tmp, caps.maxSections);
@@ -358,36 +316,7 @@ __global__ void __launch_bounds__(256) xm_pileup_kernel(IndexView ix, BatchView 
   }
 }
 
-// ---------------------------------------------------------------- pass bookkeeping on the device
-// After every pass the reads are sorted into the work lists of the passes still to come; only the list sizes travel to the host.
-struct PassCtl {
-  unsigned long long nHeavy, nHeavyLate, nScale[2], nOut[2], nPath[2];
-  unsigned long long errQuery;  // smallest query index whose status is an error (~0 = none)
-  unsigned long long nConf[2];  // reads that wait for a value of the confidence table (XM_ST_NEED_CONF)
-  unsigned long long nLight;    // reads the gapped pass handed back (XM_ST_NEED_LIGHT)
-};
-
-__global__ void __launch_bounds__(256) xm_classify_kernel(const int64_t* todo, long long nTodo, const int32_t* status, int64_t* listHeavy, int64_t* listScale, int64_t* listOut,
-                                                          int64_t* listPath, int64_t* listHeavyLate, int hintThreshold, PassCtl* ctl, int ts, int to, int tp, int64_t* listConf, int tc, int64_t* listLight) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nTodo) return;
-  int64_t q = todo ? todo[i] : (int64_t)i;
-  const int32_t word = status[q];
-  const int32_t st = word & 0xFF;
-  if (st == XM_OK) return;
-  if (st == XM_ST_NEED_HEAVY) {
-    // reads whose straight alignment was bad enough for an indel go to the front of the gapped pass: they are the long ones, and a
-    // launch ends with its longest wave (longest-processing-time-first)
-    if ((word >> 8) >= hintThreshold) listHeavy[atomicAdd(&ctl->nHeavy, 1ull)] = q;
-    else listHeavyLate[atomicAdd(&ctl->nHeavyLate, 1ull)] = q;
-  } else if (st == XM_ST_NEED_PATH) listPath[atomicAdd(&ctl->nPath[tp], 1ull)] = q;
-  else if (st == XM_ST_OVERFLOW) listScale[atomicAdd(&ctl->nScale[ts], 1ull)] = q;
-  else if (st == XM_ST_OUT_OVERFLOW) listOut[atomicAdd(&ctl->nOut[to], 1ull)] = q;
-  else if (st == XM_ST_NEED_CONF) listConf[atomicAdd(&ctl->nConf[tc], 1ull)] = q;
-  else if (st == XM_ST_NEED_LIGHT) listLight[atomicAdd(&ctl->nLight, 1ull)] = q;
-  else atomicMin(&ctl->errQuery, (unsigned long long)q);
-}
-
+// ---------------------------------------------------------------- pass bookkeeping on the device (PassCtl, PassLists: xm_kernel_common.h)
 // after a pass of the wave-per-read form (xm_wave_kernel.hip): reads for the next tier, reads with a waiting search request, reads left
 // to the lane-per-read passes
 struct WaveCtl { unsigned long long nNext, nSearch, nFallback, errQuery; };
@@ -405,16 +334,6 @@ __global__ void __launch_bounds__(256) xm_wave_classify_kernel(const int64_t* to
   } else if (st == 10 /* XM_ST_WAVE_SEARCH */ && listSearch) listSearch[atomicAdd(&ctl->nSearch, 1ull)] = q;
   else if (st == 8 /* XM_ST_WAVE_FALLBACK */ || st == 9 || st == 10) listFallback[atomicAdd(&ctl->nFallback, 1ull)] = q;
   else atomicMin(&ctl->errQuery, (unsigned long long)q);
-}
-
-// the gapped pass's work list: expensive-looking reads first, then the others; a read's position is its memo slot
-__global__ void __launch_bounds__(256) xm_heavy_list_kernel(int64_t* listHeavy, long long nFront, const int64_t* listLate, long long nLate, int32_t* slotOf) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nFront + nLate) return;
-  int64_t q;
-  if (i < nFront) q = listHeavy[i];
-  else { q = listLate[i - nFront]; listHeavy[i] = q; }
-  slotOf[q] = (int32_t)i;
 }
 
 // Exclusive prefix sums of the per-query stream lengths (query order), three small kernels: block totals, scan of the totals,
@@ -725,7 +644,20 @@ struct DeviceTables {
   std::shared_mutex rw;      // align / probe calls of any number of contexts hold it shared while their kernels read the tables; (re)upload holds it exclusive
   std::mutex allocMu;        // contexts of one GPU size and allocate their scratch one after the other (they all look at the same free memory)
   std::atomic<int> uploadedLength{-1};   // host.maxHashedLength the device tables hold (written under hs->mu + rw, read without them by ensureTablesFor's first test)
-  std::atomic<int> contexts{0};  // handles that share these tables (contexts of this GPU): a context sizes its launches for its share of the wave slots
+  std::atomic<int> contexts{0};  // handles that share these tables (contexts of this GPU)
+  // contexts of this GPU that are aligning: a context sizes its launches for its share of the wave slots among the contexts that were inside an align call
+  // during the last second (a process may hold more contexts than it keeps busy: the last batches of a job, uneven streams)
+  std::mutex activeMu;
+  std::map<const void*, int64_t> lastActive;  // context -> steady-clock ns of its last entry into / exit from an align call
+  int touchActive(const void* ctx) {
+    const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    std::lock_guard<std::mutex> lock(activeMu);
+    lastActive[ctx] = now;
+    int n = 0;
+    for (const auto& kv : lastActive) if (now - kv.second <= 1000000000ll) n++;
+    return n;
+  }
+  void dropActive(const void* ctx) { std::lock_guard<std::mutex> lock(activeMu); lastActive.erase(ctx); }
   DevBuf<int64_t> dContigStart, dSeqCumStart, dDupKeyStart;
   DevBuf<int32_t> dContigLen, dDupKeys;
   DevBuf<uint8_t> dRefCodes;
@@ -834,13 +766,10 @@ struct xm_index {
   DevBuf<int64_t> dMateOffset, dIntOff, dDblOff, dTodo;
   DevBuf<double> dExpected, dDeviation, dOutDbls;
   DevBuf<unsigned long long> dCursors;  // [0],[1] result cursors, [2] next item
-  DevBuf<int64_t> dListHeavy, dListHeavyLate, dListScale[2], dListOut[2], dListPath[2], dFinalIntOff, dFinalDblOff;
-  DevBuf<int32_t> dSlotOf, dRegionOf;
-  DevBuf<uint8_t> dMemo;
+  DevBuf<int64_t> dListHeavy, dListHeavyLate, dListScale[2], dListOut[2], dFinalIntOff, dFinalDblOff;
+  DevBuf<int32_t> dRegionOf;
   DevBuf<PNode> dWaveNodes;  // per wave: node payloads of its LDS-mode search
   DevBuf<uint8_t> dSearchPool;  // one buffer per wave for the arrays of HBM-mode searches (SearchPool, xm_extend.h)
-  DevBuf<uint8_t> dBigSets;     // scheduler kernel, batches of long reads: the pool of large search sets (BigSetPool)
-  DevBuf<int32_t> dBigSetOwner;
   // wave-per-read passes
   DevBuf<int64_t> dListWaveHeavy, dListWaveNext, dListWaveSearch[2], dListFallback;
   DevBuf<uint8_t> dWaveMemo;
@@ -861,7 +790,7 @@ struct xm_index {
   bool confDirty = true;
   DevBuf<ConfEntry> dConf;
   DevBuf<uint8_t> dConfMiss;
-  DevBuf<int64_t> dListConf[2], dListLight;
+  DevBuf<int64_t> dListConf[2];
   std::vector<int32_t> residentLens, stagedLens;  // distinct total query lengths of the batch (the table is seeded for them)
   int64_t residentNq = -1;   // batch kept in HBM by xm_batch_upload
   int64_t residentGen = 0, lastAlignedGen = -1;  // which resident batch the streams of the last align call belong to
@@ -978,7 +907,7 @@ struct xm_index {
     }
   }
   ~xm_index() {
-    if (dt) dt->contexts.fetch_sub(1);
+    if (dt) { dt->contexts.fetch_sub(1); dt->dropActive(this); }
     if (hostOnly) return;
     (void)hipSetDevice(device);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -1429,11 +1358,6 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     params.UnalignedPenalty = p->UnalignedPenalty; params.AmbiguityPenalty = p->AmbiguityPenalty; params.Max_PenaltySpan = p->Max_PenaltySpan;
     params.MaxNumMatches = p->MaxNumMatches; params.StartingInsertionStartFree = 0;
 
-    {  // XM_WSEARCH_FROM (experiment knob): the chain scale from which searches that start in HBM mode run in the form of xm_wsearch.h (default 16)
-      const int from = (int)envKnob("XM_WSEARCH_FROM", 16, 1, 0x7fffffff);
-      HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(xm_wide_search_from), &from, sizeof(from), 0, hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipStreamSynchronize(s));
-    }
     idx->confPrepare(params, s);
     view.conf = idx->dConf.p; view.confMask = (uint32_t)(idx->confHost.size() - 1); view.confMiss = (ConfMiss*)idx->dConfMiss.p;
     idx->dListConf[0].ensure((size_t)nq); idx->dListConf[1].ensure((size_t)nq);
@@ -1450,11 +1374,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // Passes, all on the GPU:
     //  (1) light pass over every read at scale 1: reads that reach the gapped extension chain stop with XM_ST_NEED_HEAVY
     //      instead of serialising their wave;
-    //  (2) gapped pass over exactly those reads at scale 4, PathAligner searches deferred: chain kernel (a read stops at its
-    //      first search it has no result for) -> xm_path_kernel (all waiting searches, one per lane) -> chain kernel over the
-    //      reads that waited (replay from their memo slots) -> ... until no read waits;
-    //  (3) reads whose scratch overflowed are rerun with inline searches and 16x, 64x, ... the scratch.
-    // The work lists are built on the GPU (xm_classify_kernel); every pass appends to the same result arenas.
+    //  (2) gapped pass over exactly those reads at scale 4, continued from the state the light pass saved (HandOver);
+    //  (3) reads whose scratch overflowed are rerun with 16x, 64x, ... the scratch.
+    // The work lists are built on the GPU by the lanes themselves (PassLists); every pass appends to the same result arenas.
 #ifdef XM_READ_TIMES
     DevBuf<unsigned long long> dReadTimes;
     const char* readTimesFile = getenv("XM_READ_TIMES_FILE");
@@ -1467,20 +1389,18 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
 #endif
     const int64_t* todo = nullptr;  // device list of the current pass; null on the first pass = all reads
     long long nTodo = nq;
-    unsigned long long pendingHeavy = 0, pendingScale = 0, pendingPath = 0;
-    int ts = 0, to = 0, tp = 0, tc = 0;  // which of the two scale / out / path / confidence lists receives new entries
+    unsigned long long pendingHeavy = 0, pendingScale = 0;
+    int ts = 0, to = 0, tc = 0;  // which of the two scale / out / confidence lists receives new entries
     unsigned long long pendingConf = 0;
     int confRounds = 0;
     // the scratch capacities are sized for ~150-300 bp mates at scale 1; batches of longer reads start at a larger scale instead of
     // sending every read through a pass that can only overflow
     int scale = idx->residentMaxLen <= 320 ? 1 : (idx->residentMaxLen <= 1280 ? 4 : 16), overflowScale = scale;
     const int gappedScale = scale < 4 ? (int)envKnob("XM_GAPPED_SCALE", 4, 1, 64, true) : scale * (int)envKnob("XM_GAPPED_FACTOR", 4, 1, 64, true);
-    bool heavy = false, defer = false, memoFresh = false, inlineRest = false;
-    int searchRounds = 0;
+    bool heavy = false;
     unsigned long long intCap = (unsigned long long)nq * 40 + 4096, dblCap = (unsigned long long)nq * 12 + 4096;
     idx->dOutInts.ensure((size_t)intCap); idx->dOutDbls.ensure((size_t)dblCap);
     intCap = idx->dOutInts.n; dblCap = idx->dOutDbls.n;
-    idx->dSlotOf.ensure((size_t)nq);
     unsigned long long cursors[4] = {0, 0, 0, 0};
     double kernelMs = 0;
     int launches = 0;
@@ -1495,7 +1415,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // other instead of side by side.  Together the contexts of a GPU ask for 12 waves per SIMD worth of light lanes and 6 of gapped lanes: two contexts 6 / 3
     // each (round 3), three 4 / 2 - 14.1-14.3 M reads/s against 13.1-13.2 with two, once the runtime has hardware queues for three contexts' streams
     // (GPU_MAX_HW_QUEUES, mapper_amd/_capi.py); with 6 / 3 each three contexts measured 12.3-12.7, four with 3 / 1 13.5 (profiles/r04/NOTES.md 15)
-    const int gpuContexts = idx->dt->contexts.load();
+    const int gpuContexts = idx->dt->touchActive(idx);
+    struct Leave { xm_index* i; ~Leave() { i->dt->touchActive(i); } } leaveActive{idx};
     const bool sharedGpu = gpuContexts > 1;
     // Batches of long reads (gapped pass beyond scale 4: every read goes through the chain, and its searches - thousands of nodes each, all in HBM mode -
     // are most of its time): the lanes of a wave run their searches one after the other, so 8 reads per wave on twice as many waves instead of 32
@@ -1503,22 +1424,14 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     const bool longReads = gappedScale > 4;
     // (long reads: every lane of the light pass holds a region of 288 KiB, and every read goes on to the gapped pass, whose lanes are 6.7 MB each:
     // two waves per SIMD worth of light lanes leave the scratch to those)
-    const long long lightWaves = envKnob("XM_LIGHT_WAVES", longReads ? 2 : (sharedGpu ? std::max(2, 12 / gpuContexts) : 8), 1, 16), fullWaves = envKnob("XM_FULL_WAVES", longReads ? 8 : (sharedGpu ? std::max(1, 6 / gpuContexts) : 4), 1, 16), pathWaves = envKnob("XM_PATH_WAVES", 4, 1, 16);
+    const long long lightWaves = envKnob("XM_LIGHT_WAVES", longReads ? 2 : (sharedGpu ? std::max(2, 12 / gpuContexts) : 8), 1, 16), fullWaves = envKnob("XM_FULL_WAVES", longReads ? 8 : (sharedGpu ? std::max(1, 6 / gpuContexts) : 4), 1, 16);
     const long long fullLpw = envKnob("XM_FULL_LPW", longReads ? 8 : 32, 1, 64), lightLpw = envKnob("XM_LIGHT_LPW", 64, 1, 64);
-    const bool deferSearches = envInt("XM_DEFER_PATH", 0) != 0;
-    const bool fullSync = envInt("XM_FULL_SYNC", 0) != 0;  // gapped pass: the lanes of a wave take their next reads together (no taper then)
-    const bool lightSync = envInt("XM_LIGHT_SYNC", 0) != 0;  // lanes of a light-pass wave take reads together (measured: no gain)
     const long long lightLevel = envKnob("XM_LIGHT_LEVEL", 0, 0, 2);  // what the light pass still does itself (Caps::heavyAllowed)
     // straight-alignment penalty x 8 from which a read is put first in the gapped pass and dealt out evenly (0: no order).  Batches of single reads of up to 320
     // bases: 8 penalty units - the reads with an indel (they mismatch on one whole side of it), whose searches are the long ones of the pass: started first
     // they do not end it (gapped pass 70.0 / 70.5 -> 65.2 / 64.8 ms per 1 M reads, same box; with 4 units 75 ms; pairs 146 -> 152-154 ms: not for them)
-    const long long heavyHintThreshold = envKnob("XM_HEAVY_HINT", (idx->residentAnyPaired || longReads || fullSync) ? 0 : 64, 0, 1 << 20);
-    if (fullSync && heavyHintThreshold > 0)  // (measured once: the launch did not end within 13 minutes; never looked into, so never run)
-      throw std::runtime_error("XM_FULL_SYNC=1 and XM_HEAVY_HINT together are not supported");
+    const long long heavyHintThreshold = envKnob("XM_HEAVY_HINT", (idx->residentAnyPaired || longReads) ? 0 : 64, 0, 1 << 20);
     const long long taperWaves = envKnob("XM_TAPER_PCT", 100, 0, 1000);  // lane l of a gapped-pass wave stops taking reads when fewer than l * waves * pct/100 are left
-    // a search round costs two launches whose time is the time of one read (a replay, a search) however few reads wait; once the
-    // waiting reads no longer fill the GPU the rest is cheaper inline: one last chain pass, one read per wave
-    const long long deferMaxRounds = envKnob("XM_DEFER_ROUNDS", 3, 0, 1000000), inlineBelow = envKnob("XM_INLINE_BELOW", 8192, 0, 1ll << 40);
     auto scratchBudget = [&]() -> unsigned long long {  // scratch: up to the limit, never more than 3/4 of what is free now (+ what this context already holds)
       unsigned long long want = scratchWanted >> scratchShift;
       size_t freeB = 0, totalB = 0;
@@ -1534,10 +1447,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       if (++scratchShift > 8) throw std::runtime_error("no room in HBM for the scratch of even a few lanes (" + std::to_string(bytes >> 20) + " MiB asked)");
       return false;
     };
-    auto scratchLanes = [&](size_t arenaBytes) -> long long { return (long long)(scratchBudget() / arenaBytes); };
     // light pass -> gapped pass hand-over (HandOver, SavedRead): the reads the light pass stops in front of the gapped chain keep their seeding
     // state in HBM and the gapped pass continues from it.  Scratch layout while saved regions are alive: [region pool | lane arenas].
-    // (Deferred searches replay a read from its start, which a consumed region does not allow: no hand-over then.)
     const bool pairMode = envInt("XM_PAIR_LANES", 1) != 0;
     // temporaries of a gapped-pass lane (reads that resume from a saved region): 7/12 of the arena of that scale by default (experiment knob: percent of it)
     // HBM-mode searches take their arrays from a pool of the launch (SearchPool) in batches of short reads (gapped pass at scale <= 4): a lane's
@@ -1549,42 +1460,11 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     auto gappedTmpBytes = [&](size_t arena) -> size_t { return ((size_t)((arena - arenaPersistBytes(arena)) * (size_t)gappedTmpPct / 100) & ~(size_t)15) + chainExtraTmpBytes(gappedScale); };
     // light pass: a lane's temporaries hold the three matchers alignMatch sets aside (37 KB at scale 1; the chain that would fill them does not
     // run there) and the joined text of overlapping mates; a read's region holds its seeding state: 49 KB single-end, 99 KB paired at scale 1
-    // (ambiguity codes add up to 20 KB per mate: such a read overflows a single-end region and is seeded again by the gapped pass)
+    // (ambiguity codes add up to 18 KB per mate: a pair with them overflows its region and is seeded again at the gapped pass's scale)
     const size_t lightTmpUnit = (size_t)envKnob("XM_LIGHT_TMP_KB", 48, 16, 16384) * 1024;
     const size_t regionPersistUnit = (size_t)envKnob("XM_REGION_KB", idx->residentAnyPaired ? 120 : 72, 32, 16384) * 1024;
-    const bool handOver = envInt("XM_HANDOVER", 1) != 0 && !deferSearches;
-    // hand-back (XM_HANDBACK=1; off: measured slower, profiles/r03/NOTES.md): a read the gapped pass resumed stops again when its candidate is
-    // through the chain; what is left of it - index walk, votes, straight alignments of further candidates - is the light pass's kind of work,
-    // which a lane of the gapped pass runs all but alone in its wave (a quarter of that pass's wave time); a pass of the light pass's shape takes
-    // those reads back, and the ones that meet another candidate for the chain go round again.  The gapped pass gets 20 % shorter, but what a
-    // read has left to do is a chain of dependent steps that takes its few milliseconds whatever runs beside it: the passes that take reads
-    // back (60 k, 415, 18 reads ...) each last as long as their slowest read, and together cost twice what the gapped pass saved.
-    const bool handBack = handOver && envInt("XM_HANDBACK", 0) != 0;
-    // the gapped pass of batches of short reads as a wave-level scheduler (xm_sched_kernel, xm_sched.h): chain phases and search phases that the lanes of a
-    // wave execute together.  A lane's scratch there: region | chain temporaries | its own search arrays | memo.  XM_SCHED=0: the lane-per-read gapped pass
-    // XM_SCHED=1: batches of short reads; XM_SCHED_LONG=1: batches of long reads (their searches - thousands of entries each - are most of their time)
-    const bool schedOn = handOver && !handBack && (longReads ? envInt("XM_SCHED_LONG", 0) != 0 : envInt("XM_SCHED", 0) != 0);
-    const bool schedSplit = schedOn && !longReads && envInt("XM_SCHED", 0) == 2;
-    long long gappedFront = 0;  // reads at the front of the gapped pass's list (the ones that look expensive)
+    const bool handOver = envInt("XM_HANDOVER", 1) != 0;
     bool orderedList = false;   // the next launch's list is the gapped pass's ordered one (expensive-looking reads first): only that list is dealt out lane-major
-    const long long schedLpw = envKnob("XM_SCHED_LPW", longReads ? 8 : 32, 1, 64), schedQuantum = envKnob("XM_SCHED_QUANTUM", 128, 1, 1 << 30), schedGate = envKnob("XM_SCHED_GATE", longReads ? 2 : 8, 1, 64);
-    SchedLayout schedLay{0, 0, 0};
-    BigSetPool bigSets{nullptr, 0, nullptr, 0, 0};
-    if (schedOn) {
-      Caps c = makeCaps(scale);
-      applyChainCaps(c, gappedScale);
-      schedLay.searchBytes = schedSearchArenaBytes(c);
-      schedLay.memoBytes = (unsigned long long)envKnob("XM_SCHED_MEMO_KB", longReads ? 4 * gappedScale : 8, 2, 4096) * 1024;
-    }
-    // (the chain temporaries of a scheduler lane: no arrays for searches in them - batches of long reads keep the matchers' share of what applyChainCaps adds)
-    auto schedTmpBytes = [&](size_t arena) -> size_t {
-      if (!longReads) return gappedTmpBytes(arena);
-      const Caps g = makeCaps(gappedScale);
-      const size_t searchArrays = (size_t)g.maxNodes * (sizeof(PNode) + 8) + (size_t)std::max(g.gridCap, g.nodeHash) * 4 + (size_t)g.maxBuckets * 20 + (size_t)g.bucketHash * 4;
-      const size_t whole = ((size_t)((arena - arenaPersistBytes(arena)) * (size_t)gappedTmpPct / 100) & ~(size_t)15);
-      return (whole > searchArrays + (256u << 10) ? whole - searchArrays : whole) + chainExtraMatcherBytes(gappedScale);
-    };
-    unsigned long long pendingLight = 0;
     int hoMode = handOver ? 1 : 0;   // mode of the next launch
     const int seedScale = scale;
     const size_t regionBytes = ((regionPersistUnit * (size_t)seedScale) & ~(size_t)15) + ((sizeof(SavedRead) + 15) & ~(size_t)15);
@@ -1707,38 +1587,16 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     while (nTodo > 0) {
       std::unique_lock<std::mutex> sizing(idx->dt->allocMu);
       size_t arenaBytes = arenaUnit * (size_t)scale;  // bytes of scratch a lane owns in this launch
-      if (hoMode == 1 || hoMode == 3) arenaBytes = lightTmpUnit * (size_t)scale;                   // temporaries only (+ one region of the pool per lane / the read's own region)
-      const bool schedPass = schedOn && heavy && hoMode == 2 && scale == gappedScale;
-      if (schedPass) schedLay.tmpBytes = schedTmpBytes(arenaBytes);
-      if (hoMode == 2) arenaBytes = schedPass ? regionBytes + (size_t)(schedLay.tmpBytes + schedLay.searchBytes + schedLay.memoBytes) : regionBytes + gappedTmpBytes(arenaBytes);  // a region for reads without saved state + temporaries
+      if (hoMode == 1) arenaBytes = lightTmpUnit * (size_t)scale;                   // temporaries only (+ one region of the pool per lane / the read's own region)
+      if (hoMode == 2) arenaBytes = regionBytes + gappedTmpBytes(arenaBytes);       // a region for reads without saved state + temporaries
       // launch shape (measured on MI355X, profiles/r01/NOTES.md): 8 waves per SIMD worth of lanes in the light pass; the gapped chain
       // diverges inside each wave, so it runs 32 reads per wave on 4 waves per SIMD.  The XM_* variables are experiment knobs.
       // a pass over few reads spreads them over all the wave slots of the GPU (the time of a launch is its longest wave)
       const long long waveSlots = (long long)numCUs * 4 * (heavy ? fullWaves : lightWaves);
-      int lpw = (int)(schedPass ? schedLpw : (heavy ? fullLpw : lightLpw));  // active lanes per wave
+      int lpw = (int)(heavy ? fullLpw : lightLpw);  // active lanes per wave
       if (heavy) lpw = (int)std::max(1ll, std::min((long long)lpw, (nTodo + waveSlots - 1) / waveSlots));
       long long lanes = waveSlots * lpw;
-      // scheduler kernel, batches of long reads: the pool of large search sets comes out of the context's scratch before the lanes are counted (a quarter of it:
-      // a lane then owns ~2 MB instead of ~7, and the reads in flight are what a batch of long reads is short of)
-      if (schedOn && longReads && hoMode == 1 && bigSets.nPerGroup == 0) {
-        Caps c = makeCaps(seedScale);
-        applyChainCaps(c, gappedScale);
-        bigSets.bufBytes = (schedBigSetBytes(c) + 4095) & ~(size_t)4095;
-        const unsigned long long share = scratchBudget() * (unsigned long long)envKnob("XM_SCHED_BIGSET_PCT", 25, 1, 90) / 100;
-        long long perGroup = (long long)(share / bigSets.bufBytes / 8);
-        while (perGroup >= 1 && !idx->dBigSets.tryEnsure((size_t)perGroup * 8 * bigSets.bufBytes)) perGroup /= 2;
-        if (perGroup >= 1) {
-          bigSets.nPerGroup = (int32_t)std::min<long long>(perGroup, 1 << 20);
-          bigSets.base = idx->dBigSets.p;
-          idx->dBigSetOwner.ensure((size_t)bigSets.nPerGroup * 8);
-          bigSets.owner = idx->dBigSetOwner.p;
-        }
-      }
-      unsigned long long budget = scratchBudget();
-      if (bigSets.nPerGroup > 0) {  // (the pool counts against the context's scratch limit)
-        const unsigned long long lim = scratchWanted >> scratchShift, used = (unsigned long long)bigSets.nPerGroup * 8 * bigSets.bufBytes;
-        budget = std::min(budget, lim > used + (64ull << 20) ? lim - used : (64ull << 20));
-      }
+      const unsigned long long budget = scratchBudget();
       if (hoMode == 1) lanes = std::min(lanes, (long long)(budget / (arenaBytes + regionBytes)));
       else if (regionsTotal > 0) lanes = std::min(lanes, (long long)((idx->dArenas.n - regionsTotal) / arenaBytes));  // (sized below, before the pool was filled)
       else lanes = std::min(lanes, (long long)(budget / arenaBytes));
@@ -1746,7 +1604,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       // long reads, scratch for fewer lanes than asked for: fewer reads per wave before fewer waves than the GPU holds at a time (4 per SIMD) - a wave's
       // reads wait for each other's searches, an empty wave slot does nothing
       // (contexts that share the GPU share its wave slots)
-      const long long slotsHeld = (long long)numCUs * 16 / std::max(1, idx->dt->contexts.load());
+      const long long slotsHeld = (long long)numCUs * 16 / std::max(1, gpuContexts);
       if (heavy && longReads && lpw > 1 && lanes / lpw < slotsHeld) lpw = (int)std::max(1ll, lanes / slotsHeld);
       long long nWaves = (lanes + lpw - 1) / lpw;
       if (nWaves < 1) nWaves = 1;
@@ -1773,8 +1631,8 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         if (extra < 0) extra = 0;
         nRegions = lanes + extra;
         regionsTotal = (size_t)nRegions * regionBytes;
-        const size_t gappedArena = arenaUnit * (size_t)gappedScale, gappedLane = schedOn ? regionBytes + schedTmpBytes(gappedArena) + (size_t)(schedLay.searchBytes + schedLay.memoBytes) : regionBytes + gappedTmpBytes(gappedArena);
-        long long gappedLanes = std::min((long long)nq, (long long)numCUs * 4 * fullWaves * (schedOn ? schedLpw : fullLpw));
+        const size_t gappedArena = arenaUnit * (size_t)gappedScale, gappedLane = regionBytes + gappedTmpBytes(gappedArena);
+        long long gappedLanes = std::min((long long)nq, (long long)numCUs * 4 * fullWaves * fullLpw);
         gappedLanes = std::min(gappedLanes, std::max(1ll, ((long long)budget - (long long)regionsTotal) / (long long)gappedLane));
         size_t behind = std::max((size_t)lanes * arenaBytes, (size_t)gappedLanes * gappedLane);
         behind = std::max(behind, gappedArena);  // (a rerun after a full result arena runs plain, at least one lane of it)
@@ -1787,10 +1645,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         if (!allocScratch((size_t)lanes * arenaBytes)) continue;
       }
       sizing.unlock();
-      const int pairLanes = (heavy && !schedPass && lpw <= 32 && !defer && !fullSync && pairMode) ? 1 : 0;  // two lanes per read (xm_extend.h, xmSetPairMode)
+      const int pairLanes = (heavy && lpw <= 32 && pairMode) ? 1 : 0;  // two lanes per read (xm_extend.h, xmSetPairMode)
       uint8_t* laneArenas = idx->dArenas.p + regionsTotal;
-      HandOver ho{hoMode, handBack ? 1 : 0, (int)lightLevel, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
-      idx->dListLight.ensure((size_t)nq);
+      HandOver ho{hoMode, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
       const int launchedMode = hoMode;
       idx->dWaveNodes.ensure((size_t)grid * (block / 64) * XM_PAL_NODES);
       SearchPool pool{nullptr, 0, 0, 0};
@@ -1800,77 +1657,38 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         idx->dSearchPool.ensure((size_t)pool.n * pool.bufBytes);
         pool.base = idx->dSearchPool.p;
       }
-      idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq); idx->dListPath[tp].ensure(defer ? (size_t)nTodo : 1);
+      idx->dListScale[ts].ensure((size_t)nq); idx->dListOut[to].ensure((size_t)nq);
       // gapped pass with an ordered list: the first read of every lane is dealt out (kernel), the counter starts behind those items
-      const long long firstStride = (heavy && orderedList && !schedPass && !defer && heavyHintThreshold > 0 && scale == gappedScale) ? (long long)grid * (block / 64) : 0;
-      const unsigned long long firstItem = (unsigned long long)std::min((long long)nTodo, (schedPass ? (long long)grid * (block / 64) : firstStride) * lpw);  // (the scheduler kernel deals every lane's first read)
+      const long long firstStride = (heavy && orderedList && heavyHintThreshold > 0 && scale == gappedScale) ? (long long)grid * (block / 64) : 0;
+      const unsigned long long firstItem = (unsigned long long)std::min((long long)nTodo, firstStride * lpw);
       HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 2, &firstItem, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
       OutView ov{idx->dOutInts.p, idx->dOutDbls.p, intCap, dblCap, idx->dCursors.p, idx->dStatus.p, idx->dIntOff.p, idx->dDblOff.p, idx->dIntLen.p, idx->dDblLen.p};
-      if (!(schedPass && schedSplit && gappedFront > 0 && gappedFront < nTodo)) HIP_CHECK(hipEventRecord(e0, s));
-      if (schedPass && schedSplit && gappedFront > 0 && gappedFront < nTodo) {
-        // XM_SCHED=2 (experiment): the reads at the front of the list - the ones with an indel, whose time is mostly searches - through the scheduler
-        // kernel, the others - mismatches only: their time is the chain, which the lane-per-read kernel runs with its lanes in step - through that one
-        const long long nFrontReads = gappedFront;
-        const unsigned long long firstA = (unsigned long long)std::min(nFrontReads, (long long)grid * (block / 64) * lpw), zero = 0;
-        HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 2, &firstA, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(idx->dCursors.p + 3, &zero, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipEventRecord(e0, s));
-        SchedLaunch sl{grid, block, view, params, bv, todo, nFrontReads, scale, lpw, (int)schedQuantum, (int)schedGate, laneArenas, (unsigned long long)arenaBytes, schedLay, ov, idx->dCursors.p + 2, idx->dCounters.p, idx->dWaveNodes.p, ho, pool, bigSets};
-        const int rc = xmSchedLaunch(sl, (void*)s);
-        if (rc != 0) throw std::runtime_error(std::string("scheduler kernel launch: ") + hipGetErrorString((hipError_t)rc));
-        hipEvent_t em;
-        HIP_CHECK(hipEventCreate(&em));
-        HIP_CHECK(hipEventRecord(em, s));
-        const int lpwB = (int)std::min<long long>(fullLpw, lpw);  // (the lanes' arenas are laid out for `lpw` lanes per wave)
-        hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, view, params, bv, todo + nFrontReads, nTodo - nFrontReads, scale, 2, lpwB,
-                           laneArenas, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 3, idx->dCounters.p, (uint8_t*)nullptr, idx->dSlotOf.p, 0, 0,
-                           (long long)((double)nWaves * taperWaves / 100.0), 0, 0ll, idx->dWaveNodes.p, ho, (lpwB <= 32 && pairMode) ? 1 : 0, pool);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipEventRecord(e1, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        float msA = 0, msB = 0;
-        HIP_CHECK(hipEventElapsedTime(&msA, e0, em)); HIP_CHECK(hipEventElapsedTime(&msB, em, e1));
-        HIP_CHECK(hipEventDestroy(em));
-        if (envInt("XM_TRACE_PASSES", 0) != 0) fprintf(stderr, "[xm] split gapped pass: scheduler kernel over %lld reads %.3f ms, lane-per-read kernel over %lld reads %.3f ms\n", nFrontReads, msA, nTodo - nFrontReads, msB);
-      }
-      else if (schedPass) {
-        if (bigSets.nPerGroup > 0) HIP_CHECK(hipMemsetAsync(bigSets.owner, 0, sizeof(int32_t) * (size_t)bigSets.nPerGroup * 8, s));
-        SchedLaunch sl{grid, block, view, params, bv, todo, nTodo, scale, lpw, (int)schedQuantum, (int)schedGate, laneArenas, (unsigned long long)arenaBytes, schedLay, ov, idx->dCursors.p + 2, idx->dCounters.p, idx->dWaveNodes.p, ho, pool, bigSets};
-        const int rc = xmSchedLaunch(sl, (void*)s);
-        if (rc != 0) throw std::runtime_error(std::string("scheduler kernel launch: ") + hipGetErrorString((hipError_t)rc));
-      }
-      else
+      // the lanes file the reads they could not finish into the work lists of the passes to come as they publish them (PassLists; no kernel behind the pass)
+      PassLists lists{idx->dListHeavy.p, idx->dListHeavyLate.p, idx->dListScale[ts].p, idx->dListOut[to].p, idx->dListConf[tc].p, (int)heavyHintThreshold, ts, to, tc, idx->dCtl.p};
+      HIP_CHECK(hipEventRecord(e0, s));
       hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
                          laneArenas, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
-                         defer ? idx->dMemo.p : (uint8_t*)nullptr, idx->dSlotOf.p, memoFresh ? 1 : 0, (defer && !inlineRest) ? 1 : 0,
-                         (heavy && !fullSync) ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, ((!heavy && lightSync) || (heavy && fullSync)) ? 1 : 0,
-                         fullSync ? 0ll : firstStride, idx->dWaveNodes.p, ho, pairLanes, pool);
+                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, firstStride, idx->dWaveNodes.p, ho, pairLanes, pool, lists);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
-      hipLaunchKernelGGL(xm_classify_kernel, dim3((unsigned)((nTodo + 255) / 256)), dim3(256), 0, s, todo, nTodo, idx->dStatus.p, idx->dListHeavy.p, idx->dListScale[ts].p,
-                         idx->dListOut[to].p, idx->dListPath[tp].p, idx->dListHeavyLate.p, (int)heavyHintThreshold, idx->dCtl.p, ts, to, tp, idx->dListConf[tc].p, tc, idx->dListLight.p);
-      HIP_CHECK(hipGetLastError());
       PassCtl ctl;
       HIP_CHECK(hipMemcpyAsync(&ctl, idx->dCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipMemcpyAsync(cursors, idx->dCursors.p, sizeof(cursors), hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
       HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       kernelMs += ms;
-      res->counters[!heavy ? 12 : (defer ? 13 : 15)] += (int64_t)(ms * 1000.0);  // kernel microseconds: light pass / gapped chain passes / inline reruns
+      res->counters[!heavy ? 12 : 15] += (int64_t)(ms * 1000.0);  // kernel microseconds: light pass / gapped pass and reruns
       launches++;
-      memoFresh = false;
       orderedList = false;
-      hoMode = 0;                                // (the gapped pass below switches to 2, the pass that takes reads back to 3; reruns run plain)
-      pendingLight = ctl.nLight;
-      // the saved reads have all been consumed once neither a handed-back read nor one that stopped in front of the chain again is waiting
-      if ((launchedMode == 2 && pendingLight == 0) || (launchedMode == 3 && ctl.nHeavy + ctl.nHeavyLate == 0)) regionsTotal = 0;
+      hoMode = 0;                                // (the gapped pass below switches to 2; reruns run plain)
+      if (launchedMode == 2) regionsTotal = 0;   // the saved reads have all been consumed
 #ifdef XM_LIGHT_ONLY
       fprintf(stderr, "[xm] light-only experiment build: pass %d %.3f ms\n", launches, ms);
       break;  // (experiment build, scripts/gpu_light_only.sh: only the first pass is meaningful)
 #endif
       const bool tracePasses = envInt("XM_TRACE_PASSES", 0) != 0;
-      if (tracePasses) fprintf(stderr, "[xm] pass %d: %s reads %lld scale %d lpw %d waves %lld: %.3f ms -> heavy %llu path %llu scale %llu out %llu\n", launches, !heavy ? "light" : (defer ? "chain" : "inline"),
-                               nTodo, scale, lpw, nWaves, ms, ctl.nHeavy, ctl.nPath[tp], ctl.nScale[ts], ctl.nOut[to]);
+      if (tracePasses) fprintf(stderr, "[xm] pass %d: %s reads %lld scale %d lpw %d waves %lld: %.3f ms -> heavy %llu scale %llu out %llu\n", launches, !heavy ? "light" : "gapped",
+                               nTodo, scale, lpw, nWaves, ms, ctl.nHeavy + ctl.nHeavyLate, ctl.nScale[ts], ctl.nOut[to]);
 #ifdef XM_PROFILE
       if (tracePasses && heavy) {  // reads of a wave that stood at a PathAligner call together, this pass
         unsigned long long a[16] = {0}, z[16] = {0};
@@ -1890,7 +1708,6 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       }
       pendingHeavy = ctl.nHeavy + ctl.nHeavyLate;
       pendingScale = ctl.nScale[ts];
-      pendingPath = ctl.nPath[tp];
       pendingConf = ctl.nConf[tc];   // (accumulates over the passes until the list is run)
       if (ctl.nOut[to] > 0) {  // result arena too small: rerun those reads with the same settings and room to spare
         todo = idx->dListOut[to].p; nTodo = (long long)ctl.nOut[to];
@@ -1903,65 +1720,18 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         rerun += nTodo;
         continue;
       }
-      if (pendingPath > 0 && (searchRounds >= deferMaxRounds || (long long)pendingPath < inlineBelow)) {
-        // last chain pass: the reads still waiting replay from their memo slots and run their remaining searches inline
-        todo = idx->dListPath[tp].p; nTodo = (long long)pendingPath;
-        tp ^= 1;
-        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nPath[tp], 0, sizeof(unsigned long long), s));
-        inlineRest = true;
-        continue;
-      }
-      if (pendingPath > 0) {  // (defer) run the waiting searches, then replay their reads
-        const long long nPath = (long long)pendingPath;
-        searchRounds++;
-        const long long pslots = (long long)numCUs * 4 * pathWaves;
-        const int plpw = (int)std::max(1ll, std::min(64ll, (nPath + pslots - 1) / pslots));
-        long long pl = std::min(pslots * plpw, scratchLanes(arenaBytes));
-        if (pl > nPath) pl = nPath;
-        long long pWaves = (pl + plpw - 1) / plpw;
-        int pblock = pWaves < 4 ? (int)pWaves * 64 : 256;
-        int pgrid = (int)((pWaves * 64 + pblock - 1) / pblock);
-        idx->dArenas.ensure((size_t)pgrid * (pblock / 64) * plpw * arenaBytes);
-        HIP_CHECK(hipMemsetAsync(idx->dCursors.p + 2, 0, sizeof(unsigned long long), s));
-        HIP_CHECK(hipEventRecord(e0, s));
-        hipLaunchKernelGGL(xm_path_kernel, dim3(pgrid), dim3(pblock), 0, s, idx->dListPath[tp].p, nPath, idx->dSlotOf.p, idx->dMemo.p, scale, plpw, idx->dArenas.p,
-                           (unsigned long long)arenaBytes, idx->dCursors.p + 2, idx->dCounters.p);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipEventRecord(e1, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        kernelMs += ms;
-        res->counters[14] += (int64_t)(ms * 1000.0);  // search kernel microseconds
-        if (tracePasses) fprintf(stderr, "[xm] search kernel: %lld searches, %d x %d threads, %d lanes per wave: %.3f ms\n", nPath, pgrid, pblock, plpw, ms);
-        launches++;
-        todo = idx->dListPath[tp].p; nTodo = nPath;
-        tp ^= 1;
-        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nPath[tp], 0, sizeof(unsigned long long), s));
-        continue;
-      }
-      if (pendingLight > 0) {  // reads the gapped pass handed back: on in a pass of the light pass's shape
-        todo = idx->dListLight.p; nTodo = (long long)pendingLight;
-        HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nLight, 0, sizeof(unsigned long long), s));
-        scale = seedScale;
-        heavy = false; defer = false; inlineRest = false;
-        hoMode = 3;
-        continue;
-      }
       if (pendingHeavy > 0) {
         // the gapped pass runs at scale 4 straight away: far fewer lanes are needed than in the light pass, and most reads whose
         // gapped search outgrows the scale-1 scratch then finish here instead of costing one more (latency-bound) pass
-        hipLaunchKernelGGL(xm_heavy_list_kernel, dim3((unsigned)((pendingHeavy + 255) / 256)), dim3(256), 0, s, idx->dListHeavy.p, (long long)ctl.nHeavy, idx->dListHeavyLate.p,
-                           (long long)ctl.nHeavyLate, idx->dSlotOf.p);
-        HIP_CHECK(hipGetLastError());
+        if (ctl.nHeavyLate > 0) {  // one list: the expensive-looking reads first, the others behind them
+          HIP_CHECK(hipMemcpyAsync(idx->dListHeavy.p + ctl.nHeavy, idx->dListHeavyLate.p, sizeof(int64_t) * (size_t)ctl.nHeavyLate, hipMemcpyDeviceToDevice, s));
+        }
         todo = idx->dListHeavy.p; nTodo = (long long)pendingHeavy;
-        gappedFront = (long long)ctl.nHeavy;
         orderedList = true;
         HIP_CHECK(hipMemsetAsync(&idx->dCtl.p->nHeavy, 0, 2 * sizeof(unsigned long long), s));  // nHeavy, nHeavyLate (a gapped pass never adds to these lists)
         scale = gappedScale;
         if (overflowScale < gappedScale) overflowScale = gappedScale;
         heavy = true;
-        defer = deferSearches;
-        if (defer) { idx->dMemo.ensure((size_t)nTodo * XM_MEMO_SLOT_BYTES); memoFresh = true; }
         if (regionsTotal > 0) hoMode = 2;
         if (envInt("XM_PROF_GAPPED_ONLY", 0) != 0)  // XM_PROFILE builds: the in-kernel timers of the gapped pass alone
           HIP_CHECK(hipMemsetAsync((char*)idx->dCounters.p + offsetof(DevCounters, t), 0, sizeof(((DevCounters*)nullptr)->t), s));
@@ -1981,7 +1751,6 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         if (scale < gappedScale) scale = gappedScale;
         if (overflowScale < scale) overflowScale = scale;
         heavy = true;
-        defer = false; inlineRest = false;
         continue;
       }
       if (pendingScale == 0) break;
@@ -1993,7 +1762,6 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       overflowScale *= 4;
       scale = overflowScale;
       heavy = true;
-      defer = false; inlineRest = false;
       if (scale > 4096) throw std::runtime_error("Failed to align: scratch scale limit reached (query needs more than 4096x the default scratch)");
     }
     // ---- canonical streams in query order: offsets by prefix sum, slices gathered on the device, one copy per stream to the host
@@ -2244,14 +2012,6 @@ void xm_pileup_free(xm_pileup* p) {
   (void)hipSetDevice(p->device);
   p->dDepth.release(); p->dAlt.release(); p->dEventCount.release(); p->dEvents.release(); p->dMid.release();
   delete p;
-}
-
-int xm_debug_sched_profile(uint64_t* out16, int32_t reset) {
-  if (!out16) return fail("xm_debug_sched_profile: null argument");
-  unsigned long long t[16];
-  if (xmSchedProfile(t, reset) != 0) return fail("xm_debug_sched_profile: cannot read the timers");
-  for (int i = 0; i < 16; i++) out16[i] = (uint64_t)t[i];
-  return 0;
 }
 
 // Test-only entry (tests/test_gpu_kat.py): see xm_test_local_kernel above and xm_test_wave_search_kernel (xm_wave_kernel.hip).

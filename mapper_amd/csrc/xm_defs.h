@@ -45,9 +45,7 @@ enum : int32_t {
   XM_ST_NEED_GROW = 4,     // a gapmer uses more bases than the largest hashed length (host must grow the index)
   XM_ST_INTERNAL = 5,      // the reference would have thrown (e.g. TreeMap.subMap fromKey > toKey): whole batch fails
   XM_ST_NEED_HEAVY = 6,    // light pass only: the read needs the gapped extension chain; the full pass reruns it
-  XM_ST_NEED_PATH = 7,     // gapped pass with deferred PathAligner: a search request is waiting in the read's memo slot
-  XM_ST_NEED_LIGHT = 12,   // gapped pass: the candidate that needed the gapped chain is done; the rest of the read is the light pass's kind of work
-                           // (index walk, votes, straight alignments) and is handed back to a pass that runs it with all lanes of a wave busy
+                           // (7 and 12 are not in use)
   XM_ST_NEED_CONF = 11,    // quicklyConfidentInBestAlignment needs a value of the confidence table the host has not put there yet (ConfView): the
                            // read left its key in the miss list; the host evaluates it and the read runs again  (8-10: the wave form's, xm_wave.h)
 };
@@ -270,9 +268,7 @@ struct Caps {
   int32_t scale;
   int32_t heavyAllowed;  // how far into the gapped chain a read may go before it stops with XM_ST_NEED_HEAVY: 0 = not at all (stops
                          // before HashBlock_Aligner), 1 = up to BlockAligner (the hash-block analysis runs, the piece-wise alignment does not), 2 = all
-  int32_t deferPath;     // 1: a PathAligner search without a logged result is left as a request (XM_ST_NEED_PATH), needs a memo slot
   int32_t searchInHbmOnly;  // test entry only (xm_test_local_align): every PathAligner search in HBM mode, the LDS slot is not tried
-  int32_t handBack;         // gapped pass, read resumed from its saved region: stop with XM_ST_NEED_LIGHT when the resumed candidate is done
   int32_t maxLevels, maxPyramidBlocks, maxHistory, maxCounters, maxPending, maxQM, maxGoodAlignments, maxBlocks,
       maxNodes, nodeHash, gridCap, maxBuckets, bucketHash, matcherEntries, maxSections, maxPieces, maxCountMap, maxJoined;
 };
@@ -280,9 +276,7 @@ XM_INL Caps makeCaps(int scale) {
   Caps c;
   c.scale = scale;
   c.heavyAllowed = 2;
-  c.deferPath = 0;
   c.searchInHbmOnly = 0;
-  c.handBack = 0;
   c.maxLevels = 48 * scale;
   c.maxPyramidBlocks = 1536 * scale;
   c.maxHistory = 192 * scale;

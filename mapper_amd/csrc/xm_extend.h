@@ -65,102 +65,7 @@ struct ExtEnv {  // everything the chain needs
   Matcher* slotA; Matcher* slotB; Matcher* slotT;
   const int32_t* baLogStep; // IndexView::baLogStep (BlockAligner's log term, evaluated on the host)
   float* heavyHint;         // light pass: where a read that stops with XM_ST_NEED_HEAVY leaves its cost hint
-  struct MemoHdr* memo;     // gapped pass with deferred PathAligner searches: the read's memo slot (null = searches run inline)
-  int32_t* memoCursor;      // replay position in the memo log
 };
-
-// ---------------------------------------------------------------- memo slot of a read in the deferred-search gapped pass
-// PathAligner's best-first search is the one part of the chain that only a lane or two of a wave ever reach at the same time,
-// so inside the chain it runs at 1/64 of the machine.  In the gapped pass the chain therefore does not run it: pathAlign()
-// writes a request into the read's memo slot and the read stops with XM_ST_NEED_PATH; xm_path_kernel then runs every waiting
-// search, one per lane and all lanes in the same code; the read is replayed and finds the result in its memo log.  To keep
-// replays short the log also holds the results of the finished enclosing calls (BlockAligner pieces, whole alignMatch calls):
-// a finished call replaces the entries of the calls it made.  A replay is deterministic, so it meets the log entries in order.
-struct MemoHdr {
-  int32_t logBytes, logCap, textCap, hasRequest;
-  // request (PathAligner.align arguments)
-  int32_t qsStart, qsEnd, rsStart, rsEnd, referenceLen, predictedBestOffset, confident, pad;
-  double maxInsExt, maxDelExt;
-  Params params;
-  // in-lane form (textCap == 0; the wave scheduler of the gapped pass, xm_sched.h): the read stays on its lane while its search runs, so the request
-  // addresses the two texts where they are (the mate in the batch, or the joined mates in the lane's temporaries; the forward contig) instead of copying them
-  const uint8_t* qBase; const uint8_t* rBase;
-  int32_t qLen, qRc;
-  int64_t pad2;
-};
-static_assert(sizeof(MemoHdr) % 16 == 0, "the log behind the header holds 16-byte aligned blocks");
-struct MemoEntry {  // followed by nb ABlocks
-  int32_t type, ok, nb, contig, referenceReversed, seqAId, aux, bytes;
-  double totalPenalty, alignedPenalty;
-};
-enum { MEMO_MATCH = 1, MEMO_PIECE = 2, MEMO_PATH = 3, MEMO_ANALYSIS = 4 };
-constexpr int XM_MEMO_SLOT_BYTES = 8192, XM_MEMO_TEXT_BYTES = 1024;
-XM_INL uint8_t* memoTexts(MemoHdr* m) { return (uint8_t*)(m + 1); }
-XM_INL uint8_t* memoLog(MemoHdr* m) { return memoTexts(m) + m->textCap; }
-XM_INL void memoInit(MemoHdr* m) {
-  m->logBytes = 0; m->hasRequest = 0; m->textCap = XM_MEMO_TEXT_BYTES;
-  m->logCap = XM_MEMO_SLOT_BYTES - (int)sizeof(MemoHdr) - XM_MEMO_TEXT_BYTES;
-}
-// a memo of `slotBytes` whose requests carry no texts (in-lane form)
-XM_INL void memoInitInLane(MemoHdr* m, int slotBytes) {
-  m->logBytes = 0; m->hasRequest = 0; m->textCap = 0;
-  m->logCap = slotBytes - (int)sizeof(MemoHdr);
-}
-XM_INL bool memoInLane(const MemoHdr* m) { return m && m->textCap == 0; }
-// a new candidate starts (alignRead): nothing logged for the previous one is looked at again
-XM_INL void memoRestart(MemoHdr* m, int32_t& cursor) { m->logBytes = 0; m->hasRequest = 0; cursor = 0; }
-XM_INL int memoPeek(MemoHdr* m, int cursor) {
-  if (cursor >= m->logBytes) return 0;
-  return ((const MemoEntry*)(memoLog(m) + cursor))->type;
-}
-// copies the entry at the cursor into `out` (blocks included) and steps over it
-XM_INL bool memoTake(MemoHdr* m, int32_t& cursor, SeqAl& out, int32_t* aux) {
-  const MemoEntry* en = (const MemoEntry*)(memoLog(m) + cursor);
-  const MemoEntry h = *en;
-  const ABlock* b = (const ABlock*)(en + 1);
-  out.nb = h.nb; out.contig = h.contig; out.referenceReversed = (uint8_t)h.referenceReversed; out.seqAId = (uint8_t)h.seqAId;
-  out.totalPenalty = h.totalPenalty; out.alignedPenalty = h.alignedPenalty;
-  for (int i = 0; i < h.nb; i++) out.blocks[i] = b[i];
-  if (aux) *aux = h.aux;
-  cursor += h.bytes;
-  return h.ok != 0;
-}
-// the finished call that started at `start` replaces everything logged since; returns false when the slot is full
-XM_INL bool memoPut(MemoHdr* m, int32_t& cursor, int start, int type, bool ok, const SeqAl& al, int nb, int aux) {
-  const int bytes = (int)sizeof(MemoEntry) + nb * (int)sizeof(ABlock);
-  if (start + bytes > m->logCap) return false;
-  MemoEntry* en = (MemoEntry*)(memoLog(m) + start);
-  MemoEntry h;
-  h.type = type; h.ok = ok ? 1 : 0; h.nb = nb; h.contig = al.contig; h.referenceReversed = al.referenceReversed; h.seqAId = al.seqAId; h.aux = aux; h.bytes = bytes;
-  h.totalPenalty = al.totalPenalty; h.alignedPenalty = al.alignedPenalty;
-  *en = h;
-  ABlock* b = (ABlock*)(en + 1);
-  for (int i = 0; i < nb; i++) b[i] = al.blocks[i];
-  m->logBytes = start + bytes;
-  cursor = m->logBytes;
-  return true;
-}
-
-// In-lane form only: the outcome of a hash-block analysis (HashBlock_Aligner.analyzePenalty) is logged too, so that a replay does not walk the query
-// over the matcher tables again (a fifth of the chain's time).  One MemoEntry + 16 bytes: minPossiblePenalty and maxInsertionExtensionPenalty in the
-// entry's two doubles, maxDeletionExtensionPenalty behind it; the offset and its count in contig / referenceReversed; ok = the analysis made
-// the matcher of its store slot the analysis' own (an.matcher).  The matchers themselves stay where they are between a read's chain phases.
-struct MemoAnalysisTail { double maxDeletionExtensionPenalty; int64_t pad; };
-XM_INL bool memoPutAnalysis(MemoHdr* m, int32_t& cursor, double minPossible, double maxIns, double maxDel, int offset, int count, bool setMatcher) {
-  const int bytes = (int)sizeof(MemoEntry) + (int)sizeof(MemoAnalysisTail);
-  const int start = cursor;
-  if (start + bytes > m->logCap) return false;
-  MemoEntry* en = (MemoEntry*)(memoLog(m) + start);
-  MemoEntry h;
-  h.type = MEMO_ANALYSIS; h.ok = setMatcher ? 1 : 0; h.nb = 0; h.contig = offset; h.referenceReversed = count; h.seqAId = 0; h.aux = 0; h.bytes = bytes;
-  h.totalPenalty = minPossible; h.alignedPenalty = maxIns;
-  *en = h;
-  MemoAnalysisTail t; t.maxDeletionExtensionPenalty = maxDel; t.pad = 0;
-  *(MemoAnalysisTail*)(en + 1) = t;
-  m->logBytes = start + bytes;
-  cursor = m->logBytes;
-  return true;
-}
 
 // ---------------------------------------------------------------- penalties (M/AlignmentParameters.java)
 XM_INL double blockPenalty(const SeqView& q, const SeqView& r, const Params& p, const ABlock& b) {  // :106-126
@@ -1290,36 +1195,6 @@ XM_NOINL bool pathSearchLds(const PaProblem& pr, Arena& tmp, const Caps& caps, i
   return pathSearchT<true>(pr, tmp, caps, status, dc, outBlocks, nb, ldsOverflow, pair, resume);
 }
 
-// The search of a request left in a memo slot (xm_path_kernel: one request per lane).  The request carries the two texts, so the
-// views address them directly; the result goes to the end of the log, where the replay of the read will look for it.
-XM_INL void memoRunPath(MemoHdr* m, Arena& tmp, const Caps& caps, DevCounters* dc) {
-  PaProblem pr;
-  pr.qs = Section{m->qsStart, m->qsEnd}; pr.rs = Section{m->rsStart, m->rsEnd};
-  const uint8_t* textA = memoTexts(m);
-  const uint8_t* textB = textA + (m->qsEnd - m->qsStart);
-  pr.qBase = textA - m->qsStart; pr.qLen = m->qsEnd; pr.qRc = false;  // at(i) = base[i] for the section's positions
-  pr.rBase = textB - m->rsStart; pr.referenceLen = m->referenceLen;
-  pr.params = m->params;
-  pr.confident = m->confident != 0; pr.maxInsExt = m->maxInsExt; pr.maxDelExt = m->maxDelExt; pr.predictedBestOffset = m->predictedBestOffset;
-  size_t mark = tmp.used;
-  ABlock* blocks = arenaArray<ABlock>(tmp, caps.maxBlocks);
-  int32_t st = tmp.overflow ? (int32_t)XM_ST_OVERFLOW : (int32_t)XM_OK;
-  int32_t nb = 0;
-  bool found = false;
-  if (!st) found = pathSearchHbm(pr, tmp, caps, &st, dc, blocks, nb);
-  SeqAl al;
-  al.blocks = blocks; al.nb = 0; al.contig = 0; al.referenceReversed = 0; al.seqAId = 0; al.totalPenalty = 0; al.alignedPenalty = 0;
-  int32_t cursor = 0;
-  if (!memoPut(m, cursor, m->logBytes, MEMO_PATH, found, al, found ? nb : 0, st)) {
-    // no room for the blocks: the replay must still find an entry, and it will send the read to the inline rerun
-    al.nb = 0;
-    m->logBytes = m->logBytes < m->logCap - (int)sizeof(MemoEntry) ? m->logBytes : m->logCap - (int)sizeof(MemoEntry);
-    memoPut(m, cursor, m->logBytes, MEMO_PATH, false, al, 0, XM_ST_OVERFLOW);
-  }
-  m->hasRequest = 0;
-  tmp.used = mark;
-}
-
 // One turn at the wave's slot: the LDS-mode search, and when it stops in front of an entry it has no room for, the HBM-mode search that
 // takes its state over (while the slot and the wave's node buffer still hold it).  ldsOverflow stays set for the searches that could not
 // even start in the slot (texts too long, too many start nodes): those are done in HBM mode from the beginning, after the turns.
@@ -1337,10 +1212,10 @@ XM_INL bool pathSearchSlot(const PaProblem& pr, Arena& tmp, const Caps& caps, in
 // The search in the form of xm_wsearch.h (lane-private tables built for few dependent trips to memory: four per explored entry against about
 // thirteen of PathAlignerT<false>), run from start to end in the lane's temporaries: what a chain whose searches start in HBM mode (scale 16 and up: long
 // reads, and the reruns of reads that outgrew scale 4 - a handful of reads whose searches put tens of thousands of nodes and whose pass lasts as long
-// as the slowest of them) uses instead of pathSearchHbm.  xm_wide_search_from: the chain scale from which it does (XM_WSEARCH_FROM; 0x7fffffff: never).
+// as the slowest of them) uses instead of pathSearchHbm.  XM_WSEARCH_FROM (a compile-time define): the chain scale from which it does.
 XM_NOINL_DECL bool pathSearchW(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb);
-#if defined(__HIPCC__)
-__device__ int xm_wide_search_from = 16;
+#ifndef XM_WSEARCH_FROM
+#define XM_WSEARCH_FROM 16
 #endif
 #if defined(__HIPCC__) && defined(XM_PROFILE)
 // profile builds: how many reads of a wave stand at a PathAligner call together ([0] arrivals, [1] reads in them, [2] arrivals of four reads or more, [3] reads in those)
@@ -1353,58 +1228,14 @@ __device__ unsigned long long xm_arrive_prof[16];
 #undef XM_PAIR_CHECK
 #define XM_PAIR_CHECK(k, v) do { } while (0)
 #endif
-XM_INL int wideSearchFrom() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return xm_wide_search_from;
-#else
-  static const int v = getenv("XMSIM_WSEARCH_FROM") ? atoi(getenv("XMSIM_WSEARCH_FROM")) : 16;
-  return v;
-#endif
-}
+XM_INL int wideSearchFrom() { return XM_WSEARCH_FROM; }
 
-// PathAligner.align.  Inline mode: LDS-mode search first (the lanes of the wave that arrive here together take the wave's slot
-// one after the other), the searches that do not fit are then redone in HBM mode.  With a memo slot (see MemoHdr): a logged result
-// is used; without one the search is deferred (caps.deferPath) or, in the last chain pass of a batch, run inline.
+// PathAligner.align: LDS-mode search first (the lanes of the wave that arrive here together take the wave's slot one after the other),
+// the searches that do not fit are then redone in HBM mode.
 XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, const Params& p, Analysis& an, SeqAl& out) {
   int32_t nb = 0;
   bool found = false;
-  if (e.memo && memoPeek(e.memo, *e.memoCursor) == MEMO_PATH) {
-    int32_t st = 0;
-    found = memoTake(e.memo, *e.memoCursor, out, &st);
-#if defined(XM_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-    // (profile builds, in-lane form: t[12] = wave time from the start of a replaying chain phase to the point where the replay has caught up)
-    if (memoInLane(e.memo) && e.memo->pad2 != 0 && *e.memoCursor >= e.memo->logBytes) { XM_TIC(now_); unsigned long long t0_ = (unsigned long long)e.memo->pad2; XM_TOC(e.dc, 12, t0_); (void)now_; e.memo->pad2 = 0; }
-#endif
-    nb = out.nb;
-    if (st) { *e.status = st; return false; }
-  } else if (e.memo && e.caps->deferPath) {
-    MemoHdr* const m = e.memo;
-    if (m->textCap == 0) {  // in-lane form: the texts stay where they are
-      m->qsStart = qs.start; m->qsEnd = qs.end; m->rsStart = rs.start; m->rsEnd = rs.end; m->referenceLen = e.reference.len;
-      m->predictedBestOffset = an.predictedBestOffset; m->confident = an.confidentAboutBestOffset ? 1 : 0; m->pad = 0;
-      m->maxInsExt = an.maxInsertionExtensionPenalty; m->maxDelExt = an.maxDeletionExtensionPenalty;
-      m->params = p;
-      m->qBase = e.query.base; m->qLen = e.query.len; m->qRc = e.query.rc; m->rBase = e.reference.base;
-      m->hasRequest = 1;
-      *e.status = XM_ST_NEED_PATH;
-      return false;
-    }
-    {
-      const int la = secLen(qs), lb = secLen(rs);
-      if (la < 0 || lb < 0 || la + lb > m->textCap) { *e.status = XM_ST_OVERFLOW; return false; }  // rerun with inline searches
-      m->qsStart = qs.start; m->qsEnd = qs.end; m->rsStart = rs.start; m->rsEnd = rs.end; m->referenceLen = e.reference.len;
-      m->predictedBestOffset = an.predictedBestOffset; m->confident = an.confidentAboutBestOffset ? 1 : 0; m->pad = 0;
-      m->maxInsExt = an.maxInsertionExtensionPenalty; m->maxDelExt = an.maxDeletionExtensionPenalty;
-      m->params = p;
-      uint8_t* t = memoTexts(m);
-      const SeqView q = e.query, r = e.reference;
-      for (int i = 0; i < la; i++) t[i] = q.at(qs.start + i);
-      for (int i = 0; i < lb; i++) t[la + i] = r.at(rs.start + i);
-      m->hasRequest = 1;
-      *e.status = XM_ST_NEED_PATH;
-      return false;
-    }
-  } else {
+  {
     PaProblem pr;
     pr.qBase = e.query.base; pr.qLen = e.query.len; pr.qRc = e.query.rc != 0; pr.rBase = e.reference.base; pr.referenceLen = e.reference.len;
     pr.qs = qs; pr.rs = rs; pr.params = p;
@@ -1588,18 +1419,6 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qsIn,
   PenaltyAnalysis result;
   result.minPossiblePenalty = 0; result.maxInsertionExtensionPenalty = 0; result.maxDeletionExtensionPenalty = 0;
   result.offsetWithMostHashblockMatches = 0; result.numHashBlockMatchesWithBestOffset = 0;
-  const bool logIt = memoInLane(e.memo);
-  if (logIt && memoPeek(e.memo, *e.memoCursor) == MEMO_ANALYSIS) {  // replay: the analysis ran in an earlier chain phase of this read
-    const MemoEntry* en = (const MemoEntry*)(memoLog(e.memo) + *e.memoCursor);
-    const MemoEntry h = *en;
-    const MemoAnalysisTail t = *(const MemoAnalysisTail*)(en + 1);
-    result.minPossiblePenalty = h.totalPenalty; result.maxInsertionExtensionPenalty = h.alignedPenalty; result.maxDeletionExtensionPenalty = t.maxDeletionExtensionPenalty;
-    result.offsetWithMostHashblockMatches = h.contig; result.numHashBlockMatchesWithBestOffset = h.referenceReversed;
-    if (h.ok && !an.matcher) an.matcher = storeSlot;
-    *e.memoCursor += h.bytes;
-    return result;
-  }
-  const bool hadMatcher = an.matcher != nullptr;
   Matcher* matcher = an.matcher;
   const SeqView query = e.query, reference = e.reference;  // register-resident copies
   DevCounters* const dc = e.dc;
@@ -1711,9 +1530,6 @@ XM_NOINL PenaltyAnalysis hbaAnalyzePenalty(const ExtEnv& e, const Section& qsIn,
   if (mostPopularOffset_count < 1) mostPopularOffset = an.predictedBestOffset;
   result.offsetWithMostHashblockMatches = mostPopularOffset;
   result.numHashBlockMatchesWithBestOffset = mostPopularOffset_count;
-  if (logIt && !memoPutAnalysis(e.memo, *e.memoCursor, result.minPossiblePenalty, result.maxInsertionExtensionPenalty, result.maxDeletionExtensionPenalty,
-                                result.offsetWithMostHashblockMatches, result.numHashBlockMatchesWithBestOffset, !hadMatcher && an.matcher != nullptr))
-    *e.status = XM_ST_OVERFLOW;
   return result;
 }
 
@@ -1770,18 +1586,7 @@ XM_NOINL bool innerChain(const ExtEnv& e, const Section& qs, const Section& rs, 
 }
 
 // ---------------------------------------------------------------- BlockAligner (M/BlockAligner.java)
-XM_NOINL bool baAlignPieceBody(const ExtEnv& e, const Section& qs, const Section& rs, double maxPenalty, const Params& p, bool firstPiece, const Analysis& parent, SeqAl& out);
-// deferred-search pass: a piece that finished in an earlier replay is taken from the memo log; a piece that finishes now is logged
-XM_INL bool baAlignPiece(const ExtEnv& e, const Section& qs, const Section& rs, double maxPenalty, const Params& p, bool firstPiece, const Analysis& parent, SeqAl& out) {
-  if (!e.memo) return baAlignPieceBody(e, qs, rs, maxPenalty, p, firstPiece, parent, out);
-  if (memoPeek(e.memo, *e.memoCursor) == MEMO_PIECE) return memoTake(e.memo, *e.memoCursor, out, nullptr);
-  const int start = *e.memoCursor;
-  bool r = baAlignPieceBody(e, qs, rs, maxPenalty, p, firstPiece, parent, out);
-  if (*e.status) return false;
-  if (!memoPut(e.memo, *e.memoCursor, start, MEMO_PIECE, r, out, r ? out.nb : 0, 0)) { *e.status = XM_ST_OVERFLOW; return false; }
-  return r;
-}
-XM_NOINL bool baAlignPieceBody(const ExtEnv& e, const Section& qs, const Section& rs, double maxPenalty, const Params& p, bool firstPiece, const Analysis& parent, SeqAl& out) {  // :215-249
+XM_NOINL bool baAlignPiece(const ExtEnv& e, const Section& qs, const Section& rs, double maxPenalty, const Params& p, bool firstPiece, const Analysis& parent, SeqAl& out) {  // :215-249
   if (maxPenalty < 0) return false;
   Section sub = rs;
   if (parent.confidentAboutBestOffset) {

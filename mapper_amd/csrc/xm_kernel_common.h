@@ -1,5 +1,4 @@
-// Device helpers and launch structures shared by the kernels of xm_capi.hip (lane-per-read passes) and xm_sched_kernel.hip (the gapped pass as a wave
-// scheduler).  Each translation unit gets its own copy of the device code (no device linking); the structures are what the host passes.
+// Device helpers and launch structures of the kernels of xm_capi.hip (lane-per-read passes); the structures are what the host passes.
 #pragma once
 #include "xm_worker.h"
 #include "xm_kernel_args.h"
@@ -11,9 +10,7 @@ namespace xm {
 // lane takes a fresh one.  mode 2 (gapped pass): a read with a saved region continues from it on whatever lane picks it up; the lane's
 // arena = [one region for reads without saved state | temporaries].  mode 0: plain runRead in the lane's arena.
 struct HandOver {
-  int mode;                        // (3: a pass of the light pass's shape over reads the gapped pass handed back, every one with a saved region)
-  int handBack;                    // mode 2: a resumed read stops with XM_ST_NEED_LIGHT when its candidate is done
-  int lightLevel;                  // mode 3: Caps::heavyAllowed of the light pass
+  int mode;
   int seedScale;                   // scale the regions are sized for (the light pass's)
   uint8_t* regions;
   unsigned long long regionBytes;
@@ -23,28 +20,20 @@ struct HandOver {
 };
 
 
-// A lane's scratch in the scheduler kernel: [region for a read that comes without saved state | chain temporaries | search arrays | memo]
-struct SchedLayout { unsigned long long tmpBytes, searchBytes, memoBytes; };
-// Large search sets of a launch (batches of long reads): buffers of bufBytes each, in eight groups of nPerGroup - a buffer is only ever used by
-// workgroups of ONE XCD (group = HW_REG_XCC_ID of the workgroup), because memory written through one XCD's L2 and reused through another's inside a
-// launch is not coherent (its write-backs can land on the new user's data).  owner[i]: 0 free, 1 taken.  n = 0: no pool.
-struct BigSetPool { uint8_t* base; unsigned long long bufBytes; int32_t* owner; int32_t nPerGroup, pad; };
-struct SchedLaunch {
-  int grid, block;
-  IndexView ix; Params params; BatchView batch;
-  const int64_t* todo; long long nTodo;
-  int scale, lanesPerWave, quantum, gate;
-  uint8_t* arenas; unsigned long long arenaBytes;
-  SchedLayout lay;
-  OutView out;
-  unsigned long long* nextItem; DevCounters* counters;
-  PNode* waveNodes;
-  HandOver ho;
-  SearchPool searchPool;
-  BigSetPool bigSets;
+// After every pass the reads it could not finish are in the work lists of the passes still to come; only the list sizes travel to the host.
+struct PassCtl {
+  unsigned long long nHeavy, nHeavyLate, nScale[2], nOut[2];
+  unsigned long long errQuery;  // smallest query index whose status is an error (~0 = none)
+  unsigned long long nConf[2];  // reads that wait for a value of the confidence table (XM_ST_NEED_CONF)
 };
-int xmSchedLaunch(const SchedLaunch& a, void* stream);  // xm_sched_kernel.hip; returns hipError_t as int
-int xmSchedProfile(unsigned long long* out16, int reset);  // XM_PROFILE builds: the scheduler kernel's phase timers
+// The lists a pass files its unfinished reads into, as the lanes publish them (a read's status decides; no kernel behind the pass, whose few microseconds
+// of work waited ~12 ms on average for a wave slot behind the other contexts' persistent launches: 12 % of the traced GPU time of round 4's headline run)
+struct PassLists {
+  int64_t* heavy; int64_t* heavyLate;  // light pass: reads for the gapped pass - the ones whose straight alignment cost hintThreshold / 8 penalty units or more first
+  int64_t* scale; int64_t* out; int64_t* conf;  // the halves [ts] / [to] / [tc] of the double-buffered lists (the pass may be reading the other halves)
+  int hintThreshold, ts, to, tc;
+  PassCtl* ctl;
+};
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ void addCounters(DevCounters* g, const DevCounters& l) {
@@ -55,8 +44,8 @@ __device__ __forceinline__ void addCounters(DevCounters* g, const DevCounters& l
   for (int i = 0; i < 16; i++) if (l.t[i]) atomicAdd(&g->t[i], l.t[i]);
 }
 
-// what a lane does with a read it is done with (both kernels): the result into the arenas, or the status the host's pass logic acts on
-__device__ __forceinline__ void publishRead(const OutView& out, int64_t q, const ReadResult& rr, const ReadCtx& cx, DevCounters& local) {
+// what a lane does with a read it is done with: the result into the arenas, or the status the host's pass logic acts on
+__device__ __forceinline__ void publishRead(const OutView& out, int64_t q, const ReadResult& rr, const ReadCtx& cx, DevCounters& local, const PassLists& L) {
   int32_t st = cx.status;
   if (st == XM_OK) {
     int64_t ni, nd;
@@ -72,12 +61,19 @@ __device__ __forceinline__ void publishRead(const OutView& out, int64_t q, const
       out.intOff[q] = (int64_t)io; out.dblOff[q] = (int64_t)dofs; out.intLen[q] = (int32_t)ni; out.dblLen[q] = (int32_t)nd;
     }
   }
-  if (st == XM_ST_NEED_HEAVY) {  // bits 8..15: cost hint (penalty x 8, capped) for the order of the gapped pass
-    float h = cx.heavyHint * 8.0f;
-    int hi = h > 255.0f ? 255 : (h > 0.0f ? (int)h : 0);
-    st |= hi << 8;
-  }
   out.status[q] = st;
+  if (st == XM_OK) return;
+  if (st == XM_ST_NEED_HEAVY) {
+    // reads whose straight alignment was bad enough for an indel go to the front of the gapped pass: they are the long ones, and a
+    // launch ends with its longest wave (longest-processing-time-first).  Cost hint: penalty x 8, capped
+    const float h = cx.heavyHint * 8.0f;
+    const int hi = h > 255.0f ? 255 : (h > 0.0f ? (int)h : 0);
+    if (hi >= L.hintThreshold) L.heavy[atomicAdd(&L.ctl->nHeavy, 1ull)] = q;
+    else L.heavyLate[atomicAdd(&L.ctl->nHeavyLate, 1ull)] = q;
+  } else if (st == XM_ST_OVERFLOW) L.scale[atomicAdd(&L.ctl->nScale[L.ts], 1ull)] = q;
+  else if (st == XM_ST_OUT_OVERFLOW) L.out[atomicAdd(&L.ctl->nOut[L.to], 1ull)] = q;
+  else if (st == XM_ST_NEED_CONF) L.conf[atomicAdd(&L.ctl->nConf[L.tc], 1ull)] = q;
+  else atomicMin(&L.ctl->errQuery, (unsigned long long)q);
 }
 
 #endif

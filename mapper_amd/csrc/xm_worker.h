@@ -45,9 +45,7 @@ struct ReadResult {
 // A read that stops in the light pass because a candidate needs the gapped chain (XM_ST_NEED_HEAVY) is resumed in the gapped pass at
 // that candidate, with its seeding state (pyramids, votes, candidate lists, accepted alignments) as the light pass left it.
 struct AlignReadState {
-  int32_t phase;  // 0 before the first candidate, 1 aligning the optimistic best match, 3 in the main loop at filtered[i], 4 in the partially-good loop at filtered[i], 5 after them (not resumable);
-                  // 11 / 13 / 14: the qmaAlign call of phase 1 / 3 / 4 is done (its result in `al`), resume behind it (hand-back of the gapped pass)
-  int32_t al;
+  int32_t phase;  // 0 before the first candidate, 1 aligning the optimistic best match, 3 in the main loop at filtered[i], 4 in the partially-good loop at filtered[i], 5 after them (not resumable)
   int32_t optimisticBestAlignment, haveOptimisticMatch, numMismatches, candidateNumMismatches, i, queryLength;
   QMatch optimisticBestMatch;
   double bestPenalty, estimatedPenalty, maxInterestingPenalty;
@@ -69,8 +67,6 @@ struct ReadCtx {
   SeedEnv seed;
   Comp comps[2];
   PathsCounter pc;
-  MemoHdr* memo;        // deferred-search gapped pass: this read's memo slot (xm_extend.h), else null
-  int32_t memoCursor;
   float heavyHint;      // light pass: largest straight-alignment penalty among the candidates that needed the gapped chain
   AlignReadState ar;
 };
@@ -118,45 +114,20 @@ XM_INL void makeExtEnv(ReadCtx& cx, ExtEnv& e, const SeqView& query, int contig)
   e.reference = refView(*cx.ix, contig, false);
   e.contig = contig;
   e.slotA = e.slotB = e.slotT = nullptr;
-  e.memo = cx.memo; e.memoCursor = &cx.memoCursor;
   e.heavyHint = &cx.heavyHint;
   e.baLogStep = cx.ix->baLogStep;
 }
 
 // alignMatch :412-462 (fromHashblockMatch is always true).  The matcher slots live in tmp for the duration of the call.
-XM_NOINL bool qmaAlignMatchBody(ReadCtx& cx, const SeqView& seqA, int contig, int offset, const Params& params, SeqAl& out);
-// deferred-search pass: an alignMatch call that finished in an earlier replay is taken from the memo log
-XM_INL bool qmaAlignMatch(ReadCtx& cx, const SeqView& seqA, int contig, int offset, const Params& params, SeqAl& out) {
-  if (!cx.memo) return qmaAlignMatchBody(cx, seqA, contig, offset, params, out);
-  if (memoPeek(cx.memo, cx.memoCursor) == MEMO_MATCH) {
-    if (cx.dc) {  // the skipped body's share of the traffic counters
-      int refLen = cx.ix->contigLen[contig];
-      int startB = imax(0, offset), endB = imin(offset + seqA.len, refLen);
-      double mip = (endB - startB) * params.MaxErrorRate;
-      int maxShift = j2i(dmax(0.0, (mip - params.DeletionStart_Penalty) / params.DeletionExtension_Penalty));
-      cx.dc->refWindowBytes += (unsigned long long)((imin(endB + maxShift, refLen) - imax(0, startB - maxShift) + 1) / 2);
-    }
-    return memoTake(cx.memo, cx.memoCursor, out, nullptr);
-  }
-  const int start = cx.memoCursor;
-  bool r = qmaAlignMatchBody(cx, seqA, contig, offset, params, out);
-  if (cx.status) return false;
-  if (!memoPut(cx.memo, cx.memoCursor, start, MEMO_MATCH, r, out, r ? out.nb : 0, 0)) { cx.status = XM_ST_OVERFLOW; return false; }
-  return r;
-}
-XM_NOINL bool qmaAlignMatchBody(ReadCtx& cx, const SeqView& seqA, int contig, int offset, const Params& params, SeqAl& out) {
+XM_NOINL bool qmaAlignMatch(ReadCtx& cx, const SeqView& seqA, int contig, int offset, const Params& params, SeqAl& out) {
   size_t mark = cx.tmp.used;
   ExtEnv e;
   makeExtEnv(cx, e, seqA, contig);
   Matcher* slots = arenaArray<Matcher>(cx.tmp, 3);
   if (cx.tmp.overflow) { cx.status = XM_ST_OVERFLOW; cx.tmp.used = mark; return false; }
-  // (in-lane memo with something logged behind the cursor: this call is being replayed by a later chain phase of the read - the matchers are
-  // as that phase left them in the lane's temporaries, and the analyses that filled them are taken from the log)
-  const bool replayed = memoInLane(cx.memo) && memoPeek(cx.memo, cx.memoCursor) != 0;
   for (int i = 0; i < 3; i++) {
     uint8_t* const present = arenaArray<uint8_t>(cx.tmp, cx.caps.maxSections);
     int16_t* const tables = arenaArray<int16_t>(cx.tmp, cx.caps.matcherEntries);
-    if (replayed) continue;
     slots[i].present = present;
     slots[i].tables = tables;
     slots[i].tableCap = cx.caps.matcherEntries;
@@ -677,9 +648,6 @@ XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr, bool resume = false) {
     if (st.phase == 1) goto resume_optimistic;
     if (st.phase == 3) goto resume_main;
     if (st.phase == 4) goto resume_partial;
-    if (st.phase == 11) goto resume_after_optimistic;
-    if (st.phase == 13) { al = st.al; goto resume_after_main; }
-    if (st.phase == 14) { al = st.al; goto resume_after_partial; }
     cx.status = XM_ST_INTERNAL;  // (the caller only resumes phases 1, 3 and 4)
     return;
   }
@@ -723,13 +691,10 @@ XM_NOINL void alignRead(ReadCtx& cx, ReadResult& rr, bool resume = false) {
     st.haveOptimisticMatch = 1;
     st.phase = 1;
     st.rr = rr;
-    if (memoInLane(cx.memo)) memoRestart(cx.memo, cx.memoCursor);
 resume_optimistic:
     if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }  // (behind the label: a resumed run counts into another lane's counters)
     st.optimisticBestAlignment = qmaAlign(cx, *aligner, st.optimisticBestMatch, 0);
     if (cx.status) return;
-    if (cx.caps.handBack) { st.phase = 11; st.rr = rr; cx.status = XM_ST_NEED_LIGHT; return; }
-resume_after_optimistic:
     st.phase = 2;
     const bool quick = quicklyConfidentInBestAlignment(cx, *aligner, st.optimisticBestAlignment, st.optimisticBestMatch);
     if (cx.status) return;  // (XM_ST_NEED_CONF: the host has a value to add to the confidence table)
@@ -769,13 +734,10 @@ resume_after_optimistic:
       } else {
         st.phase = 3;
         st.rr = rr;
-        if (memoInLane(cx.memo)) memoRestart(cx.memo, cx.memoCursor);
 resume_main:
         if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }
         al = qmaAlign(cx, *aligner, pc.filtered[st.i], 0);
         if (cx.status) return;
-        if (cx.caps.handBack) { st.al = al; st.phase = 13; st.rr = rr; cx.status = XM_ST_NEED_LIGHT; return; }
-resume_after_main:
         st.phase = 2;
       }
       if (cx.status) return;
@@ -794,13 +756,10 @@ resume_after_main:
     for (st.i = 0; st.i < pc.nFiltered; st.i++) {
       st.phase = 4;
       st.rr = rr;
-      if (memoInLane(cx.memo)) memoRestart(cx.memo, cx.memoCursor);
 resume_partial:
       if (cx.dc) { st.candidatesAtCall = cx.dc->candidatesExtended; st.refWindowBytesAtCall = cx.dc->refWindowBytes; }
       al = qmaAlign(cx, *aligner, pc.filtered[st.i], 0);
       if (cx.status) return;
-      if (cx.caps.handBack) { st.al = al; st.phase = 14; st.rr = rr; cx.status = XM_ST_NEED_LIGHT; return; }
-resume_after_partial:
       st.phase = 2;
       if (al >= 0) {
         double penalty = aligner->good[al].totalPenalty;
@@ -809,8 +768,6 @@ resume_after_partial:
     }
   }
   st.phase = 5;
-  // (the wave scheduler continues a read at phases 1, 3 and 4 only: from here on - getUnpairedAlignments - searches run inline, nothing is logged)
-  if (memoInLane(cx.memo)) { cx.memo = nullptr; cx.caps.deferPath = 0; }
   qmaGetBestAlignments(*aligner);
   {
     int numBest = aligner->nBest;
@@ -901,10 +858,10 @@ XM_INL void applyChainCaps(Caps& c, int chainScale) {
 // that stops in front of the gapped chain leaves a SavedRead at the tail of the region.  Gapped pass, read without saved state
 // (heavyAllowed 2, chainScale = the gapped scale): seeded at `scale`, chain scratch of the gapped pass.
 XM_INL void runReadRetaining(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* region, size_t regionBytes, void* laneArena, size_t laneArenaBytes,
-                             DevCounters* dc, ReadResult& rr, int heavyAllowed, int chainScale = 0, MemoHdr* memo = nullptr, bool deferPath = false) {
-  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed; cx.caps.deferPath = (memo && deferPath) ? 1 : 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
+                             DevCounters* dc, ReadResult& rr, int heavyAllowed, int chainScale = 0) {
+  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
   if (chainScale > 0 && chainScale != scale) applyChainCaps(cx.caps, chainScale);
-  cx.memo = memo; cx.memoCursor = 0; cx.heavyHint = 0;
+  cx.heavyHint = 0;
   cx.params.StartingInsertionStartFree = 0;
   cx.persist.init(region, retainedPersistBytes(regionBytes));
   cx.tmp.init(laneArena, laneArenaBytes);
@@ -926,11 +883,9 @@ XM_INL void runReadRetaining(ReadCtx& cx, const IndexView* ix, const Params& par
   }
 }
 // gapped pass, a read the light pass handed over: the context back on this lane, pointers into the context re-seated, the chain's scratch
-// capacities of the gapped pass, temporaries in this lane's arena; then on from the candidate that needed the chain.  The saved state is
-// consumed (pyramid levels, hit lists and the aligner advance in place): a read can be resumed once.
-XM_INL void runReadResumed(ReadCtx& cx, SavedRead* sv, const IndexView* ix, int chainScale, void* laneArena, size_t laneArenaBytes, DevCounters* dc, ReadResult& rr,
-                           MemoHdr* memo, bool deferPath, int heavyAllowed = 2, int handBack = 0) {
-  const DevCounters before = dc ? *dc : DevCounters();
+// capacities of the gapped pass, temporaries in this lane's arena; then on from the candidate that needed the chain, to the read's end.  The saved
+// state is consumed (pyramid levels, hit lists and the aligner advance in place): a read is resumed once.
+XM_INL void runReadResumed(ReadCtx& cx, SavedRead* sv, const IndexView* ix, int chainScale, void* laneArena, size_t laneArenaBytes, DevCounters* dc, ReadResult& rr) {
   cx = sv->cx;
   cx.ix = ix; cx.dc = dc; cx.status = XM_OK;
   cx.seed.ix = ix; cx.seed.caps = &cx.caps; cx.seed.dc = dc; cx.seed.status = &cx.status; cx.seed.listIdCounter = &cx.listIdCounter; cx.seed.mateLen = cx.in.mateLen;
@@ -938,37 +893,18 @@ XM_INL void runReadResumed(ReadCtx& cx, SavedRead* sv, const IndexView* ix, int 
   cx.pc.comps = cx.comps;
   cx.tmp.init(laneArena, laneArenaBytes);
   if (chainScale > 0) applyChainCaps(cx.caps, chainScale);
-  cx.caps.heavyAllowed = heavyAllowed;
-  cx.caps.handBack = handBack;
-  cx.caps.deferPath = (memo && deferPath) ? 1 : 0;
-  cx.memo = memo; cx.memoCursor = 0;
+  cx.caps.heavyAllowed = 2;
   if (dc) dcAccumulate(*dc, sv->partial, false);
   XM_TIC(t0);
   alignRead(cx, rr, true);
   XM_TOC(dc, T_TOTAL, t0);
-  // the read stops again - handed back by the gapped pass (XM_ST_NEED_LIGHT), or in front of another candidate's gapped chain in the pass that
-  // took it back (XM_ST_NEED_HEAVY): its context goes back into its region, with everything counted for it so far
-  const bool again = cx.status == XM_ST_NEED_LIGHT || (cx.status == XM_ST_NEED_HEAVY && (cx.ar.phase == 1 || cx.ar.phase == 3 || cx.ar.phase == 4));
   sv->valid = 0;
-  if (again) {
-    sv->cx = cx;
-    if (dc) {
-      sv->partial = *dc;
-      dcAccumulate(sv->partial, before, true);
-      if (cx.status == XM_ST_NEED_HEAVY) {  // the stopped candidate is counted by the run that finishes it
-        sv->partial.candidatesExtended -= dc->candidatesExtended - cx.ar.candidatesAtCall;
-        sv->partial.refWindowBytes -= dc->refWindowBytes - cx.ar.refWindowBytesAtCall;
-      }
-    }
-    sv->valid = 1;
-  }
 }
 
 // Carve a lane's arena and align one read.  `arena` must be 16-byte aligned.
-XM_INL void runRead(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* arena, size_t arenaBytes, DevCounters* dc, ReadResult& rr, int heavyAllowed = 2,
-                    MemoHdr* memo = nullptr, bool deferPath = false) {
-  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed; cx.caps.deferPath = (memo && deferPath) ? 1 : 0; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
-  cx.memo = memo; cx.memoCursor = 0; cx.heavyHint = 0;
+XM_INL void runRead(ReadCtx& cx, const IndexView* ix, const Params& params, const ReadIn& in, int scale, void* arena, size_t arenaBytes, DevCounters* dc, ReadResult& rr, int heavyAllowed = 2) {
+  cx.ix = ix; cx.caps = makeCaps(scale); cx.caps.heavyAllowed = heavyAllowed; cx.dc = dc; cx.status = XM_OK; cx.in = in; cx.params = params;
+  cx.heavyHint = 0;
   cx.params.StartingInsertionStartFree = 0;
   const size_t persistBytes = arenaPersistBytes(arenaBytes);
   cx.persist.init(arena, persistBytes);

@@ -1,7 +1,7 @@
-// xmapper-hip device core: PathAligner's best-first search (M/PathAligner.java:55-293, updates :555-719, putNode :446-473) in the form the wave
-// scheduler of the gapped pass runs it (xm_sched.h): MANY searches side by side, one per lane, every lane of the wave in the same loop.
+// xmapper-hip device core: PathAligner's best-first search (M/PathAligner.java:55-293, updates :555-719, putNode :446-473) in a form built for lane-private
+// state in HBM: what the chains whose searches start in HBM mode run (scale 16 and up: long reads, reruns; pathSearchW).
 //
-// Side by side, a search cannot have the wave's LDS slot (10 KB, one per wave): its structures live in the lane's own search arena in HBM, and what
+// Such a search does not have the wave's LDS slot (10 KB, one per wave): its structures live in the lane's own temporaries in HBM, and what
 // an explored entry costs is the number of DEPENDENT trips to that memory (~0.5-1 us each, however many lanes take them together).  The lane-per-read
 // form (PathAlignerT<false>, xm_extend.h) makes about thirteen per entry: list entry, per update cell -> node index -> node payload, per put bucket hash ->
 // key -> tail.  This form makes four:
@@ -15,8 +15,7 @@
 //     previous put, which are kept in registers;
 //   * the live buckets - key, slot, head in one 16-byte word each - are a dense array; priorities.poll() scans it eight words per trip (the keys
 //     only ever grow, so the array stays short: a removed bucket's place is taken by the last one).
-// A search can be suspended after any explored entry and continued later (WSearch lives in the arena): the scheduler gives the searches of a wave
-// a number of steps at a time.
+// A search can be suspended after any explored entry and continued later (WSearch lives in the arena; wsRun takes a number of steps).
 // Exactly the reference's search: one bucket per exact double key with insertion order preserved, stale re-exploration, == tie-breaks; the nodes it
 // puts are counted and compared with the oracle's (DevCounters::pathAlignerNodes).  What does not fit (more than 2048 nodes, 1536 cells or 256
 // keys; coordinates beyond an int16) reports XM_ST_OVERFLOW and is run by the lane-per-read form in the wave's big buffer.
@@ -56,7 +55,7 @@ struct alignas(16) WLive { double key; int32_t slot, head; };  // a live bucket:
 // (2048 nodes on 1536 cells, 256 keys: 90 KB, of which a search of 300 entries touches a tenth); batches of long reads give their lanes a second,
 // large set (the chain's capacities: tens of thousands of nodes) that a search starts over in when it outgrows the small one.
 struct WSizes {
-  int32_t maxNodes, maxCells, maxBuckets;
+  int32_t maxNodes, maxCells, maxBuckets, maxBlocks;
   int32_t cellSlots, cellShift, bktSlots;       // cellSlots: a multiple of 128, slot of a cell = (hash x cellSlots) >> 32; bktSlots: a power of two
   uint32_t offCellBits, offBktBits, offCells, offList, offBkt, offLive, offBlocks, bytes;
 };
@@ -67,6 +66,7 @@ XM_INL WSizes wsSizes(int maxNodes, int maxBuckets, int maxBlocks) {
   z.maxNodes = maxNodes;
   z.maxCells = maxNodes - maxNodes / 4;
   z.maxBuckets = maxBuckets;
+  z.maxBlocks = maxBlocks;
   z.cellSlots = (z.maxCells + z.maxCells / 3 + 255) & ~127;  // load <= 3/4; a multiple of 128: the bit map is cleared in 16-byte words (slot = hash x slots >> 32)
   z.cellShift = 0;
   z.bktSlots = 1 << wsLog2Ceil(2ll * (maxBuckets < 64 ? 64 : maxBuckets));
@@ -126,7 +126,7 @@ struct WRun {
   WList* list;
   WBkt* bkt; uint32_t* bktBits; uint32_t bktMask;
   WLive* live;
-  int32_t maxNodes, maxCells, maxBuckets;
+  int32_t maxNodes, maxCells, maxBuckets, maxBlocks;
   const uint8_t* qBase; int32_t qLen; bool qRc; const uint8_t* rBase;
   Params P;
   bool confident; double maxInsExt, maxDelExt;
@@ -347,7 +347,7 @@ XM_NOINL void wsBegin(uint8_t* arena, const PaProblem& prIn, const WSizes& zIn) 
   const WSizes z = zIn;
   S->pr = pr;
   S->z = z;
-  S->maxBlocks = (int32_t)((z.bytes - z.offBlocks) / sizeof(ABlock));
+  S->maxBlocks = z.maxBlocks;  // (what the caller's block array holds - the rounding of z.bytes leaves a little more room here, which must not be used)
   S->done = 0; S->found = 0; S->status = XM_OK; S->nb = 0;
   S->nodesPut = 0; S->lastSteps = 0;
   const Section qs = pr.qs, rs = pr.rs;

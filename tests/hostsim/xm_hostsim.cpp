@@ -6,7 +6,7 @@
 // or loaded by libxmapper_hip.so / the mapper_amd package, which has no CPU path.
 #include "../../include/xmapper_hip.h"
 #include "../../mapper_amd/csrc/xm_worker.h"
-#include "../../mapper_amd/csrc/xm_sched.h"
+#include "../../mapper_amd/csrc/xm_wsearch.h"
 #include "../../mapper_amd/csrc/xm_wave.h"
 #include "../../mapper_amd/csrc/xm_index_host.h"
 #include <cstdlib>
@@ -30,7 +30,6 @@ static int g_waveMode = -1;  // -1: from XMSIM_WAVE (default 0)
 static long long g_waveStatus[16];
 static long long g_waveWhy[64];
 static long long g_markHist[6][128];  // high-water marks of the wave form per read: chunks, counters, history, pending, query matches, alignments
-static long long g_schedSearches = 0, g_schedBig = 0, g_schedBigSet = 0;  // searches the scheduler path ran; of them in the lane-per-read form in the big buffer, in a large set
 static void markDump() { const char* names[6] = {"chunks", "counters", "history", "pending", "qmatches", "alignments"}; for (int k = 0; k < 6; k++) { fprintf(stderr, "[wave marks] %s:", names[k]); for (int i = 0; i < 128; i++) if (g_markHist[k][i]) fprintf(stderr, " %d:%lld", i, g_markHist[k][i]); fprintf(stderr, "\n"); } }
 
 struct SimIndex {
@@ -185,9 +184,9 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
         }
         if (finished) continue;
       }
-      // the product's pass sequence for one read: light pass at scale 1; reads that need the gapped chain rerun at scale 4 with
-      // deferred PathAligner searches (chain pass -> search "kernel" -> replay ...); scratch overflow -> inline reruns at 16x, 64x...
-      // XMSIM_INLINE=1: plain inline run at scale 1, 4, 16... (the first implementation's sequence)
+      // the product's pass sequence for one read: light pass at scale 1; a read that needs the gapped chain goes on at scale 4 from the state it
+      // saved (hand-over), on another context object and other temporaries; scratch overflow -> reruns from the start at 16x, 64x...
+      // XMSIM_INLINE=1: plain run at scale 1, 4, 16... (the first implementation's sequence)
       static const bool inlineOnly = getenv("XMSIM_INLINE") && atoi(getenv("XMSIM_INLINE")) != 0;
       // (the product sizes a batch by its longest mate: scratch scale 1 up to 320 bases, 4 up to 1280, 16 beyond, the gapped pass at four times that;
       // here every read by its own longest mate)
@@ -195,11 +194,7 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       for (int m = 0; m < in.nMates; m++) longestMate = std::max(longestMate, (int)in.mateLen[m]);
       const int seedScale = longestMate <= 320 ? 1 : (longestMate <= 1280 ? 4 : 16);
       int scale = seedScale;
-      int stage = inlineOnly ? 2 : 0;  // 0 light, 1 deferred gapped, 2 inline
-      std::vector<double> memoBuf(XM_MEMO_SLOT_BYTES / 8 + 2);
-      MemoHdr* memo = (MemoHdr*)(((uintptr_t)memoBuf.data() + 15) & ~(uintptr_t)15);
-      static const int deferRounds = getenv("XMSIM_DEFER_ROUNDS") ? atoi(getenv("XMSIM_DEFER_ROUNDS")) : 2;  // then searches run inline, as the product's last chain pass
-      int rounds = 0;
+      int stage = inlineOnly ? 2 : 0;  // 0 light, 1 gapped, 2 rerun
       static const int lightLevel = getenv("XMSIM_LIGHT_LEVEL") ? atoi(getenv("XMSIM_LIGHT_LEVEL")) : 0;
       // light pass -> gapped pass hand-over (runReadRetaining / runReadResumed): the read's region outlives the light "lane"; the gapped pass
       // runs on another context object and another temporaries buffer, as it does on another lane of the GPU
@@ -215,90 +210,18 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
       std::vector<double> regionBuf(regionBytes / 8 + 2);
       uint8_t* region = (uint8_t*)(((uintptr_t)regionBuf.data() + 15) & ~(uintptr_t)15);
       SavedRead* saved = nullptr;
-      // hand-back (XM_ST_NEED_LIGHT): the gapped "pass" stops a resumed read behind its candidate and a "pass" of the light pass's shape - another
-      // context object, small temporaries, light capacities - takes it on; a read that stops in front of the chain there goes round again
-      const bool handBack = handOver && getenv("XMSIM_HANDBACK") && atoi(getenv("XMSIM_HANDBACK")) != 0;  // (off by default, as in the product)
-      // XMSIM_SCHED=1: the gapped pass of batches of short reads as the wave scheduler runs it (the product's XM_SCHED=1)
-      // XMSIM_SCHED_LONG=1: the same for batches of long reads (the product's XM_SCHED_LONG=1): their lanes have a second, large set of search arrays
-      const bool sched = handOver && (seedScale == 1 ? (getenv("XMSIM_SCHED") && atoi(getenv("XMSIM_SCHED")) != 0) : (getenv("XMSIM_SCHED_LONG") && atoi(getenv("XMSIM_SCHED_LONG")) != 0));
-      const bool schedBigSet = seedScale > 1;
-      bool takenBack = false;
-      static ReadCtx cx3;
-      std::vector<uint8_t> arena3;
       static ReadCtx cx2;
       std::vector<uint8_t> arena2;
       while (true) {
         size_t bytes = (size_t)288 * 1024 * (size_t)scale;
         ReadResult rr;
         DevCounters before = dc;
-        if (stage == 1 && saved && takenBack) {
-          const size_t lightTmp = (size_t)48 * 1024;  // the product's light-pass temporaries
-          arena3.assign(lightTmp + 64, 0xCD);
-          uint8_t* a3 = (uint8_t*)(((uintptr_t)arena3.data() + 15) & ~(uintptr_t)15);
-          runReadResumed(cx3, saved, &idx->view, seedScale, a3, lightTmp * (size_t)seedScale, &dc, rr, nullptr, false, lightLevel, 0);
-          cx.status = cx3.status;
-          takenBack = false;
-          if (cx.status == XM_ST_NEED_HEAVY) {
-            dc = before;
-            if (saved->valid) continue;                  // another candidate for the chain: the gapped "pass" again, from the region
-            saved = nullptr; stage = 2; scale = seedScale * 4; continue;  // (stopped where it cannot be resumed: a plain run)
-          }
-          saved = nullptr;
-        } else if (stage == 1 && saved && sched && !handBack) {
-          // the gapped pass as the wave scheduler runs it (xm_sched.h, xm_sched_kernel): chain phase until the read is finished or parked at a search,
-          // search phase (the lane's own arrays; the big buffer when it outgrows them), replay from the candidate, ... - on another context object
+        if (stage == 1 && saved) {
           arena2.assign(bytes + chainExtraTmpBytes(scale) + 64, 0xAB);
           uint8_t* a2 = (uint8_t*)(((uintptr_t)arena2.data() + 15) & ~(uintptr_t)15);
-          const size_t tmpBytes = gappedTmp(bytes, scale);
-          const int memoBytes = schedBigSet ? 4 * scale * 1024 : XM_MEMO_SLOT_BYTES;  // (the product's XM_SCHED_MEMO_KB defaults)
-          std::vector<double> schedMemoBuf((size_t)memoBytes / 8 + 2);
-          memo = (MemoHdr*)(((uintptr_t)schedMemoBuf.data() + 15) & ~(uintptr_t)15);
-          memoInitInLane(memo, memoBytes);
-          runReadResumed(cx2, saved, &idx->view, scale, a2, tmpBytes, &dc, rr, memo, true, 2, 0);
-          int phases = 0;
-          while (schedParked(cx2)) {
-            if (!memo->hasRequest) throw std::runtime_error("NEED_PATH without a request");
-            const size_t sbytes = schedSearchArenaBytes(cx2.caps);
-            std::vector<double> sbuf(sbytes / 8 + 2, 0.0);
-            void* sarena = (void*)(((uintptr_t)sbuf.data() + 15) & ~(uintptr_t)15);
-            memset(sarena, 0xC7, sbytes);
-            schedSearchBegin(memo, sarena, cx2.caps);
-            static const int quantum = getenv("XMSIM_SCHED_QUANTUM") ? atoi(getenv("XMSIM_SCHED_QUANTUM")) : 64;  // (the kernel's searches run a number of steps at a time)
-            int how;
-            while ((how = schedSearchRun(memo, sarena, quantum, &dc)) == 0) { }
-            std::vector<double> bigBuf;
-            if (how == 2 && schedBigSet) {  // a large set from the launch's pool
-              const size_t bb = schedBigSetBytes(cx2.caps);
-              bigBuf.assign(bb / 8 + 2, 0.0);
-              void* barena = (void*)(((uintptr_t)bigBuf.data() + 15) & ~(uintptr_t)15);
-              memset(barena, 0xC7, bb);
-              schedSearchRestartBig(memo, barena, cx2.caps);
-              while ((how = schedSearchRun(memo, barena, quantum, &dc)) == 0) { }
-              g_schedBigSet++;
-            }
-            if (how == 3) schedLogResult(memo, false, nullptr, 0, XM_ST_OVERFLOW);
-            if (how == 2) {
-              const size_t poolBytes = searchPoolBytes(makeCaps(scale)) + (size_t)cx2.caps.maxBlocks * sizeof(ABlock) + 64;  // (the product's buffer per wave)
-              std::vector<double> bbuf(poolBytes / 8 + 2, 0.0);
-              Arena bigArena;
-              bigArena.init((void*)(((uintptr_t)bbuf.data() + 15) & ~(uintptr_t)15), poolBytes);
-              schedSearchBig(memo, bigArena, cx2.caps, &dc);
-              g_schedBig++;
-            }
-            g_schedSearches++;
-            schedReplay(cx2, rr);
-            if (++phases > 100000) throw std::runtime_error("scheduler phases do not end");
-          }
+          runReadResumed(cx2, saved, &idx->view, scale, a2, gappedTmp(bytes, scale), &dc, rr);
           cx.status = cx2.status;
-          saved = nullptr;
-        } else if (stage == 1 && saved) {
-          arena2.assign(bytes + chainExtraTmpBytes(scale) + 64, 0xAB);
-          uint8_t* a2 = (uint8_t*)(((uintptr_t)arena2.data() + 15) & ~(uintptr_t)15);
-          // a resume consumes the retained state (pyramid levels, hit lists and the aligner state advance in place), so it cannot be replayed:
-          // handed-over reads run their searches inline, as the product does (deferral only applies to reads that re-seed)
-          runReadResumed(cx2, saved, &idx->view, scale, a2, gappedTmp(bytes, scale), &dc, rr, nullptr, false, 2, handBack ? 1 : 0);
-          cx.status = cx2.status;
-          if (cx.status == XM_ST_NEED_LIGHT) { dc = before; takenBack = true; continue; }
+          cx.persist = cx2.persist; cx.tmp = cx2.tmp;  // (for the overflow trace)
           saved = nullptr;
         } else {
           arena.resize(bytes + chainExtraTmpBytes(scale) + 64);
@@ -314,19 +237,9 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
             // gapped pass, read without saved state (stopped where it cannot be resumed): seeded again in a region of light-pass size
             runReadRetaining(cx, &idx->view, params, in, seedScale, region, regionBytes, a, ((bytes - arenaPersistBytes(bytes)) & ~(size_t)15) + chainExtraTmpBytes(scale), &dc, rr, 2, scale);
           } else {
-            runRead(cx, &idx->view, params, in, scale, a, bytes, &dc, rr, stage != 0 ? 2 : lightLevel, stage == 1 ? memo : nullptr, rounds < deferRounds);
+            runRead(cx, &idx->view, params, in, scale, a, bytes, &dc, rr, stage != 0 ? 2 : lightLevel);
           }
-          if (cx.status == XM_ST_NEED_HEAVY && stage == 0) { dc = before; stage = 1; scale = seedScale * 4; memoInit(memo); continue; }
-          if (cx.status == XM_ST_NEED_PATH && stage == 1) {
-            dc = before;
-            if (!memo->hasRequest) throw std::runtime_error("NEED_PATH without a request");
-            Arena tmp;
-            tmp.init(a, bytes);
-            Caps caps = makeCaps(scale);
-            memoRunPath(memo, tmp, caps, &dc);
-            rounds++;
-            continue;
-          }
+          if (cx.status == XM_ST_NEED_HEAVY && stage == 0) { dc = before; stage = 1; scale = seedScale * 4; continue; }
         }
         if (cx.status == XM_ST_OVERFLOW) {
           if (getenv("XMSIM_TRACE_OVERFLOW")) fprintf(stderr, "[xmsim] query %lld overflow at stage %d scale %d: persist %zu of %zu%s, tmp %zu of %zu%s\n", (long long)q, stage, scale, cx.persist.used, cx.persist.size, cx.persist.overflow ? " (overflow)" : "", cx.tmp.used, cx.tmp.size, cx.tmp.overflow ? " (overflow)" : "");
@@ -421,7 +334,6 @@ int64_t xmsim_light_footprint(void* idxp, const xm_params* p, const xm_query_bat
 }
 #endif
 
-void xmsim_sched_counts(long long* out, int reset) { out[0] = g_schedSearches; out[1] = g_schedBig; out[2] = g_schedBigSet; if (reset) g_schedSearches = g_schedBig = g_schedBigSet = 0; }
 
 void xmsim_result_free(xm_result* r) {
   if (!r) return;

@@ -405,61 +405,11 @@ def test_kernel_logic_reads_of_mostly_ambiguous_bases():
     assert all(all_n.ints[all_n.int_off[q] + 1] == 0 for q in range(3))  # (the reference walks such a read and finds nothing)
 
 
-def test_hand_back_resume_points_in_the_host_simulation(monkeypatch):
-    """XM_HANDBACK (off by default in the product): the gapped pass stops a resumed read behind the candidate that needed the chain
-    (alignRead phases 11 / 13 / 14) and a pass with the light pass's capacities continues it; reads that meet another candidate for the
-    chain go round again.  Single-end reads with indels and pairs (the partially-good loop), against the oracle."""
-    monkeypatch.setenv("XMSIM_HANDBACK", "1")
-    ref = synth.synthetic_reference(200_000, seed=21)
-    R = o.OracleReference([("r", ref)])
-    S = hs.SimReference([("r", ref)])
-    p = o.make_params()
-    b = se_batch(synth.synthetic_single_end(ref, 2500, seed=22, indel_prob=0.5)[0])
-    sa, sb = R.align(b, p), S.align(b, p)
-    assert streams_equal(sa, sb), first_difference(sa, sb, b.nq)
-    m1, m2 = synth.synthetic_paired_end(ref, 1200, seed=23, indel_prob=0.4)[:2]
-    pb = pe_batch(m1, m2)
-    sa, sb = R.align(pb, p), S.align(pb, p)
-    assert streams_equal(sa, sb), first_difference(sa, sb, pb.nq)
-
-
-@pytest.mark.parametrize("quantum", ["1", "7", "100000"])
-def test_wave_scheduler_path_in_the_host_simulation(quantum, monkeypatch):
-    """XM_SCHED=1 (xm_sched.h, xm_wsearch.h): the gapped pass as chain phases and search phases - a read parks at a PathAligner search with the
-    request in its memo, the search runs in the lane's own arrays (suspended every `quantum` explored entries, as the kernel's rounds do), the read
-    re-enters alignRead at its candidate and replays from the log of its finished calls (searches, pieces, alignMatch calls, hash-block analyses;
-    the matchers stay in the temporaries).  Single-end reads with indels, pairs, reads with ambiguity codes: streams and work counters against the oracle."""
-    monkeypatch.setenv("XMSIM_SCHED", "1")
-    monkeypatch.setenv("XMSIM_SCHED_QUANTUM", quantum)
-    import ctypes as C
-    ref = synth.synthetic_reference(200_000, seed=31)
-    R = o.OracleReference([("r", ref)])
-    S = hs.SimReference([("r", ref)])
-    p = o.make_params()
-    counts = (C.c_longlong * 4)()
-    hs.lib().xmsim_sched_counts(counts, 1)
-    b = se_batch(synth.synthetic_single_end(ref, 2500, seed=32, indel_prob=0.5)[0])
-    sa, sb = R.align(b, p), S.align(b, p)
-    assert streams_equal(sa, sb), first_difference(sa, sb, b.nq)
-    # candidates extended, PathAligner calls, nodes put (the oracle's counters have one field more in front of them than the device's layout)
-    assert list(sa.counters[5:8]) == list(sb.counters[4:7])
-    m1, m2 = synth.synthetic_paired_end(ref, 1200, seed=33, indel_prob=0.4)[:2]
-    pb = pe_batch(m1, m2)
-    sa, sb = R.align(pb, p), S.align(pb, p)
-    assert streams_equal(sa, sb), first_difference(sa, sb, pb.nq)
-    reads = sprinkle_ambiguity(synth.synthetic_single_end(ref, 1500, seed=34, indel_prob=0.3)[0])
-    ab = se_batch(reads)
-    sa, sb = R.align(ab, p, threads=os.cpu_count()), S.align(ab, p)
-    assert streams_equal(sa, sb), first_difference(sa, sb, ab.nq)
-    hs.lib().xmsim_sched_counts(counts, 0)
-    assert counts[0] > 1000, "the scheduler path ran %d searches" % counts[0]
-
-
 def test_kernel_logic_on_a_repeat_rich_reference(monkeypatch):
     """synth.repeat_rich_reference (segmental duplications at 90-99.5 % identity, tandem repeats, a 28-mer whose buckets overflow): the branch of the
     path a real genome sends reads into - a read in a duplicated window gets no early accept (Readable_DuplicationDetector.java:28-47 via
     AlignerWorker.java:494-587), its candidates are all enumerated, overfull buckets are skipped (HashBlock_Database.java:569-577).  Index tables and
-    duplication keys against the oracle's, then reads and pairs: streams and work counters, lane-per-read sequence and the scheduler path."""
+    duplication keys against the oracle's, then reads and pairs: streams and work counters."""
     st = {}
     ref = synth.repeat_rich_reference(600_000, n_segdups=14, n_tandem=30, n_hot=40, stats=st)
     assert st["fraction_in_repeats"] >= 0.3
@@ -474,17 +424,14 @@ def test_kernel_logic_on_a_repeat_rich_reference(monkeypatch):
     quick = want.counters[8] / b.nq
     assert 0.2 < quick < 0.85, "quick accepts on the repeat-rich reference: %.3f of the reads (i.i.d. reference: 0.94)" % quick
     assert want.counters[5] > 1.5 * b.nq, "candidates extended per read: %.2f" % (want.counters[5] / b.nq)
-    for sched in ("0", "1"):
-        monkeypatch.setenv("XMSIM_SCHED", sched)
-        got = S.align(b, p)
-        assert streams_equal(got, want), first_difference(got, want, b.nq)
-        assert list(want.counters[5:9]) == list(got.counters[4:8])  # candidates extended, PathAligner calls, nodes put, quick accepts
-        gotp = S.align(pb, p)
-        assert streams_equal(gotp, wantp), first_difference(gotp, wantp, pb.nq)
+    got = S.align(b, p)
+    assert streams_equal(got, want), first_difference(got, want, b.nq)
+    assert list(want.counters[5:9]) == list(got.counters[4:8])  # candidates extended, PathAligner calls, nodes put, quick accepts
+    gotp = S.align(pb, p)
+    assert streams_equal(gotp, wantp), first_difference(gotp, wantp, pb.nq)
 
 
-@pytest.mark.parametrize("sched", ["0", "1"])
-def test_kernel_logic_random_configurations(sched, monkeypatch):
+def test_kernel_logic_random_configurations():
     """The differential fuzz of the GPU tier (scripts/gpu_fuzz.py: random references with repeats and ambiguity codes, read lengths 36-301, single / paired
     mixes, random alignment parameters) through the host simulation: every batch must equal the oracle bit for bit.  Round 3 of this seed is a batch of pairs
     sampled from a reference with ambiguity codes that reach getUnpairedAlignments: the seeding state of both mates, their possibilities and three aligners in
@@ -492,19 +439,15 @@ def test_kernel_logic_random_configurations(sched, monkeypatch):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import gpu_fuzz
-    monkeypatch.setenv("XMSIM_SCHED", sched)
     assert gpu_fuzz.run(rounds=6, seed=77, max_queries=1500, backend="sim") == 0
 
 
-@pytest.mark.parametrize("sched", ["0", "1"])
-def test_kernel_logic_random_shapes(sched, monkeypatch):
+def test_kernel_logic_random_shapes():
     """The second flavour of the fuzz (gpu_fuzz.run_shapes): several contigs with reads across their ends, a length per read inside one batch (long reads among
     them: chains at the long-read scales), mates of unequal length, pairs and single reads mixed - through the host simulation, equal to the oracle."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import gpu_fuzz
-    monkeypatch.setenv("XMSIM_SCHED", sched)
-    monkeypatch.setenv("XMSIM_SCHED_LONG", sched)
     assert gpu_fuzz.run_shapes(rounds=3, seed=99, max_queries=700, backend="sim") == 0
 
 
@@ -519,7 +462,7 @@ def test_kernel_logic_ambiguity_fuzz():
 
 def test_kernel_logic_reads_no_arena_memory_it_has_not_written():
     """The host simulation built with -DXM_ARENA_POISON (every arena allocation filled with 0xA5 first: hostsim_lib.build, XMSIM_POISON=1) on reads, pairs and long
-    reads, lane-per-read passes and the wave scheduler: equal to the oracle, i.e. no structure in a lane's region or temporaries is read before it is written - on the
+    reads: equal to the oracle, i.e. no structure in a lane's region or temporaries is read before it is written - on the
     GPU, where a lane's arena holds what the lane's previous read left, such a read would make a result depend on the lane's history (profiles/r04/NOTES.md 14)."""
     import subprocess, sys
     code = r'''
@@ -532,8 +475,7 @@ from mapper_amd import synth
 assert hostsim_lib.build().endswith("_poison.so")
 ref = synth.synthetic_reference(400_000, seed=0xEC011)
 R = o.OracleReference([("e", ref)])
-for sched in ("0", "1"):
-    os.environ["XMSIM_SCHED"] = sched; os.environ["XMSIM_SCHED_LONG"] = sched
+if True:
     S = hostsim_lib.SimReference([("e", ref)])
     b = se_batch(synth.synthetic_single_end(ref, 4000, read_len=150, seed=11, sub_rate=0.02, indel_prob=0.4)[0])
     assert streams_equal(S.align(b, o.make_params()), R.align(b, o.make_params(), threads=8))

@@ -87,29 +87,19 @@ def test_full_size_golden_digests():
 
 
 PASS_SHAPES = [
-    {"XM_DEFER_PATH": "1"},                                                     # deferred PathAligner searches, default hand-over to the inline last pass
-    {"XM_DEFER_PATH": "1", "XM_DEFER_ROUNDS": "1000", "XM_INLINE_BELOW": "0"},  # every search through xm_path_kernel
     {"XM_LIGHT_LEVEL": "1"},                                                    # light pass keeps the hash-block analysis
     {"XM_TAPER_PCT": "0", "XM_FULL_LPW": "64"},                                 # no end-of-list taper, full waves in the gapped pass
     {"XM_LIGHT_WAVES": "2", "XM_FULL_WAVES": "1", "XM_SCRATCH_GIB": "2"},       # few lanes: every lane aligns many reads in turn
-    {"XM_HEAVY_HINT": "64", "XM_LIGHT_SYNC": "1"},                              # gapped pass ordered by the cost hint and dealt out (the default for single reads; here for the pairs too); wave-synchronous light batches
+    {"XM_HEAVY_HINT": "64"},                                                    # gapped pass ordered by the cost hint and dealt out (the default for single reads; here for the pairs too)
     {"XM_HEAVY_HINT": "0"},                                                     # gapped pass in list order for the single reads as well
     {"XM_HEAVY_HINT": "16", "XM_FULL_LPW": "8", "XM_FULL_WAVES": "2"},          # nearly every read of the gapped pass "heavy", few lanes
     {"XM_HANDOVER": "0"},                                                       # gapped pass seeds its reads again (no saved regions)
     {"XM_PAIR_LANES": "0"},                                                     # one lane per read in the gapped pass
     {"XM_HANDOVER": "0", "XM_PAIR_LANES": "0", "XM_FULL_LPW": "64"},            # both off, full waves
     {"XM_GAPPED_TMP_PCT": "25", "XM_SCRATCH_GIB": "1"},                         # small temporaries (HBM-mode searches overflow into the rerun passes), tiny region pool
-    {"XM_HANDBACK": "1"},                                                       # the gapped pass hands a read back when its candidate is through the chain; passes of the light shape take them on
-    {"XM_HANDBACK": "1", "XM_PAIR_LANES": "0", "XM_SCRATCH_GIB": "2"},          # the same with one lane per read and few lanes
     {"XM_SEARCH_POOL": "0"},                                                    # HBM-mode searches in the lanes' temporaries (no buffer per wave)
     {"XM_SEARCH_POOL": "0", "XM_GAPPED_TMP_PCT": "20"},                         # ... and too small for them: those reads rerun
     {"XM_REGION_KB": "40", "XM_LIGHT_TMP_KB": "24"},                            # regions and light temporaries too small for anything: every read overflows into the reruns
-    {"XM_SCHED": "1"},                                                          # the gapped pass as the wave scheduler (chain phases / search phases, xm_sched_kernel)
-    {"XM_SCHED": "1", "XM_SCHED_QUANTUM": "1", "XM_SCHED_GATE": "1"},           # ... every search suspended after each explored entry, chain phases as soon as a lane is ready
-    {"XM_SCHED": "1", "XM_SCHED_LPW": "64", "XM_SCHED_GATE": "32", "XM_SCHED_QUANTUM": "1000000"},  # ... full waves, searches run to their end
-    {"XM_SCHED": "1", "XM_SCHED_LPW": "3", "XM_FULL_WAVES": "1", "XM_SCRATCH_GIB": "2"},  # ... few lanes: every lane takes many reads in turn
-    {"XM_SCHED": "1", "XM_SCHED_MEMO_KB": "2"},                                  # ... memos too small for some reads: those run again in the lane-per-read passes
-    {"XM_SCHED": "2"},                                                          # ... the reads that look expensive through the scheduler kernel, the others through the lane-per-read kernel
     {"XM_WAVE": "1"},                                                           # the wave-per-read form first (light tier, chain tiers with inline searches), lane-per-read passes for the rest
     {"XM_WAVE": "1", "XM_WAVE_TIERS": "1"},                                     # its light tier only
     {"XM_WAVE": "1", "XM_WAVE_TIERS": "2"},                                     # light + chain tier (no tier with the largest capacities)
@@ -153,16 +143,12 @@ def test_long_reads_on_gpu():
         db.close()
 
 
-@pytest.mark.parametrize("env", [{"XM_FULL_WAVES": "1"}, {"XM_FULL_WAVES": "1", "XM_FULL_LPW": "32"}, {"XM_FULL_WAVES": "1", "XM_FULL_LPW": "16", "XM_PAIR_LANES": "0"},
-                                 {"XM_SCHED_LONG": "1"}, {"XM_SCHED_LONG": "1", "XM_SCHED_LPW": "32", "XM_SCHED_QUANTUM": "16", "XM_FULL_WAVES": "1"},
-                                 {"XM_SCHED_LONG": "1", "XM_SCHED_BIGSET_PCT": "1", "XM_SCRATCH_GIB": "4"}],
+@pytest.mark.parametrize("env", [{"XM_FULL_WAVES": "1"}, {"XM_FULL_WAVES": "1", "XM_FULL_LPW": "32"}, {"XM_FULL_WAVES": "1", "XM_FULL_LPW": "16", "XM_PAIR_LANES": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_long_reads_sharing_waves_on_gpu(env, monkeypatch):
     """Enough 1,000 bp queries that the gapped pass puts several of them on every wave (its launch shape for long reads: 8 per wave; here 9 000 reads on
     1 024 waves, and the shapes of the short-read pass beside it): the searches of a wave's reads - HBM mode from the start at this chain scale - and
-    the two lanes of a read must not disturb each other.  XM_SCHED_LONG=1: the gapped pass as the wave scheduler (xm_sched_kernel) - searches side by side in the
-    lanes' small sets, the ones that outgrow them in large sets of the launch's pool (one group of buffers per XCD; the last shape: a pool of a few buffers, so that
-    searches wait for one)."""
+    the two lanes of a read must not disturb each other."""
     ref = synth.synthetic_reference(400_000, seed=41)
     reads = synth.synthetic_single_end(ref, 9000, read_len=1000, sub_rate=0.02, indel_prob=0.3, seed=42)[0]
     b = se_batch(reads)
@@ -205,14 +191,11 @@ def test_random_configurations_on_gpu():
     assert gpu_fuzz.run(rounds=8, seed=77, max_queries=1500) == 0
 
 
-@pytest.mark.parametrize("env", [{}, {"XM_SCHED": "1", "XM_SCHED_LONG": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
-def test_random_shapes_on_gpu(env, monkeypatch):
+def test_random_shapes_on_gpu():
     """Second flavour of the fuzz (gpu_fuzz.run_shapes): several contigs with reads across their ends, a length per read inside one batch (36 ... 450; every third
     round 300 ... 1 600: chains at the long-read scales, searches in the form of xm_wsearch.h), mates of unequal length, pairs and single reads mixed."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import gpu_fuzz
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     assert gpu_fuzz.run_shapes(rounds=9, seed=99, max_queries=1500) == 0
 
 
@@ -547,8 +530,7 @@ def test_grch38_regime_alignments_equal_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"XM_SCHED": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
-def test_repeat_rich_reference_equals_oracle(env, monkeypatch):
+def test_repeat_rich_reference_equals_oracle():
     """configs[1]'s and configs[2]'s read models on synth.repeat_rich_reference (5 Mb: segmental duplications at 90-99.5 % identity, tandem repeats, a 28-mer
     whose buckets overflow - over 30 % of the positions in a segment present at least twice): 100,000 reads and 50,000 pairs, result streams bit for bit and
     work counters equal to the oracle's.  This is the branch a real genome sends reads into and i.i.d. ACGT does not: no early accept in a duplicated window
@@ -563,8 +545,6 @@ def test_repeat_rich_reference_equals_oracle(env, monkeypatch):
     m1, m2 = synth.synthetic_paired_end(ref, 50_000, seed=0x5EED0002)[:2]
     pb = pe_batch(m1, m2, 100.0, 50.0)
     want, wantp = R.align(b, o.make_params(), threads=os.cpu_count()), R.align(pb, o.make_params(), threads=os.cpu_count())
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     db = api.ReferenceDatabase([("rep", ref)])
     for name, batch, w, n in (("reads", b, want, 100_000), ("pairs", pb, wantp, 50_000)):
         got, _ = gpu_align(db, batch)
