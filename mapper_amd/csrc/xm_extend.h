@@ -414,7 +414,12 @@ struct PathAlignerT {
   static constexpr double disallowed = 1000000.0;
   unsigned long long tLook, tLoad, tCompute, tPut;
   int32_t lastBucket, lastTail; double lastKey;  // the bucket the previous node went to
-  PNode* nodes; int32_t nNodes, maxNodes;  // node i is also list entry i (putNode appends exactly one of each)
+  // (the payloads are in HBM in either mode - the wave's node buffer, the lane's temporaries - and the pointer says so: a load through a generic pointer
+  // is a flat_load, whose result the compiler must take for different in every lane; everything computed from a node - the keys, the buckets, the
+  // counters, the loops over them - then needs execution-mask bookkeeping although one lane runs the search)
+  XM_GLOBAL(PNode)* nodes; int32_t nNodes, maxNodes;  // node i is also list entry i (putNode appends exactly one of each)
+  XM_INL PNode nodeAt(int i) const { PNode n; __builtin_memcpy(&n, (const void*)(nodes + i), sizeof(PNode)); return n; }
+  XM_INL void setNode(int i, const PNode& n) { __builtin_memcpy((void*)(nodes + i), &n, sizeof(PNode)); }
   // locatedNodes: (x,y) -> latest node.  HBM mode: dense grid of node indices when (textA+2)*(textB+2) fits (the four neighbour
   // lookups of an update are then four INDEPENDENT loads, issued together), open-addressing hash otherwise.  LDS mode: hash.
   int32_t* grid; int32_t gridH, gridW; bool useGrid;
@@ -635,7 +640,7 @@ struct PathAlignerT {
     lastTail = idx;
     PNode n;
     n.pen = pen; n.insX = insX; n.insY = insY; n.x = (int16_t)x; n.y = (int16_t)y; n.fl = fl; n.pad[0] = n.pad[1] = n.pad[2] = 0;
-    nodes[idx] = n;
+    setNode(idx, n);
     saveNode(idx, x, y, cellSlot, cellTaken);
     nodesPut++;
   }
@@ -674,10 +679,10 @@ struct PathAlignerT {
       diag = findNode(x - stepDelta, y - stepDelta);
     }
     XM_PA_TOC(tLook, t0);
-    const PNode nE = nodes[existing >= 0 ? existing : 0];
-    const PNode nL = nodes[left >= 0 ? left : 0];
-    const PNode nU = nodes[up >= 0 ? up : 0];
-    const PNode nD = nodes[diag >= 0 ? diag : 0];
+    const PNode nE = nodeAt(existing >= 0 ? existing : 0);
+    const PNode nL = nodeAt(left >= 0 ? left : 0);
+    const PNode nU = nodeAt(up >= 0 ? up : 0);
+    const PNode nD = nodeAt(diag >= 0 ? diag : 0);
     XM_PA_TOC(tLoad, t0);
     computeFromNodes(x, y, existing, left, up, diag, nE, nL, nU, nD, cellSlot, out);
   }
@@ -806,8 +811,16 @@ struct PaResume { int32_t valid, li, bucket, nNodes, nBuckets; unsigned long lon
 // PathAligner.align :55-293 up to and including justify: the search, the traceback and the final block list (outBlocks[0..nbOut)).
 // false = null (or *status set).  LDS mode: *ldsOverflow = true means "does not fit the slot, nothing decided".
 template <bool LDS>
-XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, int32_t* status, DevCounters* dc, ABlock* const outBlocksIn, int32_t& nbOut, bool* ldsOverflow, bool pair = false, PaResume* resume = nullptr) {
+XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmpIn, const Caps& capsIn, int32_t* status, DevCounters* dc, ABlock* const outBlocksIn, int32_t& nbOut, bool* ldsOverflow, bool pair = false, PaResume* resume = nullptr) {
   XM_TIC(tPath);
+  // LDS mode: the arguments too are the same in every active lane, and the compiler must know it - an argument of an out-of-line function counts as
+  // different per lane, a branch on one (`pair`, `resume`, `dc`) as divergent, and everything the two arms of such a branch assign - the whole search
+  // state - as divergent behind it: the search then runs on vector registers with execution-mask bookkeeping around every loop and branch
+  Arena* tmpP = &tmpIn;
+  if constexpr (LDS) {
+    pair = uniI(pair ? 1 : 0) != 0; resume = uniP(resume); dc = uniP(dc); status = uniP(status); ldsOverflow = uniP(ldsOverflow); tmpP = uniP(tmpP);
+  }
+  Arena& tmp = *tmpP;
   // by-value copies: anything read through a reference inside a loop that also stores would be re-loaded (and waited for) on
   // every iteration, because the compiler cannot prove the store does not alias it
   PaProblem pr = prIn;
@@ -849,7 +862,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
     if (pa.textALength > XM_PAL_TEXTA || pa.textBLength > XM_PAL_TEXTB - 3 || pa.textALength < 0 || pa.textBLength < 0) { *ldsOverflow = true; return false; }
     pa.maxNodes = imin(caps.maxNodes, XM_PAL_NODES);
     pa.maxBuckets = imin(caps.maxBuckets, XM_PAL_BUCKETS);
-    pa.nodes = palWaveNodes();
+    pa.nodes = (XM_GLOBAL(PNode)*)palWaveNodes();
     uint8_t* const slot = palSlot();
     pa.Lhash = (uint32_t*)(slot + XM_PAL_OFF_HASH); pa.nCells = 0; pa.Lxy = (uint16_t*)(slot + XM_PAL_OFF_XY); pa.Lnext = (uint16_t*)(slot + XM_PAL_OFF_NEXT);
     pa.Lbkey = (double*)(slot + XM_PAL_OFF_BKEY); pa.Lbhead = (uint16_t*)(slot + XM_PAL_OFF_BHEAD); pa.Lbtail = (uint16_t*)(slot + XM_PAL_OFF_BTAIL);
@@ -876,7 +889,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
     }
   } else {
     pa.maxNodes = caps.maxNodes;
-    pa.nodes = arenaArray<PNode>(tmp, caps.maxNodes);
+    pa.nodes = (XM_GLOBAL(PNode)*)arenaArray<PNode>(tmp, caps.maxNodes);
     pa.useGrid = (long long)pa.gridW * pa.gridH <= (long long)caps.gridCap;
     if (pa.useGrid) pa.grid = arenaArray<int32_t>(tmp, (size_t)pa.gridW * pa.gridH);
     else { pa.hash = arenaArray<int32_t>(tmp, caps.nodeHash); pa.hashMask = caps.nodeHash - 1; }
@@ -923,7 +936,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmp, const Caps& capsIn, i
       const int nN = resume->nNodes, nB = resume->nBuckets;
       if (nN > pa.maxNodes || nB > pa.maxBuckets) { *status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
       for (int i = 0; i < nN; i++) {
-        pa.nodes[i] = waveNodes[i];
+        pa.setNode(i, waveNodes[i]);
         const uint16_t xy = Lxy[i], nx = Lnx[i];
         pa.lx[i] = (int16_t)(xy >> 8); pa.ly[i] = (int16_t)(xy & 0xFF); pa.lnext[i] = nx == 0xFFFF ? -1 : (int32_t)nx;
       }

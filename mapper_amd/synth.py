@@ -83,12 +83,21 @@ def _mutate_reads(ref, starts, strand, read_len, r_sub, r_indel, sub_rate, indel
     return out
 
 
+def _parallel(fn, items, workers=None):
+    """fn over items on a few threads (numpy releases the GIL in the array passes these generators are made of)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    workers = workers or max(1, min(16, (os.cpu_count() or 2) // 2))
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(fn, items))
+
+
 def synthetic_single_end(ref, n_reads, read_len=150, seed=0x5EED0001, sub_rate=0.01, indel_prob=0.05, chunk=200_000, at=None):
     """Config 2: n_reads x read_len single-end reads. Returns (codes [n, read_len] uint8, starts, strand).
     at: template starts to use instead of drawing them (genome_wide_starts: reads sampled over a many-contig reference laid out in one array)."""
-    outs, all_starts, all_strand = [], [], []
     span = read_len + 3
-    for c0 in range(0, n_reads, chunk):
+
+    def one(c0):  # (a chunk is a pure function of the seed and its offset: the chunks are made on a few threads)
         n = min(chunk, n_reads - c0)
         base = np.uint64(seed) + np.uint64(c0) * np.uint64(0x1000003)
         r0 = splitmix64(base, 2 * n)
@@ -96,19 +105,18 @@ def synthetic_single_end(ref, n_reads, read_len=150, seed=0x5EED0001, sub_rate=0
         strand = (r0[n:] >> np.uint64(63)).astype(np.uint8)
         r_sub = splitmix64(base ^ np.uint64(0xA5A5A5A5), n * span)
         r_ind = splitmix64(base ^ np.uint64(0x5A5A5A5A), n * 4)
-        outs.append(_mutate_reads(ref, starts, strand, read_len, r_sub, r_ind, sub_rate, indel_prob))
-        all_starts.append(starts)
-        all_strand.append(strand)
-    return np.concatenate(outs), np.concatenate(all_starts), np.concatenate(all_strand)
+        return _mutate_reads(ref, starts, strand, read_len, r_sub, r_ind, sub_rate, indel_prob), starts, strand
+    parts = _parallel(one, range(0, n_reads, chunk)) if n_reads > chunk else [one(0)]
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])
 
 
 def synthetic_paired_end(ref, n_pairs, read_len=150, seed=0x5EED0002, sub_rate=0.01, indel_prob=0.05, chunk=200_000, at=None):
     """Config 3: FR pairs, inner distance round(N(100, 30^2)) clipped to [-100, 400]; mate 2 is the reverse
     complement strand (Illumina FR).  Returns (mate1 [n, L], mate2 [n, L], starts1, inner, strand).
     at: fragment starts to use instead of drawing them (a fragment spans at most 2 * read_len + 400 + 3 bases)."""
-    m1s, m2s, st, inn, sd = [], [], [], [], []
     span = read_len + 3
-    for c0 in range(0, n_pairs, chunk):
+
+    def one(c0):
         n = min(chunk, n_pairs - c0)
         base = np.uint64(seed) + np.uint64(c0) * np.uint64(0x1000003)
         r0 = splitmix64(base, 4 * n)
@@ -128,17 +136,9 @@ def synthetic_paired_end(ref, n_pairs, read_len=150, seed=0x5EED0002, sub_rate=0
         # a fragment from the reverse strand swaps the roles: mate1 = rc(right end), mate2 = left end as-is
         a2 = np.where(rev[:, None], b, a)
         b2 = np.where(rev[:, None], a, b)
-        m1s.append(a2); m2s.append(b2); st.append(starts1); inn.append(inner); sd.append(strand)
-    return np.concatenate(m1s), np.concatenate(m2s), np.concatenate(st), np.concatenate(inn), np.concatenate(sd)
-
-
-def _parallel(fn, items, workers=None):
-    """fn over items on a few threads (numpy releases the GIL in the array passes these generators are made of)."""
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-    workers = workers or max(1, min(16, (os.cpu_count() or 2) // 2))
-    with ThreadPoolExecutor(workers) as ex:
-        list(ex.map(fn, items))
+        return a2, b2, starts1, inner, strand
+    parts = _parallel(one, range(0, n_pairs, chunk)) if n_pairs > chunk else [one(0)]
+    return tuple(np.concatenate([p[k] for p in parts]) for k in range(5))
 
 
 # ---------------------------------------------------------------- configs[3] / configs[4]: the GRCh38-shaped reference of SURVEY.md section 8(d)

@@ -2,9 +2,11 @@
 real GRCh38 chromosome lengths, i.i.d. ACGT, 1 % of the positions in N-runs of 10 kb, seed 0x6C38 (mapper_amd/synth.py::grch38_shaped_reference).  No
 oracle finishes at this size (the oracle checks the same regime - minInterestingSize 13, several contigs, N-runs - on a 15 Mb reference of the same
 shape: tests/test_gpu_parity.py::test_grch38_regime_alignments_equal_oracle), so the checks are properties:
-  * configs[3]: 1,000,000 pairs 2 x 150 bp sampled genome-wide (seed 0x5EED0003, --spacing 100 50) come back as pairs with both mates at their origins;
+  * configs[3]: 6,250,000 pairs 2 x 150 bp - one GPU's share of the config's 50 M pairs on 8 GPUs - sampled genome-wide (seed 0x5EED0003, --spacing 100 50)
+    come back as pairs with both mates at their origins;
   * configs[4]: reads of 10 kb (seed 0x5EED0004) cut by --split-queries-past-size 1000 (the command line's splitter, SequenceSplitter.java:17,35-38)
-    into queries of 1 kb (10,000 reads here, 100,000 in bench.py --config 4): with the error rates as stated (5 % substitutions + 5 % indel events per base: above --max-penalty, almost nothing
+    into queries of 1 kb (62,500 reads = 625,000 queries here, a tenth of one GPU's share of the config's 5 M reads on 8 GPUs; the whole share is
+    profiles/r05/bench_config4_share.json): with the error rates as stated (5 % substitutions + 5 % indel events per base: above --max-penalty, almost nothing
     aligns, and what does is a short chance match) and with milder ones (2 % + 0.2 %), where the sections that align sit where they came from;
   * determinism (the same batch twice gives the same streams) and batch invariance (a query's result does not depend on the batch it travels in);
   * the index takes the paths a 5 Mb reference never takes: 64-bit position arrays, 64-byte bucket lines, tables hashed on the GPU in groups with the
@@ -46,7 +48,7 @@ def test_config3_pairs_on_the_grch38_shaped_reference(grch):
     assert info["position_bytes"] == 8 and info["built_on_device"] == 1 and info["min_interesting_size"] == 13  # HashBlock_Database.java:52
     assert abs(float((whole[:50_000_000] == 15).mean()) - 0.01) < 0.002
     params = api.AlignmentParameters()
-    n = 1_000_000
+    n = 6_250_000  # configs[3]: 50 M pairs sharded over 8 GPUs (Mapper.java:926,957-983 deal queries to workers; here: to GPUs)
     frag = 2 * 150 + 400 + 3 + 153
     g, contig, local = synth.genome_wide_starts(starts, runs, n, frag, seed=0x5EED0003 ^ 0xF00D)
     m1, m2, starts1, inner, strand = synth.synthetic_paired_end(whole, n, seed=0x5EED0003, at=g)
@@ -63,7 +65,7 @@ def test_config3_pairs_on_the_grch38_shaped_reference(grch):
     want = np.where(strand[paired] == 0, local[paired], local[paired] + 150 + inner[paired])
     assert (np.abs(off1 - want) <= 3).mean() > 0.995
     # determinism, on a part of the batch (the whole batch again would only repeat the minute)
-    sl = slice(400_000, 460_000)
+    sl = slice(4_400_000, 4_460_000)
     sb = pe_batch(m1[sl], m2[sl], 100.0, 50.0)
     r2 = db.align_arrays(*arrays(sb), params)
     r3 = db.align_arrays(*arrays(sb), params)
@@ -99,9 +101,9 @@ def test_config4_long_reads_through_the_splitter(grch):
     span = L + L // 4 + 8
     assert cli.split_sections(L, 1000) == [(1000 * k, 1000 * (k + 1)) for k in range(10)] and cli.split_sections(2500, 1000) == [(0, 833), (833, 1666), (1666, 2500)]
     # (a) the config as stated: 5 % substitutions + 5 % indel events per base -> queries of 1,000 bases
-    # (the stated size is 100,000 reads here; these reads are the slowest the path knows - every section walks the whole chain and fails, ~95 us
-    # each - so the test tier aligns a tenth of them; bench.py --config 4 runs the full hundred thousand: profiles/r03)
-    n = 10_000
+    # (one GPU's share of the config is 625,000 reads = 6.25 M queries; these reads are the slowest the path knows - every section walks the whole
+    # chain and fails, ~45 us each - so the test tier aligns a tenth of the share; bench.py --config 4 --reads 625000 runs all of it: profiles/r05)
+    n = 62_500
     g, contig, local = synth.genome_wide_starts(starts, runs, n, span, seed=0x5EED0004 ^ 0xF00D)
     strand = (synth.splitmix64(0x5EED0004 ^ 0x57A, n) >> np.uint64(63)).astype(np.uint8)
     reads = synth.synthetic_long_reads(whole, g, L, seed=0x5EED0004, sub_rate=0.05, indel_rate=0.05, strand=strand)
@@ -112,7 +114,7 @@ def test_config4_long_reads_through_the_splitter(grch):
     # count as unaligned (0.1 each, AlignmentParameters.java:73-95), not the section's origin - so no statement about places here, only about numbers
     frac_stated = one.mean()
     assert frac_stated < 0.01
-    sl = slice(30_000, 40_000)
+    sl = slice(330_000, 340_000)
     sb = oracle_lib.QueryBatch.from_arrays(b.mate_count[sl], b.mate_offset[2 * sl.start:2 * sl.stop], b.mate_length[2 * sl.start:2 * sl.stop], b.codes, b.expected_inner[sl], b.deviation[sl])
     r2 = db.align_arrays(*arrays(sb), params)
     assert np.array_equal(r2.ints, r1.ints[r1.int_off[sl.start]:r1.int_off[sl.stop]]) and np.array_equal(r2.dbls.view(np.int64), r1.dbls[r1.dbl_off[sl.start]:r1.dbl_off[sl.stop]].view(np.int64))

@@ -86,6 +86,23 @@ def test_full_size_golden_digests():
     db.close()
 
 
+def test_config2_at_its_stated_size():
+    """BASELINE.json configs[2] as stated: 10,000,000 pairs 2 x 150 bp (--spacing 100 50) against the 5 Mb reference, in ONE batch - the whole result streams
+    against the digest of the oracle's (tests/golden/synthetic_golden.json, stated_digests, made by `make_synthetic_golden.py stated`), and the work counters."""
+    from make_synthetic_golden import stated_size_cases, digest
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "synthetic_golden.json")))["stated_digests"]
+    ref, batches = stated_size_cases()
+    db = api.ReferenceDatabase([("ecoli_syn", ref)], max_query_length=150)
+    for name, make in batches.items():
+        got, _ = gpu_align(db, make())
+        g = golden[name]
+        assert (len(got.ints), len(got.dbls)) == (g["num_ints"], g["num_dbls"]), name
+        assert digest(got) == g["sha256"], name
+        oc = g["oracle_counters"]
+        assert [int(x) for x in got.counters[:8]] == [oc[0], oc[1] + oc[2], oc[2], oc[3], oc[5], oc[6], oc[7], oc[8]], name
+    db.close()
+
+
 PASS_SHAPES = [
     {"XM_LIGHT_LEVEL": "1"},                                                    # light pass keeps the hash-block analysis
     {"XM_TAPER_PCT": "0", "XM_FULL_LPW": "64"},                                 # no end-of-list taper, full waves in the gapped pass
