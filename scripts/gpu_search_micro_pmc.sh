@@ -1,0 +1,34 @@
+#!/bin/bash
+# Executed instructions per category of ONE PathAligner search (scripts/gpu_search_micro.py, the test entry: one lane of one wave), per library variant.
+# usage (on the GPU box): scripts/gpu_search_micro_pmc.sh outdir libdir [libdir ...]
+R=$GRAFT_REPO_ROOT
+O=$R/$1; shift
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for v in "$@"; do
+  export XM_LIB_PATH=$R/mapper_amd/$v/libxmapper_hip.so
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM -d $O/pmcA$v -o p --output-format csv -- python3 $R/scripts/gpu_search_micro.py 0 6 > $O/pmcA$v.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_WAVE_CYCLES -d $O/pmcB$v -o p --output-format csv -- python3 $R/scripts/gpu_search_micro.py 0 6 > $O/pmcB$v.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/pmcC$v -o p --output-format csv -- python3 $R/scripts/gpu_search_micro.py 0 6 > $O/pmcC$v.log 2>&1
+done
+cd $R
+python3 - $O "$@" <<'PY'
+import csv, sys, collections, json, os
+O = sys.argv[1]
+nodes = [365, 996, 1674, 3097]
+out = {}
+for v in sys.argv[2:]:
+    acc = collections.defaultdict(list)
+    for p in "ABC":
+        f = os.path.join(O, "pmc%s%s" % (p, v), "p_counter_collection.csv")
+        if not os.path.exists(f): continue
+        for r in csv.DictReader(open(f)):
+            if "xm_test_local_kernel" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {}
+    for c, vals in acc.items():
+        n = len(vals) // 4
+        per = [sorted(vals[i * n:(i + 1) * n])[n // 2] for i in range(4)]
+        res[c] = {"per_search": per, "per_node_put(996 vs 365 nodes)": round((per[1] - per[0]) / (nodes[1] - nodes[0]), 1)}
+    out[v] = res
+print(json.dumps(out, indent=1))
+PY
