@@ -434,7 +434,7 @@ def main():
                     traffic_source = "profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, build %s)" % (rounds[-1], pm["build"])
                 else:  # counters of another build (or another number of contexts) say nothing about this one
                     traffic_source = "none: profiles/%s/pmc_summary.json was collected on build %s, this is %s" % (rounds[-1], pm.get("build", "?"), build)
-            elif args.config in ("2", "4shape") and (args.reads, args.ref_len) == (1_000_000, 5_000_000):
+            elif args.config in ("2", "4shape", "1rep") and (args.reads, args.ref_len) == (1_000_000, 5_000_000):
                 name = "pmc_config%s.json" % args.config
                 rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, name)))
                 pm = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], name)))

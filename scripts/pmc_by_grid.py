@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM traffic of the align kernel's launches from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/gpu_profile_round_r04.sh), for workloads whose steps are
+"""HBM traffic of the align kernel's launches from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/gpu_profile_round_r05.sh), for workloads whose steps are
 not "one light launch + one gapped launch of known grids" (pairs, long reads): launches are grouped by grid size.
 
     python scripts/pmc_by_grid.py gpurun_out/r04 _config2 > profiles/r04/pmc_config2.json
@@ -11,7 +11,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for d in ("pmcF", "pmcW"):
     path = os.path.join(root, d + suffix, "pmc_counter_collection.csv")
     for r in csv.DictReader(open(path)):
-        if "xm_align_kernel" in r["Kernel_Name"] or "xm_sched_kernel" in r["Kernel_Name"]:
+        if "xm_align_kernel" in r["Kernel_Name"]:
             acc[int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 groups = []
 for g in sorted(acc, reverse=True):
@@ -21,8 +21,8 @@ for g in sorted(acc, reverse=True):
     w = sum(cs.get("WRITE_SIZE", [0])) / max(1, len(cs.get("WRITE_SIZE", [0])))
     groups.append({"grid_threads": g, "launches_profiled": n, "fetch_bytes_per_launch": f * 1024.0, "write_bytes_per_launch": w * 1024.0, "hbm_bytes_per_launch": (f + w) * 1024.0})
 out = {"kernel": "xm_align_kernel", "launches_by_grid": groups,
-       "_note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over `python3 bench.py --config %s --steps 6` without the side measurements (scripts/gpu_profile_round_r04.sh); "
-                "KiB as rocprofv3 reports them x 1024 (narrow scattered accesses: no gfx950 wide-load correction applies); the launch with the largest grid is the light pass, the next one the gapped pass" % suffix.replace("_config", "")}
+       "_note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over `python3 bench.py --config %s --steps 6` without the side measurements (scripts/gpu_profile_round_r05.sh); "
+                "KiB as rocprofv3 reports them x 1024 (narrow scattered accesses: no gfx950 wide-load correction applies); a launch is sized by the contexts aligning at the time, so one pass appears under more than one grid" % suffix.replace("_config", "")}
 try:
     line = json.load(open(os.path.join(root, "bench%s.json" % suffix)))
     out["build"] = line["build"]
