@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (configs[1]: 1,000,000)")
     ap.add_argument("--ref-len", type=int, default=5_000_000)
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--seed-probes", type=int, default=16_000_000, help="bucket-header probes of the seed-lookup micro-benchmark (0 = skip)")
+    ap.add_argument("--seed-probes", type=int, default=64_000_000, help="bucket-header probes of the seed-lookup micro-benchmark (0 = skip); the default is the size of the gather-ceiling measurement it is held against (2^26 accesses), half of them with positions")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a one-GPU box)")
     ap.add_argument("--force-device", type=int, default=-1, help="testing: every rank uses this GPU instead of its LOCAL_RANK")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads of the same workload timed on the host cores (0 = skip); default: the whole batch (about a second on the GPU box's 256 cores)")
@@ -403,7 +403,7 @@ def main():
             counts, _, ms_hdr = db.seed_probe(used, keys, 0)
             sectors_per_s, gather_ms = api.measure_random_gather(4 << 30, 1 << 26, local_rank)
             n2 = args.seed_probes // 4
-            c2, _, ms_pos = db.seed_probe(used[:n2], keys[:n2], 4)
+            c2, _, ms_pos = db.seed_probe(used[:n2], keys[:n2], 4, unpack=False)
             fetched = int(np.minimum(np.maximum(c2, 0), 4).sum())
             hdr_gbs = 8.0 * args.seed_probes / (ms_hdr * 1e-3) / 1e9
             seed = {"kernel": "xm_seed_probe_kernel", "probes": args.seed_probes, "kernel_ms": round(ms_hdr, 4),
@@ -530,7 +530,7 @@ def seed_probe_hbm(api, synth, db, index_mb, device, sectors_per_s, n_probes, rn
         db.seed_probe(u[:4096], k[:4096], 0)
         _, _, ms_hdr = db.seed_probe(u, k, 0)
         n2 = len(u) // 2
-        c2, _, ms_pos = db.seed_probe(u[:n2], k[:n2], 7)
+        c2, _, ms_pos = db.seed_probe(u[:n2], k[:n2], 7, unpack=False)
         fetched = int(np.minimum(np.maximum(c2, 0), 7).sum())
         hdr_rate, pos_rate = len(u) / (ms_hdr * 1e-3), n2 / (ms_pos * 1e-3)
         out[label] = {"header_only": {"probes_per_s": round(hdr_rate, 1), "algorithmic_frac_of_peak": round(8.0 * hdr_rate / 8e12, 5), "sector_traffic_frac_of_peak": round(64.0 * hdr_rate / 8e12, 4),

@@ -171,8 +171,12 @@ int xm_batch_commit(xm_index* index);
 
 /* Bulk form of Readable_HashBlock_Database.getNumMatchesLowerBound + matchBlock / PackedMap.get (PackedMap.java:160-172,
  * 228-236) for n (used_length, lookup key) pairs: counts[i] = number of stored positions, -1 when the bucket is overfull or
- * holds more than the table's limit; position j of probe i is written to out_positions[j*n + i] (at most max_per_probe each, probe-minor so
- * that the lanes of a wavefront write neighbouring words; not reverse-complemented).  Device-resident micro-kernel used for the seed-lookup roofline measurement. */
+ * holds more than the table's limit, -2 when used_length is not a hashed length.  Positions (at most max_per_probe <= 15 per probe, not reverse-complemented): the
+ * probes of a chunk of 64 consecutive ones (i = 64c ... 64c + 63: a wavefront's) store theirs one behind the other, in probe order, from
+ * out_positions[64c * max_per_probe] on; probe i's start within its chunk is the sum of min(max(counts[i'], 0), max_per_probe) over the chunk's probes
+ * before it (out_positions holds n * max_per_probe entries; what no probe fills is not written).  Packed because the outputs are most of what such a
+ * kernel moves: rows of max_per_probe slots would be 56 bytes a probe at 7 slots, of which a genome's buckets fill ~12.  Device-resident micro-kernel used for
+ * the seed-lookup roofline measurement. */
 int xm_seed_probe(xm_index* index, int64_t n, const int32_t* used_length, const int32_t* keys, int32_t max_per_probe, int32_t* counts, int64_t* out_positions, double* kernel_ms);
 
 /* Measurement helper for the seed-lookup roofline (SURVEY.md section 8d asks for the achieved rate next to "a measured random-64 B-gather

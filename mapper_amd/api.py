@@ -425,17 +425,29 @@ class ReferenceDatabase:
         codes = np.concatenate(chunks) if chunks else np.zeros(1, np.uint8)
         return self.align_arrays(mc, mo, ml, codes, ei, dv, parameters)
 
-    def seed_probe(self, used_length, keys, max_per_probe=8):
-        """Bulk PackedMap.get (PackedMap.java:160-172) on the device -> (counts, positions[n, max_per_probe], kernel_ms)."""
+    def seed_probe(self, used_length, keys, max_per_probe=8, unpack=True):
+        """Bulk PackedMap.get (PackedMap.java:160-172) on the device -> (counts, positions[n, max_per_probe] with -1 behind a probe's positions, kernel_ms).
+        (The C entry packs the positions of every 64 consecutive probes one behind the other: unpacked here; unpack=False returns the packed array as it is.)"""
         used = np.ascontiguousarray(used_length, dtype=np.int32)
         keys = np.ascontiguousarray(keys, dtype=np.int32)
         n = len(used)
         counts = np.zeros(n, np.int32)
-        pos = np.zeros((max(max_per_probe, 1), n), np.int64)  # (the C entry writes position j of probe i at [j, i])
+        packed = np.zeros(max(max_per_probe, 1) * max(n, 1), np.int64)
         ms = C.c_double()
-        if self._L.xm_seed_probe(self._h, n, used.ctypes.data, keys.ctypes.data, max_per_probe, counts.ctypes.data, pos.ctypes.data, C.byref(ms)):
+        if self._L.xm_seed_probe(self._h, n, used.ctypes.data, keys.ctypes.data, max_per_probe, counts.ctypes.data, packed.ctypes.data, C.byref(ms)):
             raise RuntimeError(self._L.xm_last_error().decode())
-        return counts, pos.T, ms.value
+        if not unpack:
+            return counts, packed, ms.value
+        pos = np.full((n, max(max_per_probe, 1)), -1, np.int64)
+        if max_per_probe > 0 and n > 0:
+            m = np.minimum(np.maximum(counts, 0), max_per_probe).astype(np.int64)
+            chunk = np.arange(n, dtype=np.int64) // 64
+            run = np.cumsum(m) - m                                    # exclusive running sum over all probes ...
+            start = run - run[chunk * 64] + chunk * 64 * max_per_probe  # ... made relative to the probe's chunk
+            for j in range(max_per_probe):
+                sel = m > j
+                pos[sel, j] = packed[start[sel] + j]
+        return counts, pos, ms.value
 
 
 def measure_random_gather(table_bytes=4 << 30, accesses=1 << 26, device=0):

@@ -21,6 +21,7 @@
 #include <memory>
 #include <atomic>
 #include <array>
+#include <type_traits>
 #include <map>
 #include <chrono>
 #include <algorithm>
@@ -414,107 +415,119 @@ __global__ void __launch_bounds__(256) xm_lines_kernel(Table t, const uint32_t* 
   for (int j = 0; j < 8; j++) dst[j] = line[j];
 }
 
+// Where a probe's positions go: the 64 probes i = 64 c ... 64 c + 63 (the lanes of one wavefront) write theirs one behind the other, in probe order, from
+// out_positions[64 c max_per_probe] on - whole lines leave for HBM, and only as many bytes as there are positions (rows of max_per_probe slots cost the
+// memory 56 bytes a probe at 7 slots, of which a genome's buckets fill 12; a row per position index, written only where a bucket has that many, is holes
+// in every line, and a partly written line costs a read besides the write).  The reader finds probe i's positions behind those of the probes before it
+// in its chunk: offsets are the running sum of min(max(counts, 0), max_per_probe) over the chunk.  Returns this lane's first slot.
+__device__ __forceinline__ long long xmProbeSlot(long long i, int m, int maxPerProbe) {
+  // exclusive prefix sum of m (0 ... 7: three bits) over the lanes of the wave
+  const unsigned long long b0 = __ballot(m & 1), b1 = __ballot(m & 2), b2 = __ballot(m & 4), b3 = __ballot(m & 8);
+  const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
+  const int before = __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below) + 8 * __popcll(b3 & below);
+  return (i & ~63ll) * (long long)maxPerProbe + before;
+}
+
 // PackedMap.getNumMatchesLowerBound + PackedMap.get for a batch of (used length, key): one lane per probe.
 __global__ void __launch_bounds__(256) xm_seed_probe_kernel(IndexView ix, long long n, const int32_t* usedLength, const int32_t* keys, int maxPerProbe,
                                                             int32_t* counts, int64_t* outPositions) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int used = usedLength[i];
-  if (used < 0 || used > ix.maxHashedLength) { counts[i] = -2; return; }
-  const Table* t = &ix.tables[used];
-  uint32_t k = packedKey(t, keys[i]);
-  int count;
-  int64_t first;
-  if (ix.lines32 || ix.lines64) {  // bucket lines: one access returns the header and the first XM_LINE_SLOTS positions
-    const int64_t line = (t->offBase + k) * 8;
-    if (ix.lines64) {
-      const ulonglong2* lp = (const ulonglong2*)(ix.lines64 + line);
-      // (the whole line is requested at once: four 16-byte loads of one 64-byte sector in flight together, not a second round trip after the header)
-      const ulonglong2 a = lp[0];
-      ulonglong2 b1 = a, b2 = a, b3 = a;
-      if (maxPerProbe > 0) { b1 = lp[1]; b2 = lp[2]; b3 = lp[3]; }
-      const uint32_t h = (uint32_t)a.x;
-      if (h & XM_OVERFULL) { counts[i] = -1; return; }
-      count = (int)h;
-      if (count > t->maxCount) { counts[i] = -1; return; }
-      counts[i] = count;
-      if (maxPerProbe > 0 && count > 0 && count <= XM_LINE_SLOTS) {
-        const int m = count < maxPerProbe ? count : maxPerProbe;
-        const unsigned long long w[8] = {a.x, a.y, b1.x, b1.y, b2.x, b2.y, b3.x, b3.y};
-        for (int j = 0; j < m; j++) outPositions[(long long)j * n + i] = (int64_t)w[1 + j];
-        return;
-      }
-    } else {
-      const uint4* lp = (const uint4*)(ix.lines32 + line);
-      const uint4 a = lp[0], b = lp[1];
-      if (a.x & XM_OVERFULL) { counts[i] = -1; return; }
-      count = (int)a.x;
-      if (count > t->maxCount) { counts[i] = -1; return; }
-      counts[i] = count;
-      if (maxPerProbe > 0 && count > 0 && count <= XM_LINE_SLOTS) {
-        const int m = count < maxPerProbe ? count : maxPerProbe;
-        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        for (int j = 0; j < m; j++) outPositions[(long long)j * n + i] = (int64_t)w[1 + j];
-        return;
-      }
-    }
-    if (maxPerProbe <= 0 || count == 0) return;
-    first = t->posBase + (int64_t)(ix.bucketOff[t->offBase + k] & ~XM_OVERFULL);
-  } else {
+  // (the probe through the CSR arrays - two adjacent offsets, then the positions: what an index without bucket lines offers)
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  const int used = live ? usedLength[i] : -1;
+  const bool ok = live && used >= 0 && used <= ix.maxHashedLength;
+  int count = -2;
+  int64_t first = 0;
+  if (ok) {
+    const Table* t = &ix.tables[used];
+    const uint32_t k = packedKey(t, keys[i]);
     const uint32_t* off = ix.bucketOff + t->offBase + k;
-    uint32_t o0 = off[0], o1 = off[1];
-    if (o0 & XM_OVERFULL) { counts[i] = -1; return; }
-    count = (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
-    if (count > t->maxCount) { counts[i] = -1; return; }
-    counts[i] = count;
+    const uint32_t o0 = off[0], o1 = off[1];
+    count = (o0 & XM_OVERFULL) ? -1 : (int)((o1 & ~XM_OVERFULL) - (o0 & ~XM_OVERFULL));
+    if (count > t->maxCount) count = -1;
     first = t->posBase + (int64_t)(o0 & ~XM_OVERFULL);
   }
-  int m = count < maxPerProbe ? count : maxPerProbe;
-  for (int j = 0; j < m; j++) outPositions[(long long)j * n + i] = ix.posIs64 ? (int64_t)ix.positions64[first + j] : (int64_t)ix.positions32[first + j];
+  const int m = (count > 0 && maxPerProbe > 0) ? (count < maxPerProbe ? count : maxPerProbe) : 0;
+  const long long slot = xmProbeSlot(i, m, maxPerProbe);
+  if (!live) return;
+  counts[i] = count;
+  for (int j = 0; j < m; j++) outPositions[slot + j] = ix.posIs64 ? (int64_t)ix.positions64[first + j] : (int64_t)ix.positions32[first + j];
 }
 
-// The same bulk probe over bucket lines, the way a wavefront should read them: G adjacent lanes share a probe and each loads 16 bytes of the
-// bucket's line (G = 4 with 64-bit positions: a 64-byte line; G = 2 with 32-bit positions: 32 bytes), so the memory pipeline sees ONE request per
-// line instead of G, and the header and all seven inline positions arrive together.  Buckets with more than XM_LINE_SLOTS positions fall back
-// to the CSR arrays (lane 0 of the group).
-template <int G>
+// The same bulk probe over bucket lines with several probes in flight per lane (round 5; it replaces the group-of-lanes form of round 2, which ran at half of this
+// GPU's random-sector rate): a probe's chain - (length, key) -> table descriptor -> key mod capacity -> line - is short but dependent, so what the rate
+// needs is many chains at a time.  A lane takes XM_PROBES_PER_LANE probes a whole launch apart (coalesced reads of the inputs and writes of the counts), takes
+// the table descriptors from LDS (the block copies them there once: no trip to memory between the inputs and the line), and has asked for all its lines
+// before it looks at the first.  64-bit lines: the whole 64-byte line as four 16-byte loads; 32-bit lines: two.  Header only (maxPerProbe == 0): the first
+// 16 bytes.  Buckets with more than XM_LINE_SLOTS positions (1.4 % of a genome-like index) read the CSR arrays behind that.
+constexpr int XM_PROBES_PER_LANE = 4;
+constexpr int XM_PROBE_LDS_TABLES = 512;
+template <bool W64>
 __global__ void __launch_bounds__(256) xm_seed_probe_lines_kernel(IndexView ix, long long n, const int32_t* usedLength, const int32_t* keys, int maxPerProbe,
                                                                   int32_t* counts, int64_t* outPositions) {
+  __shared__ Table sTables[XM_PROBE_LDS_TABLES];
+  const int nTables = ix.maxHashedLength + 1;
+  const bool inLds = nTables <= XM_PROBE_LDS_TABLES;
+  if (inLds) {
+    for (int t = (int)threadIdx.x; t < nTables; t += (int)blockDim.x) sTables[t] = ix.tables[t];
+    __syncthreads();
+  }
+  const long long lanes = (long long)gridDim.x * blockDim.x;
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long i = tid / G;
-  const int part = (int)(tid % G);
-  const bool live = i < n;
-  const int used = live ? usedLength[i] : 0;
-  const bool bad = used < 0 || used > ix.maxHashedLength;
-  const Table* t = &ix.tables[bad ? 0 : used];
-  const uint32_t k = packedKey(t, live ? keys[i] : 0);
-  const int64_t line = (t->offBase + k) * 8;
-  unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // this lane's words of the line (two 64-bit or four 32-bit ones)
-  if (live && !bad) {
-    if (G == 4) { const ulonglong2 v = ((const ulonglong2*)(ix.lines64 + line))[part]; w0 = v.x; w1 = v.y; }
-    else { const uint4 v = ((const uint4*)(ix.lines32 + line))[part]; w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w; }
+  int used[XM_PROBES_PER_LANE], key[XM_PROBES_PER_LANE];
+#pragma unroll
+  for (int p = 0; p < XM_PROBES_PER_LANE; p++) {
+    const long long i = tid + (long long)p * lanes;
+    used[p] = i < n ? usedLength[i] : -1;
+    key[p] = i < n ? keys[i] : 0;
   }
-  const uint32_t h = (uint32_t)__shfl((unsigned int)w0, (int)(threadIdx.x & 63u) - part);  // word 0 of the line: lane 0 of the group
-  if (!live) return;
-  if (bad) { if (part == 0) counts[i] = -2; return; }
-  int count = (h & XM_OVERFULL) ? -1 : (int)h;
-  if (count > t->maxCount) count = -1;
-  if (part == 0) counts[i] = count;
-  if (count <= 0 || maxPerProbe <= 0) return;
-  if (count <= XM_LINE_SLOTS) {
-    // word index of this lane's words in the line: G == 4: 2 * part, 2 * part + 1;  G == 2: 4 * part .. 4 * part + 3;  position j = word j + 1
-    const int perLane = 8 / G;
-    const unsigned long long mine[4] = {w0, w1, w2, w3};
-    for (int q = 0; q < perLane; q++) {
-      const int j = part * perLane + q - 1;
-      if (j >= 0 && j < count && j < maxPerProbe) outPositions[(long long)j * n + i] = (int64_t)mine[q];
+  Table tb[XM_PROBES_PER_LANE];
+  uint32_t k[XM_PROBES_PER_LANE];
+  typedef typename std::conditional<W64, ulonglong2, uint4>::type Vec;   // 16 bytes of a line
+  constexpr int NV = W64 ? 4 : 2;
+  Vec v[XM_PROBES_PER_LANE][NV];
+#pragma unroll
+  for (int p = 0; p < XM_PROBES_PER_LANE; p++) {
+    const bool ok = used[p] >= 0 && used[p] <= ix.maxHashedLength;
+    tb[p] = inLds ? sTables[ok ? used[p] : 0] : ix.tables[ok ? used[p] : 0];
+    k[p] = packedKey(&tb[p], key[p]);
+    const Vec* lp = W64 ? (const Vec*)(ix.lines64 + (tb[p].offBase + k[p]) * 8) : (const Vec*)(ix.lines32 + (tb[p].offBase + k[p]) * 8);
+    if (ok) v[p][0] = lp[0];
+  }
+  // the rest of a line only where its positions are wanted: the first 16 bytes hold the count and three positions (one with 64-bit positions), and a
+  // request costs the memory pipeline the same whether it brings 16 bytes of a new sector or the next 16 of the one before
+  int cnt[XM_PROBES_PER_LANE];
+#pragma unroll
+  for (int p = 0; p < XM_PROBES_PER_LANE; p++) {
+    const bool ok = used[p] >= 0 && used[p] <= ix.maxHashedLength;
+    const uint32_t h = W64 ? (uint32_t)((const unsigned long long*)&v[p][0])[0] : ((const uint32_t*)&v[p][0])[0];
+    int count = (h & XM_OVERFULL) ? -1 : (int)h;
+    if (ok && count > tb[p].maxCount) count = -1;
+    cnt[p] = ok ? count : -2;
+    const int want = (maxPerProbe > 0 && count > 0 && count <= XM_LINE_SLOTS) ? (count < maxPerProbe ? count : maxPerProbe) : 0;   // positions to take from the line
+    const Vec* lp = W64 ? (const Vec*)(ix.lines64 + (tb[p].offBase + k[p]) * 8) : (const Vec*)(ix.lines32 + (tb[p].offBase + k[p]) * 8);
+#pragma unroll
+    for (int q = 1; q < NV; q++) if (ok && 1 + want > q * (W64 ? 2 : 4)) v[p][q] = lp[q];
+  }
+#pragma unroll
+  for (int p = 0; p < XM_PROBES_PER_LANE; p++) {
+    const long long i = tid + (long long)p * lanes;
+    const int count = cnt[p];
+    const int m = (i < n && count > 0 && maxPerProbe > 0) ? (count < maxPerProbe ? count : maxPerProbe) : 0;
+    const long long slot = xmProbeSlot(i, m, maxPerProbe);  // (every lane of the wave: the lanes' probes of one p are 64 consecutive ones)
+    if (i >= n) continue;
+    counts[i] = count;
+    if (m == 0) continue;
+    if (count <= XM_LINE_SLOTS) {
+#pragma unroll
+      for (int j = 0; j < XM_LINE_SLOTS; j++) {
+        if (j < m) outPositions[slot + j] = W64 ? (int64_t)((const unsigned long long*)&v[p][0])[1 + j] : (int64_t)((const uint32_t*)&v[p][0])[1 + j];
+      }
+      continue;
     }
-    return;
+    const int64_t first = tb[p].posBase + (int64_t)(ix.bucketOff[tb[p].offBase + k[p]] & ~XM_OVERFULL);
+    for (int j = 0; j < m; j++) outPositions[slot + j] = ix.posIs64 ? (int64_t)ix.positions64[first + j] : (int64_t)ix.positions32[first + j];
   }
-  if (part != 0) return;
-  const int64_t first = t->posBase + (int64_t)(ix.bucketOff[t->offBase + k] & ~XM_OVERFULL);
-  const int m = count < maxPerProbe ? count : maxPerProbe;
-  for (int j = 0; j < m; j++) outPositions[(long long)j * n + i] = ix.posIs64 ? (int64_t)ix.positions64[first + j] : (int64_t)ix.positions32[first + j];
 }
 
 // Measurement helper: one random 64-byte sector per access out of a table far larger than the caches, 16 bytes of it read.
@@ -1825,6 +1838,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
 
 int xm_seed_probe(xm_index* idx, int64_t n, const int32_t* usedLength, const int32_t* keys, int32_t maxPerProbe, int32_t* counts, int64_t* outPositions, double* kernelMs) {
   if (!idx || idx->hostOnly) return fail("xm_seed_probe: needs a device-resident index");
+  if (maxPerProbe < 0 || maxPerProbe > 15) return fail("xm_seed_probe: max_per_probe must be 0 ... 15");
   try {
     std::lock_guard<std::mutex> lock(idx->mu);
     HIP_CHECK(hipSetDevice(idx->device));
@@ -1841,10 +1855,9 @@ int xm_seed_probe(xm_index* idx, int64_t n, const int32_t* usedLength, const int
     std::shared_lock<std::shared_mutex> tablesInUse(idx->dt->rw);
     IndexView view = idx->dt->view;
     if (envInt("XM_PROBE_NO_LINES", 0) != 0) { view.lines32 = nullptr; view.lines64 = nullptr; }  // measurement: the CSR probe (two dependent accesses) on the same index
-    if (n > 0 && view.lines64 && maxPerProbe > 0)
-      hipLaunchKernelGGL((xm_seed_probe_lines_kernel<4>), dim3((unsigned)((n * 4 + block - 1) / block)), dim3(block), 0, s, view, (long long)n, dUsed.p, dKeys.p, (int)maxPerProbe, dCounts.p, dPos.p);
-    else if (n > 0 && view.lines32 && maxPerProbe > 0)
-      hipLaunchKernelGGL((xm_seed_probe_lines_kernel<2>), dim3((unsigned)((n * 2 + block - 1) / block)), dim3(block), 0, s, view, (long long)n, dUsed.p, dKeys.p, (int)maxPerProbe, dCounts.p, dPos.p);
+    const unsigned batched = (unsigned)((n + (long long)block * XM_PROBES_PER_LANE - 1) / ((long long)block * XM_PROBES_PER_LANE));
+    if (n > 0 && view.lines64) hipLaunchKernelGGL((xm_seed_probe_lines_kernel<true>), dim3(batched), dim3(block), 0, s, view, (long long)n, dUsed.p, dKeys.p, (int)maxPerProbe, dCounts.p, dPos.p);
+    else if (n > 0 && view.lines32) hipLaunchKernelGGL((xm_seed_probe_lines_kernel<false>), dim3(batched), dim3(block), 0, s, view, (long long)n, dUsed.p, dKeys.p, (int)maxPerProbe, dCounts.p, dPos.p);
     else if (n > 0) hipLaunchKernelGGL(xm_seed_probe_kernel, dim3(grid), dim3(block), 0, s, view, (long long)n, dUsed.p, dKeys.p, (int)maxPerProbe, dCounts.p, dPos.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(idx->ev1, s));
