@@ -94,10 +94,6 @@ def lib():
             # (and a half-built library must never be picked up silently); __graft_entry__.build() or `make -C mapper_amd/csrc` builds it
             raise ImportError("%s is missing: build it first (python -c 'import __graft_entry__ as g; g.build()' or make -j8 -C mapper_amd/csrc); "
                               "mapper_amd has no CPU fallback" % path)
-        # The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4); every context has a compute and a copy stream, so with
-        # more than two contexts launches of different contexts would share a queue and run one after the other (repeat-rich reads, four contexts: 1.5 -> 2.2 M
-        # reads/s with 8 queues, profiles/r04/NOTES.md 13).  Read when the runtime initialises: only a default, and without effect in a process that already has.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = C.CDLL(path)  # (XM_LIB_PATH: A/B experiments with another build of the same library)
         L.xm_last_error.restype = C.c_char_p
         L.xm_build_stamp.restype = C.c_char_p
@@ -195,3 +191,20 @@ def view_result(L, res):
     return dict(ints=view(r.ints, C.c_int32, r.num_ints), dbls=view(r.dbls, C.c_double, r.num_dbls), int_off=view(r.int_off, C.c_int64, r.num_queries + 1),
                 dbl_off=view(r.dbl_off, C.c_int64, r.num_queries + 1), counters=list(r.counters), kernel_ms=r.kernel_ms, h2d_ms=r.h2d_ms,
                 d2h_ms=r.d2h_ms, kernel_launches=r.kernel_launches, prof=list(r.prof))
+
+
+def want_hardware_queues(n=8):
+    """The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4); every context has a compute and a copy stream, so with
+    more than two contexts of a GPU launches of different contexts would share a queue and run one after the other (repeat-rich reads, four contexts: 1.5 -> 2.2 M
+    reads/s with 8 queues, profiles/r04/NOTES.md 13).  The variable is read when the runtime initialises, so it is the ENTRY POINTS that set it (python -m mapper_amd,
+    bench.py) - importing the package does not touch the process environment.  A program that embeds the library and wants three contexts or more per GPU calls
+    this (or sets the variable) before anything in the process touches the GPU; returns False when the runtime is already up with another setting."""
+    import warnings
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if _lib is None and cur is None:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+        return True
+    if cur is not None and int(cur) >= n:
+        return True
+    warnings.warn("GPU_MAX_HW_QUEUES is %s and the HIP runtime may already be initialised: more than two contexts per GPU will share hardware queues" % (cur or "unset"))
+    return False

@@ -354,6 +354,8 @@ def run(argv, out=sys.stdout):
 
 
 def main(argv=None):
+    from . import _capi
+    _capi.want_hardware_queues(8)  # (an entry point: before the HIP runtime starts; three contexts per GPU need queues of their own, _capi.want_hardware_queues)
     try:
         return run(sys.argv[1:] if argv is None else argv)
     except UsageError as e:
