@@ -657,25 +657,7 @@ struct DeviceTables {
   std::shared_mutex rw;      // align / probe calls of any number of contexts hold it shared while their kernels read the tables; (re)upload holds it exclusive
   std::mutex allocMu;        // contexts of one GPU size and allocate their scratch one after the other (they all look at the same free memory)
   std::atomic<int> uploadedLength{-1};   // host.maxHashedLength the device tables hold (written under hs->mu + rw, read without them by ensureTablesFor's first test)
-  std::atomic<int> contexts{0};  // handles that share these tables (contexts of this GPU)
-  // contexts of this GPU that are aligning: a context sizes its launches for its share of the wave slots among the contexts that are inside an align call
-  // or left one during the last 20 ms (a busy context comes back within a few milliseconds) (a process may hold more contexts than it keeps busy: the last batches of a job, uneven streams)
-  std::mutex activeMu;
-  std::map<const void*, int64_t> lastActive;  // context -> steady-clock ns of its last exit from an align call; INT64_MAX while it is inside one
-  int enterActive(const void* ctx) {  // the calling context is inside an align call from now on; returns the number of contexts that are aligning
-    const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    std::lock_guard<std::mutex> lock(activeMu);
-    lastActive[ctx] = INT64_MAX;
-    int n = 0;
-    for (const auto& kv : lastActive) if (kv.second == INT64_MAX || now - kv.second <= 20000000ll) n++;
-    return n;
-  }
-  void leaveActive(const void* ctx) {
-    const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    std::lock_guard<std::mutex> lock(activeMu);
-    lastActive[ctx] = now;
-  }
-  void dropActive(const void* ctx) { std::lock_guard<std::mutex> lock(activeMu); lastActive.erase(ctx); }
+  std::atomic<int> contexts{0};  // handles that share these tables (contexts of this GPU): a context sizes its launches for its share of the wave slots
   DevBuf<int64_t> dContigStart, dSeqCumStart, dDupKeyStart;
   DevBuf<int32_t> dContigLen, dDupKeys;
   DevBuf<uint8_t> dRefCodes;
@@ -925,7 +907,7 @@ struct xm_index {
     }
   }
   ~xm_index() {
-    if (dt) { dt->contexts.fetch_sub(1); dt->dropActive(this); }
+    if (dt) dt->contexts.fetch_sub(1);
     if (hostOnly) return;
     (void)hipSetDevice(device);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -1433,8 +1415,11 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // other instead of side by side.  Together the contexts of a GPU ask for 12 waves per SIMD worth of light lanes and 6 of gapped lanes: two contexts 6 / 3
     // each (round 3), three 4 / 2 - 14.1-14.3 M reads/s against 13.1-13.2 with two, once the runtime has hardware queues for three contexts' streams
     // (GPU_MAX_HW_QUEUES, mapper_amd/_capi.py); with 6 / 3 each three contexts measured 12.3-12.7, four with 3 / 1 13.5 (profiles/r04/NOTES.md 15)
-    const int gpuContexts = idx->dt->enterActive(idx);
-    struct Leave { xm_index* i; ~Leave() { i->dt->leaveActive(i); } } leaveActive{idx};
+    // (the contexts that EXIST on the GPU, not the ones aligning at the moment: sizing by activity was tried in round 5 and made the headline bimodal - a context that
+    // finds itself alone launches for the whole GPU, the runtime then gives its queue scratch memory for a whole GPU's waves (5.8 KB per lane), and in about half the
+    // runs the other contexts' launches then ran one after the other for the rest of the process, 4.6 M reads/s instead of 15.  A process that keeps contexts it does
+    // not use should close them.)
+    const int gpuContexts = idx->dt->contexts.load();
     const bool sharedGpu = gpuContexts > 1;
     // Batches of long reads (gapped pass beyond scale 4: every read goes through the chain, and its searches - thousands of nodes each, all in HBM mode -
     // are most of its time): the lanes of a wave run their searches one after the other, so 8 reads per wave on twice as many waves instead of 32

@@ -422,14 +422,15 @@ struct PathAlignerT {
   XM_INL void setNode(int i, const PNode& n) { __builtin_memcpy((void*)(nodes + i), &n, sizeof(PNode)); }
   // locatedNodes: (x,y) -> latest node.  HBM mode: dense grid of node indices when (textA+2)*(textB+2) fits (the four neighbour
   // lookups of an update are then four INDEPENDENT loads, issued together), open-addressing hash otherwise.  LDS mode: hash.
-  int32_t* grid; int32_t gridH, gridW; bool useGrid;
-  int32_t* hash; int32_t hashMask;  // (x,y) -> latest node index + 1
+  XM_GLOBAL(int32_t)* grid; int32_t gridH, gridW; bool useGrid;
+  XM_GLOBAL(int32_t)* hash; int32_t hashMask;  // (x,y) -> latest node index + 1
   // prioritizedNodes: bucket per exact double key; list entries in insertion order.
   // buckets are never recycled (a removed key cannot reappear: new estimates are clamped to the active key); lookup by exact
   // key bits through an open-addressing hash, priorities.poll() through a binary min-heap of bucket ids
-  double* bkey; int32_t* bhead; int32_t* btail; int32_t nBuckets, maxBuckets;
-  int32_t* bhash; int32_t bhashMask, bhashCap; int32_t* heap; int32_t heapSize;
-  int16_t* lx; int16_t* ly; int32_t* lnext;
+  // (HBM-mode arrays: pointers known to address HBM, like `nodes` - what a turn at the wave's buffer loads is then the same in every active lane for the compiler too)
+  XM_GLOBAL(double)* bkey; XM_GLOBAL(int32_t)* bhead; XM_GLOBAL(int32_t)* btail; int32_t nBuckets, maxBuckets;
+  XM_GLOBAL(int32_t)* bhash; int32_t bhashMask, bhashCap; XM_GLOBAL(int32_t)* heap; int32_t heapSize;
+  XM_GLOBAL(int16_t)* lx; XM_GLOBAL(int16_t)* ly; XM_GLOBAL(int32_t)* lnext;
   // LDS mode
   uint32_t* Lhash; int32_t nCells; uint16_t* Lxy; uint16_t* Lnext; double* Lbkey; uint16_t* Lbhead; uint16_t* Lbtail; uint8_t* Lbhash; uint8_t* Lheap;
   uint8_t* LtextA; uint8_t* LtextB;
@@ -810,14 +811,15 @@ struct PaResume { int32_t valid, li, bucket, nNodes, nBuckets; unsigned long lon
 
 // PathAligner.align :55-293 up to and including justify: the search, the traceback and the final block list (outBlocks[0..nbOut)).
 // false = null (or *status set).  LDS mode: *ldsOverflow = true means "does not fit the slot, nothing decided".
-template <bool LDS>
+// UNI: one search at a time per wave (a turn at the wave's slot or buffer), so everything it computes is the same in all its active lanes
+template <bool LDS, bool UNI = LDS>
 XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmpIn, const Caps& capsIn, int32_t* status, DevCounters* dc, ABlock* const outBlocksIn, int32_t& nbOut, bool* ldsOverflow, bool pair = false, PaResume* resume = nullptr) {
   XM_TIC(tPath);
   // LDS mode: the arguments too are the same in every active lane, and the compiler must know it - an argument of an out-of-line function counts as
   // different per lane, a branch on one (`pair`, `resume`, `dc`) as divergent, and everything the two arms of such a branch assign - the whole search
   // state - as divergent behind it: the search then runs on vector registers with execution-mask bookkeeping around every loop and branch
   Arena* tmpP = &tmpIn;
-  if constexpr (LDS) {
+  if constexpr (UNI) {
     pair = uniI(pair ? 1 : 0) != 0; resume = uniP(resume); dc = uniP(dc); status = uniP(status); ldsOverflow = uniP(ldsOverflow); tmpP = uniP(tmpP);
   }
   Arena& tmp = *tmpP;
@@ -826,7 +828,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmpIn, const Caps& capsIn,
   PaProblem pr = prIn;
   Caps caps = capsIn;
   ABlock* outBlocks = outBlocksIn;
-  if constexpr (LDS) {
+  if constexpr (UNI) {
     pr.qBase = uniP(pr.qBase); pr.rBase = uniP(pr.rBase); pr.qLen = uniI(pr.qLen); pr.qRc = uniI(pr.qRc ? 1 : 0) != 0; pr.referenceLen = uniI(pr.referenceLen);
     pr.qs.start = uniI(pr.qs.start); pr.qs.end = uniI(pr.qs.end); pr.rs.start = uniI(pr.rs.start); pr.rs.end = uniI(pr.rs.end);
     Params& q = pr.params;
@@ -836,6 +838,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmpIn, const Caps& capsIn,
     q.MaxNumMatches = uniI(q.MaxNumMatches); q.StartingInsertionStartFree = uniI(q.StartingInsertionStartFree);
     pr.confident = uniI(pr.confident ? 1 : 0) != 0; pr.maxInsExt = uniD(pr.maxInsExt); pr.maxDelExt = uniD(pr.maxDelExt); pr.predictedBestOffset = uniI(pr.predictedBestOffset);
     caps.maxNodes = uniI(caps.maxNodes); caps.maxBuckets = uniI(caps.maxBuckets); caps.maxBlocks = uniI(caps.maxBlocks);
+    caps.gridCap = uniI(caps.gridCap); caps.nodeHash = uniI(caps.nodeHash); caps.bucketHash = uniI(caps.bucketHash);
     outBlocks = uniP(outBlocks);
   }
   const Section qs = pr.qs, rs = pr.rs;
@@ -889,19 +892,21 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmpIn, const Caps& capsIn,
     }
   } else {
     pa.maxNodes = caps.maxNodes;
-    pa.nodes = (XM_GLOBAL(PNode)*)arenaArray<PNode>(tmp, caps.maxNodes);
+    // (UNI: the arena's base comes out of the caller's frame - private memory, whose loads count as different per lane - so the pointers are made uniform too)
+    auto U = [](auto* q) { if constexpr (UNI) return uniP(q); else return q; };
+    pa.nodes = (XM_GLOBAL(PNode)*)U(arenaArray<PNode>(tmp, caps.maxNodes));
     pa.useGrid = (long long)pa.gridW * pa.gridH <= (long long)caps.gridCap;
-    if (pa.useGrid) pa.grid = arenaArray<int32_t>(tmp, (size_t)pa.gridW * pa.gridH);
-    else { pa.hash = arenaArray<int32_t>(tmp, caps.nodeHash); pa.hashMask = caps.nodeHash - 1; }
+    if (pa.useGrid) pa.grid = (XM_GLOBAL(int32_t)*)U(arenaArray<int32_t>(tmp, (size_t)pa.gridW * pa.gridH));
+    else { pa.hash = (XM_GLOBAL(int32_t)*)U(arenaArray<int32_t>(tmp, caps.nodeHash)); pa.hashMask = caps.nodeHash - 1; }
     pa.maxBuckets = caps.maxBuckets;
-    pa.bkey = arenaArray<double>(tmp, caps.maxBuckets); pa.bhead = arenaArray<int32_t>(tmp, caps.maxBuckets); pa.btail = arenaArray<int32_t>(tmp, caps.maxBuckets);
-    pa.bhash = arenaArray<int32_t>(tmp, caps.bucketHash); pa.bhashCap = caps.bucketHash; pa.bhashMask = imin(caps.bucketHash, 2048) - 1;
-    pa.heap = arenaArray<int32_t>(tmp, caps.maxBuckets);
-    pa.lx = arenaArray<int16_t>(tmp, caps.maxNodes); pa.ly = arenaArray<int16_t>(tmp, caps.maxNodes); pa.lnext = arenaArray<int32_t>(tmp, caps.maxNodes);
+    pa.bkey = (XM_GLOBAL(double)*)U(arenaArray<double>(tmp, caps.maxBuckets)); pa.bhead = (XM_GLOBAL(int32_t)*)U(arenaArray<int32_t>(tmp, caps.maxBuckets)); pa.btail = (XM_GLOBAL(int32_t)*)U(arenaArray<int32_t>(tmp, caps.maxBuckets));
+    pa.bhash = (XM_GLOBAL(int32_t)*)U(arenaArray<int32_t>(tmp, caps.bucketHash)); pa.bhashCap = caps.bucketHash; pa.bhashMask = imin(caps.bucketHash, 2048) - 1;
+    pa.heap = (XM_GLOBAL(int32_t)*)U(arenaArray<int32_t>(tmp, caps.maxBuckets));
+    pa.lx = (XM_GLOBAL(int16_t)*)U(arenaArray<int16_t>(tmp, caps.maxNodes)); pa.ly = (XM_GLOBAL(int16_t)*)U(arenaArray<int16_t>(tmp, caps.maxNodes)); pa.lnext = (XM_GLOBAL(int32_t)*)U(arenaArray<int32_t>(tmp, caps.maxNodes));
     if (tmp.overflow) { *status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
-    int32_t* const h1 = pa.useGrid ? pa.grid : pa.hash; const int n1 = pa.useGrid ? pa.gridW * pa.gridH : caps.nodeHash;
+    XM_GLOBAL(int32_t)* const h1 = pa.useGrid ? pa.grid : pa.hash; const int n1 = pa.useGrid ? pa.gridW * pa.gridH : caps.nodeHash;
     for (int i = 0; i < n1; i++) h1[i] = 0;
-    int32_t* const h2 = pa.bhash; const int n2 = pa.bhashMask + 1;
+    XM_GLOBAL(int32_t)* const h2 = pa.bhash; const int n2 = pa.bhashMask + 1;
     for (int i = 0; i < n2; i++) h2[i] = 0;
   }
   XM_TOC(dc, T_PATH_INIT, tPath);
@@ -922,7 +927,9 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmpIn, const Caps& capsIn,
   const double disallowed = PathAlignerT<LDS>::disallowed;
   int resumeLi = -2;  // (HBM mode taking over an LDS-mode search: the list entry to go on with)
   bool importing = false;
-  if constexpr (!LDS) importing = resume && resume->valid;
+  // (the caller's PaResume lives in its frame: private memory, whose loads count as different per lane - UNI makes what is read of it uniform)
+  auto UI = [](int v) { if constexpr (UNI) return uniI(v); else return v; };
+  if constexpr (!LDS) importing = resume && UI(resume->valid) != 0;
   if (importing) {
     if constexpr (!LDS) {
       const uint8_t* const slot = palSlot();
@@ -933,7 +940,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmpIn, const Caps& capsIn,
       const uint16_t* const Lbh = (const uint16_t*)(slot + XM_PAL_OFF_BHEAD);
       const uint16_t* const Lbt = (const uint16_t*)(slot + XM_PAL_OFF_BTAIL);
       const PNode* const waveNodes = palWaveNodes();
-      const int nN = resume->nNodes, nB = resume->nBuckets;
+      const int nN = UI(resume->nNodes), nB = UI(resume->nBuckets);
       if (nN > pa.maxNodes || nB > pa.maxBuckets) { *status = XM_ST_OVERFLOW; tmp.used = mark; return false; }
       for (int i = 0; i < nN; i++) {
         pa.setNode(i, waveNodes[i]);
@@ -965,9 +972,9 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmpIn, const Caps& capsIn,
           pa.setHeap(i, k);
         }
       }
-      pa.nodesPut = resume->nodesPut;
-      resumeLi = resume->li;
-      if (pa.heapSize < 1 || pa.heapAt(0) != resume->bucket) { *status = XM_ST_INTERNAL; tmp.used = mark; return false; }
+      pa.nodesPut = UNI ? uniU64(resume->nodesPut) : resume->nodesPut;
+      resumeLi = UI(resume->li);
+      if (pa.heapSize < 1 || pa.heapAt(0) != UI(resume->bucket)) { *status = XM_ST_INTERNAL; tmp.used = mark; return false; }
     }
   } else
   if (pa.textBLength >= pa.textALength) {
@@ -1045,17 +1052,23 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmpIn, const Caps& capsIn,
         const bool second = ((int)__lane_id() & 1) != 0;
         typename PathAlignerT<LDS>::UpdateOut mine, other, a, b;
         pa.computeUpdate(second ? x : x + pa.stepDelta, second ? y + pa.stepDelta : y, mine);
-        other.put = __shfl_xor(mine.put, 1); other.x = __shfl_xor(mine.x, 1); other.y = __shfl_xor(mine.y, 1); other.fl = __shfl_xor(mine.fl, 1);
-        other.cellSlot = __shfl_xor(mine.cellSlot, 1); other.existing = __shfl_xor(mine.existing, 1);
-        other.pen = __shfl_xor(mine.pen, 1); other.insX = __shfl_xor(mine.insX, 1); other.insY = __shfl_xor(mine.insY, 1);
-        a = second ? other : mine; b = second ? mine : other;
-        // (LDS mode: one search at a time per wave, both lanes hold the same a and b now: scalar again.  HBM mode: several pairs of the
-        // wave may be searching at once, every pair with its own values)
-        if constexpr (LDS) {
-        a.put = uniI(a.put); a.x = uniI(a.x); a.y = uniI(a.y); a.fl = uniI(a.fl); a.cellSlot = uniI(a.cellSlot); a.existing = uniI(a.existing);
-        a.pen = uniD(a.pen); a.insX = uniD(a.insX); a.insY = uniD(a.insY);
-        b.put = uniI(b.put); b.x = uniI(b.x); b.y = uniI(b.y); b.fl = uniI(b.fl); b.cellSlot = uniI(b.cellSlot); b.existing = uniI(b.existing);
-        b.pen = uniD(b.pen); b.insX = uniD(b.insX); b.insY = uniD(b.insY);
+        if constexpr (UNI) {
+          // one search at a time per wave: its two lanes are 2k and 2k + 1, and what either decided is read straight into scalar registers
+          // (v_readlane with the lane in an SGPR: no exchange through the LDS crossbar, no selects, nothing to make uniform afterwards)
+          const int laneA = uniI((int)__lane_id() & ~1), laneB = laneA + 1;
+          auto rdI = [](int v, int lane) { return __builtin_amdgcn_readlane(v, lane); };
+          auto rdD = [](double v, int lane) { uint64_t b; __builtin_memcpy(&b, &v, 8); const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+                                             b = ((uint64_t)hi << 32) | lo; __builtin_memcpy(&v, &b, 8); return v; };
+          a.put = rdI(mine.put, laneA); a.x = rdI(mine.x, laneA); a.y = rdI(mine.y, laneA); a.fl = rdI(mine.fl, laneA); a.cellSlot = rdI(mine.cellSlot, laneA); a.existing = rdI(mine.existing, laneA);
+          a.pen = rdD(mine.pen, laneA); a.insX = rdD(mine.insX, laneA); a.insY = rdD(mine.insY, laneA);
+          b.put = rdI(mine.put, laneB); b.x = rdI(mine.x, laneB); b.y = rdI(mine.y, laneB); b.fl = rdI(mine.fl, laneB); b.cellSlot = rdI(mine.cellSlot, laneB); b.existing = rdI(mine.existing, laneB);
+          b.pen = rdD(mine.pen, laneB); b.insX = rdD(mine.insX, laneB); b.insY = rdD(mine.insY, laneB);
+        } else {
+          // (searches side by side: several pairs of the wave may be searching at once, every pair with its own values)
+          other.put = __shfl_xor(mine.put, 1); other.x = __shfl_xor(mine.x, 1); other.y = __shfl_xor(mine.y, 1); other.fl = __shfl_xor(mine.fl, 1);
+          other.cellSlot = __shfl_xor(mine.cellSlot, 1); other.existing = __shfl_xor(mine.existing, 1);
+          other.pen = __shfl_xor(mine.pen, 1); other.insX = __shfl_xor(mine.insX, 1); other.insY = __shfl_xor(mine.insY, 1);
+          a = second ? other : mine; b = second ? mine : other;
         }
         if (a.put) pa.putNode(a.x, a.y, a.pen, a.insX, a.insY, (uint8_t)a.fl, a.cellSlot, a.existing != 0);
         // the first put may have taken the empty slot the second one's lookup ended at: look the cell up again then
@@ -1180,7 +1193,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmpIn, const Caps& capsIn,
 }
 
 XM_NOINL bool pathSearchHbm(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair = false, PaResume* resume = nullptr) {
-  return pathSearchT<false>(pr, tmp, caps, status, dc, outBlocks, nb, nullptr, pair, resume);
+  return pathSearchT<false, false>(pr, tmp, caps, status, dc, outBlocks, nb, nullptr, pair, resume);
 }
 // the HBM-mode search of the read whose turn it is at the wave's slot: its arrays in the wave's buffer when the launch has a pool, else in the
 // lane's temporaries
@@ -1199,9 +1212,13 @@ XM_INL size_t searchPoolBytes(const Caps& passCaps) {
   const size_t cells = (size_t)(c.gridCap > c.nodeHash ? c.gridCap : c.nodeHash);
   return ((size_t)c.maxNodes * 32 + cells * 4 + (size_t)c.maxBuckets * 20 + (size_t)c.bucketHash * 4 + (size_t)c.maxNodes * 8 + (size_t)c.maxBlocks * 16 * 4 + 4096 + 4095) & ~(size_t)4095;
 }
+// (a turn at the wave's buffer: one search at a time per wave, like a turn at the slot - the uniform instantiation)
+XM_NOINL bool pathSearchHbmTurn(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair, PaResume* resume) {
+  return pathSearchT<false, true>(pr, tmp, caps, status, dc, outBlocks, nb, nullptr, pair, resume);
+}
 XM_INL bool pathSearchHbmInTurn(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool pair, PaResume* resume = nullptr) {
   Arena wb;
-  if (xmWaveSearchBuffer(wb)) return pathSearchHbm(pr, wb, searchPoolCaps(caps), status, dc, outBlocks, nb, pair, resume);
+  if (xmWaveSearchBuffer(wb)) return pathSearchHbmTurn(pr, wb, searchPoolCaps(caps), status, dc, outBlocks, nb, pair, resume);
   return pathSearchHbm(pr, tmp, caps, status, dc, outBlocks, nb, pair, resume);
 }
 XM_NOINL bool pathSearchLds(const PaProblem& pr, Arena& tmp, const Caps& caps, int32_t* status, DevCounters* dc, ABlock* outBlocks, int32_t& nb, bool* ldsOverflow, bool pair, PaResume* resume = nullptr) {
