@@ -9,6 +9,31 @@
 #pragma once
 #include "xm_defs.h"
 
+// which functions of the index walk are out of line (experiment define XM_WALK_INLINE: 1 the path's two, 2 + the component's block fetch, 3 + the vote update, 4 = 2 + the component's step itself)
+#ifndef XM_WALK_INLINE
+#define XM_WALK_INLINE 2  // (light pass 22.4-23.2 -> 21.2-21.3 ms per 1 M reads: a call of pathAdvance saved and restored 24 registers, 30 times a read; 4: the same; 3: 21.3)
+#endif
+#if XM_WALK_INLINE >= 1
+#define XM_NOINL_W1 XM_INL
+#else
+#define XM_NOINL_W1 XM_NOINL
+#endif
+#if XM_WALK_INLINE >= 2
+#define XM_NOINL_W2 XM_INL
+#else
+#define XM_NOINL_W2 XM_NOINL
+#endif
+#if XM_WALK_INLINE == 3
+#define XM_NOINL_W3 XM_INL
+#else
+#define XM_NOINL_W3 XM_NOINL
+#endif
+#if XM_WALK_INLINE >= 4
+#define XM_NOINL_W4 XM_INL
+#else
+#define XM_NOINL_W4 XM_NOINL
+#endif
+
 namespace xm {
 
 // ---------------------------------------------------------------- pyramid
@@ -720,7 +745,7 @@ XM_INL int pathMaxNumMatchesAllowed(Comp& c, const SeedEnv& e, const QBlock& b) 
   return b.used + 1;
 }
 // :143-195.  returns false when the path is exhausted
-XM_NOINL bool pathAdvance(Comp& c, const SeedEnv& e) {
+XM_NOINL_W1 bool pathAdvance(Comp& c, const SeedEnv& e) {
   XM_TIC(t0);
   int singleLen = c.path.cur.len;
   if (maxGapmerNumBasepairsUsed(singleLen) < e.ix->minInterestingSize && e.ix->enableGapmers) {
@@ -749,7 +774,7 @@ XM_NOINL bool pathAdvance(Comp& c, const SeedEnv& e) {
   return c.path.curExists && *e.status == 0;
 }
 // getNextInterestingBlock :27-50 (+ getNextBlockWithGoodNumberOfMatches :68-96, recentlySeen :52-65)
-XM_NOINL bool pathNextInterestingBlock(Comp& c, const SeedEnv& e, QBlock& out) {
+XM_NOINL_W1 bool pathNextInterestingBlock(Comp& c, const SeedEnv& e, QBlock& out) {
   if (!c.path.curExists) return false;
   while (true) {
     if (!pathAdvance(c, e)) return false;
@@ -815,7 +840,7 @@ XM_INL void compAddMatch(Comp& c, const SeedEnv& e, int ci, const QBlock& qb, in
     }
   }
 }
-XM_NOINL void compUpdateMatches(Comp& c, const SeedEnv& e, const SeqMatch& m, const QBlock& qb, int queryBlockNumMatches) {  // :193-252
+XM_NOINL_W3 void compUpdateMatches(Comp& c, const SeedEnv& e, const SeqMatch& m, const QBlock& qb, int queryBlockNumMatches) {  // :193-252
   uint8_t mapSel = m.reversed() ? 0 : 1;
   int cur = -1, lower = -1, higher = -1;
   for (int i = 0; i < c.nCounters; i++) {
@@ -868,7 +893,7 @@ XM_INL int nextCounterInOrder(const Comp& c, uint8_t mapSel, int lastContig, int
   }
   return best;
 }
-XM_NOINL void tryEnsureGoodMatchCounter(Comp& c, const SeedEnv& e) {  // :291-308
+XM_NOINL_W2 void tryEnsureGoodMatchCounter(Comp& c, const SeedEnv& e) {  // :291-308
   if (!c.foundGood && c.nCounters <= c.query.len) {
     for (int mapSel = 0; mapSel < 2; mapSel++) {
       int lc = 0, lo = 0;
@@ -885,7 +910,7 @@ XM_NOINL void tryEnsureGoodMatchCounter(Comp& c, const SeedEnv& e) {  // :291-30
 }
 
 // getNextInterestingBlock :344-368
-XM_NOINL bool compNextInterestingBlock(Comp& c, const SeedEnv& e, QBlock& out) {
+XM_NOINL_W2 bool compNextInterestingBlock(Comp& c, const SeedEnv& e, QBlock& out) {
   c.all.id = 0;  // previousAllPositions = null
   while (true) {
     QBlock b;
@@ -906,7 +931,7 @@ XM_NOINL bool compNextInterestingBlock(Comp& c, const SeedEnv& e, QBlock& out) {
 }
 
 // step() :40-179
-XM_NOINL bool compStep(Comp& c, const SeedEnv& e) {
+XM_NOINL_W4 bool compStep(Comp& c, const SeedEnv& e) {
   if (c.done) return false;
   QBlock qb;
   int64_t first = 0;
