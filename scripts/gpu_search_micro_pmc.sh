@@ -15,7 +15,8 @@ cd $R
 python3 - $O "$@" <<'PY'
 import csv, sys, collections, json, os
 O = sys.argv[1]
-nodes = [365, 996, 1674, 3097]
+import re
+nodes = None
 out = {}
 for v in sys.argv[2:]:
     acc = collections.defaultdict(list)
@@ -28,7 +29,11 @@ for v in sys.argv[2:]:
     for c, vals in acc.items():
         n = len(vals) // 4
         per = [sorted(vals[i * n:(i + 1) * n])[n // 2] for i in range(4)]
-        res[c] = {"per_search": per, "per_node_put(996 vs 365 nodes)": round((per[1] - per[0]) / (nodes[1] - nodes[0]), 1)}
+        if nodes is None:
+            nodes = [int(x) for x in re.findall(r"nodes put (\d+)", open(os.path.join(O, "pmcA%s.log" % v)).read())]
+        res[c] = {"per_search": per, "per_node_put": round((per[2] - per[0]) / (nodes[2] - nodes[0]), 1)}
+    res["nodes_put_per_search"] = nodes
     out[v] = res
+out["_note"] = "scripts/gpu_search_micro.py: four searches through the test entry (one lane of one wave); per_node_put = (counter of search 3 - counter of search 1) / (nodes 3 - nodes 1): the slot search's executed wave instructions per node put; search 4 starts in HBM mode"
 print(json.dumps(out, indent=1))
 PY
