@@ -20,7 +20,7 @@ def problem(n, indel, nsub, shift):
     return "".join("ACGT"[i] for i in q), "".join("ACGT"[i] for i in ref[:n + 2 * shift])
 p = api.AlignmentParameters()._c()
 # (texts of up to 128 x 253 bases run in the wave's LDS slot, as nearly all searches of 150 bp reads do: BlockAligner cuts a read into pieces first; longer texts start in HBM mode)
-for name, (q, r) in (("60 bases, 1 indel + 1 sub", problem(60, 1, 1, 3)), ("120 bases, 1 indel + 2 subs", problem(120, 1, 2, 6)), ("120 bases, 2 indels + 3 subs", problem(120, -2, 3, 6)), ("150 bases (HBM mode), 1 indel + 3 subs", problem(150, 2, 3, 8))):
+for name, (q, r) in (("60 bases, 1 indel + 1 sub", problem(60, 1, 1, 3)), ("80 bases, 1 indel + 1 sub", problem(80, 1, 1, 3)), ("100 bases, 1 indel + 1 sub", problem(100, -1, 1, 3)), ("150 bases (HBM mode), 1 indel + 3 subs", problem(150, 2, 3, 8))):
     qa, ra = api.encode(q), api.encode(r)
     blocks = np.zeros(4 * 64, np.int32); nb = C.c_int32(0); pen = np.zeros(2); nodes = C.c_int64(0)
     t = []
