@@ -529,7 +529,7 @@ def seed_probe_hbm(api, synth, db, index_mb, device, sectors_per_s, n_probes, rn
     def measure(u, k, label):
         db.seed_probe(u[:4096], k[:4096], 0)
         _, _, ms_hdr = db.seed_probe(u, k, 0)
-        n2 = len(u) // 2
+        n2 = len(u)  # (the same probes with their positions: up to seven each, what a bucket line holds)
         c2, _, ms_pos = db.seed_probe(u[:n2], k[:n2], 7, unpack=False)
         fetched = int(np.minimum(np.maximum(c2, 0), 7).sum())
         hdr_rate, pos_rate = len(u) / (ms_hdr * 1e-3), n2 / (ms_pos * 1e-3)
