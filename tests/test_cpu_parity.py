@@ -40,6 +40,17 @@ def test_build_stamp_is_the_digest_of_the_sources():
     assert api._capi.check_stamp() == api._capi.source_stamp()
 
 
+def test_importing_the_package_leaves_the_process_environment_alone():
+    """GPU_MAX_HW_QUEUES belongs to the process: the entry points set it (python -m mapper_amd, bench.py; _capi.want_hardware_queues for a program that
+    embeds the package), importing mapper_amd and loading the library do not."""
+    import subprocess, sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); import mapper_amd; from mapper_amd import api, _capi; _capi.lib(); "
+            "assert 'GPU_MAX_HW_QUEUES' not in os.environ; import warnings; warnings.simplefilter('error'); "
+            "os.environ['GPU_MAX_HW_QUEUES'] = '8'; assert _capi.want_hardware_queues(8); print('ok')" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_library_refuses_to_align_without_gpu_index():
     """The product fails loudly instead of falling back to a CPU path."""
     db = api.ReferenceDatabase([("r", synth.synthetic_reference(5000))], host_only=True)
