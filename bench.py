@@ -343,6 +343,22 @@ def main():
         cpu = None
         same = None
         counters = {"device": [int(x) for x in r.counters[:11]]}
+
+        def bound_filter_check(dev, orc, batch_):
+            # The rejection filter in front of PathAligner (xm_bound.h; batches of long reads) skips searches it proves null, so the device puts fewer search nodes
+            # than the reference.  The oracle, run once more (untimed) with its observer of the same bound on, says which searches the filter takes and rejects
+            # and how many nodes the reference spent in them (and raises if a search the filter rejects returned an alignment): the counts must add up.
+            if not dev.extra[3]:
+                return None
+            import oracle_lib as ol_
+            with ol_.observe_bound():
+                w_ = orc.align(batch_, ol_.make_params(), threads=os.cpu_count() or 1)
+            oc = [int(x) for x in w_.counters]
+            f_ = {"device": {"searches_examined": int(dev.extra[0]), "searches_rejected": int(dev.extra[1]), "cells": int(dev.extra[2]), "path_aligner_calls": int(dev.counters[5]), "nodes": int(dev.counters[6])},
+                  "oracle_observer": {"searches_examined": oc[13], "searches_rejected": oc[11], "nodes_in_rejected_searches": oc[12], "searches_returning_null": oc[9], "nodes_in_null_searches": oc[10],
+                                      "path_aligner_calls": oc[6], "nodes": oc[7]}}
+            f_["equal"] = (int(dev.extra[0]) == oc[13] and int(dev.extra[1]) == oc[11] and int(dev.counters[5]) == oc[6] and int(dev.counters[6]) + oc[12] == oc[7])
+            return f_
         if extras and args.cpu_sample > 0 and big:
             # No oracle hashes 3.1 G bases in bounded time (15 Mb take it a minute), so the CPU path is timed on the same workload against the
             # SAME-SHAPED reference at 1/200 of its size (24 contigs, N-runs) with the minInterestingSize a 3 Gb reference gets (13,
@@ -364,6 +380,9 @@ def main():
             rs = small.align_arrays(*qs[:6], params)
             small.close()
             same = bool(np.array_equal(w.ints, rs.ints) and np.array_equal(w.dbls.view(np.int64), rs.dbls.view(np.int64)))
+            counters["bound_filter"] = bound_filter_check(rs, o, b)
+            if counters["bound_filter"] is not None:
+                counters["equal"] = counters["bound_filter"]["equal"]
             cpu = {"value": round(len(qs[0]) * qs[6] / cpu_s / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port", "seconds": round(cpu_s, 3),
                    "sample": "%d queries of the same read model against the GRCh38-shaped reference at 1/200 scale (15 Mb, 24 contigs, N-runs, minInterestingSize 13), oracle (C++ port of the "
                              "Java path) on every host core, index build excluded; the GPU's streams on that sample are compared with the oracle's (bit_identical)" % len(qs[0])}
@@ -386,7 +405,10 @@ def main():
             if n == nq:  # the counts the algorithmic bytes are computed from, device against oracle on the same batch
                 wc = [int(x) for x in w.counters[:9]]
                 counters["oracle"] = wc
-                counters["equal"] = counters["device"][:8] == [wc[0], wc[1] + wc[2], wc[2], wc[3], wc[5], wc[6], wc[7], wc[8]]
+                bf = bound_filter_check(r, o, b)
+                counters["bound_filter"] = bf
+                skipped = bf["oracle_observer"]["nodes_in_rejected_searches"] if bf else 0  # (nodes of searches the filter proved null without running them)
+                counters["equal"] = counters["device"][:8] == [wc[0], wc[1] + wc[2], wc[2], wc[3], wc[5], wc[6], wc[7] - skipped, wc[8]] and (bf is None or bf["equal"])
             java = java_reference(ref, codes, nq, args)
             if java is not None:
                 cpu["java_reference"] = java

@@ -97,6 +97,10 @@ typedef struct xm_result {
   int32_t kernel_launches;  /* align + search kernel launches of this call */
   int32_t reserved;
   int64_t prof[16];   /* diagnostic builds (-DXM_PROFILE=1: summed over lanes, =2: per wave) only: shader-clock ticks per phase; otherwise 0 */
+  /* (appended in ABI version 2; xm_abi_version())  the rejection filter in front of PathAligner (batches of long reads): 0 searches it examined, 1 searches it
+   * proved null without running them (PathAligner.java:169: the search would have returned null after exploring every node within the budget; their nodes
+   * are not in counters[6]), 2 cells of the bounding recurrence it computed, 3 = 1 when a pass of this call ran with the filter; 4-7 reserved (0) */
+  int64_t extra[8];
 } xm_result;
 
 typedef struct xm_index_info_t {
@@ -113,6 +117,9 @@ const char* xm_last_error(void);
 /* First 16 hex digits of the SHA-256 over the library's sources (every .h and .hip file of mapper_amd/csrc in name order, then this header) at build
  * time: lets a caller check that the loaded library was built from the sources it sits beside. */
 const char* xm_build_stamp(void);
+/* Version of this header's structs and entry points: 2 = xm_result.extra[] appended, xm_seed_probe_packed replaces xm_seed_probe.  A binding checks it once
+ * after loading the library (mapper_amd/_capi.py, bindings/java/xmapper_jni.c). */
+int32_t xm_abi_version(void);
 int xm_device_count(void);
 
 /* Replaces new SequenceDatabase + new HashBlock_Database(...).prepare() + new DuplicationDetector(...).helpSetup()
@@ -214,6 +221,15 @@ void xm_pileup_free(xm_pileup* pileup);
 int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_params* params, const uint8_t* query, int32_t query_length, const uint8_t* reference,
                         int32_t reference_length, double max_ins_ext, double max_del_ext, int32_t block_cap, int32_t* blocks, int32_t* num_blocks, double* penalties,
                         int64_t* nodes_put);
+/* Test-only: what the rejection filter in front of PathAligner (mapper_amd/csrc/xm_bound.h) did in this thread's last xm_test_local_align call with mode + 8
+ * (the search behind the filter): searches it took, searches it proved null, cells of its recurrence. */
+void xm_test_bound_counters(int64_t* out3);
+/* Test-only: the rejection filter alone on one problem - query[start_a, end_a) (query_rc: of the reverse complement of `query`) against
+ * reference[start_b, end_b), the search's predictedBestOffset - run by one lane (pair: by the two lanes of a pair) of a wave, as the gapped passes of
+ * long reads run it in front of PathAligner.align (PathAligner.java:55-293).  out3: 1 if the filter takes the problem, 1 if it proves the search null
+ * (PathAligner.java:169), cells it computed.  tests/test_gpu_bound.py compares with the oracle's observer of the same bound, which also runs the search. */
+int xm_test_bound(int32_t device, const xm_params* params, const uint8_t* query, int32_t query_length, int32_t query_rc, int32_t start_a, int32_t end_a, const uint8_t* reference,
+                  int32_t reference_length, int32_t start_b, int32_t end_b, int32_t predicted_best_offset, int32_t pair, int64_t* out3);
 
 
 #ifdef __cplusplus

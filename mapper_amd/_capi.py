@@ -37,7 +37,10 @@ class XmResult(C.Structure):
     _fields_ = [("num_queries", C.c_int64), ("num_ints", C.c_int64), ("num_dbls", C.c_int64), ("ints", C.POINTER(C.c_int32)),
                 ("dbls", C.POINTER(C.c_double)), ("int_off", C.POINTER(C.c_int64)), ("dbl_off", C.POINTER(C.c_int64)),
                 ("counters", C.c_int64 * 16), ("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
-                ("kernel_launches", C.c_int32), ("reserved", C.c_int32), ("prof", C.c_int64 * 16)]
+                ("kernel_launches", C.c_int32), ("reserved", C.c_int32), ("prof", C.c_int64 * 16), ("extra", C.c_int64 * 8)]
+
+
+ABI_VERSION = 2  # include/xmapper_hip.h, xm_abi_version(): xm_result.extra[] appended; xm_seed_probe_packed (the packed output layout under its own name)
 
 
 class XmIndexInfo(C.Structure):
@@ -47,8 +50,8 @@ class XmIndexInfo(C.Structure):
                 ("hash_seconds", C.c_double), ("duplication_seconds", C.c_double)]
 
 
-EXPORTS = ["xm_last_error", "xm_build_stamp", "xm_device_count", "xm_index_build", "xm_index_replicate", "xm_context_new", "xm_context_set_scratch", "xm_device_memory", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
-           "xm_index_table_info", "xm_index_table_shape", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe", "xm_measure_random_gather", "xm_test_local_align", "xm_pileup_new", "xm_pileup_set_query_ends", "xm_pileup_read_middle", "xm_pileup_add_last", "xm_pileup_read", "xm_pileup_events", "xm_pileup_free"]
+EXPORTS = ["xm_last_error", "xm_build_stamp", "xm_abi_version", "xm_device_count", "xm_index_build", "xm_index_replicate", "xm_context_new", "xm_context_set_scratch", "xm_device_memory", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
+           "xm_index_table_info", "xm_index_table_shape", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe", "xm_measure_random_gather", "xm_test_local_align", "xm_test_bound_counters", "xm_test_bound", "xm_pileup_new", "xm_pileup_set_query_ends", "xm_pileup_read_middle", "xm_pileup_add_last", "xm_pileup_read", "xm_pileup_events", "xm_pileup_free"]
 
 
 def build_library(force=False):
@@ -94,7 +97,11 @@ def lib():
             # (and a half-built library must never be picked up silently); __graft_entry__.build() or `make -C mapper_amd/csrc` builds it
             raise ImportError("%s is missing: build it first (python -c 'import __graft_entry__ as g; g.build()' or make -j8 -C mapper_amd/csrc); "
                               "mapper_amd has no CPU fallback" % path)
+        global _hw_queues_at_load
+        _hw_queues_at_load = os.environ.get("GPU_MAX_HW_QUEUES")  # what the HIP runtime will see when the first GPU-touching call initialises it
         L = C.CDLL(path)  # (XM_LIB_PATH: A/B experiments with another build of the same library)
+        if not hasattr(L, "xm_abi_version") or L.xm_abi_version() != ABI_VERSION:
+            raise ImportError("%s implements another version of include/xmapper_hip.h than this binding (%d): rebuild it (make -j8 -C mapper_amd/csrc)" % (path, ABI_VERSION))
         L.xm_last_error.restype = C.c_char_p
         L.xm_build_stamp.restype = C.c_char_p
         L.xm_index_build.argtypes = [C.POINTER(XmRef), C.POINTER(XmBuildOpts), C.POINTER(C.c_void_p)]
@@ -122,6 +129,10 @@ def lib():
         L.xm_measure_random_gather.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_double)]
         L.xm_test_local_align.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(XmParams), C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32,
                                           C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int64)]
+        L.xm_test_bound_counters.argtypes = [C.POINTER(C.c_int64)]
+        L.xm_test_bound_counters.restype = None
+        L.xm_test_bound.argtypes = [C.c_int32, C.POINTER(XmParams), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.POINTER(C.c_int64)]
         L.xm_pileup_new.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.xm_pileup_set_query_ends.argtypes = [C.c_void_p, C.c_double]
         L.xm_pileup_read_middle.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]
@@ -161,7 +172,7 @@ def copy_result(r):
     io = np.ctypeslib.as_array(r.int_off, shape=(r.num_queries + 1,)).copy()
     do = np.ctypeslib.as_array(r.dbl_off, shape=(r.num_queries + 1,)).copy()
     return dict(ints=ints, dbls=dbls, int_off=io, dbl_off=do, counters=list(r.counters), kernel_ms=r.kernel_ms, h2d_ms=r.h2d_ms,
-                d2h_ms=r.d2h_ms, kernel_launches=r.kernel_launches, prof=list(r.prof))
+                d2h_ms=r.d2h_ms, kernel_launches=r.kernel_launches, prof=list(r.prof), extra=list(r.extra))
 
 
 class _ResultOwner:
@@ -190,7 +201,10 @@ def view_result(L, res):
 
     return dict(ints=view(r.ints, C.c_int32, r.num_ints), dbls=view(r.dbls, C.c_double, r.num_dbls), int_off=view(r.int_off, C.c_int64, r.num_queries + 1),
                 dbl_off=view(r.dbl_off, C.c_int64, r.num_queries + 1), counters=list(r.counters), kernel_ms=r.kernel_ms, h2d_ms=r.h2d_ms,
-                d2h_ms=r.d2h_ms, kernel_launches=r.kernel_launches, prof=list(r.prof))
+                d2h_ms=r.d2h_ms, kernel_launches=r.kernel_launches, prof=list(r.prof), extra=list(r.extra))
+
+
+_hw_queues_at_load = None  # GPU_MAX_HW_QUEUES as it stood when the library was loaded (lib()): the value the HIP runtime reads when it initialises
 
 
 def want_hardware_queues(n=8):
@@ -200,11 +214,20 @@ def want_hardware_queues(n=8):
     bench.py) - importing the package does not touch the process environment.  A program that embeds the library and wants three contexts or more per GPU calls
     this (or sets the variable) before anything in the process touches the GPU; returns False when the runtime is already up with another setting."""
     import warnings
-    cur = os.environ.get("GPU_MAX_HW_QUEUES")
-    if _lib is None and cur is None:
-        os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+    if _lib is None:
+        cur = os.environ.get("GPU_MAX_HW_QUEUES")
+        if cur is None:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+            return True
+        if int(cur) >= n:
+            return True
+        warnings.warn("GPU_MAX_HW_QUEUES is set to %s: with fewer than %d hardware queues, three or more contexts of a GPU share queues and their launches run one after the other" % (cur, n))
+        return False
+    # the library is loaded: what counts is what the environment held at that moment (a value set afterwards is never read by the runtime; under rocprofv3 the
+    # profiler's preloaded library initialises the runtime before Python starts, so the variable must be exported in the shell in front of rocprofv3)
+    seen = _hw_queues_at_load
+    if seen is not None and int(seen) >= n:
         return True
-    if cur is not None and int(cur) >= n:
-        return True
-    warnings.warn("GPU_MAX_HW_QUEUES is %s and the HIP runtime may already be initialised: more than two contexts per GPU will share hardware queues" % (cur or "unset"))
+    warnings.warn("GPU_MAX_HW_QUEUES was %s when the library was loaded and the HIP runtime may already be initialised: more than two contexts per GPU will share hardware queues "
+                  "(set the variable before the first import that touches the GPU)" % (seen or "unset"))
     return False

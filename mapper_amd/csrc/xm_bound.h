@@ -1,0 +1,196 @@
+// xmapper-hip device core: an exact rejection filter in front of PathAligner's best-first search (round 6).
+//
+// PathAligner.align (M/PathAligner.java:55-293) returns null when the smallest key of its queue passes maxInterestingPenalty + 1e-6 (:169) - having
+// explored every node below that budget.  For reads that do not align (configs[4]: 10 kb reads with 5 % substitutions + 5 % indel events, cut into 1 kb
+// queries, whose pieces BlockAligner hands to the search one by one) that is the worst case of the search and nearly all of its work: 85 % of all search
+// nodes of that workload sit in searches that return null (measured with the oracle: profiles/r06/NOTES.md 1).  Any sound LOWER BOUND on the penalty of
+// every node the search can hold at x == goalX decides such a search without running it:
+//
+//   a node's three penalties (:573-719) are sums of move prices along ONE path from a start node (:120-150) - a base pair getPenalty(a, b), a new
+//   insertion left.penalty + InsertionStart + InsertionExtension (or "disallowed" = 1e6), an extended one left.insertX + InsertionExtension, the same for
+//   deletions - so none is below the value the plain affine-gap recurrence (every move allowed at its regular price, no heuristic, no band) gives its cell;
+//   the search ends with an answer only through a node at goalX that it takes from a bucket whose key is <= maxInterestingPenalty + 1e-6 (:169,180), and a
+//   node's key is never below its penalty (estimateOverallPenalty :475-521 adds to it; putNode :458-461 only raises it).
+//
+// Hence: recurrence's minimum over the cells of column goalX > maxInterestingPenalty + 1e-6  =>  align() returns null.  The filter computes that minimum on an
+// integer grid (prices rounded DOWN to 1/60 penalty unit: a lower bound of the lower bound; Mapper's default prices are multiples of it) and rejects when
+// it exceeds floor((max + 1e-6 + 1e-7) * 60) - the 1e-7 covers the rounding of the reference's double sums, which it does not reproduce.  Whatever the
+// filter does not take (a problem outside its limits, a search it cannot reject) goes to the search as before, so the result streams cannot change;
+// the oracle carries the same recurrence as an OBSERVER that never acts on it (oracle/xmo_extend.h PathAligner::boundRejects), asserts on every search of every test
+// that a rejected search did return null, and counts the nodes the reference spent in rejected searches - which is what keeps DevCounters::pathAlignerNodes
+// comparable: device nodes + oracle's nodes in rejected searches == oracle nodes, device rejects == oracle rejects (tests/test_gpu_bound.py, bench.py).
+//
+// Form: one lane (the two lanes of a pair: the same values twice), a band of diagonals d = y' - x' in search coordinates (x' counts query bases consumed,
+// y' reference bases of the window, both in the direction the search runs: chooseSearchReverse :17-53) - a path whose penalty stays within the budget
+// cannot leave the start diagonals 0 .. m - n by more bases than the budget buys insertions or deletions.  Column by column; a column's cells with a value
+// within the budget form an interval [lo, hi] of band slots, the next column is computed over [lo - 1, hi + (what a deletion run reaches)] only, and an
+// empty interval ends the filter: no path reaches goalX within the budget.  A slot is one 32-bit word of LDS (H in the low half, the insertion state E in
+// the high half; the deletion state F runs along the column in a register), the window's bases are copied into LDS once: the lanes of a wave that
+// run long-read chains (8 reads per wave, searches in lane-private tables in HBM) do not use the wave's 10 KB search slot - it is cut into 8 regions
+// of 1260 bytes (200 band slots + 460 bases), one per read of the wave.
+#pragma once
+#include "xm_defs.h"
+
+namespace xm {
+
+constexpr int XM_BOUND_SCALE = 60;        // grid: 1/60 penalty unit
+constexpr int XM_BOUND_KMAX = 200;        // band slots
+constexpr int XM_BOUND_MMAX = 460;        // bases of the reference window
+constexpr int XM_BOUND_REGION = XM_BOUND_KMAX * 4 + XM_BOUND_MMAX;  // 1260 bytes = 315 words (odd: the regions of a wave start in different LDS banks)
+constexpr int XM_BOUND_REGIONS = 8;       // per wave
+constexpr int XM_BOUND_INF = 0xFFFF;      // a value beyond the budget (budgets stay below 60000 units)
+
+// The problem as the filter sees it (PaProblem of xm_extend.h without the analysis fields it does not use)
+struct BoundProblem {
+  const uint8_t* qBase; int32_t qLen; bool qRc; const uint8_t* rBase; int32_t referenceLen;
+  int32_t startA, endA, startB, endB, predictedBestOffset;
+  double mutation, insStart, insExt, delStart, delExt, maxErrorRate, ambiguity;
+};
+
+struct BoundPrices { int32_t mut, isie, ie, dsde, de, amb[4], thr; };
+
+// prices and budget on the grid (the oracle's observer evaluates the same expressions: IEEE double products and floors)
+XM_INL bool boundPrices(const BoundProblem& b, BoundPrices& c) {
+  const double s = (double)XM_BOUND_SCALE;
+  const int n = b.endA - b.startA;
+  const double maxInterestingPenalty = n * b.maxErrorRate;  // :60
+  const double t = floor((maxInterestingPenalty + 0.000001 + 0.0000001) * s);
+  if (!(t >= 0 && t < 60000.0)) return false;
+  c.thr = (int32_t)t;
+  c.mut = (int32_t)floor(b.mutation * s);
+  c.isie = (int32_t)floor((b.insStart + b.insExt) * s);
+  c.ie = (int32_t)floor(b.insExt * s);
+  c.dsde = (int32_t)floor((b.delStart + b.delExt) * s);
+  c.de = (int32_t)floor(b.delExt * s);
+  c.amb[0] = 0;
+  for (int j = 1; j < 4; j++) c.amb[j] = (int32_t)floor(b.ambiguity * ((double)j / 3.0) * s);  // AmbiguityPenalty * getMutationFalseNegativeRate(union) (M/AlignmentParameters.java:156-180)
+  // (prices a path can collect without end must be positive, and none may be negative: the recurrence's values only grow along a path)
+  if (c.mut < 0 || c.isie < 1 || c.ie < 1 || c.dsde < 1 || c.de < 1 || c.amb[1] < 0 || c.mut > 30000 || c.isie > 30000 || c.dsde > 30000) return false;
+  return true;
+}
+
+// Geometry of the band: false = the filter does not take the problem (the search runs).  dlo: diagonal of slot 0; K slots.
+XM_INL bool boundBand(int n, int m, bool mayExtend, const BoundPrices& c, int& dlo, int& K) {
+  // not taken: windows at a contig end in the search's direction (start nodes with unaligned moves at 0.1 per base: :141-150,592-594)
+  if (mayExtend || n < 1 || m < 1 || m > XM_BOUND_MMAX) return false;
+  const int maxIns = c.thr < c.isie ? 0 : (c.thr - c.isie) / c.ie + 1;   // bases all insertions of a path within the budget can hold
+  const int maxDel = c.thr < c.dsde ? 0 : (c.thr - c.dsde) / c.de + 1;
+  // start nodes: (0, y') for y' = 0 .. m - n (:120-131), or - a window shorter than the query - (x', 0) for x' = 0 .. n - m (:132-139): diagonals 0 .. m - n or n - m .. 0
+  const int d0 = m >= n ? 0 : -(n - m), d1 = m >= n ? m - n : 0;
+  dlo = d0 - maxIns;
+  if (dlo < -n) dlo = -n;
+  int dhi = d1 + maxDel;
+  if (dhi > m) dhi = m;
+  K = dhi - dlo + 1;
+  return K <= XM_BOUND_KMAX;
+}
+
+XM_INL int boundSub(uint8_t a, uint8_t b, const BoundPrices& c) {
+  if ((a & b) == 0) return c.mut;                       // !Basepairs.canMatch
+  const int u = (a | b) & 15;
+  return c.amb[__builtin_popcount((unsigned)u) - 1];    // 0 for two equal unambiguous bases
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// (included by xm_extend.h behind palSlot(): the wave's search slot in LDS)
+__shared__ int xm_bound_filter;
+XM_INL void xmSetBoundFilter(int on) { if (threadIdx.x == 0) xm_bound_filter = on; }  // (before the block's first barrier)
+XM_INL bool xmBoundFilter() { return xm_bound_filter != 0; }
+// the region of the read this lane runs: reads sit in lanes 0 .. 7 of a wave (pairs: 0 .. 15, two lanes per read); null = the lane has none
+XM_INL uint8_t* boundRegion(bool pair) {
+  const int r = pair ? ((int)__lane_id() >> 1) : (int)__lane_id();
+  if (r >= XM_BOUND_REGIONS) return nullptr;
+  return palSlot() + r * XM_BOUND_REGION;
+}
+#else
+XM_INL bool& xmBoundFilterHost() { static thread_local bool on = false; return on; }
+XM_INL void xmSetBoundFilter(int on) { xmBoundFilterHost() = on != 0; }
+XM_INL bool xmBoundFilter() { return xmBoundFilterHost(); }
+XM_INL uint8_t* boundRegion(bool) { static thread_local uint32_t region[(XM_BOUND_REGION + 3) / 4]; return (uint8_t*)region; }  // host simulation (tests only)
+#endif
+
+// true = the search of this problem returns null (proved); false = not decided.  taken / cells: whether the filter took the problem, and the cells it computed.
+XM_INL bool boundRejects(const BoundProblem& bp, bool pair, bool& taken, unsigned long long& cells) {
+  taken = false;
+  BoundPrices c;
+  if (!boundPrices(bp, c)) return false;
+  const int n = bp.endA - bp.startA, m = bp.endB - bp.startB;
+  XM_GLOBAL(const uint8_t)* const qg = (XM_GLOBAL(const uint8_t)*)bp.qBase;
+  XM_GLOBAL(const uint8_t)* const rg = (XM_GLOBAL(const uint8_t)*)bp.rBase;
+  auto charA = [&](int i) -> uint8_t { const int k = bp.startA + i; return bp.qRc ? bpComplement(qg[bp.qLen - 1 - k]) : qg[k]; };
+  auto charB = [&](int j) -> uint8_t { return rg[bp.startB + j]; };
+  // chooseSearchReverse :17-53 (the search evaluates it again; it decides which end of the window the start nodes lie at)
+  bool searchReverse = true;
+  {
+    const int diagonal = bp.startB - (bp.startA + bp.predictedBestOffset);  // :81
+    const int s = imax(bp.startA, bp.startB - bp.predictedBestOffset), t = imin(bp.endA, bp.endB - bp.predictedBestOffset);
+    int sumMis = 0, numMis = 0, sumMatch = 0, numMatch = 0;
+    for (int i = 0; i < t - s; i++) {
+      const int j = i - diagonal;
+      if (j >= 0 && j < m) { if ((charA(i) & charB(j)) == 0) { sumMis += i; numMis++; } else { sumMatch += i; numMatch++; } }
+    }
+    if (numMis > 1 && numMatch > 1) searchReverse = (sumMis / numMis) > (sumMatch / numMatch);
+  }
+  const bool mayExtend = searchReverse ? bp.startB == 0 : bp.endB == bp.referenceLen;  // :87-93
+  int dlo, K;
+  if (!boundBand(n, m, mayExtend, c, dlo, K)) return false;
+  uint8_t* const region = boundRegion(pair);
+  if (!region) return false;
+  taken = true;
+  uint32_t* const W = (uint32_t*)region;
+  uint8_t* const TB = region + XM_BOUND_KMAX * 4;
+  // the window in search order (eight loads in flight per round)
+  for (int j0 = 0; j0 < m; j0 += 8) {
+    uint8_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int j = imin(j0 + k, m - 1); v[k] = charB(searchReverse ? m - 1 - j : j); }
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (j0 + k < m) TB[j0 + k] = v[k];
+  }
+  // column 0: the start nodes (0, y') for y' = 0 .. m - n at penalty 0, insertion state "disallowed" (:120-131 with startingInsertionStartPenalty disallowed;
+  // a window shorter than the query: (0, 0) alone, and one start node (x', 0) at the foot of every column up to n - m, :132-139)
+  int lo = -dlo, hi = -dlo + (m >= n ? m - n : 0);
+  for (int k = lo; k <= hi; k++) W[k] = (uint32_t)XM_BOUND_INF << 16;
+  const uint32_t INFW = ((uint32_t)XM_BOUND_INF << 16) | (uint32_t)XM_BOUND_INF;
+  const int thr = c.thr;
+  unsigned long long done = 0;
+  uint8_t aNext = charA(searchReverse ? n - 1 : 0);
+  for (int x = 1; x <= n; x++) {
+    const uint8_t a = aNext;
+    if (x < n) aNext = charA(searchReverse ? n - 1 - x : x);
+    // slot k of this column is the cell (x, y' = x + dlo + k); cells exist for 1 <= y' <= m
+    const int kGeom = 1 - x - dlo;
+    const bool foot = x <= n - m;                                 // a start node (x, 0) below the column's first cell
+    int k = foot ? kGeom : imax(imax(lo - 1, kGeom), 0);
+    const int kEnd = imin(K - 1, m - x - dlo);
+    int newLo = 0x7FFFFFFF, newHi = -1;
+    int f = XM_BOUND_INF, hBelow = XM_BOUND_INF;               // deletion state entering the cell, H of the cell below (slot k - 1 of this column)
+    if (foot) {                                                  // (slot kGeom - 1 >= 0: dlo <= -(n - m) - 0)
+      W[kGeom - 1] = (uint32_t)XM_BOUND_INF << 16;               // H = 0, insertion state "disallowed"
+      hBelow = 0; newLo = kGeom - 1; newHi = kGeom - 1;
+    }
+    uint32_t cur = (k >= lo && k <= hi) ? W[k] : INFW;           // slot k of the previous column = cell (x - 1, y' - 1)
+    for (; k <= kEnd; k++) {
+      const uint32_t nxt = (k + 1 >= lo && k + 1 <= hi) ? W[k + 1] : INFW;  // slot k + 1 of the previous column = cell (x - 1, y')
+      f = imin(f + c.de, hBelow + c.dsde);
+      if (k > hi && f > thr) break;                              // above the previous column's interval only a deletion run arrives
+      const int hD = (int)(cur & 0xFFFFu), hL = (int)(nxt & 0xFFFFu), eL = (int)(nxt >> 16);
+      const int diag = hD + boundSub(a, TB[x + dlo + k - 1], c);
+      int e = imin(eL + c.ie, hL + c.isie);
+      int h = imin(imin(diag, e), f);
+      if (e > thr) e = XM_BOUND_INF;
+      if (f > thr) f = XM_BOUND_INF;
+      if (h > thr) h = XM_BOUND_INF; else { if (k < newLo) newLo = k; newHi = k; }
+      W[k] = (uint32_t)h | ((uint32_t)e << 16);
+      hBelow = h;
+      cur = nxt;
+      done++;
+    }
+    if (newHi < 0) { cells = done; return true; }
+    lo = newLo; hi = newHi;
+  }
+  cells = done;
+  return false;
+}
+
+}  // namespace xm

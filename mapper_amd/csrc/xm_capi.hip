@@ -68,12 +68,13 @@ __device__ unsigned long long* xm_read_times = nullptr;
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexView ix, Params params, BatchView batch, const int64_t* todo, long long nTodo, int scale, int heavyAllowed, int lanesPerWave,
                                                        uint8_t* arenas, unsigned long long arenaBytes, OutView out, unsigned long long* nextItem, DevCounters* counters,
                                                        long long taperUnit, long long firstStride, PNode* waveNodes, HandOver ho, int pairLanes,
-                                                       SearchPool searchPool, PassLists lists) {
+                                                       SearchPool searchPool, PassLists lists, int boundFilter) {
   // lanesPerWave < 64 (gapped pass): the extension chain diverges so much that a wave runs its reads nearly one after another, so
   // spreading them over more, partly filled waves shortens the critical path; the idle lanes own no scratch arena
   xmSetWaveNodes(waveNodes);
   xmSetPairMode(pairLanes);
   xmSetSearchPool(searchPool);
+  xmSetBoundFilter(boundFilter);  // gapped passes of long reads: the rejection filter in front of PathAligner's searches (xm_bound.h)
   xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
   // pairLanes (gapped pass, lanesPerWave <= 32): a read is run by two adjacent lanes doing the same work (xm_extend.h, xmSetPairMode);
   // `laneInWave` below is the read's slot in the wave, `second` marks the lane that leaves atomics and result writes to its partner
@@ -180,6 +181,8 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(i
   xmSetWaveNodes(waveNodes);
   xmSetPairMode(0);
   xmSetSearchPool(SearchPool{nullptr, 0, 0, 0});
+  xmSetBoundFilter(mode >= 8 ? 1 : 0);  // (mode + 8: the search behind the rejection filter of xm_bound.h)
+  mode &= 7;
   xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
   if (threadIdx.x != 0) return;
   DevCounters local;
@@ -221,10 +224,32 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(i
     else found = hashBlockAlign(e, qs, rs, params, an, out, e.slotB, NextStraight3());
   }
   outInts[0] = found && status == XM_OK ? 1 : 0; outInts[1] = found ? out.nb : 0; outInts[2] = status; outInts[3] = (int32_t)local.pathAlignerNodes;
+  outInts[4 + 4 * blockCap] = (int32_t)local.boundChecks; outInts[5 + 4 * blockCap] = (int32_t)local.boundRejects; outInts[6 + 4 * blockCap] = (int32_t)local.boundCells;  // (behind the blocks)
   if (found) {
     for (int i = 0; i < out.nb && i < blockCap; i++) { outInts[4 + 4 * i] = out.blocks[i].startA; outInts[5 + 4 * i] = out.blocks[i].startB; outInts[6 + 4 * i] = out.blocks[i].lenA; outInts[7 + 4 * i] = out.blocks[i].lenB; }
     outDbls[0] = out.totalPenalty; outDbls[1] = out.alignedPenalty;
   }
+}
+
+// Test entry (xm_test_bound): the rejection filter of xm_bound.h alone, on one problem - a section of a query against a window of a reference - as a lane of a
+// long-read chain runs it (lane 0 of a wave, its region of the wave's slot; pair: lanes 0 and 1 together).  out: taken, rejected, cells.
+__global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_bound_kernel(Params params, const uint8_t* query, int queryLength, int queryRc, int startA, int endA, const uint8_t* reference, int referenceLength,
+                                                            int startB, int endB, int predictedBestOffset, int pair, int64_t* out) {
+  xmSetWaveNodes(nullptr);
+  xmSetPairMode(pair);
+  xmSetSearchPool(SearchPool{nullptr, 0, 0, 0});
+  xmSetBoundFilter(1);
+  xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
+  if (threadIdx.x > (pair ? 1u : 0u)) return;
+  BoundProblem bp;
+  bp.qBase = query; bp.qLen = queryLength; bp.qRc = queryRc != 0; bp.rBase = reference; bp.referenceLen = referenceLength;
+  bp.startA = startA; bp.endA = endA; bp.startB = startB; bp.endB = endB; bp.predictedBestOffset = predictedBestOffset;
+  bp.mutation = params.MutationPenalty; bp.insStart = params.InsertionStart_Penalty; bp.insExt = params.InsertionExtension_Penalty; bp.delStart = params.DeletionStart_Penalty;
+  bp.delExt = params.DeletionExtension_Penalty; bp.maxErrorRate = params.MaxErrorRate; bp.ambiguity = params.AmbiguityPenalty;
+  bool taken = false;
+  unsigned long long cells = 0;
+  const bool rejected = boundRejects(bp, pair != 0, taken, cells);
+  if (threadIdx.x == 0) { out[0] = taken ? 1 : 0; out[1] = rejected ? 1 : 0; out[2] = (int64_t)cells; }
 }
 
 // ---------------------------------------------------------------- pile-up of the alignments on the reference
@@ -937,6 +962,7 @@ const char* xm_last_error(void) { return g_error.c_str(); }
 #define XM_BUILD_STAMP "unstamped"
 #endif
 const char* xm_build_stamp(void) { return XM_BUILD_STAMP; }
+int32_t xm_abi_version(void) { return 2; }
 
 int xm_device_count(void) {
   int n = 0;
@@ -1453,6 +1479,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // light pass -> gapped pass hand-over (HandOver, SavedRead): the reads the light pass stops in front of the gapped chain keep their seeding
     // state in HBM and the gapped pass continues from it.  Scratch layout while saved regions are alive: [region pool | lane arenas].
     const bool pairMode = envInt("XM_PAIR_LANES", 1) != 0;
+    // (batches of long reads only: where reads align, the filter costs what it saves - 2 % of the search nodes of configs[1], 16 % of a repeat-rich reference's
+    // sit in searches it rejects, and it would look at every search: profiles/r06/NOTES.md 1.  XM_BOUND_FILTER=0: off, for comparison)
+    const bool boundFilterOn = envInt("XM_BOUND_FILTER", 1) != 0 && longReads;
+    bool boundFilterUsed = false;
     // temporaries of a gapped-pass lane (reads that resume from a saved region): 7/12 of the arena of that scale by default (experiment knob: percent of it)
     // HBM-mode searches take their arrays from a pool of the launch (SearchPool) in batches of short reads (gapped pass at scale <= 4): a lane's
     // temporaries then hold the chain's structures only (matchers 148 KB + piece lists 23 KB + small change at scale 4; default 30 % of 7/12 of
@@ -1649,6 +1679,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       }
       sizing.unlock();
       const int pairLanes = (heavy && lpw <= 32 && pairMode) ? 1 : 0;  // two lanes per read (xm_extend.h, xmSetPairMode)
+      // the rejection filter in front of PathAligner's searches (xm_bound.h): the gapped passes of batches of long reads - their searches do not use the wave's
+      // LDS slot, which the filter cuts into one region per read of the wave (8); reads that do not align spend 83 % of their search nodes in searches it proves null
+      const int boundFilter = (heavy && boundFilterOn && lpw <= XM_BOUND_REGIONS && scale >= XM_HBM_ONLY_FROM) ? 1 : 0;
+      if (boundFilter) boundFilterUsed = true;
       uint8_t* laneArenas = idx->dArenas.p + regionsTotal;
       HandOver ho{hoMode, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
       const int launchedMode = hoMode;
@@ -1671,7 +1705,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       HIP_CHECK(hipEventRecord(e0, s));
       hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
                          laneArenas, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
-                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, firstStride, idx->dWaveNodes.p, ho, pairLanes, pool, lists);
+                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, firstStride, idx->dWaveNodes.p, ho, pairLanes, pool, lists, boundFilter);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       PassCtl ctl;
@@ -1810,6 +1844,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     res->counters[4] = (int64_t)dc.candidatesExtended; res->counters[5] = (int64_t)dc.pathAlignerCalls; res->counters[6] = (int64_t)dc.pathAlignerNodes;
     res->counters[7] = (int64_t)dc.quickAccepts; res->counters[8] = (int64_t)dc.alignmentsOut; res->counters[9] = (int64_t)dc.refWindowBytes; res->counters[10] = (int64_t)dc.readBytes;
     res->counters[11] = rerun;
+    res->extra[0] = (int64_t)dc.boundChecks; res->extra[1] = (int64_t)dc.boundRejects; res->extra[2] = (int64_t)dc.boundCells; res->extra[3] = boundFilterUsed ? 1 : 0;
     for (int i = 0; i < 16; i++) res->prof[i] = (int64_t)dc.t[i];
     res->kernel_ms = kernelMs;
     res->kernel_launches = launches;
@@ -2017,11 +2052,46 @@ void xm_pileup_free(xm_pileup* p) {
   delete p;
 }
 
+// Test-only: what the rejection filter did in this thread's last xm_test_local_align call (searches taken, searches rejected, cells computed).
+static thread_local int64_t g_testBound[3] = {0, 0, 0};
+void xm_test_bound_counters(int64_t* out3) { for (int i = 0; i < 3; i++) out3[i] = g_testBound[i]; }
+
+// Test-only entry (tests/test_gpu_bound.py): the rejection filter alone on one problem (xm_test_bound_kernel).  out3: taken, rejected, cells computed.
+int xm_test_bound(int32_t device, const xm_params* p, const uint8_t* query, int32_t query_length, int32_t query_rc, int32_t start_a, int32_t end_a, const uint8_t* reference, int32_t reference_length,
+                  int32_t start_b, int32_t end_b, int32_t predicted_best_offset, int32_t pair, int64_t* out3) {
+  if (!p || !query || !reference || !out3) return fail("xm_test_bound: null argument");
+  if (query_length < 1 || reference_length < 1 || start_a < 0 || end_a > query_length || start_a > end_a || start_b < 0 || end_b > reference_length || start_b > end_b) return fail("xm_test_bound: bad sections");
+  try {
+    if (device >= 0) HIP_CHECK(hipSetDevice(device));
+    Params params;
+    memset(&params, 0, sizeof(params));
+    params.MutationPenalty = p->MutationPenalty; params.InsertionStart_Penalty = p->InsertionStart_Penalty; params.InsertionExtension_Penalty = p->InsertionExtension_Penalty;
+    params.DeletionStart_Penalty = p->DeletionStart_Penalty; params.DeletionExtension_Penalty = p->DeletionExtension_Penalty; params.MaxErrorRate = p->MaxErrorRate;
+    params.UnalignedPenalty = p->UnalignedPenalty; params.AmbiguityPenalty = p->AmbiguityPenalty; params.Max_PenaltySpan = p->Max_PenaltySpan;
+    params.MaxNumMatches = p->MaxNumMatches; params.StartingInsertionStartFree = 0;
+    DevBuf<uint8_t> dq, dr;
+    DevBuf<int64_t> dOut;
+    struct Release { DevBuf<uint8_t>&a, &b; DevBuf<int64_t>& c; ~Release() { a.release(); b.release(); c.release(); } } releaseAll{dq, dr, dOut};
+    dq.ensure((size_t)query_length); dr.ensure((size_t)reference_length); dOut.ensure(4);
+    HIP_CHECK(hipMemcpy(dq.p, query, (size_t)query_length, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dr.p, reference, (size_t)reference_length, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(dOut.p, 0, sizeof(int64_t) * 4));
+    hipLaunchKernelGGL(xm_test_bound_kernel, dim3(1), dim3(256), 0, 0, params, (const uint8_t*)dq.p, (int)query_length, (int)query_rc, (int)start_a, (int)end_a, (const uint8_t*)dr.p, (int)reference_length,
+                       (int)start_b, (int)end_b, (int)predicted_best_offset, (int)(pair ? 1 : 0), dOut.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out3, dOut.p, sizeof(int64_t) * 3, hipMemcpyDeviceToHost));
+    return 0;
+  } catch (std::exception& e) { return fail(std::string("xm_test_bound: ") + e.what()); }
+}
+
 // Test-only entry (tests/test_gpu_kat.py): see xm_test_local_kernel above and xm_test_wave_search_kernel (xm_wave_kernel.hip).
 int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_params* p, const uint8_t* query, int32_t query_length, const uint8_t* reference, int32_t reference_length,
                         double max_ins_ext, double max_del_ext, int32_t block_cap, int32_t* blocks, int32_t* num_blocks, double* penalties, int64_t* nodes_put) {
   if (!p || !query || !reference || !blocks || !num_blocks || !penalties) { fail("xm_test_local_align: null argument"); return -1; }
-  if (chain < 0 || chain > 1 || mode < 0 || mode > 4 || (chain == 1 && (mode == 2 || mode == 3)) || query_length < 1 || reference_length < 1 || query_length > 30000 || reference_length > 100000 || block_cap < 1)
+  const bool withBound = mode >= 8;  // mode + 8 (modes 0, 1, 4): the search behind the rejection filter of xm_bound.h; xm_test_bound_counters() says what it did
+  if (withBound) mode -= 8;
+  if (chain < 0 || chain > 1 || mode < 0 || mode > 4 || (withBound && (mode == 2 || mode == 3)) || (chain == 1 && (mode == 2 || mode == 3)) || query_length < 1 || reference_length < 1 || query_length > 30000 || reference_length > 100000 || block_cap < 1)
   { fail("xm_test_local_align: bad arguments (chain 0: modes 0 LDS slot, 1 HBM, 2 wave search with the search kernel's capacities, 3 with the inline capacities, 4 lane-private form; chain 1: modes 0, 1, 4)"); return -1; }
   try {
     if (device >= 0) HIP_CHECK(hipSetDevice(device));
@@ -2041,10 +2111,10 @@ int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_pa
       DevBuf<uint8_t>&a, &b, &c, &d; DevBuf<int32_t>&e; DevBuf<double>& f; DevBuf<int64_t>& g; DevBuf<int32_t>& h;
       ~Release() { a.release(); b.release(); c.release(); d.release(); e.release(); f.release(); g.release(); h.release(); }
     } releaseAll{dq, dr, arena, nodes, dInts, dDbls, dStart, dLen};
-    dq.ensure((size_t)query_length); dr.ensure((size_t)reference_length); dInts.ensure((size_t)4 + 4 * (size_t)cap); dDbls.ensure(2);
+    dq.ensure((size_t)query_length); dr.ensure((size_t)reference_length); dInts.ensure((size_t)8 + 4 * (size_t)cap); dDbls.ensure(2);
     HIP_CHECK(hipMemcpy(dq.p, query, (size_t)query_length, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dr.p, reference, (size_t)reference_length, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemset(dInts.p, 0, sizeof(int32_t) * (4 + 4 * (size_t)cap)));
+    HIP_CHECK(hipMemset(dInts.p, 0, sizeof(int32_t) * (8 + 4 * (size_t)cap)));
     HIP_CHECK(hipMemset(dDbls.p, 0, sizeof(double) * 2));
     if (mode == 2 || mode == 3) {
       TestSearch t;
@@ -2067,14 +2137,15 @@ int xm_test_local_align(int32_t device, int32_t chain, int32_t mode, const xm_pa
       const size_t arenaBytes = (size_t)288 * 1024 * scale;
       arena.ensure(arenaBytes);
       nodes.ensure((size_t)XM_PAL_NODES * 4 * sizeof(PNode));
-      hipLaunchKernelGGL(xm_test_local_kernel, dim3(1), dim3(256), 0, 0, (int)chain, (int)mode, params, (const uint8_t*)dq.p, (int)query_length, (const uint8_t*)dr.p, (int)reference_length,
+      hipLaunchKernelGGL(xm_test_local_kernel, dim3(1), dim3(256), 0, 0, (int)chain, (int)mode + (withBound ? 8 : 0), params, (const uint8_t*)dq.p, (int)query_length, (const uint8_t*)dr.p, (int)reference_length,
                          max_ins_ext, max_del_ext, scale, arena.p, (unsigned long long)arenaBytes, (PNode*)nodes.p, cap, dInts.p, dDbls.p);
       HIP_CHECK(hipGetLastError());
     }
     HIP_CHECK(hipDeviceSynchronize());
-    std::vector<int32_t> ints((size_t)4 + 4 * (size_t)cap);
+    std::vector<int32_t> ints((size_t)8 + 4 * (size_t)cap);
     double dbls[2];
     HIP_CHECK(hipMemcpy(ints.data(), dInts.p, sizeof(int32_t) * ints.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; i++) g_testBound[i] = ints[(size_t)4 + 4 * (size_t)cap + (size_t)i];
     HIP_CHECK(hipMemcpy(dbls, dDbls.p, sizeof(dbls), hipMemcpyDeviceToHost));
     if (nodes_put) *nodes_put = ints[3];
     const int ok = (mode == 2 || mode == 3) ? ints[0] : (ints[2] != XM_OK ? -1 : ints[0]);

@@ -329,6 +329,7 @@ XM_INL T* arenaArray(Arena& a, size_t n) { return (T*)a.alloc(sizeof(T) * (n ? n
 struct DevCounters {
   unsigned long long reads, headerProbes, bucketFetches, hitsFetched, candidatesExtended, pathAlignerCalls, pathAlignerNodes,
       quickAccepts, blocksOut, alignmentsOut, refWindowBytes, readBytes;
+  unsigned long long boundChecks, boundRejects, boundCells;  // the rejection filter in front of PathAligner (xm_bound.h): searches it took, searches it proved null, cells it computed
   unsigned long long t[16];  // XM_PROFILE builds only: shader-clock ticks per phase, summed over lanes
 };
 
@@ -343,6 +344,6 @@ struct DevCounters {
 #define XM_TIC(var) do { } while (0)
 #define XM_TOC(dc, slot, var) do { } while (0)
 #endif
-enum { T_TOTAL = 0, T_PYRAMID = 1, T_WALK = 2, T_HITS = 3, T_STRAIGHT = 4, T_ANALYZE = 5, T_PATH = 6, T_PATH_INIT = 7, T_BLOCK = 8, T_MATCHER_INDEX = 9, T_CONFIDENT = 10, T_OUTER = 11 };
+enum { T_TOTAL = 0, T_PYRAMID = 1, T_WALK = 2, T_HITS = 3, T_STRAIGHT = 4, T_ANALYZE = 5, T_PATH = 6, T_PATH_INIT = 7, T_BLOCK = 8, T_MATCHER_INDEX = 9, T_CONFIDENT = 10, T_OUTER = 11, T_BOUND = 12 };
 
 }  // namespace xm

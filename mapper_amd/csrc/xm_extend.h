@@ -400,6 +400,10 @@ XM_INL PNode* palWaveNodes() {
 XM_INL PNode* palWaveNodes() { static thread_local double buf[XM_PAL_NODES * 4]; return (PNode*)buf; }
 #endif
 
+}  // namespace xm
+#include "xm_bound.h"  // the rejection filter in front of the search (uses the wave's slot)
+namespace xm {
+
 // XM_PROFILE builds: where a search step spends its time (hash lookups / node loads / arithmetic / putNode), summed into t[12..15]
 #if defined(XM_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define XM_PA_TIC(var) unsigned long long var = clock64()
@@ -1009,7 +1013,7 @@ XM_INL bool pathSearchT(const PaProblem& prIn, Arena& tmpIn, const Caps& capsIn,
 #endif
     if (dc) { dc->pathAlignerCalls++; dc->pathAlignerNodes += pa.nodesPut; }
 #if defined(XM_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-    if (dc) { dc->t[12] += pa.tLook; dc->t[13] += pa.tLoad; dc->t[14] += pa.tCompute; dc->t[15] += pa.tPut; }
+    if (dc) { dc->t[13] += pa.tLook + pa.tLoad; dc->t[14] += pa.tCompute; dc->t[15] += pa.tPut; }  // (t[12] is T_BOUND since round 6: lookups and loads share a slot)
 #endif
     pa.nodesPut = 0;
     return r && !pa.overflow;
@@ -1278,6 +1282,24 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
 #define XM_HBM_ONLY_FROM 16
 #endif
     XM_PAIR_CHECK(2, ((long long)qs.start << 32) ^ (long long)rs.start ^ ((long long)qs.end << 16) ^ ((long long)rs.end << 48));
+    if (xmBoundFilter()) {
+      // the rejection filter (xm_bound.h): a search it proves null is not run (PathAligner_Runner.align was still called: the call counts)
+      BoundProblem bp;
+      bp.qBase = pr.qBase; bp.qLen = pr.qLen; bp.qRc = pr.qRc; bp.rBase = pr.rBase; bp.referenceLen = pr.referenceLen;
+      bp.startA = qs.start; bp.endA = qs.end; bp.startB = rs.start; bp.endB = rs.end; bp.predictedBestOffset = pr.predictedBestOffset;
+      bp.mutation = p.MutationPenalty; bp.insStart = p.InsertionStart_Penalty; bp.insExt = p.InsertionExtension_Penalty; bp.delStart = p.DeletionStart_Penalty;
+      bp.delExt = p.DeletionExtension_Penalty; bp.maxErrorRate = p.MaxErrorRate; bp.ambiguity = p.AmbiguityPenalty;
+      bool taken = false;
+      unsigned long long cells = 0;
+      XM_TIC(tBound);
+      const bool rejected = boundRejects(bp, xmPairMode(), taken, cells);
+      XM_TOC(e.dc, T_BOUND, tBound);
+      if (e.dc && taken) { e.dc->boundChecks++; e.dc->boundCells += cells; }
+      if (rejected) {
+        if (e.dc) { e.dc->boundRejects++; e.dc->pathAlignerCalls++; }
+        return false;
+      }
+    }
     bool ldsOverflow = e.caps->searchInHbmOnly != 0 || e.caps->scale >= XM_HBM_ONLY_FROM;  // (searchInHbmOnly: the test entry; 2 = in the form of xm_wsearch.h)
     if (!ldsOverflow) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(XM_WAVE_UNIFORM)

@@ -94,6 +94,8 @@ void addCounters(Counters& a, const Counters& b) {
   a.reads += b.reads; a.headerProbes += b.headerProbes; a.bucketFetches += b.bucketFetches; a.hitsFetched += b.hitsFetched;
   a.flankChecks += b.flankChecks; a.candidatesExtended += b.candidatesExtended; a.pathAlignerCalls += b.pathAlignerCalls;
   a.pathAlignerNodes += b.pathAlignerNodes; a.quickAccepts += b.quickAccepts;
+  a.pathNullSearches += b.pathNullSearches; a.pathNullNodes += b.pathNullNodes; a.pathBoundRejects += b.pathBoundRejects;
+  a.pathBoundRejectNodes += b.pathBoundRejectNodes; a.pathBoundChecks += b.pathBoundChecks;
 }
 
 thread_local std::string g_error;
@@ -171,6 +173,10 @@ int64_t xmo_dup_keys(void* r, int contig, int32_t* out, int64_t cap) {
 double xmo_dup_granularity(void* r) { return ((ReferenceDatabase*)r)->duplicationDetector->getDetectionGranularity(); }
 
 // ---- alignment
+// the observer of the product's rejection filter (xmo_extend.h PathAligner::boundObserve): 1 = every PathAligner search is also put to the filter's bound
+// (counters 9-13 of a result: null searches, their nodes, searches the filter rejects, the reference's nodes in those, searches the filter takes)
+void xmo_observe_bound(int on) { PathAligner::boundObserver() = on; }
+
 struct xmo_result {
   int64_t nq, nInts, nDbls;
   int32_t* ints; double* dbls; int64_t* intOff; int64_t* dblOff;
@@ -211,6 +217,8 @@ static xmo_result* packResult(std::vector<ResultStreams>& parts, int64_t nq, con
   res->counters[0] = c.reads; res->counters[1] = c.headerProbes; res->counters[2] = c.bucketFetches; res->counters[3] = c.hitsFetched;
   res->counters[4] = c.flankChecks; res->counters[5] = c.candidatesExtended; res->counters[6] = c.pathAlignerCalls;
   res->counters[7] = c.pathAlignerNodes; res->counters[8] = c.quickAccepts;
+  res->counters[9] = c.pathNullSearches; res->counters[10] = c.pathNullNodes; res->counters[11] = c.pathBoundRejects;
+  res->counters[12] = c.pathBoundRejectNodes; res->counters[13] = c.pathBoundChecks;
   return res;
 }
 
@@ -302,6 +310,39 @@ int xmo_kat_local_align(int chain, const char* queryText, const char* refText, c
     strcpy(alignedA, ta.c_str());
     strcpy(alignedB, tb.c_str());
     *penalty = result->getPenalty();
+    return 0;
+  } catch (std::exception& e) { g_error = e.what(); return 3; }
+}
+
+// The observer of the product's rejection filter on one problem: PathAligner.align on query[startA, endA) - of the reverse complement of the query when queryRc -
+// against reference[startB, endB), with the observer's verdict beside it.  out4: verdict (0 not taken, 1 taken, 2 rejected), 1 if the search returned an
+// alignment, nodes the search put, searches that returned null.  Returns non-zero when the search or the observer threw (a rejected search that aligned).
+int xmo_kat_bound(const void* paramsIn, const uint8_t* queryCodes, int queryLength, int queryRc, int startA, int endA, const uint8_t* refCodes, int refLength, int startB, int endB,
+                  int predictedBestOffset, int64_t* out4) {
+  try {
+    AlignmentParameters params = toParams((const ParamsIn*)paramsIn);
+    std::unique_ptr<Sequence> fwd(new Sequence()), b(new Sequence());
+    fwd->name = "q"; fwd->codes.assign(queryCodes, queryCodes + queryLength);
+    b->name = "r"; b->codes.assign(refCodes, refCodes + refLength);
+    std::unique_ptr<Sequence> rc = makeReverseComplement(*fwd);
+    const Sequence* a = queryRc ? rc.get() : fwd.get();
+    AlignmentAnalysis analysis;
+    analysis.predictedBestOffset = predictedBestOffset;
+    // (the limits the chain would have derived: with the constructor's 1e6 a window at a contig end gets two million start nodes, PathAligner.java:144)
+    analysis.maxInsertionExtensionPenalty = analysis.maxDeletionExtensionPenalty = std::max(1.0, (endA - startA) * params.MaxErrorRate);
+    SequenceSection qs(a, startA, endA), rs(b.get(), startB, endB);
+    Counters c;
+    PathAligner pa;
+    pa.counters = &c;
+    const int was = PathAligner::boundObserver();
+    PathAligner::boundObserver() = 1;
+    SequenceAlignmentP result;
+    try { result = pa.align(qs, rs, params, analysis); } catch (...) { PathAligner::boundObserver() = was; throw; }
+    PathAligner::boundObserver() = was;
+    out4[0] = c.pathBoundRejects ? 2 : (c.pathBoundChecks ? 1 : 0);
+    out4[1] = result ? 1 : 0;
+    out4[2] = c.pathAlignerNodes;
+    out4[3] = c.pathNullSearches;
     return 0;
   } catch (std::exception& e) { g_error = e.what(); return 3; }
 }

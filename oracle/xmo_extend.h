@@ -370,7 +370,87 @@ struct PathAligner {
     return parameters.newSequenceAlignment(sections, query->getComplementedFrom() != nullptr);
   }
 
-  SequenceAlignmentP align(const SequenceSection& querySection, const SequenceSection& referenceSection, const AlignmentParameters& params, AlignmentAnalysis& analysis) {  // :55-293
+  // OBSERVER of the product's rejection filter (mapper_amd/csrc/xm_bound.h) - test infrastructure, not part of the reference, off unless a test turns it on
+  // (xmo_observe_bound).  It never changes what align() returns: it evaluates, beside the search, the claim the product's filter makes - "the plain affine-gap
+  // recurrence over this problem (every move the search of :555-719 can make, at the price :573-719 charges for it or less, from the start nodes of :120-150)
+  // stays above maxInterestingPenalty + 1e-6 in every cell of column goalX, so align() returns null" - THROWS when a search it would have rejected returns an
+  // alignment, and counts the searches it rejects and the nodes the reference spent in them, so that the product's counters stay comparable with the oracle's.
+  // Why the claim holds: a node's three penalties are sums of move prices along one path from a start node, so none is below the recurrence's value of its
+  // cell (induction over putNode calls); the loop of :153-192 ends with an answer only through a node at goalX taken from a bucket whose key is <= max + 1e-6
+  // (:169,180), and a node's key is never below its penalty (:475-521 only adds to it, :458-461 only raises it).
+  // The recurrence is evaluated as the product does it - on an integer grid of 1/60 penalty unit with prices rounded down and the budget
+  // floor((max + 1e-6 + 1e-7) * 60) - but over the whole rectangle, in 64-bit integers, without the product's band and interval bookkeeping: the two must agree
+  // on every search, which the tests check through the counters.  Limits of the filter (restated from xm_bound.h: they decide which searches it takes):
+  static constexpr int BOUND_SCALE = 60, BOUND_KMAX = 200, BOUND_MMAX = 460;
+  // -> 0: the filter does not take the problem, 1: taken, not rejected, 2: rejected
+  int boundObserve() const {
+    const int n = textALength, m = textBLength;
+    const double s = (double)BOUND_SCALE;
+    const double t = std::floor((maxInterestingPenalty + 0.000001 + 0.0000001) * s);
+    if (!(t >= 0 && t < 60000.0)) return 0;
+    const int64_t thr = (int64_t)t;
+    const int64_t mut = (int64_t)std::floor(parameters.MutationPenalty * s);
+    const int64_t isie = (int64_t)std::floor((parameters.InsertionStart_Penalty + parameters.InsertionExtension_Penalty) * s), ie = (int64_t)std::floor(parameters.InsertionExtension_Penalty * s);
+    const int64_t dsde = (int64_t)std::floor((parameters.DeletionStart_Penalty + parameters.DeletionExtension_Penalty) * s), de = (int64_t)std::floor(parameters.DeletionExtension_Penalty * s);
+    int64_t amb[4] = {0, 0, 0, 0};
+    for (int j = 1; j < 4; j++) amb[j] = (int64_t)std::floor(parameters.AmbiguityPenalty * ((double)j / 3.0) * s);
+    if (mut < 0 || isie < 1 || ie < 1 || dsde < 1 || de < 1 || amb[1] < 0 || mut > 30000 || isie > 30000 || dsde > 30000) return 0;
+    if (mayQueryExtendPastEndOfReference || n < 1 || m < 1 || m > BOUND_MMAX) return 0;
+    const int64_t maxIns = thr < isie ? 0 : (thr - isie) / ie + 1, maxDel = thr < dsde ? 0 : (thr - dsde) / de + 1;
+    const int64_t d0 = m >= n ? 0 : -(n - m), d1 = m >= n ? m - n : 0;  // diagonals y' - x' of the start nodes
+    const int64_t dlo = std::max<int64_t>(d0 - maxIns, -n), dhi = std::min<int64_t>(d1 + maxDel, m);
+    if (dhi - dlo + 1 > BOUND_KMAX) return 0;
+    // search coordinates: x' query bases consumed, y' window bases consumed, in the direction the search runs
+    auto a = [&](int i) { return searchReverse ? queryEncodedChars[(size_t)(n - 1 - i)] : queryEncodedChars[(size_t)i]; };
+    auto b = [&](int j) { return searchReverse ? referenceEncodedChars[(size_t)(m - 1 - j)] : referenceEncodedChars[(size_t)j]; };
+    auto sub = [&](uint8_t qa, uint8_t rb) -> int64_t {
+      if (!Basepairs::canMatch(rb, qa)) return mut;
+      return amb[Basepairs::popcount(Basepairs::unionOf(qa, rb)) - 1];
+    };
+    const int64_t INF = (int64_t)1 << 40;
+    std::vector<int64_t> H((size_t)m + 1, INF), E((size_t)m + 1, INF), Hn((size_t)m + 1), En((size_t)m + 1);
+    // start nodes (not mayQueryExtendPastEndOfReference: their insertion state is "disallowed"): (0, y') for y' = 0 .. m - n (:120-131), or - a window shorter
+    // than the query - (x', 0) for x' = 0 .. n - m (:132-139)
+    for (int y = 0; y <= std::max(m - n, 0); y++) H[(size_t)y] = 0;
+    for (int x = 1; x <= n; x++) {
+      Hn[0] = x <= n - m ? 0 : INF; En[0] = INF;
+      int64_t F = INF;
+      for (int y = 1; y <= m; y++) {
+        const int64_t diag = H[(size_t)y - 1] + sub(a(x - 1), b(y - 1));
+        const int64_t e = std::min(E[(size_t)y] + ie, H[(size_t)y] + isie);
+        F = std::min(F + de, Hn[(size_t)y - 1] + dsde);
+        En[(size_t)y] = e;
+        Hn[(size_t)y] = std::min(std::min(diag, e), F);
+      }
+      H.swap(Hn); E.swap(En);
+    }
+    int64_t best = INF;
+    for (int y = 0; y <= m; y++) best = std::min(best, H[(size_t)y]);
+    return best > thr ? 2 : 1;
+  }
+  static int& boundObserver() { static int on = 0; return on; }  // xmo_observe_bound (xmo_capi.cpp)
+
+  SequenceAlignmentP align(const SequenceSection& querySection, const SequenceSection& referenceSection, const AlignmentParameters& params, AlignmentAnalysis& analysis) {
+    if (!boundObserver()) return doAlign(querySection, referenceSection, params, analysis);
+    const int64_t nodes0 = counters ? counters->pathAlignerNodes : 0;
+    SequenceAlignmentP result = doAlign(querySection, referenceSection, params, analysis);
+    const int verdict = boundObserve();
+    if (verdict == 2 && result) throw std::runtime_error("the rejection filter's bound is not a lower bound: a search it rejects returned an alignment");
+    if (counters) {
+      const int64_t spent = counters->pathAlignerNodes - nodes0;
+      if (!result) { counters->pathNullSearches++; counters->pathNullNodes += spent; }
+      if (verdict >= 1) counters->pathBoundChecks++;
+      if (verdict == 2) { counters->pathBoundRejects++; counters->pathBoundRejectNodes += spent; }
+    }
+    if (const char* f = getenv("XMO_SEARCH_LOG")) {  // (scratch analysis: one line per search)
+      static FILE* fp = fopen(f, "w");
+      fprintf(fp, "%p %d %d %.4f %d %d %d %lld\n", (const void*)query, textALength, textBLength, maxInterestingPenalty, (int)analysis.confidentAboutBestOffset, result ? 1 : 0, verdict,
+              (long long)(counters ? counters->pathAlignerNodes - nodes0 : 0));
+    }
+    return result;
+  }
+
+  SequenceAlignmentP doAlign(const SequenceSection& querySection, const SequenceSection& referenceSection, const AlignmentParameters& params, AlignmentAnalysis& analysis) {  // :55-293
     parameters = params;
     maxInterestingPenalty = querySection.getLength() * parameters.MaxErrorRate;
     query = querySection.getSequence();

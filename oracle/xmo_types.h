@@ -416,6 +416,8 @@ struct Counters {
   int64_t reads = 0, headerProbes = 0, bucketFetches = 0, hitsFetched = 0, flankChecks = 0,
           candidatesExtended = 0, ungappedOnly = 0, pathAlignerCalls = 0, pathAlignerNodes = 0,
           quickAccepts = 0, blocksOut = 0;
+  // observer of the product's rejection filter in front of PathAligner (xmo_extend.h PathAligner::boundObserve; off unless xmo_observe_bound(1)): it never changes what the oracle returns
+  int64_t pathNullSearches = 0, pathNullNodes = 0, pathBoundChecks = 0, pathBoundRejects = 0, pathBoundRejectNodes = 0;
 };
 
 }  // namespace xmo

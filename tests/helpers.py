@@ -145,3 +145,75 @@ def low_complexity_reads(n, L, seed=12):
         if q % 5 == 4:
             out[q, int(rng.integers(0, L))] = [15, 5, 14][q % 3]
     return out
+
+
+def bound_problems(seed, count):
+    """Random problems for the rejection filter in front of PathAligner (mapper_amd/csrc/xm_bound.h) and the oracle's observer of it: tuples
+    (params dict, query codes, query_rc, start_a, end_a, reference codes, start_b, end_b, predicted_best_offset).  A query section is a window of the reference
+    put through one of several error regimes (none ... unrelated text), so that searches that align, searches that fail narrowly and searches that fail by far
+    all occur; windows shorter than the query, windows at the ends of the reference, long windows, wide bands, ambiguity codes and price sets that are not
+    multiples of the filter's grid are mixed in."""
+    rng = np.random.default_rng(seed)
+    acgt = np.array([1, 2, 4, 8], dtype=np.uint8)
+    comp = np.zeros(16, dtype=np.uint8)
+    for c in range(16):
+        comp[c] = ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3)
+    out = []
+    for _ in range(count):
+        n = int(rng.choice([10, 25, 40, 60, 91, 91, 91, 120, 182, 250, 400]))
+        slack_lo, slack_hi = (int(x) for x in rng.choice([0, 0, 3, 10, 25, 60, 140], 2))
+        if rng.random() < 0.08:
+            slack_lo, slack_hi = int(rng.integers(100, 300)), int(rng.integers(100, 300))   # a window far longer than the query
+        R = int(rng.integers(n + slack_lo + slack_hi + 40, n + slack_lo + slack_hi + 400))
+        ref = acgt[rng.integers(0, 4, R)]
+        where = rng.random()
+        if where < 0.08:
+            start_b = 0
+        elif where < 0.16:
+            start_b = R - (n + slack_lo + slack_hi)
+        else:
+            start_b = int(rng.integers(1, R - (n + slack_lo + slack_hi)))
+        end_b = start_b + slack_lo + n + slack_hi
+        # the query section: the window's middle, mutated
+        regime = rng.choice(["none", "subs", "indel", "mixed", "heavy", "unrelated"], p=[0.08, 0.17, 0.2, 0.25, 0.2, 0.1])
+        src = ref[start_b + slack_lo: start_b + slack_lo + n + 40 if start_b + slack_lo + n + 40 <= R else R].copy()
+        sub, ind = {"none": (0, 0), "subs": (0.04, 0), "indel": (0.005, 0.01), "mixed": (0.03, 0.02), "heavy": (0.06, 0.05), "unrelated": (0, 0)}[regime]
+        seq = []
+        i = 0
+        while len(seq) < n and i < len(src):
+            u = rng.random()
+            if u < ind / 2:
+                seq.extend(acgt[rng.integers(0, 4, int(rng.integers(1, 4)))])   # insertion
+            elif u < ind:
+                i += int(rng.integers(1, 4))                                      # deletion
+                continue
+            b = src[i]
+            if rng.random() < sub:
+                b = acgt[(int(np.log2(b)) + int(rng.integers(1, 4))) & 3]
+            seq.append(b)
+            i += 1
+        sec = np.array(seq[:n], dtype=np.uint8)
+        if regime == "unrelated" or len(sec) < n:
+            sec = acgt[rng.integers(0, 4, n)]
+        if rng.random() < 0.1:   # ambiguity codes in the query or the window
+            k = int(rng.integers(1, 6))
+            sec[rng.integers(0, n, k)] = rng.choice([15, 5, 10, 3, 12, 7, 14], k)
+            ref[rng.integers(start_b, end_b, k)] = rng.choice([15, 5, 10, 6, 9, 11, 13], k)
+        if rng.random() < 0.07:  # a window shorter than the query
+            end_b = start_b + max(1, n - int(rng.integers(1, 30)))
+        # the section inside a longer query, possibly of its reverse complement
+        pre, post = int(rng.integers(0, 50)), int(rng.integers(0, 50))
+        view = np.concatenate([acgt[rng.integers(0, 4, pre)], sec, acgt[rng.integers(0, 4, post)]])
+        query_rc = bool(rng.random() < 0.5)
+        query = comp[view[::-1]] if query_rc else view   # the stored query; the view the aligner sees is `view`
+        start_a, end_a = pre, pre + n
+        offset = (start_b + slack_lo) - start_a + int(rng.choice([0, 0, 0, 1, -2, 7]))
+        prm = {}
+        u = rng.random()
+        if u < 0.25:
+            prm = dict(MutationPenalty=float(rng.choice([1.0, 0.8, 1.37, 2.0])), InsertionStart_Penalty=float(rng.choice([1.5, 0.9, 2.25, 0.41])),
+                       InsertionExtension_Penalty=float(rng.choice([0.6, 0.3, 0.77, 1.0])), DeletionStart_Penalty=float(rng.choice([1.5, 1.0, 3.1])),
+                       DeletionExtension_Penalty=float(rng.choice([0.5, 0.25, 0.61])), AmbiguityPenalty=float(rng.choice([0.1, 0.0, 0.33])))
+        prm["MaxErrorRate"] = float(rng.choice([0.1, 0.1, 0.1, 0.1091, 0.05, 0.02, 0.2, 0.3, 0.0]))
+        out.append((prm, query, query_rc, start_a, end_a, ref, start_b, end_b, offset))
+    return out

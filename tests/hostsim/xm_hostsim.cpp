@@ -216,6 +216,9 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
         size_t bytes = (size_t)288 * 1024 * (size_t)scale;
         ReadResult rr;
         DevCounters before = dc;
+        // the rejection filter in front of PathAligner (xm_bound.h): the product turns it on for the gapped passes of batches of long reads (xm_capi.hip, boundFilter)
+        static const bool boundFilterOn = !(getenv("XMSIM_BOUND_FILTER") && atoi(getenv("XMSIM_BOUND_FILTER")) == 0);
+        xmSetBoundFilter(boundFilterOn && stage != 0 && seedScale >= 4 && scale >= 16 ? 1 : 0);
         if (stage == 1 && saved) {
           arena2.assign(bytes + chainExtraTmpBytes(scale) + 64, 0xAB);
           uint8_t* a2 = (uint8_t*)(((uintptr_t)arena2.data() + 15) & ~(uintptr_t)15);
@@ -270,9 +273,25 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
     res->counters[4] = (int64_t)dc.candidatesExtended; res->counters[5] = (int64_t)dc.pathAlignerCalls; res->counters[6] = (int64_t)dc.pathAlignerNodes;
     res->counters[7] = (int64_t)dc.quickAccepts; res->counters[8] = (int64_t)dc.alignmentsOut; res->counters[9] = (int64_t)dc.refWindowBytes; res->counters[10] = (int64_t)dc.readBytes;
     res->counters[11] = rerun;
+    res->extra[0] = (int64_t)dc.boundChecks; res->extra[1] = (int64_t)dc.boundRejects; res->extra[2] = (int64_t)dc.boundCells; res->extra[3] = dc.boundChecks > 0 ? 1 : 0;
     *out = res;
     return 0;
   } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// the rejection filter of xm_bound.h alone on one problem (what xm_test_bound runs on the GPU); out3: taken, rejected, cells
+int xmsim_test_bound(const xm_params* p, const uint8_t* query, int queryLength, int queryRc, int startA, int endA, const uint8_t* reference, int referenceLength, int startB, int endB,
+                     int predictedBestOffset, int64_t* out3) {
+  BoundProblem bp;
+  bp.qBase = query; bp.qLen = queryLength; bp.qRc = queryRc != 0; bp.rBase = reference; bp.referenceLen = referenceLength;
+  bp.startA = startA; bp.endA = endA; bp.startB = startB; bp.endB = endB; bp.predictedBestOffset = predictedBestOffset;
+  bp.mutation = p->MutationPenalty; bp.insStart = p->InsertionStart_Penalty; bp.insExt = p->InsertionExtension_Penalty; bp.delStart = p->DeletionStart_Penalty;
+  bp.delExt = p->DeletionExtension_Penalty; bp.maxErrorRate = p->MaxErrorRate; bp.ambiguity = p->AmbiguityPenalty;
+  bool taken = false;
+  unsigned long long cells = 0;
+  const bool rejected = boundRejects(bp, false, taken, cells);
+  out3[0] = taken ? 1 : 0; out3[1] = rejected ? 1 : 0; out3[2] = (int64_t)cells;
+  return 0;
 }
 
 // 0: lane-per-read sequence only, 1: the wave form's light tier first, 2: light then heavy tier first (the product's sequence)

@@ -23,7 +23,7 @@ def build():
     with open(out + ".lock", "w") as lock:  # (pytest-xdist workers build side by side)
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-            subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"] +
+            subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"] +
                                   (["-DXM_ARENA_POISON"] if poison else []) + ["-o", out + ".tmp", SRC])
             os.replace(out + ".tmp", out)
     return out
@@ -54,6 +54,7 @@ def lib():
         L.xmsim_pyramid_dump_multi.restype = C.c_int64
         L.xmsim_kat_multi_contains.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.xmsim_kat_position_codec.argtypes = [C.c_int, C.c_int]
+        L.xmsim_test_bound.argtypes = [C.POINTER(_capi.XmParams), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
         L.xmsim_set_wave_mode.argtypes = [C.c_int]
         L.xmsim_wave_status_counts.argtypes = [C.c_void_p, C.c_int]
         _lib = L
@@ -105,7 +106,9 @@ class SimReference:
             raise RuntimeError(self.L.xmsim_last_error().decode())
         d = _capi.copy_result(res.contents)
         self.L.xmsim_result_free(res)
-        return oracle_lib.Streams(d["ints"], d["dbls"], d["int_off"], d["dbl_off"], d["counters"])
+        st = oracle_lib.Streams(d["ints"], d["dbls"], d["int_off"], d["dbl_off"], d["counters"])
+        st.extra = d["extra"]  # the rejection filter in front of PathAligner: searches taken, rejected, cells, active (include/xmapper_hip.h)
+        return st
 
     def index_info(self):
         a, b = C.c_int32(), C.c_int32()
@@ -167,3 +170,16 @@ def wave_status_counts(reset=True):
     out = np.zeros(16, dtype=np.int64)
     lib().xmsim_wave_status_counts(out.ctypes.data, 1 if reset else 0)
     return out
+
+
+def test_bound(params, query, query_rc, start_a, end_a, reference, start_b, end_b, predicted_best_offset=0):
+    """the rejection filter of xm_bound.h alone (host-compiled) -> (taken, rejected, cells)"""
+    q = np.ascontiguousarray(query, dtype=np.uint8)
+    r = np.ascontiguousarray(reference, dtype=np.uint8)
+    p = _capi.XmParams()
+    for f, _ in _capi.XmParams._fields_:
+        if f != "reserved":
+            setattr(p, f, getattr(params, f))
+    out = (C.c_int64 * 3)()
+    lib().xmsim_test_bound(C.byref(p), q.ctypes.data, len(q), 1 if query_rc else 0, start_a, end_a, r.ctypes.data, len(r), start_b, end_b, predicted_best_offset, out)
+    return int(out[0]), int(out[1]), int(out[2])

@@ -97,6 +97,9 @@ def lib():
         L.xmo_align_batch.restype = C.POINTER(_Result)
         L.xmo_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.xmo_result_free.argtypes = [C.POINTER(_Result)]
+        L.xmo_kat_bound.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+        L.xmo_observe_bound.argtypes = [C.c_int]
+        L.xmo_observe_bound.restype = None
         L.xmo_kat_multi_contains.argtypes = [C.c_char_p, C.c_char_p]
         L.xmo_kat_position_codec.argtypes = [C.c_int, C.c_int]
         L.xmo_kat_packed_map_large.argtypes = []
@@ -113,6 +116,19 @@ def lib():
         L.xmo_pyramid_dump_multi.restype = C.c_int64
         _lib = L
     return _lib
+
+
+class observe_bound:
+    """with observe_bound(): the oracle also evaluates, beside every PathAligner search, the bound of the product's rejection filter (xmo_extend.h
+    PathAligner::boundObserve) - it raises when a search the filter rejects returns an alignment, and Streams.counters[9:14] then hold: searches that returned
+    null, their nodes, searches the filter rejects, the reference's nodes in those, searches the filter takes.  Off by default (the CPU baseline does not pay for it)."""
+
+    def __enter__(self):
+        lib().xmo_observe_bound(1)
+        return self
+
+    def __exit__(self, *a):
+        lib().xmo_observe_bound(0)
 
 
 class QueryBatch:
@@ -293,3 +309,14 @@ def pyramid_dump_multi(codes):
         if n <= cap:
             return out[:n]
         cap = n
+
+
+def kat_bound(params, query, query_rc, start_a, end_a, reference, start_b, end_b, predicted_best_offset=0):
+    """PathAligner.align on one problem with the observer of the product's rejection filter beside it -> (verdict: 0 not taken / 1 taken / 2 rejected,
+    found, nodes the search put).  Raises if the observer's bound rejected a search that returned an alignment."""
+    q = np.ascontiguousarray(query, dtype=np.uint8)
+    r = np.ascontiguousarray(reference, dtype=np.uint8)
+    out = (C.c_int64 * 4)()
+    if lib().xmo_kat_bound(C.byref(params), q.ctypes.data, len(q), 1 if query_rc else 0, start_a, end_a, r.ctypes.data, len(r), start_b, end_b, predicted_best_offset, out):
+        raise RuntimeError(lib().xmo_last_error().decode())
+    return int(out[0]), int(out[1]), int(out[2])

@@ -8,7 +8,7 @@ import pytest
 import oracle_lib as o
 import hostsim_lib as hs
 from helpers import (KAT, streams_equal, first_difference, se_batch, pe_batch, ragged_se_batch, check_align_case, sprinkle_ambiguity, ambiguous_reference,
-                     heavy_ambiguity, low_complexity_reads)
+                     heavy_ambiguity, low_complexity_reads, bound_problems)
 from mapper_amd import api, synth, _capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,8 +45,19 @@ def test_importing_the_package_leaves_the_process_environment_alone():
     embeds the package), importing mapper_amd and loading the library do not."""
     import subprocess, sys
     code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); import mapper_amd; from mapper_amd import api, _capi; _capi.lib(); "
-            "assert 'GPU_MAX_HW_QUEUES' not in os.environ; import warnings; warnings.simplefilter('error'); "
-            "os.environ['GPU_MAX_HW_QUEUES'] = '8'; assert _capi.want_hardware_queues(8); print('ok')" % ROOT)
+            "assert 'GPU_MAX_HW_QUEUES' not in os.environ; import warnings; "
+            # a value set AFTER the library was loaded is never seen by the HIP runtime: the function must not report success (round-5 advice)
+            "os.environ['GPU_MAX_HW_QUEUES'] = '8'; "
+            "w = warnings.catch_warnings(record=True); rec = w.__enter__(); warnings.simplefilter('always'); ok = _capi.want_hardware_queues(8); w.__exit__(None, None, None); "
+            "assert ok is False and len(rec) == 1 and 'when the library was loaded' in str(rec[0].message), (ok, [str(r.message) for r in rec]); print('ok')" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+    # set before the library is loaded (what the entry points do): success, no warning; a user's smaller value: a warning that says so
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); import warnings; warnings.simplefilter('error'); from mapper_amd import _capi; "
+            "assert _capi.want_hardware_queues(8) and os.environ['GPU_MAX_HW_QUEUES'] == '8'; _capi.lib(); assert _capi.want_hardware_queues(8); "
+            "os.environ['GPU_MAX_HW_QUEUES'] = '2'; _capi._lib = None; warnings.simplefilter('always'); "
+            "w = warnings.catch_warnings(record=True); rec = w.__enter__(); warnings.simplefilter('always'); ok = _capi.want_hardware_queues(8); w.__exit__(None, None, None); "
+            "assert ok is False and 'is set to 2' in str(rec[0].message); print('ok')" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
@@ -305,9 +316,35 @@ def test_kernel_logic_long_reads_in_the_product_pass_sequence(sub, indel, most_r
     R = o.OracleReference([("r", ref)])
     S = hs.SimReference([("r", ref)])
     p = o.make_params()
-    sa, sb = R.align(b, p, threads=os.cpu_count()), S.align(b, p)
+    with o.observe_bound():  # the oracle also evaluates the bound of the product's rejection filter beside every search (and raises if it is not a bound)
+        sa = R.align(b, p, threads=os.cpu_count())
+    sb = S.align(b, p)
     assert streams_equal(sa, sb), first_difference(sa, sb, b.nq)
     assert sb.counters[11] <= most_reruns, "reads run again at a larger scale: %d of %d" % (sb.counters[11], b.nq)
+    # the rejection filter (xm_bound.h) took and rejected exactly the searches the oracle's observer does, and the nodes the product did not put are
+    # the ones the reference spent in those searches
+    calls, nodes, null, null_nodes, rejects, reject_nodes, checks = sa.counters[6], sa.counters[7], sa.counters[9], sa.counters[10], sa.counters[11], sa.counters[12], sa.counters[13]
+    assert sb.extra[3] == 1 and sb.extra[0] == checks and sb.extra[1] == rejects, (sb.extra, checks, rejects)
+    assert sb.counters[5] == calls and sb.counters[6] + reject_nodes == nodes, (sb.counters[5:7], calls, nodes, reject_nodes)
+    assert checks > 0.5 * calls and rejects <= null  # (not taken: windows at a contig end, bands of more than 200 diagonals, windows of more than 460 bases)
+    if indel == 0.05:  # reads that do not align: most of the search's work is in searches that return null, and the filter proves most of those null
+        assert rejects > 0.9 * null and reject_nodes > 0.75 * nodes, (calls, null, rejects, nodes, reject_nodes)
+
+
+def test_kernel_logic_rejection_filter_decides_like_the_oracle_observer():
+    """The rejection filter in front of PathAligner (xm_bound.h, compiled for the host) on random problems: it takes and rejects exactly the searches the
+    oracle's observer of the same bound does - the observer runs the reference's search beside its bound and raises when a search the bound rejects
+    returns an alignment, so every problem also checks that the bound IS one (searches that align, fail narrowly, fail by far; windows shorter than the
+    query, at the ends of the reference, long windows, wide bands, ambiguity codes, prices off the filter's grid)."""
+    seen = {}
+    for prm, q, rc, sa, ea, ref, sb, eb, off in bound_problems(0xB07D, 2500):
+        p = o.make_params(prm)
+        verdict, found, _ = o.kat_bound(p, q, rc, sa, ea, ref, sb, eb, off)
+        taken, rejected, cells = hs.test_bound(p, q, rc, sa, ea, ref, sb, eb, off)
+        assert (taken, rejected) == (1 if verdict else 0, 1 if verdict == 2 else 0), (prm, rc, sa, ea, sb, eb, off, verdict, found, taken, rejected)
+        assert not (rejected and found)
+        seen[(verdict, found)] = seen.get((verdict, found), 0) + 1
+    assert seen.get((2, 0), 0) > 400 and seen.get((1, 1), 0) > 400 and seen.get((0, 0), 0) + seen.get((0, 1), 0) > 200, seen
 
 
 def test_kernel_logic_edge_cases():
