@@ -30,14 +30,17 @@
 // of 1260 bytes (200 band slots + 460 bases), one per read of the wave.
 #pragma once
 #include "xm_defs.h"
+#include <type_traits>
 
 namespace xm {
 
 constexpr int XM_BOUND_SCALE = 60;        // grid: 1/60 penalty unit
-constexpr int XM_BOUND_KMAX = 200;        // band slots
-constexpr int XM_BOUND_MMAX = 460;        // bases of the reference window
-constexpr int XM_BOUND_REGION = XM_BOUND_KMAX * 4 + XM_BOUND_MMAX;  // 1260 bytes = 315 words (odd: the regions of a wave start in different LDS banks)
+constexpr int XM_BOUND_KMAX = 200;        // band slots of a region in LDS (+ one slot that stays "beyond the budget" behind the band)
+constexpr int XM_BOUND_MMAX = 456;        // bases of the reference window in a region in LDS
+constexpr int XM_BOUND_REGION = (XM_BOUND_KMAX + 1) * 4 + XM_BOUND_MMAX;  // 1260 bytes = 315 words (odd: the regions of a wave start in different LDS banks)
 constexpr int XM_BOUND_REGIONS = 8;       // per wave
+constexpr int XM_BOUND_KMAX_WIDE = 1024;  // problems that do not fit a region (a window far longer than the query: a third of a percent of the searches of configs[4],
+constexpr int XM_BOUND_MMAX_WIDE = 4096;  // a seventh of their nodes): the same recurrence in the lane's temporaries in HBM
 constexpr int XM_BOUND_INF = 0xFFFF;      // a value beyond the budget (budgets stay below 60000 units)
 
 // The problem as the filter sees it (PaProblem of xm_extend.h without the analysis fields it does not use)
@@ -47,7 +50,7 @@ struct BoundProblem {
   double mutation, insStart, insExt, delStart, delExt, maxErrorRate, ambiguity;
 };
 
-struct BoundPrices { int32_t mut, isie, ie, dsde, de, amb[4], thr; };
+struct BoundPrices { int32_t mut, isie, ie, dsde, de, amb1, amb2, amb3, thr; };
 
 // prices and budget on the grid (the oracle's observer evaluates the same expressions: IEEE double products and floors)
 XM_INL bool boundPrices(const BoundProblem& b, BoundPrices& c) {
@@ -62,17 +65,17 @@ XM_INL bool boundPrices(const BoundProblem& b, BoundPrices& c) {
   c.ie = (int32_t)floor(b.insExt * s);
   c.dsde = (int32_t)floor((b.delStart + b.delExt) * s);
   c.de = (int32_t)floor(b.delExt * s);
-  c.amb[0] = 0;
-  for (int j = 1; j < 4; j++) c.amb[j] = (int32_t)floor(b.ambiguity * ((double)j / 3.0) * s);  // AmbiguityPenalty * getMutationFalseNegativeRate(union) (M/AlignmentParameters.java:156-180)
+  // AmbiguityPenalty * getMutationFalseNegativeRate(union) (M/AlignmentParameters.java:156-180): a union of 2, 3, 4 bases
+  c.amb1 = (int32_t)floor(b.ambiguity * (1.0 / 3.0) * s); c.amb2 = (int32_t)floor(b.ambiguity * (2.0 / 3.0) * s); c.amb3 = (int32_t)floor(b.ambiguity * (3.0 / 3.0) * s);
   // (prices a path can collect without end must be positive, and none may be negative: the recurrence's values only grow along a path)
-  if (c.mut < 0 || c.isie < 1 || c.ie < 1 || c.dsde < 1 || c.de < 1 || c.amb[1] < 0 || c.mut > 30000 || c.isie > 30000 || c.dsde > 30000) return false;
+  if (c.mut < 0 || c.isie < 1 || c.ie < 1 || c.dsde < 1 || c.de < 1 || c.amb1 < 0 || c.mut > 30000 || c.isie > 30000 || c.dsde > 30000 || c.amb3 > 30000) return false;
   return true;
 }
 
 // Geometry of the band: false = the filter does not take the problem (the search runs).  dlo: diagonal of slot 0; K slots.
 XM_INL bool boundBand(int n, int m, bool mayExtend, const BoundPrices& c, int& dlo, int& K) {
   // not taken: windows at a contig end in the search's direction (start nodes with unaligned moves at 0.1 per base: :141-150,592-594)
-  if (mayExtend || n < 1 || m < 1 || m > XM_BOUND_MMAX) return false;
+  if (mayExtend || n < 1 || m < 1 || m > XM_BOUND_MMAX_WIDE) return false;
   const int maxIns = c.thr < c.isie ? 0 : (c.thr - c.isie) / c.ie + 1;   // bases all insertions of a path within the budget can hold
   const int maxDel = c.thr < c.dsde ? 0 : (c.thr - c.dsde) / c.de + 1;
   // start nodes: (0, y') for y' = 0 .. m - n (:120-131), or - a window shorter than the query - (x', 0) for x' = 0 .. n - m (:132-139): diagonals 0 .. m - n or n - m .. 0
@@ -82,20 +85,20 @@ XM_INL bool boundBand(int n, int m, bool mayExtend, const BoundPrices& c, int& d
   int dhi = d1 + maxDel;
   if (dhi > m) dhi = m;
   K = dhi - dlo + 1;
-  return K <= XM_BOUND_KMAX;
-}
-
-XM_INL int boundSub(uint8_t a, uint8_t b, const BoundPrices& c) {
-  if ((a & b) == 0) return c.mut;                       // !Basepairs.canMatch
-  const int u = (a | b) & 15;
-  return c.amb[__builtin_popcount((unsigned)u) - 1];    // 0 for two equal unambiguous bases
+  return K <= XM_BOUND_KMAX_WIDE;
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // (included by xm_extend.h behind palSlot(): the wave's search slot in LDS)
+#if defined(XM_WAVE_UNIFORM) || defined(XM_BOUND_OFF)
+// (XM_BOUND_OFF: experiment builds without the filter's code; the wave-per-read kernels, xm_wave_kernel.hip: their searches are wave-cooperative and use the wave's slot; no filter there)
+XM_INL void xmSetBoundFilter(int) {}
+XM_INL bool xmBoundFilter() { return false; }
+#else
 __shared__ int xm_bound_filter;
 XM_INL void xmSetBoundFilter(int on) { if (threadIdx.x == 0) xm_bound_filter = on; }  // (before the block's first barrier)
 XM_INL bool xmBoundFilter() { return xm_bound_filter != 0; }
+#endif
 // the region of the read this lane runs: reads sit in lanes 0 .. 7 of a wave (pairs: 0 .. 15, two lanes per read); null = the lane has none
 XM_INL uint8_t* boundRegion(bool pair) {
   const int r = pair ? ((int)__lane_id() >> 1) : (int)__lane_id();
@@ -109,16 +112,113 @@ XM_INL bool xmBoundFilter() { return xmBoundFilterHost(); }
 XM_INL uint8_t* boundRegion(bool) { static thread_local uint32_t region[(XM_BOUND_REGION + 3) / 4]; return (uint8_t*)region; }  // host simulation (tests only)
 #endif
 
+// The recurrence over a band held in `W` (K + 1 words: slot K stays "beyond the budget") and the window's bases in `TB`, both in LDS (a region of the wave's slot)
+// or both in the lane's temporaries in HBM (WIDE).  true = no cell of column n stays within the budget.
+template <bool WIDE, typename CharA>
+XM_INL bool boundSweep(typename std::conditional<WIDE, XM_GLOBAL(uint32_t)*, uint32_t*>::type const W, typename std::conditional<WIDE, XM_GLOBAL(const uint8_t)*, const uint8_t*>::type const TB,
+                       const BoundPrices& c, int n, int m, int dlo, int K, bool searchReverse, CharA charA, unsigned long long& cells) {
+  // (prices as scalars: a struct the compiler keeps in private memory would cost a trip to it per use)
+  const int thr = c.thr, mut = c.mut, isie = c.isie, ie = c.ie, dsde = c.dsde, de = c.de;
+  const unsigned long long ambPacked = ((unsigned long long)(unsigned)c.amb1 << 16) | ((unsigned long long)(unsigned)c.amb2 << 32) | ((unsigned long long)(unsigned)c.amb3 << 48);
+  const uint32_t INFW = ((uint32_t)XM_BOUND_INF << 16) | (uint32_t)XM_BOUND_INF;
+  auto sub = [&](uint8_t a, uint8_t b) -> int {
+    if ((a & b) == 0) return mut;                                             // !Basepairs.canMatch
+    return (int)((ambPacked >> (16 * (__builtin_popcount((unsigned)((a | b) & 15)) - 1))) & 0xFFFFu);   // 0 for two equal unambiguous bases
+  };
+  // column 0: the start nodes (0, y') for y' = 0 .. m - n at penalty 0, insertion state "disallowed" (:120-131 with startingInsertionStartPenalty disallowed;
+  // a window shorter than the query: (0, 0) alone, and one start node (x', 0) at the foot of every column up to n - m, :132-139)
+  int lo = -dlo, hi = -dlo + (m >= n ? m - n : 0);
+  for (int k = lo; k <= hi; k++) W[k] = (uint32_t)XM_BOUND_INF << 16;
+  unsigned long long done = 0;
+  uint8_t aNext = charA(searchReverse ? n - 1 : 0);
+  for (int x = 1; x <= n; x++) {
+    const uint8_t a = aNext;
+    if (x < n) aNext = charA(searchReverse ? n - 1 - x : x);
+    // slot k of this column is the cell (x, y' = x + dlo + k); cells exist for 1 <= y' <= m
+    const int kGeom = 1 - x - dlo;
+    const bool foot = x <= n - m;                                 // a start node (x, 0) below the column's first cell
+    int k = foot ? kGeom : imax(imax(lo - 1, kGeom), 0);
+    const int kEnd = imin(K - 1, m - x - dlo);
+    int newLo = 0x7FFFFFFF, newHi = -1;
+    int f = XM_BOUND_INF, hBelow = XM_BOUND_INF;               // deletion state entering the cell, H of the cell below (slot k - 1 of this column)
+    if (foot) {                                                  // (slot kGeom - 1 >= 0: dlo <= -(n - m))
+      W[kGeom - 1] = (uint32_t)XM_BOUND_INF << 16;               // H = 0, insertion state "disallowed"
+      hBelow = 0; newLo = kGeom - 1; newHi = kGeom - 1;
+    }
+    uint32_t cur = (k >= lo && k <= hi) ? W[k] : INFW;           // slot k of the previous column = cell (x - 1, y' - 1)
+    const int tb0 = x + dlo - 1;                                 // base of the window under slot k: TB[tb0 + k]
+    if (!foot) {
+      // the slots up to the previous column's interval [lo, hi]: slot k + 1 of that column is read as it stands (k + 1 >= lo here, and slot hi + 1 is made
+      // "beyond the budget" first), so the loop has no test in it and its loads do not wait for each other
+      W[hi + 1] = INFW;
+      const int kMain = imin(kEnd, hi);
+      for (; k <= kMain; k++) {
+        const uint32_t nxt = W[k + 1];                           // cell (x - 1, y')
+        const int s = sub(a, TB[tb0 + k]);
+        f = imin(f + de, hBelow + dsde);
+        const int hD = (int)(cur & 0xFFFFu), hL = (int)(nxt & 0xFFFFu), eL = (int)(nxt >> 16);
+        int e = imin(eL + ie, hL + isie);
+        int h = imin(imin(hD + s, e), f);
+        e = e > thr ? XM_BOUND_INF : e;
+        f = f > thr ? XM_BOUND_INF : f;
+        const bool live = h <= thr;
+        h = live ? h : XM_BOUND_INF;
+        newLo = imin(newLo, live ? k : 0x7FFFFFFF);
+        newHi = imax(newHi, live ? k : -1);
+        W[k] = (uint32_t)h | ((uint32_t)e << 16);
+        hBelow = h;
+        cur = nxt;
+      }
+      done += (unsigned long long)(k - imax(imax(lo - 1, kGeom), 0));
+      // above the interval only a deletion run arrives
+      for (; k <= kEnd; k++) {
+        f = imin(f + de, hBelow + dsde);
+        if (f > thr) break;
+        W[k] = (uint32_t)f | ((uint32_t)XM_BOUND_INF << 16);
+        newLo = imin(newLo, k); newHi = k;
+        hBelow = f;
+        done++;
+      }
+    } else {
+      for (; k <= kEnd; k++) {
+        const uint32_t nxt = (k + 1 >= lo && k + 1 <= hi) ? W[k + 1] : INFW;  // slot k + 1 of the previous column = cell (x - 1, y')
+        f = imin(f + de, hBelow + dsde);
+        if (k > hi && f > thr) break;                            // above the previous column's interval only a deletion run arrives
+        const int hD = (int)(cur & 0xFFFFu), hL = (int)(nxt & 0xFFFFu), eL = (int)(nxt >> 16);
+        int e = imin(eL + ie, hL + isie);
+        int h = imin(imin(hD + sub(a, TB[tb0 + k]), e), f);
+        if (e > thr) e = XM_BOUND_INF;
+        if (f > thr) f = XM_BOUND_INF;
+        if (h > thr) h = XM_BOUND_INF; else { if (k < newLo) newLo = k; newHi = k; }
+        W[k] = (uint32_t)h | ((uint32_t)e << 16);
+        hBelow = h;
+        cur = nxt;
+        done++;
+      }
+    }
+    if (newHi < 0) { cells = done; return true; }
+    lo = newLo; hi = newHi;
+  }
+  cells = done;
+  return false;
+}
+
 // true = the search of this problem returns null (proved); false = not decided.  taken / cells: whether the filter took the problem, and the cells it computed.
-XM_INL bool boundRejects(const BoundProblem& bp, bool pair, bool& taken, unsigned long long& cells) {
+// tmp: the lane's temporaries (a problem too wide for a region of the wave's slot keeps its band there, for the length of this call)
+// (out of line: inlined into pathAlign - i.e. into innerChain - the same code made gapped passes with several reads per wave end in a memory fault, with the
+// filter switched on or off, while a build with this function out of line, or without it, ran the same batches; profiles/r06/NOTES.md 2)
+XM_NOINL bool boundRejects(const BoundProblem& bp, bool pair, Arena& tmp, bool& taken, unsigned long long& cells) {
   taken = false;
+  cells = 0;
   BoundPrices c;
   if (!boundPrices(bp, c)) return false;
   const int n = bp.endA - bp.startA, m = bp.endB - bp.startB;
   XM_GLOBAL(const uint8_t)* const qg = (XM_GLOBAL(const uint8_t)*)bp.qBase;
   XM_GLOBAL(const uint8_t)* const rg = (XM_GLOBAL(const uint8_t)*)bp.rBase;
-  auto charA = [&](int i) -> uint8_t { const int k = bp.startA + i; return bp.qRc ? bpComplement(qg[bp.qLen - 1 - k]) : qg[k]; };
-  auto charB = [&](int j) -> uint8_t { return rg[bp.startB + j]; };
+  const int startA = bp.startA, startB = bp.startB, qLen = bp.qLen;
+  const bool qRc = bp.qRc;
+  auto charA = [=](int i) -> uint8_t { const int k = startA + i; return qRc ? bpComplement(qg[qLen - 1 - k]) : qg[k]; };
+  auto charB = [=](int j) -> uint8_t { return rg[startB + j]; };
   // chooseSearchReverse :17-53 (the search evaluates it again; it decides which end of the window the start nodes lie at)
   bool searchReverse = true;
   {
@@ -134,63 +234,39 @@ XM_INL bool boundRejects(const BoundProblem& bp, bool pair, bool& taken, unsigne
   const bool mayExtend = searchReverse ? bp.startB == 0 : bp.endB == bp.referenceLen;  // :87-93
   int dlo, K;
   if (!boundBand(n, m, mayExtend, c, dlo, K)) return false;
-  uint8_t* const region = boundRegion(pair);
-  if (!region) return false;
+  const bool wide = K > XM_BOUND_KMAX || m > XM_BOUND_MMAX;
+  uint8_t* region = nullptr;
+  const size_t mark = tmp.used;
+  if (wide) {
+    if (tmp.overflow) return false;
+    region = (uint8_t*)tmp.alloc((size_t)(K + 1) * 4 + (size_t)m);
+    if (tmp.overflow) { tmp.overflow = false; tmp.used = mark; return false; }  // (no room: the search runs as it would have)
+  } else {
+    region = boundRegion(pair);
+    if (!region) return false;
+  }
   taken = true;
-  uint32_t* const W = (uint32_t*)region;
-  uint8_t* const TB = region + XM_BOUND_KMAX * 4;
-  // the window in search order (eight loads in flight per round)
-  for (int j0 = 0; j0 < m; j0 += 8) {
-    uint8_t v[8];
+  bool rejected;
+  if (wide) {
+    XM_GLOBAL(uint32_t)* const W = (XM_GLOBAL(uint32_t)*)region;
+    XM_GLOBAL(uint8_t)* const TB = (XM_GLOBAL(uint8_t)*)(region + (size_t)(K + 1) * 4);
+    for (int j = 0; j < m; j++) TB[j] = charB(searchReverse ? m - 1 - j : j);
+    rejected = boundSweep<true>(W, (XM_GLOBAL(const uint8_t)*)TB, c, n, m, dlo, K, searchReverse, charA, cells);
+    tmp.used = mark;
+  } else {
+    uint32_t* const W = (uint32_t*)region;
+    uint8_t* const TB = region + (XM_BOUND_KMAX + 1) * 4;
+    // the window in search order (eight loads in flight per round)
+    for (int j0 = 0; j0 < m; j0 += 8) {
+      uint8_t v[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const int j = imin(j0 + k, m - 1); v[k] = charB(searchReverse ? m - 1 - j : j); }
+      for (int k = 0; k < 8; k++) { const int j = imin(j0 + k, m - 1); v[k] = charB(searchReverse ? m - 1 - j : j); }
 #pragma unroll
-    for (int k = 0; k < 8; k++) if (j0 + k < m) TB[j0 + k] = v[k];
-  }
-  // column 0: the start nodes (0, y') for y' = 0 .. m - n at penalty 0, insertion state "disallowed" (:120-131 with startingInsertionStartPenalty disallowed;
-  // a window shorter than the query: (0, 0) alone, and one start node (x', 0) at the foot of every column up to n - m, :132-139)
-  int lo = -dlo, hi = -dlo + (m >= n ? m - n : 0);
-  for (int k = lo; k <= hi; k++) W[k] = (uint32_t)XM_BOUND_INF << 16;
-  const uint32_t INFW = ((uint32_t)XM_BOUND_INF << 16) | (uint32_t)XM_BOUND_INF;
-  const int thr = c.thr;
-  unsigned long long done = 0;
-  uint8_t aNext = charA(searchReverse ? n - 1 : 0);
-  for (int x = 1; x <= n; x++) {
-    const uint8_t a = aNext;
-    if (x < n) aNext = charA(searchReverse ? n - 1 - x : x);
-    // slot k of this column is the cell (x, y' = x + dlo + k); cells exist for 1 <= y' <= m
-    const int kGeom = 1 - x - dlo;
-    const bool foot = x <= n - m;                                 // a start node (x, 0) below the column's first cell
-    int k = foot ? kGeom : imax(imax(lo - 1, kGeom), 0);
-    const int kEnd = imin(K - 1, m - x - dlo);
-    int newLo = 0x7FFFFFFF, newHi = -1;
-    int f = XM_BOUND_INF, hBelow = XM_BOUND_INF;               // deletion state entering the cell, H of the cell below (slot k - 1 of this column)
-    if (foot) {                                                  // (slot kGeom - 1 >= 0: dlo <= -(n - m) - 0)
-      W[kGeom - 1] = (uint32_t)XM_BOUND_INF << 16;               // H = 0, insertion state "disallowed"
-      hBelow = 0; newLo = kGeom - 1; newHi = kGeom - 1;
+      for (int k = 0; k < 8; k++) if (j0 + k < m) TB[j0 + k] = v[k];
     }
-    uint32_t cur = (k >= lo && k <= hi) ? W[k] : INFW;           // slot k of the previous column = cell (x - 1, y' - 1)
-    for (; k <= kEnd; k++) {
-      const uint32_t nxt = (k + 1 >= lo && k + 1 <= hi) ? W[k + 1] : INFW;  // slot k + 1 of the previous column = cell (x - 1, y')
-      f = imin(f + c.de, hBelow + c.dsde);
-      if (k > hi && f > thr) break;                              // above the previous column's interval only a deletion run arrives
-      const int hD = (int)(cur & 0xFFFFu), hL = (int)(nxt & 0xFFFFu), eL = (int)(nxt >> 16);
-      const int diag = hD + boundSub(a, TB[x + dlo + k - 1], c);
-      int e = imin(eL + c.ie, hL + c.isie);
-      int h = imin(imin(diag, e), f);
-      if (e > thr) e = XM_BOUND_INF;
-      if (f > thr) f = XM_BOUND_INF;
-      if (h > thr) h = XM_BOUND_INF; else { if (k < newLo) newLo = k; newHi = k; }
-      W[k] = (uint32_t)h | ((uint32_t)e << 16);
-      hBelow = h;
-      cur = nxt;
-      done++;
-    }
-    if (newHi < 0) { cells = done; return true; }
-    lo = newLo; hi = newHi;
+    rejected = boundSweep<false>(W, (const uint8_t*)TB, c, n, m, dlo, K, searchReverse, charA, cells);
   }
-  cells = done;
-  return false;
+  return rejected;
 }
 
 }  // namespace xm

@@ -166,7 +166,8 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
 #endif
     if (st != XM_OK) local = before;  // work of a read that is rerun by a later pass is counted there
     if (second) continue;             // (pair mode: the first lane of the read publishes)
-    publishRead(out, q, rr, cx, local, lists);
+    // (a read that found the result arena full is run again too: round 6 - its work used to be counted twice, PathAligner calls and nodes of the first call on a fresh context)
+    if (publishRead(out, q, rr, cx, local, lists) == XM_ST_OUT_OVERFLOW) local = before;
   }
   if (!second) addCounters(counters, local);
 }
@@ -234,7 +235,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(i
 // Test entry (xm_test_bound): the rejection filter of xm_bound.h alone, on one problem - a section of a query against a window of a reference - as a lane of a
 // long-read chain runs it (lane 0 of a wave, its region of the wave's slot; pair: lanes 0 and 1 together).  out: taken, rejected, cells.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_bound_kernel(Params params, const uint8_t* query, int queryLength, int queryRc, int startA, int endA, const uint8_t* reference, int referenceLength,
-                                                            int startB, int endB, int predictedBestOffset, int pair, int64_t* out) {
+                                                            int startB, int endB, int predictedBestOffset, int pair, uint8_t* arena, unsigned long long arenaBytes, int64_t* out) {
   xmSetWaveNodes(nullptr);
   xmSetPairMode(pair);
   xmSetSearchPool(SearchPool{nullptr, 0, 0, 0});
@@ -248,7 +249,9 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_bound_kernel(P
   bp.delExt = params.DeletionExtension_Penalty; bp.maxErrorRate = params.MaxErrorRate; bp.ambiguity = params.AmbiguityPenalty;
   bool taken = false;
   unsigned long long cells = 0;
-  const bool rejected = boundRejects(bp, pair != 0, taken, cells);
+  Arena tmp;
+  tmp.init(arena, (size_t)arenaBytes);  // (the two lanes of a pair keep the same band in the same memory, as they do in the passes: same values twice)
+  const bool rejected = boundRejects(bp, pair != 0, tmp, taken, cells);
   if (threadIdx.x == 0) { out[0] = taken ? 1 : 0; out[1] = rejected ? 1 : 0; out[2] = (int64_t)cells; }
 }
 
@@ -2069,15 +2072,15 @@ int xm_test_bound(int32_t device, const xm_params* p, const uint8_t* query, int3
     params.DeletionStart_Penalty = p->DeletionStart_Penalty; params.DeletionExtension_Penalty = p->DeletionExtension_Penalty; params.MaxErrorRate = p->MaxErrorRate;
     params.UnalignedPenalty = p->UnalignedPenalty; params.AmbiguityPenalty = p->AmbiguityPenalty; params.Max_PenaltySpan = p->Max_PenaltySpan;
     params.MaxNumMatches = p->MaxNumMatches; params.StartingInsertionStartFree = 0;
-    DevBuf<uint8_t> dq, dr;
+    DevBuf<uint8_t> dq, dr, dArena;
     DevBuf<int64_t> dOut;
-    struct Release { DevBuf<uint8_t>&a, &b; DevBuf<int64_t>& c; ~Release() { a.release(); b.release(); c.release(); } } releaseAll{dq, dr, dOut};
-    dq.ensure((size_t)query_length); dr.ensure((size_t)reference_length); dOut.ensure(4);
+    struct Release { DevBuf<uint8_t>&a, &b, &d; DevBuf<int64_t>& c; ~Release() { a.release(); b.release(); c.release(); d.release(); } } releaseAll{dq, dr, dArena, dOut};
+    dq.ensure((size_t)query_length); dr.ensure((size_t)reference_length); dOut.ensure(4); dArena.ensure(64 * 1024);
     HIP_CHECK(hipMemcpy(dq.p, query, (size_t)query_length, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dr.p, reference, (size_t)reference_length, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemset(dOut.p, 0, sizeof(int64_t) * 4));
     hipLaunchKernelGGL(xm_test_bound_kernel, dim3(1), dim3(256), 0, 0, params, (const uint8_t*)dq.p, (int)query_length, (int)query_rc, (int)start_a, (int)end_a, (const uint8_t*)dr.p, (int)reference_length,
-                       (int)start_b, (int)end_b, (int)predicted_best_offset, (int)(pair ? 1 : 0), dOut.p);
+                       (int)start_b, (int)end_b, (int)predicted_best_offset, (int)(pair ? 1 : 0), dArena.p, (unsigned long long)(64 * 1024), dOut.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(out3, dOut.p, sizeof(int64_t) * 3, hipMemcpyDeviceToHost));

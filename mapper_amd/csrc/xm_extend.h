@@ -1292,7 +1292,7 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
       bool taken = false;
       unsigned long long cells = 0;
       XM_TIC(tBound);
-      const bool rejected = boundRejects(bp, xmPairMode(), taken, cells);
+      const bool rejected = boundRejects(bp, xmPairMode(), *e.tmp, taken, cells);
       XM_TOC(e.dc, T_BOUND, tBound);
       if (e.dc && taken) { e.dc->boundChecks++; e.dc->boundCells += cells; }
       if (rejected) {

@@ -46,7 +46,8 @@ __device__ __forceinline__ void addCounters(DevCounters* g, const DevCounters& l
 }
 
 // what a lane does with a read it is done with: the result into the arenas, or the status the host's pass logic acts on
-__device__ __forceinline__ void publishRead(const OutView& out, int64_t q, const ReadResult& rr, const ReadCtx& cx, DevCounters& local, const PassLists& L) {
+// -> the status the read ends this pass with (XM_ST_OUT_OVERFLOW is only known here: the caller takes the read's work out of its counters then, as for every read a later pass runs again)
+__device__ __forceinline__ int32_t publishRead(const OutView& out, int64_t q, const ReadResult& rr, const ReadCtx& cx, DevCounters& local, const PassLists& L) {
   int32_t st = cx.status;
   if (st == XM_OK) {
     int64_t ni, nd;
@@ -63,7 +64,7 @@ __device__ __forceinline__ void publishRead(const OutView& out, int64_t q, const
     }
   }
   out.status[q] = st;
-  if (st == XM_OK) return;
+  if (st == XM_OK) return st;
   if (st == XM_ST_NEED_HEAVY) {
     // reads whose straight alignment was bad enough for an indel go to the front of the gapped pass: they are the long ones, and a
     // launch ends with its longest wave (longest-processing-time-first).  Cost hint: penalty x 8, capped
@@ -75,6 +76,7 @@ __device__ __forceinline__ void publishRead(const OutView& out, int64_t q, const
   else if (st == XM_ST_OUT_OVERFLOW) L.out[atomicAdd(&L.ctl->nOut[L.to], 1ull)] = q;
   else if (st == XM_ST_NEED_CONF) L.conf[atomicAdd(&L.ctl->nConf[L.tc], 1ull)] = q;
   else atomicMin(&L.ctl->errQuery, (unsigned long long)q);
+  return st;
 }
 
 #endif

@@ -11,24 +11,29 @@ from .api import decode, reverse_complement
 
 
 def java_double(x):
-    """Double.toString for the values that occur here (shortest round-trip decimal, at least one fractional digit)."""
+    """Double.toString: the shortest decimal that reads back as the same double (what repr() gives), in plain notation with at least one fractional digit for
+    1e-3 <= |x| < 1e7 and as d.dddE<n> otherwise."""
     if x != x:
         return "NaN"
     if x in (float("inf"), float("-inf")):
         return "Infinity" if x > 0 else "-Infinity"
     if x == 0:
         return "0.0"
-    a = abs(x)
+    a = abs(float(x))
+    r = repr(a)
+    mant, _, e = r.partition("e")
+    ip, _, fp = mant.partition(".")
+    digits = (ip + fp).lstrip("0")
+    exp10 = (int(e) if e else 0) + len(ip) - 1 - (len(ip + fp) - len((ip + fp).lstrip("0")) if ip.strip("0") == "" else 0)
+    digits = digits.rstrip("0") or "0"
+    sign = "-" if x < 0 else ""
     if 1e-3 <= a < 1e7:
-        s = repr(float(x))
-        if "e" in s or "E" in s:
-            s = "%.17g" % x
-        return s if "." in s else s + ".0"
-    m, e = ("%r" % float(x)).split("e") if "e" in repr(float(x)) else ("%.17e" % x).split("e")
-    m = m.rstrip("0") if "." in m else m + ".0"
-    if m.endswith("."):
-        m += "0"
-    return "%sE%d" % (m, int(e))
+        if exp10 >= 0:
+            whole = digits[:exp10 + 1].ljust(exp10 + 1, "0")
+            frac = digits[exp10 + 1:] or "0"
+            return sign + whole + "." + frac
+        return sign + "0." + "0" * (-exp10 - 1) + digits
+    return "%s%s.%sE%d" % (sign, digits[0], digits[1:] or "0", exp10)
 
 
 def cigar(seq_al, query_len):

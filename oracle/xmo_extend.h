@@ -381,7 +381,7 @@ struct PathAligner {
   // The recurrence is evaluated as the product does it - on an integer grid of 1/60 penalty unit with prices rounded down and the budget
   // floor((max + 1e-6 + 1e-7) * 60) - but over the whole rectangle, in 64-bit integers, without the product's band and interval bookkeeping: the two must agree
   // on every search, which the tests check through the counters.  Limits of the filter (restated from xm_bound.h: they decide which searches it takes):
-  static constexpr int BOUND_SCALE = 60, BOUND_KMAX = 200, BOUND_MMAX = 460;
+  static constexpr int BOUND_SCALE = 60, BOUND_KMAX = 1024, BOUND_MMAX = 4096;  // (the product's wide limits: what does not fit a region of LDS keeps its band in HBM)
   // -> 0: the filter does not take the problem, 1: taken, not rejected, 2: rejected
   int boundObserve() const {
     const int n = textALength, m = textBLength;

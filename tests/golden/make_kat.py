@@ -274,9 +274,32 @@ examples = dict(
     queries=[["query1-matches", "AAAACCAAAGG"], ["query2-1SNP", "AAAACCAAATG"], ["query3-matches", "ACGTAC"], ["query4-insertion", "AAAACCCAAAGG"],
              ["query5-deletion", "CCGGTTAAACCCGGTTTAAAACCCC"], ["query6-too-different", "ACGCGCTAAACCGAGG"]])
 
+# T/MultiHashBlock_Test.java:12-77: an ambiguous text must offer, among its possibilities, the block of every text it can stand for
+# (checkExpandingAmbiguities :79-82 replaces up to maxNumAmbiguities positions of `text` by every code that contains the base there;
+# checkExpandingAmbiguitiesInto :84-133 is the pairwise check; the last pair is testHighlyAmbiguousShortSequence :67-77)
+multi_cases = dict(
+    cite="T/MultiHashBlock_Test.java:12-77",
+    expanding=[dict(name="testShortAmbiguities", text="A", maxNumAmbiguities=1), dict(name="testMediumAmbiguities", text="AAA", maxNumAmbiguities=3),
+               dict(name="testLongAmbiguity", text="AAAAAAAAAAAAAAA", maxNumAmbiguities=3), dict(name="testNonUniformAmbiguity", text="TTATGC", maxNumAmbiguities=1)],
+    into=[[3 * b, b + code + b] for code, bases in (("R", "AG"), ("Y", "CT"), ("W", "AT"), ("S", "CG"), ("K", "GT"), ("M", "AC"), ("D", "AGT"), ("V", "ACG"), ("H", "ACT"), ("B", "CGT"))
+          for b in bases] + [["AAAAAA", "ARRRRA"]])
+
+# T/SequenceDatabase_Test.java:16-42: positions of many / of very long sequences encode and decode to themselves
+codec_cases = dict(cite="T/SequenceDatabase_Test.java:16-42",
+                   cases=[dict(name="testEncodingLargeSequences", numSequences=16, sequenceLength=1073741824),
+                          dict(name="testEncodingManyLargeSequences", numSequences=8192, sequenceLength=2097152)])
+
+# T/PackedMap_Test.java:13-49: buckets whose positions need more than 32 bits
+packed_map_cases = dict(cite="T/PackedMap_Test.java:13-49",
+                        note="8 repeating sequences of (int)Math.pow(2, 31) bases + reverse complements, PackedMap(5, 10, db, 1), blocks HashBlock(i, 1, i % 10, -(i % 10) - 1), "
+                             "i < 20: get(i) = positions {i, i + 10}")
+
 out = dict(align_cases=align_cases, local_cases=local_cases, symmetry_cases=symmetry_cases, counting_cases=counting_cases, paths_cases=paths_cases,
-           sam_cases=sam_cases, basepairs_cases=basepairs_cases, examples=examples)
-path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_reference.json")
-with open(path, "w") as f:
-    json.dump(out, f, indent=1)
-print("wrote", path, len(align_cases), "align cases")
+           sam_cases=sam_cases, basepairs_cases=basepairs_cases, examples=examples, multi_cases=multi_cases, codec_cases=codec_cases,
+           packed_map_cases=packed_map_cases)
+if __name__ == "__main__":
+    import sys
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_reference.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path, len(align_cases), "align cases")

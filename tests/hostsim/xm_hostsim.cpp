@@ -289,7 +289,10 @@ int xmsim_test_bound(const xm_params* p, const uint8_t* query, int queryLength, 
   bp.delExt = p->DeletionExtension_Penalty; bp.maxErrorRate = p->MaxErrorRate; bp.ambiguity = p->AmbiguityPenalty;
   bool taken = false;
   unsigned long long cells = 0;
-  const bool rejected = boundRejects(bp, false, taken, cells);
+  static thread_local std::vector<uint8_t> arena(64 * 1024 + 64);
+  Arena tmp;
+  tmp.init((void*)(((uintptr_t)arena.data() + 15) & ~(uintptr_t)15), 64 * 1024);
+  const bool rejected = boundRejects(bp, false, tmp, taken, cells);
   out3[0] = taken ? 1 : 0; out3[1] = rejected ? 1 : 0; out3[2] = (int64_t)cells;
   return 0;
 }

@@ -332,6 +332,41 @@ def _tables_equal(A, B, what):
         assert np.array_equal(A.dup_keys(c), B.dup_keys(c)), what
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,contigs,ambiguous", [("mapper", [300_000], False), ("mapper", [40_000, 9_000, 300], True), ("api", [6000], False)], ids=["300kb", "contigs+ambiguity", "api"])
+def test_index_hashed_on_the_gpu_equals_the_oracle_tables(mode, contigs, ambiguous, monkeypatch):
+    """The GPU tier's own link from the device-built index to the ORACLE (round-5 verdict: the comparison with the host builder is product against
+    product, and the host builder's comparison with the oracle runs in the CPU tier only): every PackedMap of an index hashed on the GPU - capacity, per-key
+    limit, per-bucket counts with their overfull marks, packed positions - and the duplication keys equal the oracle's literal restatement of
+    HashBlock_Database / DuplicationDetector (M/HashBlock_Database.java:490-616, M/PackedMap.java:99-153, M/DuplicationDetector.java:97-436), for the lengths
+    hashed at build time and for those added by lazy growth (M/Readable_HashBlock_Database.java:108-113)."""
+    refs = [("c%d" % i, (ambiguous_reference(n, seed=0xA0 + i) if ambiguous and i == 0 else synth.synthetic_reference(n, seed=0xEC011 + i))) for i, n in enumerate(contigs)]
+    refs[0] = (refs[0][0], np.concatenate([refs[0][1], refs[0][1][:900]]))  # a repeat: overfull buckets and duplication keys
+    R = o.OracleReference(refs, mode=mode)
+    R.align(["ACGTACGTACGTAGCATCGACTAGCAGCATCGAC"], o.make_params())  # triggers prepare()
+    monkeypatch.setenv("XM_DEVICE_BUILD", "1")
+    D = api.ReferenceDatabase(refs, mode=mode)
+    try:
+        assert D.info()["built_on_device"] == 1
+        mn, mx = R.index_info()
+        assert (D.info()["min_interesting_size"], D.info()["max_hashed_length"]) == (mn, mx)
+
+        def same(lengths):
+            for L in lengths:
+                ta, tb = R.table(L), D.table(L)
+                assert ta["capacity"] == tb["capacity"] and ta["maxCount"] == tb["maxCount"], L
+                assert np.array_equal(ta["counts"], tb["counts"]), L
+                assert np.array_equal(ta["positions"], tb["positions"]), L
+        same(range(0, mx + 1))
+        for c in range(len(refs)):
+            assert np.array_equal(R.dup_keys(c), D.dup_keys(c)), c
+        R.require_size(mx + 20)
+        D.ensure_length(R.index_info()[1])
+        same(range(mx + 1, R.index_info()[1] + 1))
+    finally:
+        D.close()
+
+
 @pytest.mark.parametrize("mode,contigs,gapmers,group", [("mapper", [300_000], True, None), ("mapper", [50_000, 31_000, 700, 1], True, "20000"),
                                                          ("api", [4000], True, "1"), ("mapper", [120_000], False, None)])
 def test_index_hashed_on_the_gpu_equals_host_builder(mode, contigs, gapmers, group, monkeypatch):
