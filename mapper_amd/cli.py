@@ -164,6 +164,8 @@ def parse_args(argv):
                 raise UsageError("--contexts must be >= 1")
         elif a == "--devices":  # (not a Mapper flag) explicit GPU ordinals, comma-separated; an ordinal may repeat (two contexts on one GPU)
             o["devices"] = [int(x) for x in argv[i + 1].split(",")]; i += 1
+        elif a == "--per-object":  # (not a Mapper flag) the harness's first implementation: one Python object per read and per alignment (the reference for the formats; tests)
+            o["per_object"] = True
         elif a == "--device":  # (not a Mapper flag) which GPU
             o["device"] = int(argv[i + 1]); i += 1
         elif a == "--spacing":
@@ -246,6 +248,107 @@ def sam_header(contigs):
     return lines
 
 
+def run_streaming(o, params, contigs, out):
+    """The harness without an object per read (round 6): the query files are parsed by libxm_hostio.so straight into batch arrays (mapper_amd/hostio.py), the
+    batches stream through the GPU contexts (align_stream: the copy of batch k + 1 overlaps the alignment of batch k; several contexts align side by side),
+    and a writer thread turns each batch's result streams into SAM text in native code while the next batches are being aligned.  Memory is O(batches in
+    flight), not O(job).  Same records, same statistics lines as the per-object path below, which stays for the outputs that need objects
+    (--out-mutations, --out-refs-map-count)."""
+    import queue
+    import threading
+    from . import hostio
+    ordered = api.sort_reference(contigs)  # Mapper.sortAndComplementReference: alignment results refer to this order
+    names = [n for n, _ in ordered]
+    batch_size = o.get("batch_size") or 1_000_000
+    keep_qual = bool(o["out_unaligned"])
+
+    def batches():
+        for path, split in o["queries"]:
+            yield from hostio.read_batches(path, None, batch_size, split=split, keep_qualities=keep_qual)
+        for left, right, expected, deviation in o["paired"]:
+            yield from hostio.read_batches(left, right, batch_size, keep_qualities=keep_qual, expected_inner=expected, deviation=deviation)
+
+    # the first batch decides the launch shapes (longest mate) and the number of contexts
+    it = batches()
+    first = next(it, None)
+    if first is None:
+        raise UsageError("no queries found")
+    max_len = int(first.mate_length.max())
+    devices = o.get("devices") or (list(range(o["gpus"])) if o.get("gpus", 1) > 1 else None)
+    contexts = o.get("contexts")
+    if contexts is None:  # (as the per-object path chooses them: three contexts for single reads of up to 320 bases, else two; one for a job of one batch)
+        full = len(first) >= batch_size
+        contexts = 1 if not full or devices is not None else (3 if int(first.mate_count.max()) == 1 and max_len <= 320 else 2)
+    if contexts > 1:
+        devices = [d for d in (devices or [o["device"]]) for _ in range(contexts)]
+    # (a job whose later reads are longer than the first batch's grows the index on demand: xm_index_ensure_length)
+    if devices and len(devices) > 1:
+        from . import multi
+        db = multi.MultiGpuDatabase(ordered, devices, mode="mapper", enable_gapmers=o["enable_gapmers"], max_query_length=max_len, cache_dir=o.get("cache_dir"))
+    else:
+        db = api.ReferenceDatabase(ordered, mode="mapper", enable_gapmers=o["enable_gapmers"], device=devices[0] if devices else o["device"],
+                                   max_query_length=max_len, cache_dir=o.get("cache_dir"))
+    sam_out = un_out = None
+    if o["out_sam"]:
+        sam_out = sys.stdout if o["out_sam"] == "-" else open(o["out_sam"], "w")
+        sam_out.write("\n".join(sam_header(contigs)) + "\n")
+    if o["out_unaligned"]:
+        un_out = open(o["out_unaligned"], "w")
+    writer = hostio.Writer(names, sam_out, un_out)
+    in_flight = queue.Queue()     # batches in the order they were dealt to the GPUs
+    to_write = queue.Queue(maxsize=2 * max(1, len(devices or [0])))
+    failure = []
+
+    def feed():
+        for b in [first]:
+            in_flight.put(b)
+            yield b.arrays()
+        for b in it:
+            in_flight.put(b)
+            yield b.arrays()
+
+    def write_loop():
+        try:
+            while True:
+                item = to_write.get()
+                if item is None:
+                    return
+                b, r = item
+                writer.write(b, r)
+                b.close()
+        except BaseException as e:  # noqa: BLE001  (handed to the main thread)
+            failure.append(e)
+
+    wt = threading.Thread(target=write_loop, daemon=True)
+    wt.start()
+    import time
+    t_stream = time.perf_counter()
+    try:
+        for r in db.align_stream(feed(), params):
+            if failure:
+                break
+            to_write.put((in_flight.get(), r))
+    finally:
+        to_write.put(None)
+        wt.join()
+        db.close()
+    if failure:
+        raise failure[0]
+    if sam_out is not None and sam_out is not sys.stdout:
+        sam_out.close()
+    if un_out is not None:
+        un_out.close()
+    st = writer.stats
+    n = int(st.num_queries)
+    o["timing"] = {"queries": n, "stream_seconds": time.perf_counter() - t_stream}  # first read of the query files .. last byte of the outputs (bench.py's end_to_end leg)
+    out.write("\nStatistics: \n")
+    out.write(" Alignment rate                : %d%% of queries (%d/%d)\n" % (st.num_aligned * 100 // n if n else 0, st.num_aligned, n))
+    if st.total_aligned_length:
+        out.write(" Average penalty               : %s per base (%d/%d) in aligned queries\n" % (java_float(st.total_penalty / st.total_aligned_length), int(st.total_penalty), st.total_aligned_length))
+        out.write(" Num indels                    : %s per base (%d/%d) in aligned queries\n" % (java_float(st.num_indels / st.total_aligned_length), st.num_indels, st.total_aligned_length))
+    return 0
+
+
 def run(argv, out=sys.stdout):
     o = parse_args(argv)
     if o["help"] or not argv:
@@ -258,6 +361,8 @@ def run(argv, out=sys.stdout):
     out.write("%d reference files:\n" % len(o["references"]))
     for path in o["references"]:
         out.write("Reference path = %s\n" % path)
+    if not o.get("out_mutations") and not o.get("out_refs_map_count") and not o.get("per_object"):
+        return run_streaming(o, params, contigs, out)
     queries = load_queries(o)
     ordered = api.sort_reference(contigs)  # Mapper.sortAndComplementReference: alignment results refer to this order
     names = [n for n, _ in ordered]

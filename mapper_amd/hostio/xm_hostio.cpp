@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 #include <unistd.h>
+#include <fcntl.h>
 
 namespace {
 
@@ -47,20 +48,32 @@ struct Source {
   size_t pos = 0, end = 0;
   bool eof = false;
   long long line = 0;
+  int fd = -1;  // an uncompressed file is read directly (zlib's transparent mode would copy every byte once more)
   bool open(const char* p) {
     path = p;
-    f = gzopen(p, "rb");
-    if (!f) return false;
-    gzbuffer(f, 1 << 20);
     buf.resize(8 << 20);
+    FILE* probe = fopen(p, "rb");
+    if (!probe) return false;
+    unsigned char magic[2] = {0, 0};
+    const size_t got = fread(magic, 1, 2, probe);
+    fclose(probe);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+      f = gzopen(p, "rb");
+      if (!f) return false;
+      gzbuffer(f, 1 << 20);
+    } else {
+      fd = ::open(p, O_RDONLY);
+      if (fd < 0) return false;
+    }
     return true;
   }
-  void close() { if (f) gzclose(f); f = nullptr; }
+  void close() { if (f) gzclose(f); f = nullptr; if (fd >= 0) ::close(fd); fd = -1; }
   bool fill() {  // keeps [pos, end), reads more behind it
     if (eof) return false;
     if (pos > 0) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
     if (end == buf.size()) buf.resize(buf.size() * 2);
-    int n = gzread(f, buf.data() + end, (unsigned)std::min<size_t>(buf.size() - end, 1u << 30));
+    const size_t room = std::min<size_t>(buf.size() - end, 1u << 30);
+    long n = f ? (long)gzread(f, buf.data() + end, (unsigned)room) : (long)::read(fd, buf.data() + end, room);
     if (n <= 0) { eof = true; return false; }
     end += (size_t)n;
     return true;
@@ -203,7 +216,66 @@ int xmio_next(xmio_reader* r, int64_t max_queries, xmio_batch** out) {
   };
   int64_t nq = 0;
   Record ra, rb;
-  while (nq < max_queries) {
+  st->codes.reserve((size_t)std::min<int64_t>(max_queries, 1 << 20) * 160);
+  // one mate straight from the file buffer into the batch (the common case: no sections); 0 = added, 1 = end of input, -1 = error
+  auto directMate = [&](Source& src) -> int {
+    const char* s; size_t n;
+    while (true) {
+      if (!src.getline(s, n)) return 1;
+      if (n > 0) break;
+    }
+    if (s[0] != '>' && s[0] != '@') return fail(src.path + ": line " + std::to_string(src.line) + " is neither a FASTA nor a FASTQ header");
+    const bool fastq = s[0] == '@';
+    size_t k = 1;
+    while (k < n && s[k] != ' ' && s[k] != '\t') k++;
+    st->nameOff.push_back((int64_t)st->names.size());
+    st->names.append(s + 1, k - 1);
+    const size_t at = st->codes.size();
+    st->mateOffset.push_back((int64_t)at);
+    auto addBases = [&](const char* p, size_t m) {
+      const size_t a0 = st->codes.size();
+      st->codes.resize(a0 + m);
+      uint8_t* c = st->codes.data() + a0;
+      for (size_t i = 0; i < m; i++) c[i] = g_code[(uint8_t)p[i]];
+    };
+    if (fastq) {
+      if (!src.getline(s, n)) return fail(src.path + ": FASTQ record without a sequence line at line " + std::to_string(src.line));
+      trim(s, n);
+      addBases(s, n);
+      bool haveQual = false;
+      if (src.getline(s, n) && src.getline(s, n)) { trim(s, n); haveQual = true; }
+      if (r->keepQual) {
+        st->qualOff.push_back((int64_t)st->quals.size());
+        st->hasQual.push_back(1);
+        if (haveQual) st->quals.append(s, n);
+      }
+    } else {
+      while (true) {
+        const int c = src.peek();
+        if (c < 0 || c == '>') break;
+        src.getline(s, n);
+        trim(s, n);
+        addBases(s, n);
+      }
+      if (r->keepQual) { st->qualOff.push_back((int64_t)st->quals.size()); st->hasQual.push_back(0); }
+    }
+    st->mateLength.push_back((int32_t)(st->codes.size() - at));
+    return 0;
+  };
+  while (r->split <= 0 && nq < max_queries) {
+    int rc = directMate(r->a);
+    if (rc < 0) { delete st; return -1; }
+    if (r->paired) {
+      int rc2 = rc == 1 ? nextRecord(r->b, rb) : directMate(r->b);   // (at the end of the first file the second must end too)
+      if (rc2 < 0) { delete st; return -1; }
+      if (rc != rc2) { delete st; return fail("paired query files have different numbers of reads: " + r->a.path + ", " + r->b.path); }
+    }
+    if (rc == 1) break;
+    if (!r->paired) padMate();
+    st->mateCount.push_back(r->paired ? 2 : 1);
+    nq++;
+  }
+  while (r->split > 0 && nq < max_queries) {
     if (r->pendingNext < r->pendingSections.size()) {  // sections of a long read left over from the previous batch
       const auto se = r->pendingSections[r->pendingNext++];
       addMate(r->pending.name, r->pending.seq.data() + se.first, (size_t)(se.second - se.first), nullptr);

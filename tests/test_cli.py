@@ -108,3 +108,38 @@ def test_examples_through_the_command_line(tmp_path):
     assert cli.run(["--reference", os.path.join(EX, "reference.fasta"), "--queries", os.path.join(EX, "queries.fasta"), "--out-sam", sam3,
                     "--out-unaligned", un3, "--batch-size", "2"], out=io.StringIO()) == 0
     assert open(sam3).read().splitlines() == lines and open(un3).read() == open(un_path).read()
+
+
+@pytest.mark.gpu
+def test_streaming_harness_equals_the_per_object_harness(tmp_path):
+    """The harness without an object per read (native reader and SAM formatter, batches streamed through several contexts: cli.run_streaming) writes the
+    files of the per-object harness (--per-object: api.Query, sam.records - the reference for the formats) byte for byte: single reads from FASTQ with
+    unaligned queries kept, pairs with --spacing, long reads cut by --split-queries-past-size; batches smaller than the job, two contexts."""
+    import numpy as np
+    from mapper_amd import api, synth
+    ref = synth.synthetic_reference(200_000, seed=0xEC011)
+    dec = np.frombuffer(b"?ACMGRSVTWYHKDBN", dtype=np.uint8)
+    (tmp_path / "ref.fa").write_text(">chrA\n%s\n>chrB\n%s\n" % (dec[ref[:120_000]].tobytes().decode(), dec[ref[120_000:]].tobytes().decode()))
+    reads = synth.synthetic_single_end(ref[:120_000], 5000, seed=5)[0]
+    junk = synth.synthetic_single_end(synth.synthetic_reference(50_000, seed=99), 300, seed=6)[0]   # reads from elsewhere: unaligned
+    every = np.concatenate([reads, junk])
+    (tmp_path / "se.fq").write_text("".join("@r%d\n%s\n+\n%s\n" % (i, dec[r].tobytes().decode(), "I" * len(r)) for i, r in enumerate(every)))
+    m1, m2 = synth.synthetic_paired_end(ref[120_000:], 3000, seed=7)[:2]
+    (tmp_path / "p1.fq").write_text("".join("@p%d/1\n%s\n+\n%s\n" % (i, dec[r].tobytes().decode(), "F" * len(r)) for i, r in enumerate(m1)))
+    (tmp_path / "p2.fq").write_text("".join("@p%d/2\n%s\n+\n%s\n" % (i, dec[r].tobytes().decode(), "F" * len(r)) for i, r in enumerate(m2)))
+    long_reads = synth.synthetic_single_end(ref[:120_000], 40, read_len=2600, seed=8)[0]
+    (tmp_path / "long.fa").write_text("".join(">L%d\n%s\n" % (i, dec[r].tobytes().decode()) for i, r in enumerate(long_reads)))
+    jobs = {"single": ["--queries", str(tmp_path / "se.fq")],
+            "paired": ["--paired-queries", str(tmp_path / "p1.fq"), str(tmp_path / "p2.fq"), "--spacing", "100", "50"],
+            "split": ["--split-queries-past-size", "1000", "--queries", str(tmp_path / "long.fa")]}
+    for name, args in jobs.items():
+        outs = {}
+        for mode in ("stream", "object"):
+            sam_path, un_path, log = str(tmp_path / (name + mode + ".sam")), str(tmp_path / (name + mode + ".un")), io.StringIO()
+            argv = ["--reference", str(tmp_path / "ref.fa")] + args + ["--out-sam", sam_path, "--out-unaligned", un_path, "--batch-size", "1024", "--contexts", "2"]
+            assert cli.run(argv + (["--per-object"] if mode == "object" else []), out=log) == 0
+            outs[mode] = (open(sam_path).read(), open(un_path).read(), log.getvalue())
+        assert outs["stream"][0] == outs["object"][0], name
+        assert outs["stream"][1] == outs["object"][1], name
+        assert outs["stream"][2] == outs["object"][2], name   # the statistics lines
+        assert outs["stream"][0].count("\n") > {"single": 4000, "paired": 4000, "split": 100}[name] and (name != "single" or outs["stream"][1].count("@r") >= 250)
