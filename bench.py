@@ -43,10 +43,12 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (configs[1]: 1,000,000)")
     ap.add_argument("--ref-len", type=int, default=5_000_000)
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--seed-probes", type=int, default=64_000_000, help="bucket-header probes of the seed-lookup micro-benchmark (0 = skip); the default is the size of the gather-ceiling measurement it is held against (2^26 accesses), half of them with positions")
+    ap.add_argument("--seed-probes", type=int, default=64_000_000, help="bucket-header probes of the seed-lookup micro-benchmark (0 = skip); the default is the size of the gather-ceiling measurement it is held against (2^26 accesses); a quarter of them are run again with up to four positions each on the workload's index, all of them with up to seven on the HBM-resident index")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to exercise the multi-rank path on a one-GPU box)")
     ap.add_argument("--force-device", type=int, default=-1, help="testing: every rank uses this GPU instead of its LOCAL_RANK")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads of the same workload timed on the host cores (0 = skip); default: the whole batch (about a second on the GPU box's 256 cores)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="the CPU baseline's timed run is repeated until the oracle has worked this long (best and median run reported)")
+    ap.add_argument("--end-to-end-reads", type=int, default=2_000_000, help="reads of the end_to_end leg (--config 1 / 2, N = 1): `python -m mapper_amd` from a FASTQ file on disk to a SAM file on disk (0 = skip)")
     ap.add_argument("--config", default="1", choices=["1", "1rep", "2", "4shape", "3shape", "4", "4mild"],
                     help="1: BASELINE.json configs[1] (single-end 150 bp, the headline); 2: configs[2] shape (2x150 bp pairs, --spacing 100 50); "
                     "4shape: the 1,000 bp queries --split-queries-past-size 1000 makes of configs[4]'s reads, against the same 5 Mb reference; "
@@ -395,13 +397,21 @@ def main():
             o.align(warm, oracle_lib.make_params(), threads=1)   # builds the index (not timed, like the reference's prepare())
             o.require_size(args.read_len)
             b = oracle_lib.QueryBatch.from_arrays(mc[:n], mo[:2 * n], ml[:2 * n], codes, exp_in[:n], dev_in[:n])
-            t1 = time.perf_counter()
-            w = o.align(b, oracle_lib.make_params(), threads=cores)
-            cpu_s = time.perf_counter() - t1
+            # (round-5 verdict: one run of ~1.3 s on 256 threads is thread start-up and page faults to a visible degree and wandered 0.75-1.08 M reads/s from
+            # round to round: the run is repeated until the oracle has worked for --cpu-seconds; `value` is the best run, the median is beside it)
+            cpu_runs = []
+            w = None
+            while not cpu_runs or (sum(cpu_runs) < args.cpu_seconds and len(cpu_runs) < 64):
+                t1 = time.perf_counter()
+                w = o.align(b, oracle_lib.make_params(), threads=cores)
+                cpu_runs.append(time.perf_counter() - t1)
+            cpu_s = min(cpu_runs)
             same = bool(np.array_equal(w.ints, r.ints[:r.int_off[n]]) and np.array_equal(w.dbls.view(np.int64), r.dbls[:r.dbl_off[n]].view(np.int64)))
             cpu = {"value": round(n * reads_per_query / cpu_s / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port", "seconds": round(cpu_s, 3),
+                   "runs": len(cpu_runs), "total_seconds": round(sum(cpu_runs), 3), "median_value": round(n * reads_per_query / float(np.median(cpu_runs)) / 1e6, 4),
                    "sample": "%s %d queries of the same batch, oracle (C++ port of the Java path) with one worker thread per host core taking jobs of >= 50,000 bases "
-                             "(Mapper.java:926), index build excluded" % ("all" if n == nq else "first", n)}
+                             "(Mapper.java:926), index build excluded; the run repeated until %.0f s of oracle time: value = best run, median_value = median run"
+                             % ("all" if n == nq else "first", n, args.cpu_seconds)}
             if n == nq:  # the counts the algorithmic bytes are computed from, device against oracle on the same batch
                 wc = [int(x) for x in w.counters[:9]]
                 counters["oracle"] = wc
@@ -428,7 +438,7 @@ def main():
             c2, _, ms_pos = db.seed_probe(used[:n2], keys[:n2], 4, unpack=False)
             fetched = int(np.minimum(np.maximum(c2, 0), 4).sum())
             hdr_gbs = 8.0 * args.seed_probes / (ms_hdr * 1e-3) / 1e9
-            seed = {"kernel": "xm_seed_probe_kernel", "probes": args.seed_probes, "kernel_ms": round(ms_hdr, 4),
+            seed = {"kernel": "xm_seed_probe_lines_kernel<%s>" % ("64-byte lines" if info["bucket_line_bytes"] == 64 else "32-byte lines") if info.get("bucket_line_bytes") else "xm_seed_probe_kernel", "probes": args.seed_probes, "kernel_ms": round(ms_hdr, 4),
                     "probes_per_s": round(args.seed_probes / (ms_hdr * 1e-3), 1), "achieved": round(hdr_gbs, 2), "unit": "GB/s", "peak": 8000.0,
                     "frac": round(hdr_gbs / 8000.0, 5),
                     "random_64B_gather_ceiling_sectors_per_s": round(sectors_per_s, 1),
@@ -521,12 +531,70 @@ def main():
             rc = 1  # a parity failure is not a measurement
     for c_ in ctx:
         c_.close()
+    if rank == 0 and line is not None and world == 1 and args.end_to_end_reads > 0 and args.config in ("1", "2") and args.ref_len <= 50_000_000:
+        # (after the contexts of the timed region are closed: the command line builds its own index and contexts)
+        line["end_to_end"] = end_to_end(args, ref, synth)
     if rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return rc
+
+
+def end_to_end(args, ref, synth):
+    """`python -m mapper_amd --reference R --queries Q --out-sam S` (cli.run, in this process) from a FASTQ file on disk to a SAM file on disk: the whole harness of
+    SURVEY.md section 8(f) rank 1 - native reader, batches streamed through the GPU contexts, native SAM formatter (mapper_amd/hostio.py).  `value` counts from the
+    first byte read of the query file to the last byte written of the SAM file (the reference is parsed and hashed before that: wall_seconds has everything).
+    PCIe- and disk-inclusive: never the headline value."""
+    import io
+    import shutil
+    import tempfile
+    from mapper_amd import cli
+    n = args.end_to_end_reads
+    d = tempfile.mkdtemp(prefix="xm_e2e_")
+    try:
+        dec = np.frombuffer(b"?ACMGRSVTWYHKDBN", dtype=np.uint8)
+        with open(os.path.join(d, "ref.fa"), "wb") as f:
+            f.write(b">ecoli_syn\n" + dec[ref].tobytes() + b"\n")
+
+        def fastq(path, reads_, tag):  # fixed-width records, written as one byte matrix
+            m, L = reads_.shape
+            head = np.frombuffer(("@r%09d" + tag + "\n") .encode() % 0, dtype=np.uint8)
+            rows = np.empty((m, len(head) + L + 3 + L + 1), dtype=np.uint8)
+            rows[:, :len(head)] = head
+            idx = np.arange(m)
+            for k in range(9):  # the nine digits of the read number
+                rows[:, 2 + k] = 48 + (idx // 10 ** (8 - k)) % 10
+            rows[:, len(head):len(head) + L] = dec[reads_]
+            rows[:, len(head) + L:len(head) + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+            rows[:, len(head) + L + 3:len(head) + 2 * L + 3] = 73  # 'I'
+            rows[:, -1] = 10
+            rows.tofile(path)
+        if args.config == "2":
+            m1, m2 = synth.synthetic_paired_end(ref, n // 2, read_len=150, seed=0x5EED0E2E)[:2]
+            fastq(os.path.join(d, "r1.fq"), m1, "/1"); fastq(os.path.join(d, "r2.fq"), m2, "/2")
+            qargs = ["--paired-queries", os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq"), "--spacing", "100", "50"]
+            n_queries, n_reads = n // 2, 2 * (n // 2)
+        else:
+            fastq(os.path.join(d, "reads.fq"), synth.synthetic_single_end(ref, n, read_len=args.read_len, seed=0x5EED0E2E)[0], "")
+            qargs = ["--queries", os.path.join(d, "reads.fq")]
+            n_queries = n_reads = n
+        in_bytes = sum(os.path.getsize(os.path.join(d, f_)) for f_ in os.listdir(d) if f_.endswith(".fq"))
+        log = io.StringIO()
+        t0 = time.perf_counter()
+        rc = cli.run(["--reference", os.path.join(d, "ref.fa")] + qargs + ["--out-sam", os.path.join(d, "out.sam")], out=log)
+        wall = time.perf_counter() - t0
+        t = cli.last_timing or {}
+        sam_bytes = os.path.getsize(os.path.join(d, "out.sam"))
+        rate_line = [l_ for l_ in log.getvalue().splitlines() if "Alignment rate" in l_]
+        return {"value": round(n_reads / t["stream_seconds"] / 1e6, 4) if rc == 0 and t.get("queries") == n_queries else None, "unit": "Mreads/s", "reads": n_reads,
+                "stream_seconds": round(t.get("stream_seconds", 0.0), 3), "wall_seconds": round(wall, 3), "contexts": t.get("contexts"), "fastq_bytes": in_bytes, "sam_bytes": sam_bytes,
+                "alignment_rate_line": rate_line[0].strip() if rate_line else None,
+                "note": "python -m mapper_amd (cli.run) from FASTQ on disk to SAM on disk, batches of 1 M queries; value = reads / (first byte of the query files read .. last byte of the SAM "
+                        "file written); wall_seconds adds parsing and hashing the reference and starting the contexts"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def seed_probe_hbm(api, synth, db, index_mb, device, sectors_per_s, n_probes, rng):

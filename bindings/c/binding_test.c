@@ -34,7 +34,7 @@ static int do_symbols(void) {
                        (const void*)xm_index_load, (const void*)xm_index_ensure_length, (const void*)xm_index_free, (const void*)xm_index_get_info,
                        (const void*)xm_index_table_info, (const void*)xm_index_table_shape, (const void*)xm_index_table_dump, (const void*)xm_index_dup_keys, (const void*)xm_align_batch,
                        (const void*)xm_result_free, (const void*)xm_batch_upload, (const void*)xm_batch_stage, (const void*)xm_batch_commit,
-                       (const void*)xm_align_resident, (const void*)xm_seed_probe, (const void*)xm_measure_random_gather, (const void*)xm_test_local_align, (const void*)xm_pileup_new, (const void*)xm_pileup_set_query_ends, (const void*)xm_pileup_read_middle, (const void*)xm_pileup_add_last, (const void*)xm_pileup_read,
+                       (const void*)xm_align_resident, (const void*)xm_seed_probe_packed, (const void*)xm_measure_random_gather, (const void*)xm_test_local_align, (const void*)xm_pileup_new, (const void*)xm_pileup_set_query_ends, (const void*)xm_pileup_read_middle, (const void*)xm_pileup_add_last, (const void*)xm_pileup_read,
                        (const void*)xm_pileup_events, (const void*)xm_pileup_free};
   size_t i;
   for (i = 0; i < sizeof(fns) / sizeof(fns[0]); i++) if (!fns[i]) return 1;

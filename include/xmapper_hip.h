@@ -108,7 +108,7 @@ typedef struct xm_index_info_t {
   int64_t total_forward_size, index_bytes, num_positions;
   double dup_granularity;
   int32_t built_on_device;       /* 1: the tables were hashed on the GPU (xm_index_device.hip), 0: by the host builder (or read from a file) */
-  int32_t reserved;
+  int32_t bucket_line_bytes;     /* 32 / 64: the index has bucket lines of that size in HBM (a probe is one access: xm_seed_probe_lines_kernel); 0: CSR arrays only (xm_seed_probe_kernel) */
   double hash_seconds;           /* wall time of hashing the reference into tables (all calls so far), */
   double duplication_seconds;    /* and of the duplication map */
 } xm_index_info_t;
@@ -184,7 +184,10 @@ int xm_batch_commit(xm_index* index);
  * before it (out_positions holds n * max_per_probe entries; what no probe fills is not written).  Packed because the outputs are most of what such a
  * kernel moves: rows of max_per_probe slots would be 56 bytes a probe at 7 slots, of which a genome's buckets fill ~12.  Device-resident micro-kernel used for
  * the seed-lookup roofline measurement. */
-int xm_seed_probe(xm_index* index, int64_t n, const int32_t* used_length, const int32_t* keys, int32_t max_per_probe, int32_t* counts, int64_t* out_positions, double* kernel_ms);
+int xm_seed_probe_packed(xm_index* index, int64_t n, const int32_t* used_length, const int32_t* keys, int32_t max_per_probe, int32_t* counts, int64_t* out_positions, double* kernel_ms);
+/* (ABI version 2: this entry was xm_seed_probe with out_positions[j * n + i]; the packed layout has its own name so that a caller built against the old
+ * header fails to link instead of reading garbage.  out_positions may be NULL: the kernel still fetches the positions - that is what is measured - and only
+ * the counts are copied back.) */
 
 /* Measurement helper for the seed-lookup roofline (SURVEY.md section 8d asks for the achieved rate next to "a measured random-64 B-gather
  * ceiling on the same GPU"): `accesses` reads of one random 64-byte sector each from a zero-filled device table of table_bytes;

@@ -46,12 +46,12 @@ ABI_VERSION = 2  # include/xmapper_hip.h, xm_abi_version(): xm_result.extra[] ap
 class XmIndexInfo(C.Structure):
     _fields_ = [("num_contigs", C.c_int32), ("min_interesting_size", C.c_int32), ("max_hashed_length", C.c_int32), ("enable_gapmers", C.c_int32),
                 ("dup_window", C.c_int32), ("position_bytes", C.c_int32), ("total_forward_size", C.c_int64), ("index_bytes", C.c_int64),
-                ("num_positions", C.c_int64), ("dup_granularity", C.c_double), ("built_on_device", C.c_int32), ("reserved", C.c_int32),
+                ("num_positions", C.c_int64), ("dup_granularity", C.c_double), ("built_on_device", C.c_int32), ("bucket_line_bytes", C.c_int32),
                 ("hash_seconds", C.c_double), ("duplication_seconds", C.c_double)]
 
 
 EXPORTS = ["xm_last_error", "xm_build_stamp", "xm_abi_version", "xm_device_count", "xm_index_build", "xm_index_replicate", "xm_context_new", "xm_context_set_scratch", "xm_device_memory", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
-           "xm_index_table_info", "xm_index_table_shape", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe", "xm_measure_random_gather", "xm_test_local_align", "xm_test_bound_counters", "xm_test_bound", "xm_pileup_new", "xm_pileup_set_query_ends", "xm_pileup_read_middle", "xm_pileup_add_last", "xm_pileup_read", "xm_pileup_events", "xm_pileup_free"]
+           "xm_index_table_info", "xm_index_table_shape", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe_packed", "xm_measure_random_gather", "xm_test_local_align", "xm_test_bound_counters", "xm_test_bound", "xm_pileup_new", "xm_pileup_set_query_ends", "xm_pileup_read_middle", "xm_pileup_add_last", "xm_pileup_read", "xm_pileup_events", "xm_pileup_free"]
 
 
 def build_library(force=False):
@@ -125,7 +125,7 @@ def lib():
         L.xm_batch_stage.argtypes = [C.c_void_p, C.POINTER(XmQueryBatch)]
         L.xm_batch_commit.argtypes = [C.c_void_p]
         L.xm_align_resident.argtypes = [C.c_void_p, C.POINTER(XmParams), C.POINTER(C.POINTER(XmResult))]
-        L.xm_seed_probe.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.xm_seed_probe_packed.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.xm_measure_random_gather.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_double)]
         L.xm_test_local_align.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(XmParams), C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32,
                                           C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int64)]

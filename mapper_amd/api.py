@@ -427,14 +427,16 @@ class ReferenceDatabase:
 
     def seed_probe(self, used_length, keys, max_per_probe=8, unpack=True):
         """Bulk PackedMap.get (PackedMap.java:160-172) on the device -> (counts, positions[n, max_per_probe] with -1 behind a probe's positions, kernel_ms).
-        (The C entry packs the positions of every 64 consecutive probes one behind the other: unpacked here; unpack=False returns the packed array as it is.)"""
+        max_per_probe: 0 ... 15 (a bucket line holds seven; xm_seed_probe_packed refuses more than 15).  The C entry packs the positions of every 64 consecutive
+        probes one behind the other: unpacked here.  unpack=False: (counts, None, kernel_ms) - the kernel fetches the positions all the same (that is what a
+        measurement times), but they are not copied back to the host (n * max_per_probe * 8 bytes: 3.6 GB for 64 M probes with seven positions)."""
         used = np.ascontiguousarray(used_length, dtype=np.int32)
         keys = np.ascontiguousarray(keys, dtype=np.int32)
         n = len(used)
         counts = np.zeros(n, np.int32)
-        packed = np.zeros(max(max_per_probe, 1) * max(n, 1), np.int64)
+        packed = np.zeros(max(max_per_probe, 1) * max(n, 1), np.int64) if unpack else None
         ms = C.c_double()
-        if self._L.xm_seed_probe(self._h, n, used.ctypes.data, keys.ctypes.data, max_per_probe, counts.ctypes.data, packed.ctypes.data, C.byref(ms)):
+        if self._L.xm_seed_probe_packed(self._h, n, used.ctypes.data, keys.ctypes.data, max_per_probe, counts.ctypes.data, packed.ctypes.data if unpack else None, C.byref(ms)):
             raise RuntimeError(self._L.xm_last_error().decode())
         if not unpack:
             return counts, packed, ms.value

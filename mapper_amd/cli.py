@@ -28,6 +28,9 @@ class UsageError(Exception):
     pass
 
 
+last_timing = None  # run_streaming: queries and seconds of the last job's streaming phase (bench.py's end_to_end leg)
+
+
 def _open(path):
     return gzip.open(path, "rt") if path.endswith(".gz") else open(path, "r")
 
@@ -340,7 +343,8 @@ def run_streaming(o, params, contigs, out):
         un_out.close()
     st = writer.stats
     n = int(st.num_queries)
-    o["timing"] = {"queries": n, "stream_seconds": time.perf_counter() - t_stream}  # first read of the query files .. last byte of the outputs (bench.py's end_to_end leg)
+    global last_timing
+    last_timing = {"queries": n, "stream_seconds": time.perf_counter() - t_stream, "contexts": len(devices) if devices else 1}  # first read of the query files .. last byte of the outputs (bench.py's end_to_end leg)
     out.write("\nStatistics: \n")
     out.write(" Alignment rate                : %d%% of queries (%d/%d)\n" % (st.num_aligned * 100 // n if n else 0, st.num_aligned, n))
     if st.total_aligned_length:

@@ -1149,7 +1149,8 @@ int xm_index_get_info(const xm_index* idx, xm_index_info_t* info) {
   info->num_positions = (int64_t)h.positions.size();
   info->index_bytes = (int64_t)(h.bucketOff.size() * 4 + h.positions.size() * (size_t)info->position_bytes + h.refCodes.size() + h.dupKeys.size() * 4);
   info->dup_granularity = h.dupGranularity();
-  info->built_on_device = h.builtOnDevice ? 1 : 0; info->reserved = 0;
+  info->built_on_device = h.builtOnDevice ? 1 : 0;
+  info->bucket_line_bytes = idx->hostOnly ? 0 : (idx->dt->view.lines64 ? 64 : (idx->dt->view.lines32 ? 32 : 0));
   info->hash_seconds = h.hashSeconds; info->duplication_seconds = h.dupSeconds;
   return 0;
 }
@@ -1859,9 +1860,9 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
   }
 }
 
-int xm_seed_probe(xm_index* idx, int64_t n, const int32_t* usedLength, const int32_t* keys, int32_t maxPerProbe, int32_t* counts, int64_t* outPositions, double* kernelMs) {
-  if (!idx || idx->hostOnly) return fail("xm_seed_probe: needs a device-resident index");
-  if (maxPerProbe < 0 || maxPerProbe > 15) return fail("xm_seed_probe: max_per_probe must be 0 ... 15");
+int xm_seed_probe_packed(xm_index* idx, int64_t n, const int32_t* usedLength, const int32_t* keys, int32_t maxPerProbe, int32_t* counts, int64_t* outPositions, double* kernelMs) {
+  if (!idx || idx->hostOnly) return fail("xm_seed_probe_packed: needs a device-resident index");
+  if (maxPerProbe < 0 || maxPerProbe > 15) return fail("xm_seed_probe_packed: max_per_probe must be 0 ... 15");
   try {
     std::lock_guard<std::mutex> lock(idx->mu);
     HIP_CHECK(hipSetDevice(idx->device));
@@ -1891,7 +1892,7 @@ int xm_seed_probe(xm_index* idx, int64_t n, const int32_t* usedLength, const int
     HIP_CHECK(hipMemcpy(counts, dCounts.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
     if (outPositions && maxPerProbe > 0) HIP_CHECK(hipMemcpy(outPositions, dPos.p, sizeof(int64_t) * (size_t)n * (size_t)maxPerProbe, hipMemcpyDeviceToHost));
     return 0;
-  } catch (std::exception& e) { return fail(std::string("xm_seed_probe: ") + e.what()); }
+  } catch (std::exception& e) { return fail(std::string("xm_seed_probe_packed: ") + e.what()); }
 }
 
 int xm_measure_random_gather(int device, int64_t table_bytes, int64_t accesses, double* kernel_ms) {

@@ -106,7 +106,7 @@ def test_index_builder_matches_oracle(mode, contigs):
 
 
 def _layout(info):  # what describes the index itself (not where or how fast it was built)
-    return {k: v for k, v in info.items() if k not in ("built_on_device", "reserved", "hash_seconds", "duplication_seconds")}
+    return {k: v for k, v in info.items() if k not in ("built_on_device", "reserved", "bucket_line_bytes", "hash_seconds", "duplication_seconds")}
 
 
 def _same_index(A, B):

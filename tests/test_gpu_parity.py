@@ -317,7 +317,7 @@ def test_ambiguous_reference_on_gpu():
 
 
 def _layout(info):  # what describes the index itself (not where or how fast it was built)
-    return {k: v for k, v in info.items() if k not in ("built_on_device", "reserved", "hash_seconds", "duplication_seconds")}
+    return {k: v for k, v in info.items() if k not in ("built_on_device", "reserved", "bucket_line_bytes", "hash_seconds", "duplication_seconds")}
 
 
 def _tables_equal(A, B, what):
