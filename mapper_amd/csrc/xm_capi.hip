@@ -22,8 +22,6 @@
 #include <atomic>
 #include <array>
 #include <type_traits>
-#include <map>
-#include <chrono>
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -1497,7 +1495,10 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     auto gappedTmpBytes = [&](size_t arena) -> size_t { return ((size_t)((arena - arenaPersistBytes(arena)) * (size_t)gappedTmpPct / 100) & ~(size_t)15) + chainExtraTmpBytes(gappedScale); };
     // light pass: a lane's temporaries hold the three matchers alignMatch sets aside (37 KB at scale 1; the chain that would fill them does not
     // run there) and the joined text of overlapping mates; a read's region holds its seeding state: 49 KB single-end, 99 KB paired at scale 1
-    // (ambiguity codes add up to 18 KB per mate: a pair with them overflows its region and is seeded again at the gapped pass's scale)
+    // (ambiguity codes add up to 18 KB per mate: a pair with them in both mates overflows its region - and the region of the same size a gapped-pass lane seeds reads
+    // without saved state in - so it is filed for the pass behind the gapped pass and run from its start at four times the gapped pass's scale, one read per wave.
+    // Correct (the ambiguity fuzz equals the oracle) and late: FASTQ pairs with N tails in both mates pay a latency-bound extra pass.  Known, not fixed: knowing it
+    // at upload would mean reading every base of the batch on the host.)
     const size_t lightTmpUnit = (size_t)envKnob("XM_LIGHT_TMP_KB", 48, 16, 16384) * 1024;
     const size_t regionPersistUnit = (size_t)envKnob("XM_REGION_KB", idx->residentAnyPaired ? 120 : 72, 32, 16384) * 1024;
     const bool handOver = envInt("XM_HANDOVER", 1) != 0;

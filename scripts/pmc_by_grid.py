@@ -22,7 +22,7 @@ for g in sorted(acc, reverse=True):
     groups.append({"grid_threads": g, "launches_profiled": n, "fetch_bytes_per_launch": f * 1024.0, "write_bytes_per_launch": w * 1024.0, "hbm_bytes_per_launch": (f + w) * 1024.0})
 out = {"kernel": "xm_align_kernel", "launches_by_grid": groups,
        "_note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over `python3 bench.py --config %s --steps 6` without the side measurements (scripts/gpu_profile_round_r05.sh); "
-                "KiB as rocprofv3 reports them x 1024 (narrow scattered accesses: no gfx950 wide-load correction applies); a launch is sized by the contexts aligning at the time, so one pass appears under more than one grid" % suffix.replace("_config", "")}
+                "KiB as rocprofv3 reports them x 1024 (narrow scattered accesses: no gfx950 wide-load correction applies); a launch is sized by the contexts that exist on the GPU and by the scratch it gets, so one pass can appear under more than one grid" % suffix.replace("_config", "")}
 try:
     line = json.load(open(os.path.join(root, "bench%s.json" % suffix)))
     out["build"] = line["build"]
