@@ -49,11 +49,13 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads of the same workload timed on the host cores (0 = skip); default: the whole batch (about a second on the GPU box's 256 cores)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="the CPU baseline's timed run is repeated until the oracle has worked this long (best and median run reported)")
     ap.add_argument("--end-to-end-reads", type=int, default=2_000_000, help="reads of the end_to_end leg (--config 1 / 2, N = 1): `python -m mapper_amd` from a FASTQ file on disk to a SAM file on disk (0 = skip)")
-    ap.add_argument("--config", default="1", choices=["1", "1rep", "2", "4shape", "3shape", "4", "4mild"],
+    ap.add_argument("--config", default="1", choices=["1", "1rep", "2", "4shape", "3shape", "3rep", "4", "4mild"],
                     help="1: BASELINE.json configs[1] (single-end 150 bp, the headline); 2: configs[2] shape (2x150 bp pairs, --spacing 100 50); "
                     "4shape: the 1,000 bp queries --split-queries-past-size 1000 makes of configs[4]'s reads, against the same 5 Mb reference; "
                     "3shape / 4 / 4mild: configs[3] / configs[4] on ONE GPU against the 3.1 Gb GRCh38-shaped reference of SURVEY.md section 8(d) "
-                    "(pairs; 10 kb reads split at 1000 with the error rates as stated; the same with 2 %% substitutions + 0.2 %% indel events)")
+                    "(pairs; 10 kb reads split at 1000 with the error rates as stated; the same with 2 %% substitutions + 0.2 %% indel events); "
+                    "3rep: configs[3]'s pairs against the same shape with the repeat structure of a genome (synth.grch38_repeat_rich_reference: 120 k copies of 300 bp families at 85-95 %% "
+                    "identity, 2 000 segmental duplications, 50 000 tandem repeats)")
     ap.add_argument("--stream-batches", type=int, default=4, help="batches of the PCIe-inclusive streamed measurement (api.align_stream: the upload of batch k+1 overlaps the alignment of batch k; 0 = skip)")
     ap.add_argument("--seed-index-mb", type=int, default=500, help="size (M bases) of the second, HBM-resident index the seed-probe leg builds so that its probes miss every cache (0 = probes on the workload's own index only)")
     ap.add_argument("--big-scale", type=float, default=1.0, help="testing: the GRCh38-shaped reference of --config 3shape / 4 / 4mild at this fraction of its size (1.0 = the 3.1 Gb of SURVEY.md section 8(d))")
@@ -91,7 +93,7 @@ def main():
     from mapper_amd import api, synth, _capi
     build = _capi.check_stamp()  # refuses to measure a library that was not built from the sources in the tree
 
-    big = args.config in ("3shape", "4", "4mild")   # the 3.1 Gb GRCh38-shaped reference of SURVEY.md section 8(d), on one GPU
+    big = args.config in ("3shape", "3rep", "4", "4mild")   # the 3.1 Gb GRCh38-shaped reference of SURVEY.md section 8(d), on one GPU
     build_kw = {}
     share = None
     if big and world > 1:
@@ -102,7 +104,11 @@ def main():
         os.makedirs(share, exist_ok=True)
     if big:
         if share is None or rank == 0:
-            contigs, whole, gstarts, gruns = synth.grch38_shaped_reference(scale=args.big_scale)
+            rep_stats = {}
+            if args.config == "3rep":
+                contigs, whole, gstarts, gruns = synth.grch38_repeat_rich_reference(scale=args.big_scale, stats=rep_stats)
+            else:
+                contigs, whole, gstarts, gruns = synth.grch38_shaped_reference(scale=args.big_scale)
             if share is not None:
                 np.save(os.path.join(share, "whole.tmp.npy"), whole)
                 os.replace(os.path.join(share, "whole.tmp.npy"), os.path.join(share, "whole.npy"))
@@ -130,8 +136,8 @@ def main():
 
     def make_queries(cfg, n_reads, source, seed_shift, where=None):
         """-> (mc, mo, ml, codes, exp_in, dev_in, reads_per_query, read_len) of one batch of config `cfg` sampled from `source` (one array)."""
-        if cfg in ("2", "3shape"):
-            seed = (0x5EED0002 if cfg == "2" else 0x5EED0003) + seed_shift
+        if cfg in ("2", "3shape", "3rep"):
+            seed = (0x5EED0002 if cfg == "2" else 0x5EED0003) + seed_shift  # (3rep: configs[3]'s pairs)
             m1, m2 = synth.synthetic_paired_end(source, n_reads, read_len=150, seed=seed, at=where)[:2]
             n, L = m1.shape
             codes_ = np.ascontiguousarray(np.concatenate([m1, m2], axis=1).reshape(-1))
@@ -158,11 +164,11 @@ def main():
         return np.ones(n, np.int32), mo_, ml_, np.ascontiguousarray(reads_.reshape(-1)), np.zeros(n), np.ones(n), 1, L
 
     def sample_starts(cfg, n_reads, starts_, runs_, seed_shift):
-        span = {"3shape": 2 * 150 + 400 + 3 + 153, "4": 10_000 + 2_500 + 8, "4mild": 10_000 + 2_500 + 8}[cfg]
-        return synth.genome_wide_starts(starts_, runs_, n_reads, span, seed=(0x5EED0003 if cfg == "3shape" else 0x5EED0004) ^ 0xF00D ^ seed_shift)[0]
+        span = {"3shape": 2 * 150 + 400 + 3 + 153, "3rep": 2 * 150 + 400 + 3 + 153, "4": 10_000 + 2_500 + 8, "4mild": 10_000 + 2_500 + 8}[cfg]
+        return synth.genome_wide_starts(starts_, runs_, n_reads, span, seed=(0x5EED0003 if cfg in ("3shape", "3rep") else 0x5EED0004) ^ 0xF00D ^ seed_shift)[0]
 
     if big:
-        n_src = args.reads if args.config == "3shape" else max(1, args.reads // 10)   # --reads counts queries (sections) for the long reads
+        n_src = args.reads if args.config in ("3shape", "3rep") else max(1, args.reads // 10)   # --reads counts queries (sections) for the long reads
         mc, mo, ml, codes, exp_in, dev_in, reads_per_query, args.read_len = make_queries(args.config, n_src, whole, 7919 * rank, sample_starts(args.config, n_src, gstarts, gruns, 7919 * rank))
     else:
         mc, mo, ml, codes, exp_in, dev_in, reads_per_query, args.read_len = make_queries(args.config, args.reads, ref, 7919 * rank)
@@ -263,6 +269,7 @@ def main():
 
     if rank == 0:
         info = db.info()
+        overfull = db.bucket_stats() if args.config in ("1rep", "3rep", "3shape") else None
         c = r.counters
         # algorithmic bytes of one step: B_in + 8*P + sum_hits(B_pos + 20) + window bytes + B_out
         pos_bytes = info["position_bytes"]
@@ -366,9 +373,9 @@ def main():
             # SAME-SHAPED reference at 1/200 of its size (24 contigs, N-runs) with the minInterestingSize a 3 Gb reference gets (13,
             # HashBlock_Database.java:52) - the regime of the walk is the big reference's, the tables are smaller (cache-friendlier: flatters the CPU).
             import oracle_lib
-            sc, sw, ss, sr = synth.grch38_shaped_reference(scale=0.005)
-            n_small = min(args.cpu_sample, 100_000 if args.config == "3shape" else 20_000)
-            n_src = n_small if args.config == "3shape" else max(1, n_small // 10)
+            sc, sw, ss, sr = (synth.grch38_repeat_rich_reference if args.config == "3rep" else synth.grch38_shaped_reference)(scale=0.005)
+            n_small = min(args.cpu_sample, 100_000 if args.config in ("3shape", "3rep") else 20_000)
+            n_src = n_small if args.config in ("3shape", "3rep") else max(1, n_small // 10)
             qs = make_queries(args.config, n_src, sw, 0, sample_starts(args.config, n_src, ss, sr, 0))
             o = oracle_lib.OracleReference(sc, mode="mapper", min_interesting_size=13)
             cores = os.cpu_count() or 1
@@ -489,12 +496,14 @@ def main():
                                     "2": "configs[2] shape: %d synthetic 2 x %d bp pairs (--spacing 100 50) per GPU vs %d bp synthetic E. coli-sized reference",
                                     "4shape": "configs[4] shape: %d synthetic %d bp queries (what --split-queries-past-size 1000 makes of 10 kb reads) per GPU vs %d bp synthetic reference",
                                     "3shape": "configs[3] on one GPU: %d synthetic 2 x %d bp pairs (--spacing 100 50, seed 0x5EED0003) sampled genome-wide vs the %d bp GRCh38-shaped synthetic reference (24 contigs, real chromosome lengths, 1 %% N-runs of 10 kb, seed 0x6C38)",
+                                    "3rep": "configs[3]'s read model against a genome that looks like one, on one GPU: %d synthetic 2 x %d bp pairs (--spacing 100 50, seed 0x5EED0003) sampled genome-wide vs the %d bp GRCh38-shaped reference with interspersed repeat families (85-95 %% identity), segmental duplications, tandem repeats and N-runs (synth.grch38_repeat_rich_reference)",
                                     "4": "configs[4] on one GPU: %d queries of %d bp = 10 kb reads (5 %% substitutions + 5 %% indel events per base, seed 0x5EED0004) cut by --split-queries-past-size 1000, vs the %d bp GRCh38-shaped synthetic reference",
                                     "4mild": "configs[4] shape on one GPU with milder reads: %d queries of %d bp = 10 kb reads (2 %% substitutions + 0.2 %% indel events per base) cut by --split-queries-past-size 1000, vs the %d bp GRCh38-shaped synthetic reference"}[args.config] % (nq, args.read_len, args.ref_len),
                        "reads_per_gpu": nq * reads_per_query, "read_len": args.read_len, "reference_len": args.ref_len, "parallelism": "reads sharded x%d" % world,
                        "aligned_reads": aligned, "quick_accept_fraction": round(int(c[7]) / max(1, nq), 4), "candidates_extended_per_query": round(int(c[4]) / max(1, nq), 3),
                        "header_probes_per_query": round(int(c[1]) / max(1, nq), 2),
-                       "reference_repeats": rep_stats if args.config == "1rep" else None,
+                       "reference_repeats": rep_stats if args.config in ("1rep", "3rep") else None,
+                       "overfull_buckets": overfull,
                        "index_build_s": round(index_build_s, 3), "index_bytes": info["index_bytes"],
                        "index_build": {"hashed_on": "gpu" if info["built_on_device"] else "host", "hash_s": round(info["hash_seconds"], 3),
                                        "duplication_map_s": round(info["duplication_seconds"], 3)}},

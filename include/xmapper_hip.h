@@ -153,6 +153,9 @@ int xm_index_load(const char* path, const xm_ref* ref, const xm_build_opts* opts
 int xm_index_ensure_length(xm_index* index, int32_t length);
 void xm_index_free(xm_index* index);
 int xm_index_get_info(const xm_index* index, xm_index_info_t* info);
+/* Diagnostics: buckets of all hashed tables, buckets that hold at least one position, buckets marked overfull (more than max(L^2, 5) entries: their positions
+ * are dropped, HashBlock_Database.java:569-577) - what a repeat-rich genome does to the index. */
+int xm_index_bucket_stats(const xm_index* index, int64_t* buckets, int64_t* occupied, int64_t* overfull);
 /* inspection (parity tests): one PackedMap as (counts per bucket or -1 if overfull, concatenated encoded positions) */
 int xm_index_table_info(const xm_index* index, int32_t used_length, int32_t* capacity, int32_t* max_count_per_key, int64_t* num_stored, int64_t* num_overfull);
 int xm_index_table_dump(const xm_index* index, int32_t used_length, int32_t* counts, int64_t* positions);

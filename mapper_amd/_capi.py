@@ -51,7 +51,7 @@ class XmIndexInfo(C.Structure):
 
 
 EXPORTS = ["xm_last_error", "xm_build_stamp", "xm_abi_version", "xm_device_count", "xm_index_build", "xm_index_replicate", "xm_context_new", "xm_context_set_scratch", "xm_device_memory", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
-           "xm_index_table_info", "xm_index_table_shape", "xm_index_table_dump", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe_packed", "xm_measure_random_gather", "xm_test_local_align", "xm_test_bound_counters", "xm_test_bound", "xm_pileup_new", "xm_pileup_set_query_ends", "xm_pileup_read_middle", "xm_pileup_add_last", "xm_pileup_read", "xm_pileup_events", "xm_pileup_free"]
+           "xm_index_table_info", "xm_index_table_shape", "xm_index_table_dump", "xm_index_bucket_stats", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe_packed", "xm_measure_random_gather", "xm_test_local_align", "xm_test_bound_counters", "xm_test_bound", "xm_pileup_new", "xm_pileup_set_query_ends", "xm_pileup_read_middle", "xm_pileup_add_last", "xm_pileup_read", "xm_pileup_events", "xm_pileup_free"]
 
 
 def build_library(force=False):
@@ -116,6 +116,7 @@ def lib():
         L.xm_index_get_info.argtypes = [C.c_void_p, C.POINTER(XmIndexInfo)]
         L.xm_index_table_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.xm_index_table_shape.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.xm_index_bucket_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.xm_index_table_dump.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.xm_index_dup_keys.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         L.xm_index_dup_keys.restype = C.c_int64

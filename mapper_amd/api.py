@@ -293,6 +293,13 @@ class ReferenceDatabase:
         self._L.xm_index_table_dump(self._h, used_length, counts.ctypes.data, pos.ctypes.data)
         return dict(capacity=cap.value, maxCount=mx.value, counts=counts, positions=pos[:n.value])
 
+    def bucket_stats(self):
+        """{buckets, occupied, overfull} over all hashed tables (overfull: more than max(L^2, 5) entries, HashBlock_Database.java:569-577)."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        if self._L.xm_index_bucket_stats(self._h, C.byref(a), C.byref(b), C.byref(c)):
+            raise RuntimeError(self._L.xm_last_error().decode())
+        return {"buckets": a.value, "occupied": b.value, "overfull": c.value, "overfull_share_of_occupied": round(c.value / max(1, b.value + c.value), 6)}
+
     def dup_keys(self, contig):
         n = self._L.xm_index_dup_keys(self._h, contig, None, 0)
         out = np.zeros(max(n, 1), dtype=np.int32)

@@ -1176,6 +1176,26 @@ int xm_index_table_shape(const xm_index* idx, int32_t L, int32_t* capacity, int3
   return 0;
 }
 
+// How many buckets the hashed tables have, how many hold at least one position, and how many are overfull (more than max(L^2, 5) entries: dropped, HashBlock_Database.java:569-577)
+int xm_index_bucket_stats(const xm_index* idx, int64_t* buckets, int64_t* occupied, int64_t* overfull) {
+  if (!idx || !buckets || !occupied || !overfull) return fail("null argument");
+  std::lock_guard<std::mutex> hostLock(idx->hs->mu);
+  const HostIndex& h = idx->host();
+  int64_t nb = 0, no = 0, nf = 0;
+  for (int L = 0; L <= h.maxHashedLength; L++) {
+    const Table& t = h.tables[(size_t)L];
+    if (t.capacity <= 1) continue;  // (the placeholder maps of lengths that are not hashed)
+    nb += t.capacity;
+    for (int k = 0; k < t.capacity; k++) {
+      const uint32_t a = h.bucketOff[(size_t)t.offBase + (size_t)k], b = h.bucketOff[(size_t)t.offBase + (size_t)k + 1];
+      if (a & XM_OVERFULL) nf++;
+      else if ((b & ~XM_OVERFULL) > (a & ~XM_OVERFULL)) no++;
+    }
+  }
+  *buckets = nb; *occupied = no; *overfull = nf;
+  return 0;
+}
+
 int xm_index_table_dump(const xm_index* idx, int32_t L, int32_t* counts, int64_t* positionsOut) {
   if (!idx) return fail("null index");
   std::lock_guard<std::mutex> hostLock(idx->hs->mu);  // (another context's batch may be growing the shared host tables)

@@ -314,3 +314,84 @@ def repeat_rich_reference(length=5_000_000, seed=0x4E9EA7, n_segdups=100, n_tand
     if stats is not None:
         stats.update(segdup_copy_bases=int(dup_bases), tandem_bases=int(tandem_bases), hot_kmer_copies=int(n_hot), fraction_in_repeats=float(covered.mean()))
     return ref
+
+
+# ---------------------------------------------------------------- the GRCh38 shape with the repeat structure of a genome (round 6)
+def grch38_repeat_rich_reference(scale=1.0, seed=0x6C38, n_families=6, copies=120_000, n_segdups=2_000, n_tandem=50_000, n_hot=5_000, stats=None):
+    """The GRCh38-shaped reference of SURVEY.md section 8(d) (grch38_shaped_reference: 24 contigs with the real length ratios, 1 % of the positions in N-runs of
+    10 kb) with what a real genome has and i.i.d. ACGT lacks, at genome scale (counts are for scale 1.0 and follow `scale`):
+      * interspersed repeats: n_families consensus sequences of 300 bp, `copies` copies in all (family sizes 1 : 2 : 3 ...), each at 85-95 % identity to its
+        consensus (substitutions), either strand, anywhere in the genome - the Alu-like families whose k-mers fill buckets past max(L^2, 5) entries
+        (HashBlock_Database.java:569-577) and whose copies are what DuplicationDetector.java:129-250 has to tell from unique sequence;
+      * segmental duplications: n_segdups segments of 1-50 kb copied to 1-2 other places (any contig) at 95-99.5 % identity, a third reverse-complemented;
+      * tandem repeats: n_tandem loci of a 2-60 bp unit repeated 5-50 times, 2 % of the unit copies with a substitution;
+      * one 28-mer at n_hot places.
+    Returns (contigs, whole, starts, runs) like grch38_shaped_reference; the N-runs are put back last (a repeat never overwrites one).  Pure function of the
+    arguments.  stats (a dict, optional): bases written by each kind, fraction of the positions in a repeat."""
+    contigs, whole, starts, runs = grch38_shaped_reference(scale=scale, seed=seed)
+    total = len(whole)
+    covered = np.zeros(total, dtype=bool)
+    rng = np.random.default_rng(seed ^ 0x3AE9)
+
+    def mutate(seg, rate_ppm, r):
+        do_sub = (r >> np.uint64(44)).astype(np.int64) < np.asarray(rate_ppm, dtype=np.int64) * (1 << 20) // 1_000_000
+        which = ((r & np.uint64(0xFFFF)) % np.uint64(3)).astype(np.int64) + 1
+        return np.where(do_sub & (seg != 15), _CODES[(np.log2(np.where(seg == 15, 1, seg)).astype(np.int64) + which) & 3], seg)
+
+    # interspersed repeats, all copies of a family at once
+    n_copies = max(int(copies * scale), 20 * n_families)
+    fam_len = 300
+    weights = np.arange(1, n_families + 1, dtype=np.float64)
+    per_family = np.maximum((n_copies * weights / weights.sum()).astype(np.int64), 2)
+    family_bases = 0
+    for f in range(n_families):
+        cons = _CODES[(splitmix64(np.uint64(seed ^ (0xFA111 + f)), fam_len) >> np.uint64(62)).astype(np.int64)]
+        k = int(per_family[f])
+        at = rng.integers(0, total - fam_len, k)
+        ident_ppm = rng.integers(850_000, 950_001, k)
+        rs = splitmix64(np.uint64(seed ^ (0xC0B1E5 + f)), k * fam_len).reshape(k, fam_len)
+        cp = mutate(np.broadcast_to(cons, (k, fam_len)), (1_000_000 - ident_ppm)[:, None], rs)
+        rc = rng.random(k) < 0.5
+        cp[rc] = _COMP[cp[rc][:, ::-1]]
+        idx = at[:, None] + np.arange(fam_len)[None, :]
+        whole[idx.reshape(-1)] = cp.reshape(-1)   # (later copies overwrite earlier ones where they overlap)
+        covered[idx.reshape(-1)] = True
+        family_bases += k * fam_len
+    # segmental duplications
+    dup_bases = 0
+    for _ in range(max(int(n_segdups * scale), 10)):
+        seg_len = int(rng.integers(1000, 50_001))
+        if seg_len * 4 > total:
+            seg_len = total // 8
+        src = int(rng.integers(0, total - seg_len))
+        covered[src:src + seg_len] = True
+        for _c in range(int(rng.integers(1, 3))):
+            dst = int(rng.integers(0, total - seg_len))
+            seg = mutate(whole[src:src + seg_len].copy(), 1_000_000 - int(rng.integers(950_000, 995_001)), splitmix64(np.uint64(rng.integers(0, 2**62)), seg_len))
+            if rng.random() < 1 / 3:
+                seg = _COMP[seg[::-1]]
+            whole[dst:dst + seg_len] = seg
+            covered[dst:dst + seg_len] = True
+            dup_bases += seg_len
+    # tandem repeats
+    tandem_bases = 0
+    for _ in range(max(int(n_tandem * scale), 50)):
+        unit, reps = int(rng.integers(2, 61)), int(rng.integers(5, 51))
+        at = int(rng.integers(0, total - unit * reps))
+        t = np.tile(_CODES[rng.integers(0, 4, unit)], reps)
+        t = mutate(t, 20_000, splitmix64(np.uint64(rng.integers(0, 2**62)), len(t)))
+        whole[at:at + len(t)] = t
+        covered[at:at + len(t)] = True
+        tandem_bases += len(t)
+    hot = _CODES[(splitmix64(np.uint64(seed ^ 0x407), 28) >> np.uint64(62)).astype(np.int64)]
+    k_hot = max(int(n_hot * scale), 60)
+    at = rng.integers(0, total - 28, k_hot)
+    whole[(at[:, None] + np.arange(28)[None, :]).reshape(-1)] = np.tile(hot, k_hot)
+    # contig ends and N-runs as they were: a repeat that ran over a contig end is cut there (the arrays are views of `whole`), the N-runs are stamped again
+    for c in range(len(contigs)):
+        for s in runs[c]:
+            whole[starts[c] + s:starts[c] + s + 10_000] = 15
+    if stats is not None:
+        stats.update(interspersed_copies=int(per_family.sum()), interspersed_bases=int(family_bases), segdup_copy_bases=int(dup_bases), tandem_bases=int(tandem_bases),
+                     hot_kmer_copies=int(k_hot), fraction_in_repeats=float(covered.mean()))
+    return contigs, whole, starts, runs

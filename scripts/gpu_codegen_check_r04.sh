@@ -13,7 +13,7 @@ if [ "${1:-build}" = build ]; then
   one() { # name flags...
     n=$1; shift; mkdir -p $V/$n
     /opt/rocm/bin/hipcc $BASE -DXM_BUILD_STAMP='"variant"' "$@" -c -o $V/$n/xm_capi.o xm_capi.hip 2> $V/$n/err.txt &&
-    /opt/rocm/bin/hipcc $BASE -shared -o $V/$n/libxmapper_hip.so $V/$n/xm_capi.o ../_lib/xm_index_device.o ../_lib/xm_sched_kernel.o ../_lib/xm_wave_k*.o && rm -f $V/$n/xm_capi.o
+    /opt/rocm/bin/hipcc $BASE -shared -o $V/$n/libxmapper_hip.so $V/$n/xm_capi.o ../_lib/xm_index_device.o ../_lib/xm_wave_k*.o && rm -f $V/$n/xm_capi.o
   }
   one basic_plain -mllvm -wwm-regalloc=basic &
   one basic_pattern -mllvm -wwm-regalloc=basic -ftrivial-auto-var-init=pattern &

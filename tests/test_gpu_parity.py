@@ -543,13 +543,16 @@ def test_full_size_properties():
     db.close()
 
 
-def test_grch38_regime_alignments_equal_oracle():
+@pytest.mark.parametrize("generator", ["grch38_shaped_reference", "grch38_repeat_rich_reference"], ids=["iid", "repeat-rich"])
+def test_grch38_regime_alignments_equal_oracle(generator):
     """The regime of the walk a 3 Gb reference puts the path in, against the oracle: minInterestingSize = 13 (HashBlock_Database.java:52; passed as the
     constructor argument of :34 on both sides, as the reference itself would derive it from 3.1 G bases) changes which tables exist and how
     HashBlockPath.advanceToNextPosition moves (HashBlockPath.java:143-195).  Reference: the GRCh38-shaped one of SURVEY.md section 8(d) at 1/200 of its
     size (24 contigs, 15 Mb, N-runs of 10 kb; synth.grch38_shaped_reference) - what the oracle can hash; 64-bit position arrays forced as a 3 Gb
-    index has them.  150 bp reads, pairs (--spacing 100 50) and 1 kb reads sampled genome-wide: streams bit for bit, work counters equal."""
-    contigs, whole, starts, runs = synth.grch38_shaped_reference(scale=0.005)
+    index has them.  150 bp reads, pairs (--spacing 100 50) and 1 kb reads sampled genome-wide: streams bit for bit, work counters equal.
+    repeat-rich (round 6): the same shape with interspersed repeat families at 85-95 % identity, segmental duplications and tandem repeats
+    (synth.grch38_repeat_rich_reference: what `bench.py --config 3rep` measures at full size) - overfull buckets, duplication windows, many candidates per read."""
+    contigs, whole, starts, runs = getattr(synth, generator)(scale=0.005)
     assert len(contigs) == 24 and sum(len(r) for r in runs) >= 10
     os.environ["XM_FORCE_POS64"] = "1"
     try:
