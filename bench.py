@@ -63,6 +63,8 @@ def main():
                     "it built (xm_index_save; the other ranks xm_index_load it): one generation and one hashing per node instead of N (default: a directory under the system's temporary directory named after MASTER_PORT)")
     ap.add_argument("--contexts", type=int, default=None, help="contexts per GPU (default: --config 1 three, --config 1rep four, the others two): the steps are dealt to this many contexts of the GPU (xm_context_new: they share the index) that align their resident batches at the same time (1: one launch at a time)")
     ap.add_argument("--single-context-steps", type=int, default=3, help="steps of the one-launch-at-a-time measurement beside the headline at N=1 (0 = skip)")
+    ap.add_argument("--engine", default="gpu", choices=["gpu", "hostsim"], help="testing only: hostsim = a DRY RUN of this script's flow (ranks, barriers, max-over-ranks timing, the rank-0 line) "
+                    "with the kernel sources compiled for the host (tests/hostsim, tests/sim_engine.py) instead of the GPU library; the line it prints is marked as such and is not a measurement")
     ap.add_argument("--wave-steps", type=int, default=2, help="steps of the opt-in wave-per-read form (XM_WAVE=1) measured beside the headline (0 = skip)")
     args = ap.parse_args()
 
@@ -78,20 +80,34 @@ def main():
     import torch
     if args.force_device >= 0:
         local_rank = args.force_device
+    dry = args.engine == "hostsim"
+    if dry and args.backend == "nccl":
+        args.backend = "gloo"
+
+    class _NoGpu:  # (dry run: nothing to select or to wait for)
+        @staticmethod
+        def set_device(i): pass
+        @staticmethod
+        def synchronize(): pass
+    gpu = _NoGpu if dry else torch.cuda
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        gpu.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=args.backend)
     else:
         dist = None
-        torch.cuda.set_device(local_rank)
+        gpu.set_device(local_rank)
     assert args.gpus == world, "--gpus must equal the number of launched ranks"
 
     from mapper_amd import api, synth, _capi
     build = _capi.check_stamp()  # refuses to measure a library that was not built from the sources in the tree
+    if dry:  # TEST HARNESS ONLY: the api's database replaced by the host simulation of the kernel sources (the product has no CPU path)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import sim_engine
+        api = sim_engine.Api(api)
 
     big = args.config in ("3shape", "3rep", "4", "4mild")   # the 3.1 Gb GRCh38-shaped reference of SURVEY.md section 8(d), on one GPU
     build_kw = {}
@@ -178,7 +194,7 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        gpu.synchronize()
 
     def run_steps(contexts, steps):
         """`steps` passes of the hot path, each over one resident batch, dealt to the contexts (one host thread and stream each) as they become free.
@@ -240,7 +256,7 @@ def main():
     if n_ctx > 1 and world == 1 and args.single_context_steps > 0:
         db.upload_arrays(mc, mo, ml, codes, exp_in, dev_in)
         run_steps([db], max(1, args.warmup))
-        torch.cuda.synchronize()
+        gpu.synchronize()
         k1 = args.single_context_steps
         sec, kms, nl, _, pus, _ = run_steps([db], k1)
         single = {"value": round(nq * reads_per_query * k1 / sec / 1e6, 4), "unit": "Mreads/s", "steps": k1, "ms_per_step": round(sec / k1 * 1e3, 3),
@@ -263,10 +279,16 @@ def main():
     elapsed, kernel_ms, launches, d2h_ms, pass_us, r = run_steps(ctx, args.steps)
     barrier()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dry or args.backend != "nccl" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # which reads every rank aligned (a digest of its batch): the ranks' shards must differ (seed shift 7919 x rank)
+        import hashlib
+        digests = [None] * world
+        dist.all_gather_object(digests, hashlib.sha256(np.ascontiguousarray(codes).tobytes()).hexdigest()[:16])
 
+    if world == 1:
+        digests = None
     if rank == 0:
         info = db.info()
         overfull = db.bucket_stats() if args.config in ("1rep", "3rep", "3shape") else None
@@ -490,7 +512,8 @@ def main():
         line = {
             "metric": "M reads/s aligned (150 bp)", "value": round(value, 4), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not dry else "synthetic; DRY RUN on the host simulation of the kernel sources (--engine hostsim): the multi-rank flow is exercised, nothing is measured",
+            "rank_batch_digests": digests if world > 1 else None,
             "config": {"workload": {"1": "configs[1]: %d synthetic %d bp single-end reads per GPU vs %d bp synthetic E. coli-sized reference (index replicated, reads sharded, no collective)",
                                     "1rep": "configs[1]'s reads on a repeat-rich reference: %d synthetic %d bp single-end reads per GPU vs %d bp synthetic reference with segmental duplications (90-99.5 %% identity), tandem repeats and an overfull-bucket 28-mer (synth.repeat_rich_reference)",
                                     "2": "configs[2] shape: %d synthetic 2 x %d bp pairs (--spacing 100 50) per GPU vs %d bp synthetic E. coli-sized reference",
