@@ -286,9 +286,12 @@ def main():
         import hashlib
         digests = [None] * world
         dist.all_gather_object(digests, hashlib.sha256(np.ascontiguousarray(codes).tobytes()).hexdigest()[:16])
+        pinned = [None] * world
+        dist.all_gather_object(pinned, _capi.pinned_host_bytes()[1])   # page-locked host memory of every rank's result buffers (high-water mark): eight ranks share one host
 
     if world == 1:
         digests = None
+        pinned = [_capi.pinned_host_bytes()[1]]
     if rank == 0:
         info = db.info()
         overfull = db.bucket_stats() if args.config in ("1rep", "3rep", "3shape") else None
@@ -514,6 +517,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not dry else "synthetic; DRY RUN on the host simulation of the kernel sources (--engine hostsim): the multi-rank flow is exercised, nothing is measured",
             "rank_batch_digests": digests if world > 1 else None,
+            "pinned_host_bytes_high_water_per_rank": pinned,
             "config": {"workload": {"1": "configs[1]: %d synthetic %d bp single-end reads per GPU vs %d bp synthetic E. coli-sized reference (index replicated, reads sharded, no collective)",
                                     "1rep": "configs[1]'s reads on a repeat-rich reference: %d synthetic %d bp single-end reads per GPU vs %d bp synthetic reference with segmental duplications (90-99.5 %% identity), tandem repeats and an overfull-bucket 28-mer (synth.repeat_rich_reference)",
                                     "2": "configs[2] shape: %d synthetic 2 x %d bp pairs (--spacing 100 50) per GPU vs %d bp synthetic E. coli-sized reference",

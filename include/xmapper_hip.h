@@ -120,6 +120,9 @@ const char* xm_build_stamp(void);
 /* Version of this header's structs and entry points: 2 = xm_result.extra[] appended, xm_seed_probe_packed replaces xm_seed_probe.  A binding checks it once
  * after loading the library (mapper_amd/_capi.py, bindings/java/xmapper_jni.c). */
 int32_t xm_abi_version(void);
+/* Page-locked host memory this process holds through the library's pool of result buffers (in use + kept for reuse; at most 4 GiB are kept idle), and - through
+ * high_water, if not NULL - the most it ever held.  Eight ranks of a node, each with several contexts, all pin host memory: bench.py prints the mark per rank. */
+int64_t xm_pinned_host_bytes(int64_t* high_water);
 int xm_device_count(void);
 
 /* Replaces new SequenceDatabase + new HashBlock_Database(...).prepare() + new DuplicationDetector(...).helpSetup()

@@ -50,7 +50,7 @@ class XmIndexInfo(C.Structure):
                 ("hash_seconds", C.c_double), ("duplication_seconds", C.c_double)]
 
 
-EXPORTS = ["xm_last_error", "xm_build_stamp", "xm_abi_version", "xm_device_count", "xm_index_build", "xm_index_replicate", "xm_context_new", "xm_context_set_scratch", "xm_device_memory", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
+EXPORTS = ["xm_last_error", "xm_build_stamp", "xm_abi_version", "xm_pinned_host_bytes", "xm_device_count", "xm_index_build", "xm_index_replicate", "xm_context_new", "xm_context_set_scratch", "xm_device_memory", "xm_index_save", "xm_index_load", "xm_index_ensure_length", "xm_index_free", "xm_index_get_info",
            "xm_index_table_info", "xm_index_table_shape", "xm_index_table_dump", "xm_index_bucket_stats", "xm_index_dup_keys", "xm_align_batch", "xm_result_free", "xm_batch_upload", "xm_batch_stage", "xm_batch_commit", "xm_align_resident", "xm_seed_probe_packed", "xm_measure_random_gather", "xm_test_local_align", "xm_test_bound_counters", "xm_test_bound", "xm_pileup_new", "xm_pileup_set_query_ends", "xm_pileup_read_middle", "xm_pileup_add_last", "xm_pileup_read", "xm_pileup_events", "xm_pileup_free"]
 
 
@@ -104,6 +104,8 @@ def lib():
             raise ImportError("%s implements another version of include/xmapper_hip.h than this binding (%d): rebuild it (make -j8 -C mapper_amd/csrc)" % (path, ABI_VERSION))
         L.xm_last_error.restype = C.c_char_p
         L.xm_build_stamp.restype = C.c_char_p
+        L.xm_pinned_host_bytes.restype = C.c_int64
+        L.xm_pinned_host_bytes.argtypes = [C.POINTER(C.c_int64)]
         L.xm_index_build.argtypes = [C.POINTER(XmRef), C.POINTER(XmBuildOpts), C.POINTER(C.c_void_p)]
         L.xm_index_save.argtypes = [C.c_void_p, C.c_char_p]
         L.xm_index_replicate.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
@@ -232,3 +234,10 @@ def want_hardware_queues(n=8):
     warnings.warn("GPU_MAX_HW_QUEUES was %s when the library was loaded and the HIP runtime may already be initialised: more than two contexts per GPU will share hardware queues "
                   "(set the variable before the first import that touches the GPU)" % (seen or "unset"))
     return False
+
+
+def pinned_host_bytes():
+    """(bytes of page-locked host memory the library's result-buffer pool holds now, the most it ever held) in this process."""
+    hw = C.c_int64()
+    now = lib().xm_pinned_host_bytes(C.byref(hw))
+    return int(now), int(hw.value)

@@ -621,6 +621,12 @@ struct PinnedPool {
   std::mutex mu;
   std::vector<Buf> idle;
   size_t idleBytes = 0;
+  std::atomic<size_t> allocatedBytes{0}, highWater{0};  // pinned host memory this process holds through the pool (in use + idle), and the most it ever held
+  void account(long long delta) {
+    const size_t now = (size_t)((long long)allocatedBytes.fetch_add((size_t)delta) + delta);
+    size_t hw = highWater.load();
+    while (now > hw && !highWater.compare_exchange_weak(hw, now)) {}
+  }
   void* get(size_t bytes, size_t* got) {
     if (bytes < 64) bytes = 64;
     {
@@ -639,6 +645,7 @@ struct PinnedPool {
     void* p = nullptr;
     size_t want = bytes + bytes / 8;  // headroom so that the next, slightly larger batch reuses it
     HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocPortable));
+    account((long long)want);
     *got = want;
     return p;
   }
@@ -655,7 +662,7 @@ struct PinnedPool {
         idle.erase(idle.begin());
       }
     }
-    for (auto& b : drop) (void)hipHostFree(b.p);
+    for (auto& b : drop) { (void)hipHostFree(b.p); account(-(long long)b.bytes); }
   }
 };
 static PinnedPool* g_pinned = new PinnedPool();  // never destroyed: the HIP runtime may be gone before static destructors run
@@ -964,6 +971,10 @@ const char* xm_last_error(void) { return g_error.c_str(); }
 #endif
 const char* xm_build_stamp(void) { return XM_BUILD_STAMP; }
 int32_t xm_abi_version(void) { return 2; }
+int64_t xm_pinned_host_bytes(int64_t* high_water) {
+  if (high_water) *high_water = (int64_t)g_pinned->highWater.load();
+  return (int64_t)g_pinned->allocatedBytes.load();
+}
 
 int xm_device_count(void) {
   int n = 0;
