@@ -19,6 +19,8 @@
 #include <string.h>
 #include "xmapper_hip.h"
 
+#define XMJ_ABI_VERSION 2  /* include/xmapper_hip.h as of round 6 */
+
 /* ---------------------------------------------------------------- part 1: marshalling on plain C arrays ---------------------------------------- */
 
 /* AlignmentParameters (AlignmentParameters.java:8-33) as NativeAligner passes them: nine doubles in field order + MaxNumMatches. */
@@ -42,6 +44,8 @@ int xmj_build_index(int32_t num_contigs, const uint8_t* const* codes, const int6
                     int32_t duplication_window, int32_t max_query_length, int32_t device, xm_index** out) {
   xm_ref ref;
   xm_build_opts o;
+  /* the library must implement the header this shim was compiled against (version 2: xm_result.extra[], xm_seed_probe_packed); -2 = it does not */
+  if (xm_abi_version() != XMJ_ABI_VERSION) return -2;
   memset(&ref, 0, sizeof(ref));
   memset(&o, 0, sizeof(o));
   ref.num_contigs = num_contigs;
