@@ -347,6 +347,17 @@ def test_kernel_logic_rejection_filter_decides_like_the_oracle_observer():
     assert seen.get((2, 0), 0) > 400 and seen.get((1, 1), 0) > 400 and seen.get((0, 0), 0) + seen.get((0, 1), 0) > 200, seen
 
 
+def test_kernel_logic_rejection_filter_fuzz_through_the_whole_chain(monkeypatch):
+    """scripts/cpu_filter_fuzz.py (profiles/r06/fuzz_filter_sim.log has 200 batches of it): batches of long reads with random lengths, error rates, ambiguity codes and prices
+    through the kernel sources with the filter on against the oracle with its observer on - streams bit for bit, the filter's counters equal the observer's batch by batch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cpu_filter_fuzz", os.path.join(ROOT, "scripts", "cpu_filter_fuzz.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    monkeypatch.setattr("sys.argv", ["cpu_filter_fuzz.py", "10", "61"])
+    fuzz.main()
+
+
 def test_kernel_logic_edge_cases():
     """ragged / tiny / unalignable reads, reads hanging over contig ends, repeats, multi-contig reference, long reads."""
     rng = np.random.default_rng(3)

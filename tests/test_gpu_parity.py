@@ -575,11 +575,14 @@ def test_grch38_regime_alignments_equal_oracle(generator):
     near = np.concatenate([starts[c] + runs[c][:2] - 100 for c in range(24) if len(runs[c])])
     batches["at N-runs"] = se_batch(synth.synthetic_single_end(whole, len(near), seed=0x140, at=near)[0])
     for name, b in batches.items():
-        got, _ = gpu_align(db, b, params)
-        want = R.align(b, oparams, threads=os.cpu_count())
+        got, raw = gpu_align(db, b, params)
+        with o.observe_bound():   # (the 1 kb batch runs with the rejection filter in front of PathAligner: the observer says which searches it skips)
+            want = R.align(b, oparams, threads=os.cpu_count())
         assert streams_equal(got, want), name + ": " + str(first_difference(got, want, b.nq))
         wc = [int(x) for x in want.counters[:9]]  # (the oracle counts probes and fetches apart; compared as bench.py compares them)
-        assert [int(x) for x in got.counters[:8]] == [wc[0], wc[1] + wc[2], wc[2], wc[3], wc[5], wc[6], wc[7], wc[8]], name
+        skipped = int(want.counters[12]) if raw.extra[3] else 0   # nodes of the searches the filter proved null without running them
+        assert (raw.extra[3] == 1) == (name == "1 kb") and int(raw.extra[1]) == (int(want.counters[11]) if raw.extra[3] else 0), name
+        assert [int(x) for x in got.counters[:8]] == [wc[0], wc[1] + wc[2], wc[2], wc[3], wc[5], wc[6], wc[7] - skipped, wc[8]], name
     assert R.index_info()[0] == 13
     db.close()
 
