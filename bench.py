@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--share-dir", default=None, help="--gpus N with --config 3shape / 4 / 4mild: where rank 0 leaves the synthetic reference (memory-mapped by the other ranks) and the index "
                     "it built (xm_index_save; the other ranks xm_index_load it): one generation and one hashing per node instead of N (default: a directory under the system's temporary directory named after MASTER_PORT)")
     ap.add_argument("--contexts", type=int, default=None, help="contexts per GPU (default: --config 1 three, --config 1rep four, the others two): the steps are dealt to this many contexts of the GPU (xm_context_new: they share the index) that align their resident batches at the same time (1: one launch at a time)")
+    ap.add_argument("--scratch-gib", type=float, default=0.0, help="upper limit of a context's scratch in GiB (0: what is free, divided between the contexts, up to 200 GiB): the headline against the scratch budget (profiles/r06/scratch_budget.log)")
     ap.add_argument("--single-context-steps", type=int, default=3, help="steps of the one-launch-at-a-time measurement beside the headline at N=1 (0 = skip)")
     ap.add_argument("--engine", default="gpu", choices=["gpu", "hostsim"], help="testing only: hostsim = a DRY RUN of this script's flow (ranks, barriers, max-over-ranks timing, the rank-0 line) "
                     "with the kernel sources compiled for the host (tests/hostsim, tests/sim_engine.py) instead of the GPU library; the line it prints is marked as such and is not a measurement")
@@ -265,11 +266,14 @@ def main():
                   "note": "one context with the whole scratch budget, one launch on the GPU at a time"}
     ctx = [db] + [db.new_context() for _ in range(n_ctx - 1)]  # contexts share the index (host tables and tables in HBM), xm_context_new
     if n_ctx > 1:
-        n_use, scratch_each = api.divide_scratch(ctx, local_rank)  # what is free now (the index is resident), in equal parts
+        n_use, scratch_each = api.divide_scratch(ctx, local_rank, **({"most": int(args.scratch_gib * 2**30)} if args.scratch_gib > 0 else {}))  # what is free now (the index is resident), in equal parts
         for c_ in ctx[n_use:]:
             c_.close()
         ctx = ctx[:n_use]
         n_ctx = len(ctx)
+    if n_ctx == 1 and args.scratch_gib > 0:
+        db.set_scratch(int(args.scratch_gib * 2**30))
+        scratch_each = int(args.scratch_gib * 2**30)
     for c_ in ctx:
         c_.upload_arrays(mc, mo, ml, codes, exp_in, dev_in)  # inputs resident in HBM before the timed region: every context has its batch
 
@@ -548,7 +552,7 @@ def main():
                                  "launch at a time; frac_one_launch_at_a_time is this fraction from that leg) and frac_of_all_concurrent_launches is the algorithmic rate of the GPU as a whole.  traffic (PMC) is per-lane scratch in HBM, touched in "
                                  "scattered 32-64 B pieces: traffic_rate (GB/s, traffic / average launch duration) is to be read against this GPU's measured "
                                  "random-64-B-sector ceiling (seed_probe.random_64B_gather_ceiling_sectors_per_s x 64 B), not against the stream peak"},
-            "contexts": {"per_gpu": n_ctx, "scratch_gib_each": round(scratch_each / 2**30, 1) if n_ctx > 1 else None,
+            "contexts": {"per_gpu": n_ctx, "scratch_gib_each": round(scratch_each / 2**30, 1) if scratch_each else None,
                          "note": "a step is one whole pass of the hot path over one resident batch; the steps are dealt to %d contexts of the GPU (xm_context_new: one index - host "
                                  "tables and tables in HBM - shared by all; a resident copy of the batch, a host thread, a stream and a share of the scratch each) that align at the same time: "
                                  "the wave slots one context's gapped pass leaves idle are filled by the others' passes (profiles/r02/NOTES.md 12, 14; profiles/r03/NOTES.md)" % n_ctx if n_ctx > 1 else "one context"},
