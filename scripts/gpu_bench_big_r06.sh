@@ -8,5 +8,10 @@ cd $R
 ulimit -c 0
 TAG=${1:-on}
 if [ "$TAG" = "off" ]; then export XM_BOUND_FILTER=0; fi
-timeout 2400 python3 bench.py --config 4 --reads ${2:-6250000} --contexts 1 --steps 1 --warmup 0 --seed-probes 0 --stream-batches 0 --single-context-steps 0 --cpu-sample 20000 2> $O/bench_config4_share_$TAG.err | tail -n 1 > $O/bench_config4_share_$TAG.json
-cut -c1-900 $O/bench_config4_share_$TAG.json; echo; tail -3 $O/bench_config4_share_$TAG.err
+[ "$3" = "3rep" ] || timeout 2400 python3 bench.py --config 4 --reads ${2:-6250000} --contexts 1 --steps 1 --warmup 0 --seed-probes 0 --stream-batches 0 --single-context-steps 0 --cpu-sample 20000 2> $O/bench_config4_share_$TAG.err | tail -n 1 > $O/bench_config4_share_$TAG.json
+[ "$3" = "3rep" ] || { cut -c1-900 $O/bench_config4_share_$TAG.json; echo; tail -3 $O/bench_config4_share_$TAG.err; }
+# configs[3]'s pairs at one GPU's share against the GRCh38 shape with the repeat structure of a genome (third argument "3rep")
+if [ "$3" = "3rep" ]; then
+timeout 2400 python3 bench.py --config 3rep --reads ${4:-6250000} --steps 4 --warmup 1 --seed-probes 0 --stream-batches 0 --single-context-steps 1 --cpu-sample 200000 2> $O/bench_config3rep.err | tail -n 1 > $O/bench_config3rep.json
+cut -c1-1500 $O/bench_config3rep.json; echo; tail -3 $O/bench_config3rep.err
+fi
