@@ -392,10 +392,13 @@ def main():
             with ol_.observe_bound():
                 w_ = orc.align(batch_, ol_.make_params(), threads=os.cpu_count() or 1)
             oc = [int(x) for x in w_.counters]
-            f_ = {"device": {"searches_examined": int(dev.extra[0]), "searches_rejected": int(dev.extra[1]), "cells": int(dev.extra[2]), "path_aligner_calls": int(dev.counters[5]), "nodes": int(dev.counters[6])},
-                  "oracle_observer": {"searches_examined": oc[13], "searches_rejected": oc[11], "nodes_in_rejected_searches": oc[12], "searches_returning_null": oc[9], "nodes_in_null_searches": oc[10],
-                                      "path_aligner_calls": oc[6], "nodes": oc[7]}}
-            f_["equal"] = (int(dev.extra[0]) == oc[13] and int(dev.extra[1]) == oc[11] and int(dev.counters[5]) == oc[6] and int(dev.counters[6]) + oc[12] == oc[7])
+            want_ = {"searches_examined": oc[13], "searches_rejected": oc[11], "pieces_examined": oc[14], "pieces_rejected": oc[15], "path_aligner_calls": oc[6] - oc[16], "nodes": oc[7] - oc[12] - oc[17]}
+            got_ = {"searches_examined": int(dev.extra[0]), "searches_rejected": int(dev.extra[1]), "pieces_examined": int(dev.extra[4]), "pieces_rejected": int(dev.extra[5]),
+                    "path_aligner_calls": int(dev.counters[5]), "nodes": int(dev.counters[6])}
+            f_ = {"device": dict(got_, cells=int(dev.extra[2])), "oracle_observer": want_,
+                  "reference": {"path_aligner_calls": oc[6], "nodes": oc[7], "searches_returning_null": oc[9], "nodes_in_null_searches": oc[10], "nodes_in_rejected_searches": oc[12],
+                                "calls_in_rejected_pieces": oc[16], "nodes_in_rejected_pieces": oc[17]},
+                  "equal": got_ == want_}
             return f_
         if extras and args.cpu_sample > 0 and big:
             # No oracle hashes 3.1 G bases in bounded time (15 Mb take it a minute), so the CPU path is timed on the same workload against the
@@ -453,8 +456,9 @@ def main():
                 counters["oracle"] = wc
                 bf = bound_filter_check(r, o, b)
                 counters["bound_filter"] = bf
-                skipped = bf["oracle_observer"]["nodes_in_rejected_searches"] if bf else 0  # (nodes of searches the filter proved null without running them)
-                counters["equal"] = counters["device"][:8] == [wc[0], wc[1] + wc[2], wc[2], wc[3], wc[5], wc[6], wc[7] - skipped, wc[8]] and (bf is None or bf["equal"])
+                skipped = bf["reference"]["nodes_in_rejected_searches"] + bf["reference"]["nodes_in_rejected_pieces"] if bf else 0  # (nodes the filter made unnecessary)
+                skipped_calls = bf["reference"]["calls_in_rejected_pieces"] if bf else 0
+                counters["equal"] = counters["device"][:8] == [wc[0], wc[1] + wc[2], wc[2], wc[3], wc[5], wc[6] - skipped_calls, wc[7] - skipped, wc[8]] and (bf is None or bf["equal"])
             java = java_reference(ref, codes, nq, args)
             if java is not None:
                 cpu["java_reference"] = java

@@ -99,7 +99,9 @@ typedef struct xm_result {
   int64_t prof[16];   /* diagnostic builds (-DXM_PROFILE=1: summed over lanes, =2: per wave) only: shader-clock ticks per phase; otherwise 0 */
   /* (appended in ABI version 2; xm_abi_version())  the rejection filter in front of PathAligner (batches of long reads): 0 searches it examined, 1 searches it
    * proved null without running them (PathAligner.java:169: the search would have returned null after exploring every node within the budget; their nodes
-   * are not in counters[6]), 2 cells of the bounding recurrence it computed, 3 = 1 when a pass of this call ran with the filter; 4-7 reserved (0) */
+   * are not in counters[6]), 2 cells of the bounding recurrence it computed, 3 = 1 when a pass of this call ran with the filter; 4 pieces (BlockAligner.alignPiece,
+   * BlockAligner.java:215-249) the filter examined, 5 pieces it proved unalignable within their budget before their chain ran (their PathAligner calls and nodes are in neither counters[5] nor
+   * counters[6]); 6-7 reserved (0) */
   int64_t extra[8];
 } xm_result;
 

@@ -39,7 +39,7 @@ constexpr int XM_BOUND_KMAX = 200;        // band slots of a region in LDS (+ on
 constexpr int XM_BOUND_MMAX = 456;        // bases of the reference window in a region in LDS
 constexpr int XM_BOUND_REGION = (XM_BOUND_KMAX + 1) * 4 + XM_BOUND_MMAX;  // 1260 bytes = 315 words (odd: the regions of a wave start in different LDS banks)
 constexpr int XM_BOUND_REGIONS = 8;       // per wave
-constexpr int XM_BOUND_KMAX_WIDE = 1024;  // problems that do not fit a region (a window far longer than the query: a third of a percent of the searches of configs[4],
+constexpr int XM_BOUND_KMAX_WIDE = 2048;  // problems that do not fit a region (a window far longer than the query: a third of a percent of the searches of configs[4],
 constexpr int XM_BOUND_MMAX_WIDE = 4096;  // a seventh of their nodes): the same recurrence in the lane's temporaries in HBM
 constexpr int XM_BOUND_INF = 0xFFFF;      // a value beyond the budget (budgets stay below 60000 units)
 
@@ -48,6 +48,8 @@ struct BoundProblem {
   const uint8_t* qBase; int32_t qLen; bool qRc; const uint8_t* rBase; int32_t referenceLen;
   int32_t startA, endA, startB, endB, predictedBestOffset;
   double mutation, insStart, insExt, delStart, delExt, maxErrorRate, ambiguity;
+  double budget;   // the penalty the answer must stay within (a search: its maxInterestingPenalty = section length x MaxErrorRate, :60; a piece: BlockAligner's maxPenalty)
+  int32_t piece;   // 1: the bound over a piece's whole inner chain (boundPieceProblem below): both ends of the window free, the piece's first and last base left out
 };
 
 struct BoundPrices { int32_t mut, isie, ie, dsde, de, amb1, amb2, amb3, thr; };
@@ -55,9 +57,7 @@ struct BoundPrices { int32_t mut, isie, ie, dsde, de, amb1, amb2, amb3, thr; };
 // prices and budget on the grid (the oracle's observer evaluates the same expressions: IEEE double products and floors)
 XM_INL bool boundPrices(const BoundProblem& b, BoundPrices& c) {
   const double s = (double)XM_BOUND_SCALE;
-  const int n = b.endA - b.startA;
-  const double maxInterestingPenalty = n * b.maxErrorRate;  // :60
-  const double t = floor((maxInterestingPenalty + 0.000001 + 0.0000001) * s);
+  const double t = floor((b.budget + 0.000001 + 0.0000001) * s);
   if (!(t >= 0 && t < 60000.0)) return false;
   c.thr = (int32_t)t;
   c.mut = (int32_t)floor(b.mutation * s);
@@ -73,13 +73,14 @@ XM_INL bool boundPrices(const BoundProblem& b, BoundPrices& c) {
 }
 
 // Geometry of the band: false = the filter does not take the problem (the search runs).  dlo: diagonal of slot 0; K slots.
-XM_INL bool boundBand(int n, int m, bool mayExtend, const BoundPrices& c, int& dlo, int& K) {
+XM_INL bool boundBand(int n, int m, bool mayExtend, const BoundPrices& c, int& dlo, int& K, bool freeStart = false) {
   // not taken: windows at a contig end in the search's direction (start nodes with unaligned moves at 0.1 per base: :141-150,592-594)
   if (mayExtend || n < 1 || m < 1 || m > XM_BOUND_MMAX_WIDE) return false;
   const int maxIns = c.thr < c.isie ? 0 : (c.thr - c.isie) / c.ie + 1;   // bases all insertions of a path within the budget can hold
   const int maxDel = c.thr < c.dsde ? 0 : (c.thr - c.dsde) / c.de + 1;
   // start nodes: (0, y') for y' = 0 .. m - n (:120-131), or - a window shorter than the query - (x', 0) for x' = 0 .. n - m (:132-139): diagonals 0 .. m - n or n - m .. 0
-  const int d0 = m >= n ? 0 : -(n - m), d1 = m >= n ? m - n : 0;
+  // (freeStart - the bound over a piece's whole chain: a start node at every row of column 0)
+  const int d0 = freeStart ? 0 : (m >= n ? 0 : -(n - m)), d1 = freeStart ? m : (m >= n ? m - n : 0);
   dlo = d0 - maxIns;
   if (dlo < -n) dlo = -n;
   int dhi = d1 + maxDel;
@@ -116,7 +117,7 @@ XM_INL uint8_t* boundRegion(bool) { static thread_local uint32_t region[(XM_BOUN
 // or both in the lane's temporaries in HBM (WIDE).  true = no cell of column n stays within the budget.
 template <bool WIDE, typename CharA>
 XM_INL bool boundSweep(typename std::conditional<WIDE, XM_GLOBAL(uint32_t)*, uint32_t*>::type const W, typename std::conditional<WIDE, XM_GLOBAL(const uint8_t)*, const uint8_t*>::type const TB,
-                       const BoundPrices& c, int n, int m, int dlo, int K, bool searchReverse, CharA charA, unsigned long long& cells) {
+                       const BoundPrices& c, int n, int m, int dlo, int K, bool searchReverse, CharA charA, unsigned long long& cells, bool freeStart = false) {
   // (prices as scalars: a struct the compiler keeps in private memory would cost a trip to it per use)
   const int thr = c.thr, mut = c.mut, isie = c.isie, ie = c.ie, dsde = c.dsde, de = c.de;
   const unsigned long long ambPacked = ((unsigned long long)(unsigned)c.amb1 << 16) | ((unsigned long long)(unsigned)c.amb2 << 32) | ((unsigned long long)(unsigned)c.amb3 << 48);
@@ -127,8 +128,9 @@ XM_INL bool boundSweep(typename std::conditional<WIDE, XM_GLOBAL(uint32_t)*, uin
   };
   // column 0: the start nodes (0, y') for y' = 0 .. m - n at penalty 0, insertion state "disallowed" (:120-131 with startingInsertionStartPenalty disallowed;
   // a window shorter than the query: (0, 0) alone, and one start node (x', 0) at the foot of every column up to n - m, :132-139)
-  int lo = -dlo, hi = -dlo + (m >= n ? m - n : 0);
-  for (int k = lo; k <= hi; k++) W[k] = (uint32_t)XM_BOUND_INF << 16;
+  // (freeStart: every row of column 0 is a start node, and a path may arrive there in the middle of an insertion: insertion state 0 as well)
+  int lo = -dlo, hi = -dlo + (freeStart ? m : (m >= n ? m - n : 0));
+  for (int k = lo; k <= hi; k++) W[k] = freeStart ? 0u : (uint32_t)XM_BOUND_INF << 16;
   unsigned long long done = 0;
   uint8_t aNext = charA(searchReverse ? n - 1 : 0);
   for (int x = 1; x <= n; x++) {
@@ -136,7 +138,7 @@ XM_INL bool boundSweep(typename std::conditional<WIDE, XM_GLOBAL(uint32_t)*, uin
     if (x < n) aNext = charA(searchReverse ? n - 1 - x : x);
     // slot k of this column is the cell (x, y' = x + dlo + k); cells exist for 1 <= y' <= m
     const int kGeom = 1 - x - dlo;
-    const bool foot = x <= n - m;                                 // a start node (x, 0) below the column's first cell
+    const bool foot = !freeStart && x <= n - m;                   // a start node (x, 0) below the column's first cell
     int k = foot ? kGeom : imax(imax(lo - 1, kGeom), 0);
     const int kEnd = imin(K - 1, m - x - dlo);
     int newLo = 0x7FFFFFFF, newHi = -1;
@@ -203,6 +205,29 @@ XM_INL bool boundSweep(typename std::conditional<WIDE, XM_GLOBAL(uint32_t)*, uin
   return false;
 }
 
+// The bound over a PIECE's whole inner chain (BlockAligner.alignPiece :215-249 -> StraightAligner -> HashBlock_Aligner -> StraightAligner -> PathAligner_Runner): when it holds,
+// alignPiece returns null, and the chain below it - its hash-block analyses above all - need not run.  Why: every way the chain has of answering is a path through the same grid.
+//   * A search (PathAligner) is handed the piece and a window INSIDE this one (HashBlock_Aligner only narrows, :64-80), in either direction; its nodes' penalties are bounded from
+//     below by the recurrence over the larger window with a start node at every row (fewer start nodes, a smaller grid: only higher values).  A window one base shorter than the
+//     piece (an offset of maxPossibleOffset + 1, which the matcher's inclusive upper limit allows, :128-131) gives the search one free query base (:132-139): the piece's first
+//     and last base are left out of the recurrence, which only lowers it.
+//   * A straight alignment (StraightAligner.straightAlignment :73-94) at an offset inside [minPossibleOffset, maxPossibleOffset + 1] covers all of the piece but possibly its last
+//     base, one diagonal of the grid; StraightAligner returns it only if its aligned penalty is within the budget (:28-70: "<= 0", "<= maxInterestingPenalty").
+//   * The budgets down the chain only shrink (StraightAligner :62-64, MaxErrorRate = min(rate, MaxErrorRate)).
+//   * A path may arrive at the first kept column in the middle of an insertion or of a deletion run: the start nodes carry insertion state 0, and sit at every row.
+// Conditions (the caller checks them; the oracle's observer the same ones): the window touches neither end of the contig (no unaligned moves, :141-150,592-594); it is at least as
+// long as the piece; the offset the chain starts from lies in [minPossibleOffset, maxPossibleOffset + 1] (a straight alignment is not cut by the window); and the analyses of the
+// chain would not share the caller's matcher (HashBlock_Aligner.java:113-121: its section length is more than 1.5 x the piece's lookup uncertainty, or there is none) - a shared
+// matcher's sections are indexed, or marked null, in the order lookups reach them (:203-215), and skipping lookups would change what later analyses see.
+XM_INL bool boundPieceApplies(int qStart, int qEnd, int wStart, int wEnd, int referenceLen, int parentOffset, bool parentHasMatcher, int parentSectionLength) {
+  const int n = qEnd - qStart, m = wEnd - wStart;
+  if (n < 8 || m < n || wStart <= 0 || wEnd >= referenceLen) return false;
+  const int minOff = wStart - qStart, maxOff = wEnd - qEnd, u = maxOff - minOff;
+  if (parentOffset < minOff || parentOffset > maxOff + 1) return false;
+  if (parentHasMatcher && !(parentSectionLength > u + u / 2)) return false;
+  return true;
+}
+
 // true = the search of this problem returns null (proved); false = not decided.  taken / cells: whether the filter took the problem, and the cells it computed.
 // tmp: the lane's temporaries (a problem too wide for a region of the wave's slot keeps its band there, for the length of this call)
 // (out of line: inlined into pathAlign - i.e. into innerChain - the same code made gapped passes with several reads per wave end in a memory fault, with the
@@ -212,16 +237,19 @@ XM_NOINL bool boundRejects(const BoundProblem& bp, bool pair, Arena& tmp, bool& 
   cells = 0;
   BoundPrices c;
   if (!boundPrices(bp, c)) return false;
-  const int n = bp.endA - bp.startA, m = bp.endB - bp.startB;
+  const bool piece = bp.piece != 0;
+  // (a piece: the bound must hold for every search and every straight alignment of the piece's chain - any window inside this one, either direction, the piece's first or
+  // last base possibly left out: forward coordinates, the bases 1 .. n - 2 of the piece, a start node at every row; boundPieceProblem has the conditions)
+  const int n = bp.endA - bp.startA - (piece ? 2 : 0), m = bp.endB - bp.startB;
   XM_GLOBAL(const uint8_t)* const qg = (XM_GLOBAL(const uint8_t)*)bp.qBase;
   XM_GLOBAL(const uint8_t)* const rg = (XM_GLOBAL(const uint8_t)*)bp.rBase;
-  const int startA = bp.startA, startB = bp.startB, qLen = bp.qLen;
+  const int startA = bp.startA + (piece ? 1 : 0), startB = bp.startB, qLen = bp.qLen;
   const bool qRc = bp.qRc;
   auto charA = [=](int i) -> uint8_t { const int k = startA + i; return qRc ? bpComplement(qg[qLen - 1 - k]) : qg[k]; };
   auto charB = [=](int j) -> uint8_t { return rg[startB + j]; };
   // chooseSearchReverse :17-53 (the search evaluates it again; it decides which end of the window the start nodes lie at)
-  bool searchReverse = true;
-  {
+  bool searchReverse = !piece;
+  if (!piece) {
     const int diagonal = bp.startB - (bp.startA + bp.predictedBestOffset);  // :81
     const int s = imax(bp.startA, bp.startB - bp.predictedBestOffset), t = imin(bp.endA, bp.endB - bp.predictedBestOffset);
     int sumMis = 0, numMis = 0, sumMatch = 0, numMatch = 0;
@@ -231,9 +259,9 @@ XM_NOINL bool boundRejects(const BoundProblem& bp, bool pair, Arena& tmp, bool& 
     }
     if (numMis > 1 && numMatch > 1) searchReverse = (sumMis / numMis) > (sumMatch / numMatch);
   }
-  const bool mayExtend = searchReverse ? bp.startB == 0 : bp.endB == bp.referenceLen;  // :87-93
+  const bool mayExtend = piece ? (bp.startB == 0 || bp.endB == bp.referenceLen) : (searchReverse ? bp.startB == 0 : bp.endB == bp.referenceLen);  // :87-93
   int dlo, K;
-  if (!boundBand(n, m, mayExtend, c, dlo, K)) return false;
+  if (!boundBand(n, m, mayExtend, c, dlo, K, piece)) return false;
   const bool wide = K > XM_BOUND_KMAX || m > XM_BOUND_MMAX;
   uint8_t* region = nullptr;
   const size_t mark = tmp.used;
@@ -251,7 +279,7 @@ XM_NOINL bool boundRejects(const BoundProblem& bp, bool pair, Arena& tmp, bool& 
     XM_GLOBAL(uint32_t)* const W = (XM_GLOBAL(uint32_t)*)region;
     XM_GLOBAL(uint8_t)* const TB = (XM_GLOBAL(uint8_t)*)(region + (size_t)(K + 1) * 4);
     for (int j = 0; j < m; j++) TB[j] = charB(searchReverse ? m - 1 - j : j);
-    rejected = boundSweep<true>(W, (XM_GLOBAL(const uint8_t)*)TB, c, n, m, dlo, K, searchReverse, charA, cells);
+    rejected = boundSweep<true>(W, (XM_GLOBAL(const uint8_t)*)TB, c, n, m, dlo, K, searchReverse, charA, cells, piece);
     tmp.used = mark;
   } else {
     uint32_t* const W = (uint32_t*)region;
@@ -264,7 +292,7 @@ XM_NOINL bool boundRejects(const BoundProblem& bp, bool pair, Arena& tmp, bool& 
 #pragma unroll
       for (int k = 0; k < 8; k++) if (j0 + k < m) TB[j0 + k] = v[k];
     }
-    rejected = boundSweep<false>(W, (const uint8_t*)TB, c, n, m, dlo, K, searchReverse, charA, cells);
+    rejected = boundSweep<false>(W, (const uint8_t*)TB, c, n, m, dlo, K, searchReverse, charA, cells, piece);
   }
   return rejected;
 }

@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_bound_kernel(P
   bp.startA = startA; bp.endA = endA; bp.startB = startB; bp.endB = endB; bp.predictedBestOffset = predictedBestOffset;
   bp.mutation = params.MutationPenalty; bp.insStart = params.InsertionStart_Penalty; bp.insExt = params.InsertionExtension_Penalty; bp.delStart = params.DeletionStart_Penalty;
   bp.delExt = params.DeletionExtension_Penalty; bp.maxErrorRate = params.MaxErrorRate; bp.ambiguity = params.AmbiguityPenalty;
+  bp.budget = (endA - startA) * params.MaxErrorRate; bp.piece = 0;
   bool taken = false;
   unsigned long long cells = 0;
   Arena tmp;
@@ -1880,7 +1881,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     res->counters[4] = (int64_t)dc.candidatesExtended; res->counters[5] = (int64_t)dc.pathAlignerCalls; res->counters[6] = (int64_t)dc.pathAlignerNodes;
     res->counters[7] = (int64_t)dc.quickAccepts; res->counters[8] = (int64_t)dc.alignmentsOut; res->counters[9] = (int64_t)dc.refWindowBytes; res->counters[10] = (int64_t)dc.readBytes;
     res->counters[11] = rerun;
-    res->extra[0] = (int64_t)dc.boundChecks; res->extra[1] = (int64_t)dc.boundRejects; res->extra[2] = (int64_t)dc.boundCells; res->extra[3] = boundFilterUsed ? 1 : 0;
+    res->extra[0] = (int64_t)dc.boundChecks; res->extra[1] = (int64_t)dc.boundRejects; res->extra[2] = (int64_t)dc.boundCells; res->extra[3] = boundFilterUsed ? 1 : 0; res->extra[4] = (int64_t)dc.boundPieceChecks; res->extra[5] = (int64_t)dc.boundPieceRejects;
     for (int i = 0; i < 16; i++) res->prof[i] = (int64_t)dc.t[i];
     res->kernel_ms = kernelMs;
     res->kernel_launches = launches;

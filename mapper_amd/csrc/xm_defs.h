@@ -329,7 +329,7 @@ XM_INL T* arenaArray(Arena& a, size_t n) { return (T*)a.alloc(sizeof(T) * (n ? n
 struct DevCounters {
   unsigned long long reads, headerProbes, bucketFetches, hitsFetched, candidatesExtended, pathAlignerCalls, pathAlignerNodes,
       quickAccepts, blocksOut, alignmentsOut, refWindowBytes, readBytes;
-  unsigned long long boundChecks, boundRejects, boundCells;  // the rejection filter in front of PathAligner (xm_bound.h): searches it took, searches it proved null, cells it computed
+  unsigned long long boundChecks, boundRejects, boundCells, boundPieceChecks, boundPieceRejects;  // (the last two: pieces the filter examined / proved unalignable before their chain ran)  // the rejection filter in front of PathAligner (xm_bound.h): searches it took, searches it proved null, cells it computed
   unsigned long long t[16];  // XM_PROFILE builds only: shader-clock ticks per phase, summed over lanes
 };
 

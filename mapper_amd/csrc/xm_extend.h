@@ -1289,6 +1289,7 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
       bp.startA = qs.start; bp.endA = qs.end; bp.startB = rs.start; bp.endB = rs.end; bp.predictedBestOffset = pr.predictedBestOffset;
       bp.mutation = p.MutationPenalty; bp.insStart = p.InsertionStart_Penalty; bp.insExt = p.InsertionExtension_Penalty; bp.delStart = p.DeletionStart_Penalty;
       bp.delExt = p.DeletionExtension_Penalty; bp.maxErrorRate = p.MaxErrorRate; bp.ambiguity = p.AmbiguityPenalty;
+      bp.budget = secLen(qs) * p.MaxErrorRate; bp.piece = 0;  // :60
       bool taken = false;
       unsigned long long cells = 0;
       XM_TIC(tBound);
@@ -1648,6 +1649,26 @@ XM_NOINL bool baAlignPiece(const ExtEnv& e, const Section& qs, const Section& rs
     int referenceStart = imax(rs.start, qs.start + parent.predictedBestOffset - maxIndelLength);
     int referenceEnd = imin(rs.end, qs.end + parent.predictedBestOffset + maxIndelLength);
     if (referenceEnd > referenceStart) { sub.start = referenceStart; sub.end = referenceEnd; }
+  }
+  if (xmBoundFilter() && boundPieceApplies(qs.start, qs.end, sub.start, sub.end, e.reference.len, parent.predictedBestOffset, parent.matcher != nullptr, parent.matcher ? parent.matcher->sectionLength : 0)) {
+    // the rejection filter over the piece's whole chain (xm_bound.h, boundPieceApplies): a piece it proves unalignable within maxPenalty is not sent down the chain -
+    // no hash-block analysis, no straight alignments, no search; alignPiece returns null as it would have
+    BoundProblem bp;
+    bp.qBase = e.query.base; bp.qLen = e.query.len; bp.qRc = e.query.rc != 0; bp.rBase = e.reference.base; bp.referenceLen = e.reference.len;
+    bp.startA = qs.start; bp.endA = qs.end; bp.startB = sub.start; bp.endB = sub.end; bp.predictedBestOffset = parent.predictedBestOffset;
+    bp.mutation = p.MutationPenalty; bp.insStart = p.InsertionStart_Penalty; bp.insExt = p.InsertionExtension_Penalty; bp.delStart = p.DeletionStart_Penalty;
+    bp.delExt = p.DeletionExtension_Penalty; bp.maxErrorRate = p.MaxErrorRate; bp.ambiguity = p.AmbiguityPenalty;
+    bp.budget = maxPenalty; bp.piece = 1;
+    bool taken = false;
+    unsigned long long cells = 0;
+    XM_TIC(tBound);
+    const bool rejected = boundRejects(bp, xmPairMode(), *e.tmp, taken, cells);
+    XM_TOC(e.dc, T_BOUND, tBound);
+    if (e.dc && taken) { e.dc->boundPieceChecks++; e.dc->boundCells += cells; }
+    if (rejected) {
+      if (e.dc) e.dc->boundPieceRejects++;
+      return false;
+    }
   }
   Params sp = p;
   if (!firstPiece) sp.StartingInsertionStartFree = 1;

@@ -41,7 +41,7 @@ __device__ __forceinline__ void addCounters(DevCounters* g, const DevCounters& l
   atomicAdd(&g->hitsFetched, l.hitsFetched); atomicAdd(&g->candidatesExtended, l.candidatesExtended); atomicAdd(&g->pathAlignerCalls, l.pathAlignerCalls);
   atomicAdd(&g->pathAlignerNodes, l.pathAlignerNodes); atomicAdd(&g->quickAccepts, l.quickAccepts); atomicAdd(&g->alignmentsOut, l.alignmentsOut);
   atomicAdd(&g->refWindowBytes, l.refWindowBytes); atomicAdd(&g->readBytes, l.readBytes);
-  if (l.boundChecks) { atomicAdd(&g->boundChecks, l.boundChecks); atomicAdd(&g->boundRejects, l.boundRejects); atomicAdd(&g->boundCells, l.boundCells); }
+  if (l.boundChecks | l.boundPieceChecks) { atomicAdd(&g->boundChecks, l.boundChecks); atomicAdd(&g->boundRejects, l.boundRejects); atomicAdd(&g->boundCells, l.boundCells); atomicAdd(&g->boundPieceChecks, l.boundPieceChecks); atomicAdd(&g->boundPieceRejects, l.boundPieceRejects); }
   for (int i = 0; i < 16; i++) if (l.t[i]) atomicAdd(&g->t[i], l.t[i]);
 }
 

@@ -96,6 +96,7 @@ void addCounters(Counters& a, const Counters& b) {
   a.pathAlignerNodes += b.pathAlignerNodes; a.quickAccepts += b.quickAccepts;
   a.pathNullSearches += b.pathNullSearches; a.pathNullNodes += b.pathNullNodes; a.pathBoundRejects += b.pathBoundRejects;
   a.pathBoundRejectNodes += b.pathBoundRejectNodes; a.pathBoundChecks += b.pathBoundChecks;
+  a.pieceChecks += b.pieceChecks; a.pieceRejects += b.pieceRejects; a.skippedCalls += b.skippedCalls; a.skippedNodes += b.skippedNodes;
 }
 
 thread_local std::string g_error;
@@ -174,13 +175,14 @@ double xmo_dup_granularity(void* r) { return ((ReferenceDatabase*)r)->duplicatio
 
 // ---- alignment
 // the observer of the product's rejection filter (xmo_extend.h PathAligner::boundObserve): 1 = every PathAligner search is also put to the filter's bound
-// (counters 9-13 of a result: null searches, their nodes, searches the filter rejects, the reference's nodes in those, searches the filter takes)
+// (counters 9-17 of a result: null searches, their nodes, searches the filter rejects, the reference's nodes in those, searches the filter takes - all outside rejected
+// pieces - then pieces the piece-level filter takes, pieces it rejects, PathAligner calls and nodes the reference spent inside rejected pieces)
 void xmo_observe_bound(int on) { PathAligner::boundObserver() = on; }
 
 struct xmo_result {
   int64_t nq, nInts, nDbls;
   int32_t* ints; double* dbls; int64_t* intOff; int64_t* dblOff;
-  int64_t counters[16];
+  int64_t counters[24];
 };
 
 void xmo_result_free(xmo_result* res) {
@@ -219,6 +221,7 @@ static xmo_result* packResult(std::vector<ResultStreams>& parts, int64_t nq, con
   res->counters[7] = c.pathAlignerNodes; res->counters[8] = c.quickAccepts;
   res->counters[9] = c.pathNullSearches; res->counters[10] = c.pathNullNodes; res->counters[11] = c.pathBoundRejects;
   res->counters[12] = c.pathBoundRejectNodes; res->counters[13] = c.pathBoundChecks;
+  res->counters[14] = c.pieceChecks; res->counters[15] = c.pieceRejects; res->counters[16] = c.skippedCalls; res->counters[17] = c.skippedNodes;
   return res;
 }
 

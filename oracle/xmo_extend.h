@@ -158,6 +158,59 @@ struct LocalAligner {  // M/LocalAligner.java
   Counters* counters = nullptr;
 };
 
+// ---------------------------------------------------------------- the recurrence of the product's rejection filter (observer side: xm_bound.h has the product's form)
+// Test infrastructure, not part of the reference.  Prices and budget on the filter's grid of 1/60 penalty unit (rounded down), and the plain affine-gap recurrence over the whole
+// rectangle in 64-bit integers: a(i) / b(j) give the query's and the window's bases in the direction of the sweep.  freeStart: a start node at every row of column 0 with insertion
+// state 0 (the bound over a piece's whole chain); otherwise the start nodes of PathAligner.java:120-139 for a window that does not let the query extend past the reference.
+struct BoundGrid {
+  static constexpr int SCALE = 60, KMAX = 2048, MMAX = 4096;
+  int64_t thr = 0, mut = 0, isie = 0, ie = 0, dsde = 0, de = 0, amb[4] = {0, 0, 0, 0};
+  bool prices(const AlignmentParameters& p, double budget) {
+    const double s = (double)SCALE;
+    const double t = std::floor((budget + 0.000001 + 0.0000001) * s);
+    if (!(t >= 0 && t < 60000.0)) return false;
+    thr = (int64_t)t;
+    mut = (int64_t)std::floor(p.MutationPenalty * s);
+    isie = (int64_t)std::floor((p.InsertionStart_Penalty + p.InsertionExtension_Penalty) * s); ie = (int64_t)std::floor(p.InsertionExtension_Penalty * s);
+    dsde = (int64_t)std::floor((p.DeletionStart_Penalty + p.DeletionExtension_Penalty) * s); de = (int64_t)std::floor(p.DeletionExtension_Penalty * s);
+    for (int j = 1; j < 4; j++) amb[j] = (int64_t)std::floor(p.AmbiguityPenalty * ((double)j / 3.0) * s);
+    return !(mut < 0 || isie < 1 || ie < 1 || dsde < 1 || de < 1 || amb[1] < 0 || mut > 30000 || isie > 30000 || dsde > 30000 || amb[3] > 30000);
+  }
+  // the band the product would need (it decides which problems the filter takes)
+  bool bandFits(int n, int m, bool freeStart) const {
+    const int64_t maxIns = thr < isie ? 0 : (thr - isie) / ie + 1, maxDel = thr < dsde ? 0 : (thr - dsde) / de + 1;
+    const int64_t d0 = freeStart ? 0 : (m >= n ? 0 : -(n - m)), d1 = freeStart ? m : (m >= n ? m - n : 0);
+    const int64_t dlo = std::max<int64_t>(d0 - maxIns, -n), dhi = std::min<int64_t>(d1 + maxDel, m);
+    return dhi - dlo + 1 <= KMAX;
+  }
+  template <typename A, typename B>
+  bool exceedsBudget(int n, int m, A a, B b, bool freeStart) const {
+    auto sub = [&](uint8_t qa, uint8_t rb) -> int64_t {
+      if (!Basepairs::canMatch(rb, qa)) return mut;
+      return amb[Basepairs::popcount(Basepairs::unionOf(qa, rb)) - 1];
+    };
+    const int64_t INF = (int64_t)1 << 40;
+    std::vector<int64_t> H((size_t)m + 1, INF), E((size_t)m + 1, INF), Hn((size_t)m + 1), En((size_t)m + 1);
+    if (freeStart) { for (int y = 0; y <= m; y++) { H[(size_t)y] = 0; E[(size_t)y] = 0; } }
+    else for (int y = 0; y <= std::max(m - n, 0); y++) H[(size_t)y] = 0;
+    for (int x = 1; x <= n; x++) {
+      Hn[0] = (!freeStart && x <= n - m) ? 0 : INF; En[0] = INF;
+      int64_t F = INF;
+      for (int y = 1; y <= m; y++) {
+        const int64_t diag = H[(size_t)y - 1] + sub(a(x - 1), b(y - 1));
+        const int64_t e = std::min(E[(size_t)y] + ie, H[(size_t)y] + isie);
+        F = std::min(F + de, Hn[(size_t)y - 1] + dsde);
+        En[(size_t)y] = e;
+        Hn[(size_t)y] = std::min(std::min(diag, e), F);
+      }
+      H.swap(Hn); E.swap(En);
+    }
+    int64_t best = INF;
+    for (int y = 0; y <= m; y++) best = std::min(best, H[(size_t)y]);
+    return best > thr;
+  }
+};
+
 // ---------------------------------------------------------------- PathAligner (M/PathAligner.java)
 struct PathAligner {
   static constexpr double disallowed = 1000000.0;  // :771
@@ -380,53 +433,18 @@ struct PathAligner {
   // (:169,180), and a node's key is never below its penalty (:475-521 only adds to it, :458-461 only raises it).
   // The recurrence is evaluated as the product does it - on an integer grid of 1/60 penalty unit with prices rounded down and the budget
   // floor((max + 1e-6 + 1e-7) * 60) - but over the whole rectangle, in 64-bit integers, without the product's band and interval bookkeeping: the two must agree
-  // on every search, which the tests check through the counters.  Limits of the filter (restated from xm_bound.h: they decide which searches it takes):
-  static constexpr int BOUND_SCALE = 60, BOUND_KMAX = 1024, BOUND_MMAX = 4096;  // (the product's wide limits: what does not fit a region of LDS keeps its band in HBM)
+  // on every search, which the tests check through the counters (BoundGrid above has the recurrence and the filter's limits).
   // -> 0: the filter does not take the problem, 1: taken, not rejected, 2: rejected
   int boundObserve() const {
     const int n = textALength, m = textBLength;
-    const double s = (double)BOUND_SCALE;
-    const double t = std::floor((maxInterestingPenalty + 0.000001 + 0.0000001) * s);
-    if (!(t >= 0 && t < 60000.0)) return 0;
-    const int64_t thr = (int64_t)t;
-    const int64_t mut = (int64_t)std::floor(parameters.MutationPenalty * s);
-    const int64_t isie = (int64_t)std::floor((parameters.InsertionStart_Penalty + parameters.InsertionExtension_Penalty) * s), ie = (int64_t)std::floor(parameters.InsertionExtension_Penalty * s);
-    const int64_t dsde = (int64_t)std::floor((parameters.DeletionStart_Penalty + parameters.DeletionExtension_Penalty) * s), de = (int64_t)std::floor(parameters.DeletionExtension_Penalty * s);
-    int64_t amb[4] = {0, 0, 0, 0};
-    for (int j = 1; j < 4; j++) amb[j] = (int64_t)std::floor(parameters.AmbiguityPenalty * ((double)j / 3.0) * s);
-    if (mut < 0 || isie < 1 || ie < 1 || dsde < 1 || de < 1 || amb[1] < 0 || mut > 30000 || isie > 30000 || dsde > 30000) return 0;
-    if (mayQueryExtendPastEndOfReference || n < 1 || m < 1 || m > BOUND_MMAX) return 0;
-    const int64_t maxIns = thr < isie ? 0 : (thr - isie) / ie + 1, maxDel = thr < dsde ? 0 : (thr - dsde) / de + 1;
-    const int64_t d0 = m >= n ? 0 : -(n - m), d1 = m >= n ? m - n : 0;  // diagonals y' - x' of the start nodes
-    const int64_t dlo = std::max<int64_t>(d0 - maxIns, -n), dhi = std::min<int64_t>(d1 + maxDel, m);
-    if (dhi - dlo + 1 > BOUND_KMAX) return 0;
+    BoundGrid g;
+    if (!g.prices(parameters, maxInterestingPenalty)) return 0;
+    if (mayQueryExtendPastEndOfReference || n < 1 || m < 1 || m > BoundGrid::MMAX) return 0;
+    if (!g.bandFits(n, m, false)) return 0;
     // search coordinates: x' query bases consumed, y' window bases consumed, in the direction the search runs
     auto a = [&](int i) { return searchReverse ? queryEncodedChars[(size_t)(n - 1 - i)] : queryEncodedChars[(size_t)i]; };
     auto b = [&](int j) { return searchReverse ? referenceEncodedChars[(size_t)(m - 1 - j)] : referenceEncodedChars[(size_t)j]; };
-    auto sub = [&](uint8_t qa, uint8_t rb) -> int64_t {
-      if (!Basepairs::canMatch(rb, qa)) return mut;
-      return amb[Basepairs::popcount(Basepairs::unionOf(qa, rb)) - 1];
-    };
-    const int64_t INF = (int64_t)1 << 40;
-    std::vector<int64_t> H((size_t)m + 1, INF), E((size_t)m + 1, INF), Hn((size_t)m + 1), En((size_t)m + 1);
-    // start nodes (not mayQueryExtendPastEndOfReference: their insertion state is "disallowed"): (0, y') for y' = 0 .. m - n (:120-131), or - a window shorter
-    // than the query - (x', 0) for x' = 0 .. n - m (:132-139)
-    for (int y = 0; y <= std::max(m - n, 0); y++) H[(size_t)y] = 0;
-    for (int x = 1; x <= n; x++) {
-      Hn[0] = x <= n - m ? 0 : INF; En[0] = INF;
-      int64_t F = INF;
-      for (int y = 1; y <= m; y++) {
-        const int64_t diag = H[(size_t)y - 1] + sub(a(x - 1), b(y - 1));
-        const int64_t e = std::min(E[(size_t)y] + ie, H[(size_t)y] + isie);
-        F = std::min(F + de, Hn[(size_t)y - 1] + dsde);
-        En[(size_t)y] = e;
-        Hn[(size_t)y] = std::min(std::min(diag, e), F);
-      }
-      H.swap(Hn); E.swap(En);
-    }
-    int64_t best = INF;
-    for (int y = 0; y <= m; y++) best = std::min(best, H[(size_t)y]);
-    return best > thr ? 2 : 1;
+    return g.exceedsBudget(n, m, a, b, false) ? 2 : 1;
   }
   static int& boundObserver() { static int on = 0; return on; }  // xmo_observe_bound (xmo_capi.cpp)
 
@@ -950,7 +968,40 @@ struct BlockAligner : LocalAligner {
     subParameters.MaxErrorRate = maxPenalty / querySection.getLength();
     AlignmentAnalysis childAnalysis = parentAlignmentAnalysis.child();
     childAnalysis.confidentAboutBestOffset = false;
-    return nextAligner->align(querySection, referenceSubsection, subParameters, childAnalysis);
+    if (!PathAligner::boundObserver() || !counters) return nextAligner->align(querySection, referenceSubsection, subParameters, childAnalysis);
+    // OBSERVER of the product's piece-level rejection (xm_bound.h boundPieceApplies / boundRejects with piece = 1) - test infrastructure, never acts on the verdict:
+    // does the recurrence over the piece (its first and last base left out) and this window, a start node at every row, stay above maxPenalty?  If so the chain below must
+    // return null - THROWS if it does not - and everything the reference does inside it is what the product skips: its PathAligner calls and nodes are counted apart, and what
+    // the search-level observer saw inside is taken back out (the product never gets there).
+    const int verdict = pieceObserve(querySection, referenceSubsection, maxPenalty, parameters, parentAlignmentAnalysis);
+    const Counters before = *counters;
+    SequenceAlignmentP result = nextAligner->align(querySection, referenceSubsection, subParameters, childAnalysis);
+    if (verdict == 2 && result) throw std::runtime_error("the rejection filter's bound over a piece is not a lower bound: a piece it rejects aligned");
+    if (verdict >= 1) counters->pieceChecks++;
+    if (verdict == 2) {
+      counters->pieceRejects++;
+      counters->skippedCalls += counters->pathAlignerCalls - before.pathAlignerCalls;
+      counters->skippedNodes += counters->pathAlignerNodes - before.pathAlignerNodes;
+      counters->pathNullSearches = before.pathNullSearches; counters->pathNullNodes = before.pathNullNodes; counters->pathBoundChecks = before.pathBoundChecks;
+      counters->pathBoundRejects = before.pathBoundRejects; counters->pathBoundRejectNodes = before.pathBoundRejectNodes;
+    }
+    return result;
+  }
+  // -> 0: the piece-level filter does not take the piece, 1: taken, not rejected, 2: rejected (the conditions: xm_bound.h boundPieceApplies)
+  int pieceObserve(const SequenceSection& q, const SequenceSection& w, double maxPenalty, const AlignmentParameters& parameters, const AlignmentAnalysis& parent) const {
+    const int n = q.getLength(), m = w.getLength();
+    if (n < 8 || m < n || w.getStartIndex() <= 0 || w.getEndIndex() >= w.getSequence()->getLength()) return 0;
+    const int minOff = w.getStartIndex() - q.getStartIndex(), maxOff = w.getEndIndex() - q.getEndIndex(), u = maxOff - minOff;
+    if (parent.predictedBestOffset < minOff || parent.predictedBestOffset > maxOff + 1) return 0;
+    if (parent.hashBlock_matcher && !(parent.hashBlock_matcher->getSectionLength() > u + u / 2)) return 0;
+    BoundGrid g;
+    if (!g.prices(parameters, maxPenalty)) return 0;
+    if (m > BoundGrid::MMAX || !g.bandFits(n - 2, m, true)) return 0;
+    const Sequence* qs = q.getSequence(); const Sequence* ws = w.getSequence();
+    const int qa = q.getStartIndex() + 1, wb = w.getStartIndex();
+    auto a = [&](int i) { return qs->encodedCharAt(qa + i); };
+    auto b = [&](int j) { return ws->encodedCharAt(wb + j); };
+    return g.exceedsBudget(n - 2, m, a, b, true) ? 2 : 1;
   }
 };
 
@@ -969,6 +1020,7 @@ struct QueryMatch_Aligner {
   QueryMatch_Aligner(const Query& query, const AlignmentParameters& initialParameters, Counters* counters)
       : parameters(initialParameters), query(query), a1(&a0), a2(&a1), a3(&a2), a4(&a3), a5(&a4), a6(&a5), a7(&a6), aligner(&a7), counters(counters) {
     a0.counters = counters;
+    a4.counters = counters;  // (BlockAligner: the observer of the product's piece-level rejection)
   }
 
   static double divideRoundUp(double a, double b) {  // :56-61

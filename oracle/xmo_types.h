@@ -418,6 +418,8 @@ struct Counters {
           quickAccepts = 0, blocksOut = 0;
   // observer of the product's rejection filter in front of PathAligner (xmo_extend.h PathAligner::boundObserve; off unless xmo_observe_bound(1)): it never changes what the oracle returns
   int64_t pathNullSearches = 0, pathNullNodes = 0, pathBoundChecks = 0, pathBoundRejects = 0, pathBoundRejectNodes = 0;
+  // (pieces: BlockAligner.alignPiece calls the piece-level filter takes / rejects; PathAligner calls and nodes the reference spent inside rejected pieces)
+  int64_t pieceChecks = 0, pieceRejects = 0, skippedCalls = 0, skippedNodes = 0;
 };
 
 }  // namespace xmo

@@ -1,13 +1,13 @@
 """(CPU) differential fuzz of the rejection filter inside the whole chain: batches of long reads with random lengths, error rates and prices through the host simulation of the
 kernel sources (tests/hostsim: the device code compiled for the host, the filter on as in the gapped passes of long reads) against the oracle with its observer of the same
-bound on.  Per batch: result streams bit for bit; searches examined / rejected equal the observer's; PathAligner calls unchanged; nodes put + the reference's nodes in rejected
-searches = the reference's nodes.  The observer raises if a search the bound rejects ever returns an alignment.   usage: cpu_filter_fuzz.py [batches] [seed]"""
+bound on.  Per batch: result streams bit for bit; pieces and searches examined / rejected equal the observer's; PathAligner calls and nodes = the reference's minus what it
+spent in rejected searches and inside rejected pieces (tests/helpers.py filter_counters).  The observer raises if a search the bound rejects ever returns an alignment.   usage: cpu_filter_fuzz.py [batches] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib as o, hostsim_lib as hs
-from helpers import streams_equal, first_difference
+from helpers import streams_equal, first_difference, filter_counters
 from mapper_amd import synth
 
 
@@ -28,7 +28,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     rng = np.random.default_rng(seed)
     t0 = time.time()
-    tot = dict(calls=0, nodes=0, null=0, rejects=0, reject_nodes=0)
+    tot = dict(calls=0, nodes=0, pieces=0, piece_rejects=0, rejects=0, skipped_nodes=0)
     for k in range(n_batches):
         ref = synth.synthetic_reference(int(rng.choice([60_000, 200_000, 700_000])), seed=int(rng.integers(1, 2**31)))
         if rng.random() < 0.3:   # a repeat: more candidates per read
@@ -44,14 +44,14 @@ def main():
             want = R.align(b, p, threads=os.cpu_count())
         got = S.align(b, p)
         assert streams_equal(want, got), (k, first_difference(want, got, b.nq))
-        calls, nodes, null, rejects, reject_nodes, checks = want.counters[6], want.counters[7], want.counters[9], want.counters[11], want.counters[12], want.counters[13]
-        assert got.extra[3] == 1 and (got.extra[0], got.extra[1]) == (checks, rejects), (k, got.extra[:4], checks, rejects)
-        assert got.counters[5] == calls and got.counters[6] + reject_nodes == nodes, (k, got.counters[5:7], calls, nodes, reject_nodes)
-        for key, v in zip(tot, (calls, nodes, null, rejects, reject_nodes)):
+        ok, what = filter_counters(got.counters, got.extra, want.counters)
+        assert got.extra[3] == 1 and ok, (k, what)
+        ref, ob = what["reference"], what["oracle_observer"]
+        for key, v in zip(tot, (ref["path_aligner_calls"], ref["nodes"], ob["pieces_examined"], ob["pieces_rejected"], ob["searches_rejected"], ref["nodes_in_rejected_searches"] + ref["nodes_in_rejected_pieces"])):
             tot[key] += v
         if (k + 1) % 20 == 0:
-            print("batch %d: all identical so far; searches %d, returning null %d, rejected by the filter %d; nodes %d, in rejected searches %d; %.0f s" % (
-                k + 1, tot["calls"], tot["null"], tot["rejects"], tot["nodes"], tot["reject_nodes"], time.time() - t0), flush=True)
+            print("batch %d: all identical so far; pieces examined %d, rejected %d; searches of the reference %d, rejected by the filter outside rejected pieces %d; nodes of the reference %d, skipped %d; %.0f s" % (
+                k + 1, tot["pieces"], tot["piece_rejects"], tot["calls"], tot["rejects"], tot["nodes"], tot["skipped_nodes"], time.time() - t0), flush=True)
     print("%d batches: result streams and filter counters identical to the oracle's (observer never raised)" % n_batches)
 
 

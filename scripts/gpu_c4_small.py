@@ -26,8 +26,8 @@ for s in range(steps + 1):
     t = time.perf_counter()
     r = db.align_resident(p)
     dt = time.perf_counter() - t
-    print("step %d: %d queries in %.3f s = %.1f k queries/s; kernel %.1f ms (light %.1f, gapped %.1f), launches %d; calls %d nodes %d; filter: on %d examined %d rejected %d cells %d; reruns %d" % (
-        s, n, dt, n / dt / 1e3, r.kernel_ms, r.counters[12] / 1e3, r.counters[15] / 1e3, r.kernel_launches, r.counters[5], r.counters[6], r.extra[3], r.extra[0], r.extra[1], r.extra[2], r.counters[11]), flush=True)
+    print("step %d: %d queries in %.3f s = %.1f k queries/s; kernel %.1f ms (light %.1f, gapped %.1f), launches %d; calls %d nodes %d; filter: on %d examined %d rejected %d cells %d pieces %d rejected %d; reruns %d" % (
+        s, n, dt, n / dt / 1e3, r.kernel_ms, r.counters[12] / 1e3, r.counters[15] / 1e3, r.kernel_launches, r.counters[5], r.counters[6], r.extra[3], r.extra[0], r.extra[1], r.extra[2], r.extra[4], r.extra[5], r.counters[11]), flush=True)
 if any(r.prof):
     names = ["TOTAL", "PYRAMID", "WALK", "HITS", "STRAIGHT", "ANALYZE", "PATH", "PATH_INIT", "BLOCK", "MATCHER_INDEX", "CONFIDENT", "OUTER", "BOUND", "PA_LOOK+LOAD", "PA_COMPUTE", "PA_PUT"]
     tot = max(1, r.prof[0])

@@ -217,3 +217,17 @@ def bound_problems(seed, count):
         prm["MaxErrorRate"] = float(rng.choice([0.1, 0.1, 0.1, 0.1091, 0.05, 0.02, 0.2, 0.3, 0.0]))
         out.append((prm, query, query_rc, start_a, end_a, ref, start_b, end_b, offset))
     return out
+
+
+def filter_counters(device_counters, device_extra, oracle_counters):
+    """The work counters of a call that ran with the rejection filter (mapper_amd/csrc/xm_bound.h) against the oracle's with its observer on (oracle_lib.observe_bound):
+    -> (equal, what).  The product skips the searches the filter proves null (their nodes) and the whole chain of the pieces it proves unalignable (their PathAligner calls and
+    nodes); the observer counts both, and what the search-level filter sees outside rejected pieces."""
+    oc = [int(x) for x in oracle_counters]
+    calls, nodes, rejects, reject_nodes, checks, piece_checks, piece_rejects, skipped_calls, skipped_nodes = oc[6], oc[7], oc[11], oc[12], oc[13], oc[14], oc[15], oc[16], oc[17]
+    want = dict(searches_examined=checks, searches_rejected=rejects, pieces_examined=piece_checks, pieces_rejected=piece_rejects, path_aligner_calls=calls - skipped_calls,
+                nodes=nodes - reject_nodes - skipped_nodes)
+    got = dict(searches_examined=int(device_extra[0]), searches_rejected=int(device_extra[1]), pieces_examined=int(device_extra[4]), pieces_rejected=int(device_extra[5]),
+               path_aligner_calls=int(device_counters[5]), nodes=int(device_counters[6]))
+    return got == want, dict(device=got, oracle_observer=want, reference=dict(path_aligner_calls=calls, nodes=nodes, searches_returning_null=oc[9], nodes_in_null_searches=oc[10],
+                                                                                nodes_in_rejected_searches=reject_nodes, calls_in_rejected_pieces=skipped_calls, nodes_in_rejected_pieces=skipped_nodes))

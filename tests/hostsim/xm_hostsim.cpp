@@ -273,7 +273,7 @@ int xmsim_align_batch(void* idxp, const xm_params* p, const xm_query_batch* b, x
     res->counters[4] = (int64_t)dc.candidatesExtended; res->counters[5] = (int64_t)dc.pathAlignerCalls; res->counters[6] = (int64_t)dc.pathAlignerNodes;
     res->counters[7] = (int64_t)dc.quickAccepts; res->counters[8] = (int64_t)dc.alignmentsOut; res->counters[9] = (int64_t)dc.refWindowBytes; res->counters[10] = (int64_t)dc.readBytes;
     res->counters[11] = rerun;
-    res->extra[0] = (int64_t)dc.boundChecks; res->extra[1] = (int64_t)dc.boundRejects; res->extra[2] = (int64_t)dc.boundCells; res->extra[3] = dc.boundChecks > 0 ? 1 : 0;
+    res->extra[0] = (int64_t)dc.boundChecks; res->extra[1] = (int64_t)dc.boundRejects; res->extra[2] = (int64_t)dc.boundCells; res->extra[3] = (dc.boundChecks | dc.boundPieceChecks) > 0 ? 1 : 0; res->extra[4] = (int64_t)dc.boundPieceChecks; res->extra[5] = (int64_t)dc.boundPieceRejects;
     *out = res;
     return 0;
   } catch (std::exception& e) { g_err = e.what(); return 1; }
@@ -287,6 +287,7 @@ int xmsim_test_bound(const xm_params* p, const uint8_t* query, int queryLength, 
   bp.startA = startA; bp.endA = endA; bp.startB = startB; bp.endB = endB; bp.predictedBestOffset = predictedBestOffset;
   bp.mutation = p->MutationPenalty; bp.insStart = p->InsertionStart_Penalty; bp.insExt = p->InsertionExtension_Penalty; bp.delStart = p->DeletionStart_Penalty;
   bp.delExt = p->DeletionExtension_Penalty; bp.maxErrorRate = p->MaxErrorRate; bp.ambiguity = p->AmbiguityPenalty;
+  bp.budget = (endA - startA) * p->MaxErrorRate; bp.piece = 0;
   bool taken = false;
   unsigned long long cells = 0;
   static thread_local std::vector<uint8_t> arena(64 * 1024 + 64);

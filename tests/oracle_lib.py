@@ -68,7 +68,7 @@ def build_oracle():
 class _Result(C.Structure):
     _fields_ = [("nq", C.c_int64), ("nInts", C.c_int64), ("nDbls", C.c_int64), ("ints", C.POINTER(C.c_int32)),
                 ("dbls", C.POINTER(C.c_double)), ("intOff", C.POINTER(C.c_int64)), ("dblOff", C.POINTER(C.c_int64)),
-                ("counters", C.c_int64 * 16)]
+                ("counters", C.c_int64 * 24)]
 
 
 _lib = None

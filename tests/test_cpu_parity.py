@@ -8,7 +8,7 @@ import pytest
 import oracle_lib as o
 import hostsim_lib as hs
 from helpers import (KAT, streams_equal, first_difference, se_batch, pe_batch, ragged_se_batch, check_align_case, sprinkle_ambiguity, ambiguous_reference,
-                     heavy_ambiguity, low_complexity_reads, bound_problems)
+                     heavy_ambiguity, low_complexity_reads, bound_problems, filter_counters)
 from mapper_amd import api, synth, _capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -321,14 +321,15 @@ def test_kernel_logic_long_reads_in_the_product_pass_sequence(sub, indel, most_r
     sb = S.align(b, p)
     assert streams_equal(sa, sb), first_difference(sa, sb, b.nq)
     assert sb.counters[11] <= most_reruns, "reads run again at a larger scale: %d of %d" % (sb.counters[11], b.nq)
-    # the rejection filter (xm_bound.h) took and rejected exactly the searches the oracle's observer does, and the nodes the product did not put are
-    # the ones the reference spent in those searches
-    calls, nodes, null, null_nodes, rejects, reject_nodes, checks = sa.counters[6], sa.counters[7], sa.counters[9], sa.counters[10], sa.counters[11], sa.counters[12], sa.counters[13]
-    assert sb.extra[3] == 1 and sb.extra[0] == checks and sb.extra[1] == rejects, (sb.extra, checks, rejects)
-    assert sb.counters[5] == calls and sb.counters[6] + reject_nodes == nodes, (sb.counters[5:7], calls, nodes, reject_nodes)
-    assert checks > 0.5 * calls and rejects <= null  # (not taken: windows at a contig end, bands of more than 200 diagonals, windows of more than 460 bases)
-    if indel == 0.05:  # reads that do not align: most of the search's work is in searches that return null, and the filter proves most of those null
-        assert rejects > 0.9 * null and reject_nodes > 0.75 * nodes, (calls, null, rejects, nodes, reject_nodes)
+    # the rejection filter (xm_bound.h) took and rejected exactly the searches and pieces the oracle's observer does; the PathAligner calls and nodes the product did not
+    # make are the ones the reference spent in rejected searches and inside rejected pieces
+    ok, what = filter_counters(sb.counters, sb.extra, sa.counters)
+    assert sb.extra[3] == 1 and ok, what
+    ref = what["reference"]
+    assert what["oracle_observer"]["searches_examined"] + ref["calls_in_rejected_pieces"] > 0.5 * ref["path_aligner_calls"]
+    if indel == 0.05:  # reads that do not align: most of the search's work is in searches that return null, and the filter proves most of it unnecessary
+        assert ref["nodes_in_rejected_searches"] + ref["nodes_in_rejected_pieces"] > 0.75 * ref["nodes"], what
+        assert what["oracle_observer"]["pieces_rejected"] > 0.5 * what["oracle_observer"]["pieces_examined"] > 0, what
 
 
 def test_kernel_logic_rejection_filter_decides_like_the_oracle_observer():

@@ -5,15 +5,15 @@ What is asserted, and against what:
   does (oracle/xmo_extend.h PathAligner::boundObserve) - the observer runs the reference's search beside its bound and raises when a search the bound
   rejects returns an alignment, so "the filter never rejects a search the oracle completes" is checked on every problem;
 * batches of long reads (BASELINE.json configs[4]: 10 kb reads cut into 1 kb queries) give the oracle's streams bit for bit with the filter on and off, and the
-  counters add up: searches examined / rejected equal the observer's, PathAligner calls are unchanged, nodes put + the reference's nodes in rejected searches
-  = the reference's nodes."""
+  counters add up (tests/helpers.py filter_counters): pieces and searches examined / rejected equal the observer's; PathAligner calls and nodes = the reference's minus what it
+  spent in rejected searches and inside rejected pieces."""
 import ctypes as C
 import os
 import numpy as np
 import pytest
 
 import oracle_lib as o
-from helpers import streams_equal, first_difference, bound_problems
+from helpers import streams_equal, first_difference, bound_problems, filter_counters
 from mapper_amd import api, synth, cli, _capi
 
 
@@ -58,21 +58,22 @@ def test_long_read_batches_equal_oracle_with_the_filter_and_the_counters_add_up(
     R = o.OracleReference([("r", ref)])
     with o.observe_bound():
         want = R.align(b, o.make_params(), threads=os.cpu_count())
-    calls, nodes, null, rejects, reject_nodes, checks = want.counters[6], want.counters[7], want.counters[9], want.counters[11], want.counters[12], want.counters[13]
+    calls, nodes = want.counters[6], want.counters[7]
     db = api.ReferenceDatabase([("r", ref)], max_query_length=1000)
     try:
         got = db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, api.AlignmentParameters())
         assert streams_equal(want, got), first_difference(want, got, b.nq)
         assert got.extra[3] == 1, "a batch of long reads runs its gapped pass with the filter"
-        assert (got.extra[0], got.extra[1]) == (checks, rejects), (got.extra[:4], checks, rejects)
-        assert got.counters[5] == calls and got.counters[6] + reject_nodes == nodes, (got.counters[5:7], calls, nodes, reject_nodes)
-        assert rejects <= null
-        if indel == 0.05:
-            assert rejects > 0.9 * null and reject_nodes > 0.75 * nodes
+        ok, what = filter_counters(got.counters, got.extra, want.counters)
+        assert ok, what
+        ref_side = what["reference"]
+        if indel == 0.05:   # reads that do not align: most pieces are proved unalignable before their chain runs, most of the reference's search nodes are never put
+            assert what["oracle_observer"]["pieces_rejected"] > 0.5 * what["oracle_observer"]["pieces_examined"] > 0, what
+            assert ref_side["nodes_in_rejected_searches"] + ref_side["nodes_in_rejected_pieces"] > 0.75 * ref_side["nodes"], what
         monkeypatch.setenv("XM_BOUND_FILTER", "0")   # the same batch without the filter: same streams, the reference's node count
         off = db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, api.AlignmentParameters())
         assert streams_equal(want, off), first_difference(want, off, b.nq)
-        assert off.extra[3] == 0 and off.extra[1] == 0 and off.counters[5] == calls and off.counters[6] == nodes
+        assert off.extra[3] == 0 and off.extra[1] == 0 and off.extra[5] == 0 and off.counters[5] == calls and off.counters[6] == nodes
     finally:
         db.close()
 
