@@ -76,7 +76,8 @@ XM_INL bool boundPrices(const BoundProblem& b, BoundPrices& c) {
 XM_INL bool boundBand(int n, int m, bool mayExtend, const BoundPrices& c, int& dlo, int& K, bool freeStart = false) {
   // not taken: windows at a contig end in the search's direction (start nodes with unaligned moves at 0.1 per base: :141-150,592-594)
   if (mayExtend || n < 1 || m < 1 || m > XM_BOUND_MMAX_WIDE) return false;
-  const int maxIns = c.thr < c.isie ? 0 : (c.thr - c.isie) / c.ie + 1;   // bases all insertions of a path within the budget can hold
+  // bases all insertions of a path within the budget can hold (freeStart: a path may begin in the middle of an insertion, which then costs its extensions only)
+  const int maxIns = freeStart ? c.thr / c.ie + 1 : (c.thr < c.isie ? 0 : (c.thr - c.isie) / c.ie + 1);
   const int maxDel = c.thr < c.dsde ? 0 : (c.thr - c.dsde) / c.de + 1;
   // start nodes: (0, y') for y' = 0 .. m - n (:120-131), or - a window shorter than the query - (x', 0) for x' = 0 .. n - m (:132-139): diagonals 0 .. m - n or n - m .. 0
   // (freeStart - the bound over a piece's whole chain: a start node at every row of column 0)
@@ -95,42 +96,112 @@ XM_INL bool boundBand(int n, int m, bool mayExtend, const BoundPrices& c, int& d
 // (XM_BOUND_OFF: experiment builds without the filter's code; the wave-per-read kernels, xm_wave_kernel.hip: their searches are wave-cooperative and use the wave's slot; no filter there)
 XM_INL void xmSetBoundFilter(int) {}
 XM_INL bool xmBoundFilter() { return false; }
+XM_INL bool xmBoundCooperative() { return false; }
 #else
 __shared__ int xm_bound_filter;
 XM_INL void xmSetBoundFilter(int on) { if (threadIdx.x == 0) xm_bound_filter = on; }  // (before the block's first barrier)
 XM_INL bool xmBoundFilter() { return xm_bound_filter != 0; }
+XM_INL bool xmBoundCooperative() { return (xm_bound_filter & 2) != 0; }  // (experiment switch: XM_GROUP_SWEEP=0 - eight lanes per read, every lane computing every cell)
 #endif
-// the region of the read this lane runs: reads sit in lanes 0 .. 7 of a wave (pairs: 0 .. 15, two lanes per read); null = the lane has none
-XM_INL uint8_t* boundRegion(bool pair) {
-  const int r = pair ? ((int)__lane_id() >> 1) : (int)__lane_id();
+// the region of the read this lane runs: reads sit in lanes 0 .. 7 of a wave (2^groupShift lanes per read: 0 .. 15, 0 .. 63); null = the lane has none
+XM_INL uint8_t* boundRegion(int groupShift) {
+  const int r = (int)__lane_id() >> groupShift;
   if (r >= XM_BOUND_REGIONS) return nullptr;
   return palSlot() + r * XM_BOUND_REGION;
 }
+XM_INL int boundLaneOfEight() { return (int)__lane_id() & 7; }
 #else
+XM_INL int boundLaneOfEight() { return 0; }
 XM_INL bool& xmBoundFilterHost() { static thread_local bool on = false; return on; }
 XM_INL void xmSetBoundFilter(int on) { xmBoundFilterHost() = on != 0; }
 XM_INL bool xmBoundFilter() { return xmBoundFilterHost(); }
-XM_INL uint8_t* boundRegion(bool) { static thread_local uint32_t region[(XM_BOUND_REGION + 3) / 4]; return (uint8_t*)region; }  // host simulation (tests only)
+XM_INL bool xmBoundCooperative() { return false; }
+XM_INL uint8_t* boundRegion(int) { static thread_local uint32_t region[(XM_BOUND_REGION + 3) / 4]; return (uint8_t*)region; }  // host simulation (tests only)
 #endif
+
+// The lanes that run one read (xmSetPairMode: 2^GS adjacent lanes, all on the same instructions with the same values) as the recurrence uses them: lane g of the
+// group takes every 2^GS-th cell of a column.  GS = 0 (one lane, the two lanes of a pair, the host simulation): every lane computes every cell.
+template <int GS>
+struct BoundGroup {
+  static constexpr int G = 1 << GS;
+#if defined(__HIP_DEVICE_COMPILE__)
+  int g, base;
+  XM_INL BoundGroup() : g(GS ? ((int)__lane_id() & (G - 1)) : 0), base(GS ? ((int)__lane_id() & ~(G - 1)) : (int)__lane_id()) {}
+  // min of v over the lanes of the group before this one (`none` for the first).  Eight lanes: data-parallel primitives inside the 16-lane row (row_shr:n takes
+  // the value n lanes down; what crosses into the group from its neighbour is masked out) - no trip through the LDS crossbar, no wait
+  // (`old` = what a lane without a source in its row keeps.  The result is pinned to a register of its own: ROCm 7.2's compiler folded `g >= 1 ? dpp(v) : none`
+  // into one conditional move and lost the shift - scripts/dpp_check/dpp_check.hip shows it, profiles/r06/NOTES.md)
+  template <int CTRL> static XM_INL int dpp(int old, int v) { int r = __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false); asm volatile("" : "+v"(r)); return r; }
+  XM_INL int exclusiveMin(int v, int none) const {
+    if constexpr (GS == 0) return none;
+    else if constexpr (GS == 3) {
+      int t = dpp<0x111>(none, v);
+      int ex = g >= 1 ? t : none;
+      t = dpp<0x111>(none, ex); ex = imin(ex, g >= 1 ? t : none);
+      t = dpp<0x112>(none, ex); ex = imin(ex, g >= 2 ? t : none);
+      t = dpp<0x114>(none, ex); ex = imin(ex, g >= 4 ? t : none);
+      return ex;
+    } else {
+      int ex = __shfl_up(v, 1, G);
+      if (g == 0) ex = none;
+#pragma unroll
+      for (int d = 1; d < G; d <<= 1) { const int t = __shfl_up(ex, d, G); if (g >= d) ex = imin(ex, t); }
+      return ex;
+    }
+  }
+  // min of v over all lanes of the group, in every lane (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror: the other half of the eight)
+  XM_INL int allMin(int v) const {
+    if constexpr (GS == 0) return v;
+    else if constexpr (GS == 3) {
+      v = imin(v, dpp<0xB1>(v, v));
+      v = imin(v, dpp<0x4E>(v, v));
+      v = imin(v, dpp<0x141>(v, v));
+      return v;
+    } else {
+#pragma unroll
+      for (int d = 1; d < G; d <<= 1) v = imin(v, __shfl_xor(v, d, G));
+      return v;
+    }
+  }
+  XM_INL uint32_t liveMask(bool live) const { return (uint32_t)(__ballot(live ? 1 : 0) >> base) & ((1u << G) - 1u); }
+  // what the lanes of the group wrote is read by the others from here on (one wave: its memory operations complete in order; this keeps the compiler from moving them)
+  XM_INL void sync() const { if constexpr (GS != 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } }
+#else
+  static constexpr int g = 0;
+  XM_INL int exclusiveMin(int, int none) const { return none; }
+  XM_INL int allMin(int v) const { return v; }
+  XM_INL uint32_t liveMask(bool live) const { return live ? 1u : 0u; }
+  XM_INL void sync() const {}
+#endif
+};
 
 // The recurrence over a band held in `W` (K + 1 words: slot K stays "beyond the budget") and the window's bases in `TB`, both in LDS (a region of the wave's slot)
 // or both in the lane's temporaries in HBM (WIDE).  true = no cell of column n stays within the budget.
-template <bool WIDE, typename CharA>
-XM_INL bool boundSweep(typename std::conditional<WIDE, XM_GLOBAL(uint32_t)*, uint32_t*>::type const W, typename std::conditional<WIDE, XM_GLOBAL(const uint8_t)*, const uint8_t*>::type const TB,
+// The deletion state along a column is the one dependency between its cells: F(k) = min(F(k-1) + de, H(k-1) + ds + de).  Written out it is a prefix minimum,
+//   F(k) = min over j < k of ( H0(j) - j de ) + ds + de + (k - 1) de,   H0 = the cell's value without its deletion state (a run that starts from a cell which itself
+// came out of a run costs a second start: never the minimum, ds >= 0) - so a group of lanes computes H0 of 2^GS cells at once, takes the prefix minimum
+// across its lanes, and carries the minimum of the cells done so far up the column.
+template <bool WIDE, int GS, typename CharA>
+XM_INL bool boundSweep(typename std::conditional<WIDE, XM_GLOBAL(uint32_t)*, XM_LDS(uint32_t)*>::type const W, typename std::conditional<WIDE, XM_GLOBAL(const uint8_t)*, XM_LDS(const uint8_t)*>::type const TB,
                        const BoundPrices& c, int n, int m, int dlo, int K, bool searchReverse, CharA charA, unsigned long long& cells, bool freeStart = false) {
+  constexpr int G = 1 << GS;
+  const BoundGroup<GS> grp;
+  const int g = grp.g;
   // (prices as scalars: a struct the compiler keeps in private memory would cost a trip to it per use)
   const int thr = c.thr, mut = c.mut, isie = c.isie, ie = c.ie, dsde = c.dsde, de = c.de;
   const unsigned long long ambPacked = ((unsigned long long)(unsigned)c.amb1 << 16) | ((unsigned long long)(unsigned)c.amb2 << 32) | ((unsigned long long)(unsigned)c.amb3 << 48);
   const uint32_t INFW = ((uint32_t)XM_BOUND_INF << 16) | (uint32_t)XM_BOUND_INF;
-  auto sub = [&](uint8_t a, uint8_t b) -> int {
-    if ((a & b) == 0) return mut;                                             // !Basepairs.canMatch
-    return (int)((ambPacked >> (16 * (__builtin_popcount((unsigned)((a | b) & 15)) - 1))) & 0xFFFFu);   // 0 for two equal unambiguous bases
+  const int BIG = 1 << 28;                            // "no cell yet" in the prefix minimum (prices x slots stay below 2^27)
+  auto sub = [&](uint32_t a, uint32_t b) -> int {   // (selects, no branch: the loop body stays straight-line code)
+    const int amb = (int)((ambPacked >> (16 * (__builtin_popcount((a | b) & 15u) - 1))) & 0xFFFFu);   // 0 for two equal unambiguous bases
+    return (a & b) == 0 ? mut : amb;                                                                   // !Basepairs.canMatch -> a mutation
   };
   // column 0: the start nodes (0, y') for y' = 0 .. m - n at penalty 0, insertion state "disallowed" (:120-131 with startingInsertionStartPenalty disallowed;
   // a window shorter than the query: (0, 0) alone, and one start node (x', 0) at the foot of every column up to n - m, :132-139)
   // (freeStart: every row of column 0 is a start node, and a path may arrive there in the middle of an insertion: insertion state 0 as well)
   int lo = -dlo, hi = -dlo + (freeStart ? m : (m >= n ? m - n : 0));
-  for (int k = lo; k <= hi; k++) W[k] = freeStart ? 0u : (uint32_t)XM_BOUND_INF << 16;
+  for (int k = lo + g; k <= hi; k += G) W[k] = freeStart ? 0u : (uint32_t)XM_BOUND_INF << 16;
+  grp.sync();
   unsigned long long done = 0;
   uint8_t aNext = charA(searchReverse ? n - 1 : 0);
   for (int x = 1; x <= n; x++) {
@@ -139,49 +210,60 @@ XM_INL bool boundSweep(typename std::conditional<WIDE, XM_GLOBAL(uint32_t)*, uin
     // slot k of this column is the cell (x, y' = x + dlo + k); cells exist for 1 <= y' <= m
     const int kGeom = 1 - x - dlo;
     const bool foot = !freeStart && x <= n - m;                   // a start node (x, 0) below the column's first cell
-    int k = foot ? kGeom : imax(imax(lo - 1, kGeom), 0);
     const int kEnd = imin(K - 1, m - x - dlo);
     int newLo = 0x7FFFFFFF, newHi = -1;
-    int f = XM_BOUND_INF, hBelow = XM_BOUND_INF;               // deletion state entering the cell, H of the cell below (slot k - 1 of this column)
-    if (foot) {                                                  // (slot kGeom - 1 >= 0: dlo <= -(n - m))
-      W[kGeom - 1] = (uint32_t)XM_BOUND_INF << 16;               // H = 0, insertion state "disallowed"
-      hBelow = 0; newLo = kGeom - 1; newHi = kGeom - 1;
-    }
-    uint32_t cur = (k >= lo && k <= hi) ? W[k] : INFW;           // slot k of the previous column = cell (x - 1, y' - 1)
     const int tb0 = x + dlo - 1;                                 // base of the window under slot k: TB[tb0 + k]
     if (!foot) {
       // the slots up to the previous column's interval [lo, hi]: slot k + 1 of that column is read as it stands (k + 1 >= lo here, and slot hi + 1 is made
       // "beyond the budget" first), so the loop has no test in it and its loads do not wait for each other
-      W[hi + 1] = INFW;
+      // (values are kept below 2^16 by a min, not reset to "beyond the budget": a value above the budget stays above it along every path, and only values within
+      // it count as alive)
+      const int kStart = imax(imax(lo - 1, kGeom), 0);
       const int kMain = imin(kEnd, hi);
-      for (; k <= kMain; k++) {
-        const uint32_t nxt = W[k + 1];                           // cell (x - 1, y')
-        const int s = sub(a, TB[tb0 + k]);
-        f = imin(f + de, hBelow + dsde);
+      W[hi + 1] = INFW;
+      grp.sync();
+      const uint32_t a32 = a;
+      int carry = BIG;                                           // min of H0(j) - j de over the cells of this column so far
+      for (int kb = kStart; kb <= kMain; kb += G) {
+        const int k = kb + g;
+        const bool in = k <= kMain;
+        const int kk = in ? k : kMain;
+        uint32_t cur = W[kk];                                    // slot k of the previous column = cell (x - 1, y' - 1)
+        if (kk < lo) cur = INFW;
+        const uint32_t nxt = W[kk + 1];                          // cell (x - 1, y')
+        const int s = sub(a32, TB[tb0 + kk]);
         const int hD = (int)(cur & 0xFFFFu), hL = (int)(nxt & 0xFFFFu), eL = (int)(nxt >> 16);
-        int e = imin(eL + ie, hL + isie);
-        int h = imin(imin(hD + s, e), f);
-        e = e > thr ? XM_BOUND_INF : e;
-        f = f > thr ? XM_BOUND_INF : f;
-        const bool live = h <= thr;
-        h = live ? h : XM_BOUND_INF;
-        newLo = imin(newLo, live ? k : 0x7FFFFFFF);
-        newHi = imax(newHi, live ? k : -1);
-        W[k] = (uint32_t)h | ((uint32_t)e << 16);
-        hBelow = h;
-        cur = nxt;
+        const int e = imin(imin(eL + ie, hL + isie), XM_BOUND_INF);
+        const int h0 = imin(hD + s, e);
+        const int v = in ? h0 - k * de : BIG;
+        const int ex = grp.exclusiveMin(v, BIG);
+        const int f = imin(carry, ex) + dsde + (k - 1) * de;
+        const int h = imin(imin(h0, f), XM_BOUND_INF);
+        if (in) W[k] = (uint32_t)h | ((uint32_t)e << 16);
+        const uint32_t lm = grp.liveMask(in && h <= thr);
+        if (lm) { newLo = imin(newLo, kb + __builtin_ctz(lm)); newHi = kb + 31 - __builtin_clz(lm); }
+        carry = imin(carry, grp.allMin(v));
       }
-      done += (unsigned long long)(k - imax(imax(lo - 1, kGeom), 0));
-      // above the interval only a deletion run arrives
-      for (; k <= kEnd; k++) {
-        f = imin(f + de, hBelow + dsde);
-        if (f > thr) break;
-        W[k] = (uint32_t)f | ((uint32_t)XM_BOUND_INF << 16);
-        newLo = imin(newLo, k); newHi = k;
-        hBelow = f;
-        done++;
+      done += (unsigned long long)imax(kMain - kStart + 1, 0);
+      // above the interval only a deletion run arrives: cell k holds carry + ds + de + (k - 1) de, while that stays within the budget
+      for (int kb = kMain + 1; kb <= kEnd; kb += G) {
+        const int k = kb + g;
+        const int f = carry + dsde + (k - 1) * de;
+        const bool live = k <= kEnd && f <= thr;
+        if (live) W[k] = (uint32_t)f | ((uint32_t)XM_BOUND_INF << 16);
+        const uint32_t lm = grp.liveMask(live);
+        if (!lm) break;
+        newLo = imin(newLo, kb); newHi = kb + 31 - __builtin_clz(lm);
+        done += (unsigned long long)__builtin_popcount(lm);
+        if (lm != (1u << G) - 1u) break;
       }
     } else {
+      // (rare: a window shorter than the query.  Every lane computes every cell)
+      int k = kGeom;
+      int f = XM_BOUND_INF, hBelow = 0;                          // deletion state entering the cell, H of the cell below (slot k - 1 of this column)
+      W[kGeom - 1] = (uint32_t)XM_BOUND_INF << 16;               // (slot kGeom - 1 >= 0: dlo <= -(n - m))  H = 0, insertion state "disallowed"
+      newLo = kGeom - 1; newHi = kGeom - 1;
+      uint32_t cur = (k >= lo && k <= hi) ? W[k] : INFW;
       for (; k <= kEnd; k++) {
         const uint32_t nxt = (k + 1 >= lo && k + 1 <= hi) ? W[k + 1] : INFW;  // slot k + 1 of the previous column = cell (x - 1, y')
         f = imin(f + de, hBelow + dsde);
@@ -198,6 +280,7 @@ XM_INL bool boundSweep(typename std::conditional<WIDE, XM_GLOBAL(uint32_t)*, uin
         done++;
       }
     }
+    grp.sync();
     if (newHi < 0) { cells = done; return true; }
     lo = newLo; hi = newHi;
   }
@@ -232,7 +315,7 @@ XM_INL bool boundPieceApplies(int qStart, int qEnd, int wStart, int wEnd, int re
 // tmp: the lane's temporaries (a problem too wide for a region of the wave's slot keeps its band there, for the length of this call)
 // (out of line: inlined into pathAlign - i.e. into innerChain - the same code made gapped passes with several reads per wave end in a memory fault, with the
 // filter switched on or off, while a build with this function out of line, or without it, ran the same batches; profiles/r06/NOTES.md 2)
-XM_NOINL bool boundRejects(const BoundProblem& bp, bool pair, Arena& tmp, bool& taken, unsigned long long& cells) {
+XM_NOINL bool boundRejects(const BoundProblem& bp, int groupShift, Arena& tmp, bool& taken, unsigned long long& cells) {
   taken = false;
   cells = 0;
   BoundPrices c;
@@ -270,29 +353,41 @@ XM_NOINL bool boundRejects(const BoundProblem& bp, bool pair, Arena& tmp, bool& 
     region = (uint8_t*)tmp.alloc((size_t)(K + 1) * 4 + (size_t)m);
     if (tmp.overflow) { tmp.overflow = false; tmp.used = mark; return false; }  // (no room: the search runs as it would have)
   } else {
-    region = boundRegion(pair);
+    region = boundRegion(groupShift);
     if (!region) return false;
   }
   taken = true;
   bool rejected;
+  const bool coop = groupShift == 3 && xmBoundCooperative();
   if (wide) {
     XM_GLOBAL(uint32_t)* const W = (XM_GLOBAL(uint32_t)*)region;
     XM_GLOBAL(uint8_t)* const TB = (XM_GLOBAL(uint8_t)*)(region + (size_t)(K + 1) * 4);
-    for (int j = 0; j < m; j++) TB[j] = charB(searchReverse ? m - 1 - j : j);
-    rejected = boundSweep<true>(W, (XM_GLOBAL(const uint8_t)*)TB, c, n, m, dlo, K, searchReverse, charA, cells, piece);
+    if (coop) {
+      for (int j = boundLaneOfEight(); j < m; j += 8) TB[j] = charB(searchReverse ? m - 1 - j : j);
+      rejected = boundSweep<true, 3>(W, (XM_GLOBAL(const uint8_t)*)TB, c, n, m, dlo, K, searchReverse, charA, cells, piece);
+    } else {
+      for (int j = 0; j < m; j++) TB[j] = charB(searchReverse ? m - 1 - j : j);
+      rejected = boundSweep<true, 0>(W, (XM_GLOBAL(const uint8_t)*)TB, c, n, m, dlo, K, searchReverse, charA, cells, piece);
+    }
     tmp.used = mark;
   } else {
-    uint32_t* const W = (uint32_t*)region;
-    uint8_t* const TB = region + (XM_BOUND_KMAX + 1) * 4;
-    // the window in search order (eight loads in flight per round)
-    for (int j0 = 0; j0 < m; j0 += 8) {
-      uint8_t v[8];
+    XM_LDS(uint32_t)* const W = (XM_LDS(uint32_t)*)region;
+    XM_LDS(uint8_t)* const TB = (XM_LDS(uint8_t)*)(region + (XM_BOUND_KMAX + 1) * 4);
+    if (coop) {
+      // the window in search order, a base per lane and round
+      for (int j = boundLaneOfEight(); j < m; j += 8) TB[j] = charB(searchReverse ? m - 1 - j : j);
+      rejected = boundSweep<false, 3>(W, (XM_LDS(const uint8_t)*)TB, c, n, m, dlo, K, searchReverse, charA, cells, piece);
+    } else {
+      // the window in search order (eight loads in flight per round)
+      for (int j0 = 0; j0 < m; j0 += 8) {
+        uint8_t v[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) { const int j = imin(j0 + k, m - 1); v[k] = charB(searchReverse ? m - 1 - j : j); }
+        for (int k = 0; k < 8; k++) { const int j = imin(j0 + k, m - 1); v[k] = charB(searchReverse ? m - 1 - j : j); }
 #pragma unroll
-      for (int k = 0; k < 8; k++) if (j0 + k < m) TB[j0 + k] = v[k];
+        for (int k = 0; k < 8; k++) if (j0 + k < m) TB[j0 + k] = v[k];
+      }
+      rejected = boundSweep<false, 0>(W, (XM_LDS(const uint8_t)*)TB, c, n, m, dlo, K, searchReverse, charA, cells, piece);
     }
-    rejected = boundSweep<false>(W, (const uint8_t*)TB, c, n, m, dlo, K, searchReverse, charA, cells, piece);
   }
   return rejected;
 }

@@ -74,11 +74,12 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
   xmSetSearchPool(searchPool);
   xmSetBoundFilter(boundFilter);  // gapped passes of long reads: the rejection filter in front of PathAligner's searches (xm_bound.h)
   xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
-  // pairLanes (gapped pass, lanesPerWave <= 32): a read is run by two adjacent lanes doing the same work (xm_extend.h, xmSetPairMode);
-  // `laneInWave` below is the read's slot in the wave, `second` marks the lane that leaves atomics and result writes to its partner
+  // pairLanes (gapped pass, lanesPerWave <= 32): a read is run by 2^pairLanes adjacent lanes doing the same work (xm_extend.h, xmSetPairMode: 1 = two lanes,
+  // 3 = eight, passes of long reads); `laneInWave` below is the read's slot in the wave, `second` marks the lanes that leave atomics and result writes to the first
   const int physLane = (int)(threadIdx.x & 63u);
-  const int laneInWave = pairLanes ? (physLane >> 1) : physLane;
-  const bool second = pairLanes && (physLane & 1);
+  const int groupMask = (1 << pairLanes) - 1;
+  const int laneInWave = physLane >> pairLanes;
+  const bool second = (physLane & groupMask) != 0;
   if (laneInWave >= lanesPerWave) return;
   unsigned long long lane = ((unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (unsigned)lanesPerWave + (unsigned)laneInWave;
   uint8_t* arena = arenas + lane * arenaBytes;
@@ -110,12 +111,12 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_align_kernel(IndexV
           long long remaining = nTodo - (long long)__hip_atomic_load(nextItem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           leave = remaining < (long long)laneInWave * taperUnit;
         }
-        if (pairLanes) leave = __shfl(leave, physLane & ~1);
+        if (pairLanes) leave = __shfl(leave, physLane & ~groupMask);
         if (leave) break;
       }
       item = 0;
       if (!second) item = atomicAdd(nextItem, 1ull);
-      if (pairLanes) item = (unsigned long long)__shfl((long long)item, physLane & ~1);
+      if (pairLanes) item = (unsigned long long)__shfl((long long)item, physLane & ~groupMask);
       if ((long long)item >= nTodo) break;
     }
     int64_t q = todo ? todo[item] : (int64_t)item;
@@ -231,15 +232,15 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_local_kernel(i
 }
 
 // Test entry (xm_test_bound): the rejection filter of xm_bound.h alone, on one problem - a section of a query against a window of a reference - as a lane of a
-// long-read chain runs it (lane 0 of a wave, its region of the wave's slot; pair: lanes 0 and 1 together).  out: taken, rejected, cells.
+// long-read chain runs it (lane 0 of a wave, its region of the wave's slot; pair = 1: lanes 0 and 1 together, 3: lanes 0 .. 7).  out: taken, rejected, cells.
 __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_bound_kernel(Params params, const uint8_t* query, int queryLength, int queryRc, int startA, int endA, const uint8_t* reference, int referenceLength,
                                                             int startB, int endB, int predictedBestOffset, int pair, uint8_t* arena, unsigned long long arenaBytes, int64_t* out) {
   xmSetWaveNodes(nullptr);
   xmSetPairMode(pair);
   xmSetSearchPool(SearchPool{nullptr, 0, 0, 0});
-  xmSetBoundFilter(1);
+  xmSetBoundFilter(3);
   xmLoadMergeRule();  // (every thread of the block: it ends with a barrier)
-  if (threadIdx.x > (pair ? 1u : 0u)) return;
+  if (threadIdx.x >= (1u << pair)) return;
   BoundProblem bp;
   bp.qBase = query; bp.qLen = queryLength; bp.qRc = queryRc != 0; bp.rBase = reference; bp.referenceLen = referenceLength;
   bp.startA = startA; bp.endA = endA; bp.startB = startB; bp.endB = endB; bp.predictedBestOffset = predictedBestOffset;
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(256, XM_WAVES_PER_SIMD) xm_test_bound_kernel(P
   unsigned long long cells = 0;
   Arena tmp;
   tmp.init(arena, (size_t)arenaBytes);  // (the two lanes of a pair keep the same band in the same memory, as they do in the passes: same values twice)
-  const bool rejected = boundRejects(bp, pair != 0, tmp, taken, cells);
+  const bool rejected = boundRejects(bp, pair, tmp, taken, cells);
   if (threadIdx.x == 0) { out[0] = taken ? 1 : 0; out[1] = rejected ? 1 : 0; out[2] = (int64_t)cells; }
 }
 
@@ -1513,6 +1514,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
     // light pass -> gapped pass hand-over (HandOver, SavedRead): the reads the light pass stops in front of the gapped chain keep their seeding
     // state in HBM and the gapped pass continues from it.  Scratch layout while saved regions are alive: [region pool | lane arenas].
     const bool pairMode = envInt("XM_PAIR_LANES", 1) != 0;
+    const bool groupLanes = envInt("XM_GROUP_LANES", 1) != 0;
     // (batches of long reads only: where reads align, the filter costs what it saves - 2 % of the search nodes of configs[1], 16 % of a repeat-rich reference's
     // sit in searches it rejects, and it would look at every search: profiles/r06/NOTES.md 1.  XM_BOUND_FILTER=0: off, for comparison)
     const bool boundFilterOn = envInt("XM_BOUND_FILTER", 1) != 0 && longReads;
@@ -1715,11 +1717,15 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
         if (!allocScratch((size_t)lanes * arenaBytes)) continue;
       }
       sizing.unlock();
-      const int pairLanes = (heavy && lpw <= 32 && pairMode) ? 1 : 0;  // two lanes per read (xm_extend.h, xmSetPairMode)
+      // two lanes per read (xm_extend.h, xmSetPairMode); eight in the passes that run the rejection filter (8 reads per wave at most): its recurrence
+      // spreads a column's cells over them (XM_GROUP_LANES=0: two there as well)
+      int pairLanes = (heavy && lpw <= 32 && pairMode) ? 1 : 0;
       // the rejection filter in front of PathAligner's searches (xm_bound.h): the gapped passes of batches of long reads - their searches do not use the wave's
       // LDS slot, which the filter cuts into one region per read of the wave (8); reads that do not align spend 83 % of their search nodes in searches it proves null
       const int boundFilter = (heavy && boundFilterOn && lpw <= XM_BOUND_REGIONS && scale >= XM_HBM_ONLY_FROM) ? 1 : 0;
       if (boundFilter) boundFilterUsed = true;
+      if (boundFilter && pairLanes && groupLanes) pairLanes = 3;
+      const int boundFilterArg = boundFilter ? (1 | (envInt("XM_GROUP_SWEEP", 1) != 0 ? 2 : 0)) : 0;
       uint8_t* laneArenas = idx->dArenas.p + regionsTotal;
       HandOver ho{hoMode, seedScale, idx->dArenas.p, (unsigned long long)regionBytes, nRegions, idx->dRegionOf.p, idx->dCursors.p + 3};
       const int launchedMode = hoMode;
@@ -1742,7 +1748,7 @@ static int alignResidentLocked(xm_index* idx, const xm_params* p, xm_result** ou
       HIP_CHECK(hipEventRecord(e0, s));
       hipLaunchKernelGGL(xm_align_kernel, dim3(grid), dim3(block), 0, s, view, params, bv, todo, nTodo, scale, heavy ? 2 : (int)lightLevel, lpw,
                          laneArenas, (unsigned long long)arenaBytes, ov, idx->dCursors.p + 2, idx->dCounters.p,
-                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, firstStride, idx->dWaveNodes.p, ho, pairLanes, pool, lists, boundFilter);
+                         heavy ? (long long)((double)nWaves * taperWaves / 100.0) : 0ll, firstStride, idx->dWaveNodes.p, ho, pairLanes, pool, lists, boundFilterArg);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipEventRecord(e1, s));
       PassCtl ctl;
@@ -2114,7 +2120,7 @@ int xm_test_bound(int32_t device, const xm_params* p, const uint8_t* query, int3
     HIP_CHECK(hipMemcpy(dr.p, reference, (size_t)reference_length, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemset(dOut.p, 0, sizeof(int64_t) * 4));
     hipLaunchKernelGGL(xm_test_bound_kernel, dim3(1), dim3(256), 0, 0, params, (const uint8_t*)dq.p, (int)query_length, (int)query_rc, (int)start_a, (int)end_a, (const uint8_t*)dr.p, (int)reference_length,
-                       (int)start_b, (int)end_b, (int)predicted_best_offset, (int)(pair ? 1 : 0), dArena.p, (unsigned long long)(64 * 1024), dOut.p);
+                       (int)start_b, (int)end_b, (int)predicted_best_offset, (int)(pair == 3 ? 3 : (pair ? 1 : 0)), dArena.p, (unsigned long long)(64 * 1024), dOut.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(out3, dOut.p, sizeof(int64_t) * 3, hipMemcpyDeviceToHost));

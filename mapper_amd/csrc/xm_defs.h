@@ -17,8 +17,10 @@
 #define XM_HD __host__ __device__
 #if defined(__HIP_DEVICE_COMPILE__)
 #define XM_GLOBAL(T) T __attribute__((address_space(1)))  // pointer known to address HBM: global_load/store instead of flat
+#define XM_LDS(T) T __attribute__((address_space(3)))     // pointer known to address the local data share: ds_read/ds_write instead of flat
 #else
 #define XM_GLOBAL(T) T
+#define XM_LDS(T) T
 #endif
 #define XM_INL __host__ __device__ __forceinline__
 #ifndef XM_NOINL_LINKAGE
@@ -29,6 +31,7 @@
 #else
 #define XM_HD
 #define XM_GLOBAL(T) T
+#define XM_LDS(T) T
 #define XM_INL inline
 #define XM_NOINL
 #define XM_NOINL_DECL

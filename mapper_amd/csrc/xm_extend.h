@@ -153,8 +153,65 @@ XM_INL int matcherEncodeBlock(const Matcher& m, const SeqView& s, int index) {  
 // GPU note: everything below takes the sequences and the matcher BY VALUE / as locals.  Structures reached through a pointer
 // (ExtEnv, Matcher in the arena) cost a dependent memory round trip per field on this hardware, and the compiler must reload
 // them after every store it cannot disambiguate; locals stay in registers.
+XM_INL int xmGroupShift();
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(XM_WAVE_UNIFORM)
+// The same table built by the EIGHT lanes that run a long read (xmSetPairMode 3).  What the reference's loop leaves in an entry does not depend on the order of the
+// positions - the position of a code that occurs once, M_MULTIPLE for one that occurs more often - so every lane takes an eighth of the section (a run of
+// consecutive positions: the code rolls from one to the next), and a round handles one position of each lane: eight table entries read, codes that meet in a round
+// found by comparing across the lanes (data-parallel primitives, no memory), eight entries written.  Lanes of one wave: their memory operations complete in program
+// order, so a round sees what the round before wrote.  false = not done (an ambiguous base in the section: the (sic) of the loop below - a block with an ambiguous
+// last base leaves the rolling code at its stale value - is order-dependent; the caller runs that loop).
+XM_INL bool matcherIndexSectionEight(const Matcher& m, const SeqView& ref, int sectionIndex, int16_t* section) {
+  const int g = (int)__lane_id() & 7;
+  const int startIndex = m.referenceStart + sectionIndex * m.sectionLength;
+  const int endIndex = imin(startIndex + m.sectionLength, m.referenceStart + m.referenceLength - m.blockLength);
+  if (endIndex > startIndex && endIndex - 1 + m.blockLength > ref.len) return false;
+  {
+    struct alignas(16) W { uint32_t w[4]; };
+    W* const t = (W*)section;
+    W v;
+    v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0xFFFFFFFFu;
+    const int nW = m.numPossibilities / 8;
+    for (int i = g; i < nW; i += 8) t[i] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  XM_GLOBAL(int16_t)* const table = (XM_GLOBAL(int16_t)*)section;
+  const int count = imax(endIndex - startIndex, 0), chunk = (count + 7) >> 3;
+  int i = startIndex + g * chunk;
+  const int iEnd = imin(i + chunk, endIndex);
+  bool amb = false;
+  int code = 0;
+  if (i < iEnd) {
+    for (int b = 0; b < m.blockLength - 1; b++) { const uint8_t c = ref.at(i + b); amb |= bpIsAmbiguous(c); code = code * 4 + encodedCharToInt(c); }
+  }
+  for (int r = 0; r < chunk; r++, i++) {
+    const bool valid = i < iEnd;
+    int enc = -1 - g;                                        // (no position: a value no other lane holds)
+    if (valid) {
+      const uint8_t c = ref.at(i + m.blockLength - 1);
+      amb |= bpIsAmbiguous(c);
+      code = ((code * 4) & m.maxPossibility) + encodedCharToInt(c);
+      enc = code;
+    }
+    const int16_t cur = valid ? table[enc] : (int16_t)0;
+    // the codes of the other seven lanes: the three other lanes of the quad, then the other quad (row_half_mirror) and its three rotations
+    auto other = [](int v, auto ctrl) { int r = __builtin_amdgcn_update_dpp(v, v, decltype(ctrl)::value, 0xF, 0xF, false); asm volatile("" : "+v"(r)); return r; };  // (pinned: xm_bound.h, BoundGroup::dpp)
+    using C39 = std::integral_constant<int, 0x39>; using C4E = std::integral_constant<int, 0x4E>; using C93 = std::integral_constant<int, 0x93>; using C141 = std::integral_constant<int, 0x141>;
+    const int q1 = other(enc, C39()), q2 = other(enc, C4E()), q3 = other(enc, C93()), h0 = other(enc, C141());
+    const int h1 = other(h0, C39()), h2 = other(h0, C4E()), h3 = other(h0, C93());
+    const bool dup = (enc == q1) | (enc == q2) | (enc == q3) | (enc == h0) | (enc == h1) | (enc == h2) | (enc == h3);
+    if (valid) table[enc] = (dup || cur != (int16_t)M_NO_MATCHES) ? (int16_t)M_MULTIPLE : (int16_t)(i - m.referenceStart);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  const uint32_t anyAmb = (uint32_t)(__ballot(amb ? 1 : 0) >> ((int)__lane_id() & ~7)) & 0xFFu;
+  return anyAmb == 0;
+}
+#endif
 XM_NOINL void matcherIndexSection(const Matcher m, const SeqView ref, int sectionIndex, int16_t* section, DevCounters* dc) {  // :40-77
   XM_TIC(t0);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(XM_WAVE_UNIFORM)
+  if (xmGroupShift() == 3 && matcherIndexSectionEight(m, ref, sectionIndex, section)) { XM_TOC(dc, T_MATCHER_INDEX, t0); return; }
+#endif
   {  // numPossibilities is a power of four >= 64 and the tables are 16-byte aligned: fill with 16-byte stores
     struct alignas(16) W { uint32_t w[4]; };
     W* const t = (W*)section;
@@ -357,9 +414,12 @@ XM_INL PNode* palWaveNodes();
 // gapped pass holds at most 32 reads, so the other 32 lanes would idle anyway).  The second lane costs nothing while both do the same,
 // and wherever a step of the read has two independent halves, each lane takes one and they swap results (PathAligner: the first two
 // updates of an explored node).  Atomics and result writes are the first lane's.
+// Round 6: the value is a shift - a read is run by 2^shift adjacent lanes (1: the pair above; 3: passes of long reads, whose waves hold 8 reads at most - the
+// lanes beyond the first two repeat what the pair does, and the rejection filter's recurrence (xm_bound.h) spreads the cells of a column over all of them).
 __shared__ int xm_pair_mode;
-XM_INL void xmSetPairMode(int on) { if (threadIdx.x == 0) xm_pair_mode = on; }  // (before the block's first barrier)
+XM_INL void xmSetPairMode(int shift) { if (threadIdx.x == 0) xm_pair_mode = shift; }  // (before the block's first barrier)
 XM_INL bool xmPairMode() { return __builtin_amdgcn_readfirstlane(xm_pair_mode) != 0; }
+XM_INL int xmGroupShift() { return __builtin_amdgcn_readfirstlane(xm_pair_mode); }
 // The arrays of an HBM-mode search (nodes, grid or hash, buckets, lists: 480 KB at the gapped pass's scale) are needed by under one search in a
 // hundred, so a lane does not own them: every WAVE owns one such buffer (SearchPool: buffer w belongs to wave w of the launch), used by the read
 // whose turn it is at the wave's search slot (pathAlign: HBM-mode searches take turns like the LDS-mode ones, so no claim is needed).  A lane's
@@ -385,6 +445,7 @@ XM_INL void xmSetWaveNodes(PNode*) {}
 XM_INL PNode* palWaveNodes();
 XM_INL void xmSetPairMode(int) {}
 XM_INL bool xmPairMode() { return false; }
+XM_INL int xmGroupShift() { return 0; }
 struct SearchPool { uint8_t* base; unsigned long long bufBytes; int32_t n; int32_t pad; };
 XM_INL void xmSetSearchPool(const SearchPool&) {}
 XM_INL bool xmHaveSearchPool() { return false; }
@@ -1293,7 +1354,7 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
       bool taken = false;
       unsigned long long cells = 0;
       XM_TIC(tBound);
-      const bool rejected = boundRejects(bp, xmPairMode(), *e.tmp, taken, cells);
+      const bool rejected = boundRejects(bp, xmGroupShift(), *e.tmp, taken, cells);
       XM_TOC(e.dc, T_BOUND, tBound);
       if (e.dc && taken) { e.dc->boundChecks++; e.dc->boundCells += cells; }
       if (rejected) {
@@ -1312,16 +1373,17 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
     const int lane = (int)__lane_id();
 #ifdef XM_PROFILE
     if (lane == __ffsll((long long)pending) - 1) {
-      const unsigned long long reads = (unsigned long long)(xmPairMode() ? (__popcll(pending) + 1) / 2 : __popcll(pending));
+      const unsigned long long reads = (unsigned long long)((__popcll(pending) + (1 << xmGroupShift()) - 1) >> xmGroupShift());
       atomicAdd(&xm_arrive_prof[0], 1ull); atomicAdd(&xm_arrive_prof[1], reads);
       if (reads >= 4) { atomicAdd(&xm_arrive_prof[2], 1ull); atomicAdd(&xm_arrive_prof[3], reads); }
     }
 #endif
-    if (xmPairMode()) {  // the two lanes of a read take the slot together
+    if (xmPairMode()) {  // the lanes of a read take the slot together
+      const int gm = (1 << xmGroupShift()) - 1;
       while (pending) {
-        const int leader = (__ffsll((long long)pending) - 1) & ~1;
-        if ((lane & ~1) == leader) found = pathSearchSlot(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, true);
-        pending &= ~(3ull << leader);
+        const int leader = (__ffsll((long long)pending) - 1) & ~gm;
+        if ((lane & ~gm) == leader) found = pathSearchSlot(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, &ldsOverflow, true);
+        pending &= ~(((2ull << gm) - 1ull) << leader);
       }
     } else {
       while (pending) {
@@ -1340,10 +1402,11 @@ XM_INL bool pathAlign(const ExtEnv& e, const Section& qs, const Section& rs, con
       unsigned long long waiting = __ballot(ldsOverflow ? 1 : 0);
       const int lane2 = (int)__lane_id();
       const bool pm = xmPairMode();
+      const int gm2 = (1 << xmGroupShift()) - 1;
       while (waiting) {
-        const int leader = pm ? ((__ffsll((long long)waiting) - 1) & ~1) : (__ffsll((long long)waiting) - 1);
-        if (ldsOverflow && (pm ? ((lane2 & ~1) == leader) : (lane2 == leader))) found = pathSearchHbmInTurn(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, pm);
-        waiting &= pm ? ~(3ull << leader) : ~(1ull << leader);
+        const int leader = (__ffsll((long long)waiting) - 1) & ~gm2;
+        if (ldsOverflow && (lane2 & ~gm2) == leader) found = pathSearchHbmInTurn(pr, *e.tmp, *e.caps, e.status, e.dc, out.blocks, nb, pm);
+        waiting &= ~(((2ull << gm2) - 1ull) << leader);
       }
     } else
 #endif
@@ -1662,7 +1725,7 @@ XM_NOINL bool baAlignPiece(const ExtEnv& e, const Section& qs, const Section& rs
     bool taken = false;
     unsigned long long cells = 0;
     XM_TIC(tBound);
-    const bool rejected = boundRejects(bp, xmPairMode(), *e.tmp, taken, cells);
+    const bool rejected = boundRejects(bp, xmGroupShift(), *e.tmp, taken, cells);
     XM_TOC(e.dc, T_BOUND, tBound);
     if (e.dc && taken) { e.dc->boundPieceChecks++; e.dc->boundCells += cells; }
     if (rejected) {

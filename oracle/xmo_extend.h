@@ -178,7 +178,7 @@ struct BoundGrid {
   }
   // the band the product would need (it decides which problems the filter takes)
   bool bandFits(int n, int m, bool freeStart) const {
-    const int64_t maxIns = thr < isie ? 0 : (thr - isie) / ie + 1, maxDel = thr < dsde ? 0 : (thr - dsde) / de + 1;
+    const int64_t maxIns = freeStart ? thr / ie + 1 : (thr < isie ? 0 : (thr - isie) / ie + 1), maxDel = thr < dsde ? 0 : (thr - dsde) / de + 1;
     const int64_t d0 = freeStart ? 0 : (m >= n ? 0 : -(n - m)), d1 = freeStart ? m : (m >= n ? m - n : 0);
     const int64_t dlo = std::max<int64_t>(d0 - maxIns, -n), dhi = std::min<int64_t>(d1 + maxDel, m);
     return dhi - dlo + 1 <= KMAX;

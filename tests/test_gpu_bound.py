@@ -23,16 +23,16 @@ def device_bound(prm, query, query_rc, start_a, end_a, ref, start_b, end_b, offs
     q = np.ascontiguousarray(query, dtype=np.uint8)
     r = np.ascontiguousarray(ref, dtype=np.uint8)
     out = (C.c_int64 * 3)()
-    if L.xm_test_bound(0, C.byref(p), q.ctypes.data, len(q), 1 if query_rc else 0, start_a, end_a, r.ctypes.data, len(r), start_b, end_b, offset, 1 if pair else 0, out):
+    if L.xm_test_bound(0, C.byref(p), q.ctypes.data, len(q), 1 if query_rc else 0, start_a, end_a, r.ctypes.data, len(r), start_b, end_b, offset, int(pair), out):
         raise RuntimeError(L.xm_last_error().decode())
     return int(out[0]), int(out[1]), int(out[2])
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pair", [False, True], ids=["one-lane", "pair-of-lanes"])
+@pytest.mark.parametrize("pair", [0, 1, 3], ids=["one-lane", "pair-of-lanes", "eight-lanes"])
 def test_filter_rejects_exactly_what_the_oracle_observer_rejects(pair):
     taken = rejected = 0
-    for prm, q, rc, sa, ea, ref, sb, eb, off in bound_problems(0xB0 + (1 if pair else 0), 700):
+    for prm, q, rc, sa, ea, ref, sb, eb, off in bound_problems(0xB0 + int(pair), 700):
         verdict, found, _ = o.kat_bound(o.make_params(prm), q, rc, sa, ea, ref, sb, eb, off)   # (raises if the bound rejected a search that aligned)
         t, rj, cells = device_bound(prm, q, rc, sa, ea, ref, sb, eb, off, pair)
         assert (t, rj) == (1 if verdict else 0, 1 if verdict == 2 else 0), (prm, rc, sa, ea, sb, eb, off, verdict, found, t, rj)
