@@ -20,14 +20,18 @@
 // that a rejected search did return null, and counts the nodes the reference spent in rejected searches - which is what keeps DevCounters::pathAlignerNodes
 // comparable: device nodes + oracle's nodes in rejected searches == oracle nodes, device rejects == oracle rejects (tests/test_gpu_bound.py, bench.py).
 //
-// Form: one lane (the two lanes of a pair: the same values twice), a band of diagonals d = y' - x' in search coordinates (x' counts query bases consumed,
-// y' reference bases of the window, both in the direction the search runs: chooseSearchReverse :17-53) - a path whose penalty stays within the budget
-// cannot leave the start diagonals 0 .. m - n by more bases than the budget buys insertions or deletions.  Column by column; a column's cells with a value
-// within the budget form an interval [lo, hi] of band slots, the next column is computed over [lo - 1, hi + (what a deletion run reaches)] only, and an
-// empty interval ends the filter: no path reaches goalX within the budget.  A slot is one 32-bit word of LDS (H in the low half, the insertion state E in
-// the high half; the deletion state F runs along the column in a register), the window's bases are copied into LDS once: the lanes of a wave that
-// run long-read chains (8 reads per wave, searches in lane-private tables in HBM) do not use the wave's 10 KB search slot - it is cut into 8 regions
-// of 1260 bytes (200 band slots + 460 bases), one per read of the wave.
+// Form: a band of diagonals d = y' - x' in search coordinates (x' counts query bases consumed, y' reference bases of the window, both in the direction the
+// search runs: chooseSearchReverse :17-53) - a path whose penalty stays within the budget cannot leave the start diagonals 0 .. m - n by more bases than the
+// budget buys insertions or deletions.  Column by column; a column's cells with a value within the budget form an interval [lo, hi] of band slots, the next
+// column is computed over [lo - 1, hi + (what a deletion run reaches)] only, and an empty interval ends the filter: no path reaches goalX within the budget.
+// A slot is one 32-bit word of LDS (H in the low half, the insertion state E in the high half), the window's bases are copied into LDS once: the wave's 10 KB
+// search slot is cut into 8 regions of 1260 bytes (200 band slots + 460 bases), one per read of the wave (the passes that run the filter hold 8 reads per
+// wave at most; a search that takes its turn at the slot never runs while a lane is in here - a wave executes one path at a time).
+// Lanes: the passes that run the filter give a read EIGHT adjacent lanes (xm_extend.h, xmSetPairMode 3).  A column's cells are computed eight at a time; the one
+// dependency between them, the deletion state that runs up the column, is a prefix minimum taken across the lanes (boundSweep).  One lane, or the two of a
+// pair, compute every cell each (the host simulation of the tests as well).
+// Two places call it: pathAlign (every search) and BlockAligner's alignPiece (boundPieceApplies: the bound over a piece's whole inner chain - a piece it proves
+// unalignable skips its hash-block analyses, straight alignments and searches).
 #pragma once
 #include "xm_defs.h"
 #include <type_traits>

@@ -19,14 +19,21 @@ __global__ void k(const int* in, int* out, int activeLanes) {
   a = imin(a, dpp<0xB1>(a)); a = imin(a, dpp<0x4E>(a)); a = imin(a, dpp<0x141>(a));
   const int q1 = dpp<0x39>(v), q2 = dpp<0x4E>(v), q3 = dpp<0x93>(v), h0 = dpp<0x141>(v);
   const int h1 = dpp<0x39>(h0), h2 = dpp<0x4E>(h0), h3 = dpp<0x93>(h0);
+  // the form that went wrong: the same scan with the shifted value itself as `old` and the first step written as one conditional expression - the compiler
+  // (ROCm 7.2, gfx950, -O3) folds the DPP move into the conditional move and the shift is lost for the lanes whose condition holds
+  int fx = g >= 1 ? dpp<0x111>(v) : none;
+  int ft = dpp<0x111>(fx); fx = imin(fx, g >= 1 ? ft : none);
+  ft = dpp<0x112>(fx); fx = imin(fx, g >= 2 ? ft : none);
+  ft = dpp<0x114>(fx); fx = imin(fx, g >= 4 ? ft : none);
   int* o = out + threadIdx.x * 16;
+  o[12] = fx;
   o[0] = ex; o[1] = a; o[2] = q1; o[3] = q2; o[4] = q3; o[5] = h0; o[6] = h1; o[7] = h2; o[8] = h3;
   o[9] = dpp<0x111>(v); o[10] = dpp<0x112>(v); o[11] = dpp<0x114>(v);
 }
 int main() {
   int h[64], *din, *dout, ho[64 * 16];
   srand(7);
-  int bad = 0;
+  int bad = 0, badFolded = 0;
   for (int trial = 0; trial < 4; trial++) {
     const int active = trial == 0 ? 8 : trial == 1 ? 40 : trial == 2 ? 64 : 16;
     for (int i = 0; i < 64; i++) h[i] = rand() % 1000;
@@ -41,6 +48,7 @@ int main() {
       for (int j = 0; j < g; j++) ex = ex < h[b + j] ? ex : h[b + j];
       for (int j = 0; j < 8; j++) all = all < h[b + j] ? all : h[b + j];
       const int* o = ho + l * 16;
+      if (o[12] != ex) badFolded++;
       if (o[0] != ex || o[1] != all) { bad++; if (bad < 12) printf("active %d lane %d: ex %d want %d, all %d want %d; shr1 %d shr2 %d shr4 %d (v %d)\n", active, l, o[0], ex, o[1], all, o[9], o[10], o[11], h[l]); }
       // the seven others, each exactly once
       int seen = 0;
@@ -52,6 +60,6 @@ int main() {
       for (int x = 0; x < 7; x++) if (want[x] != got[x]) { bad++; if (bad < 12) printf("active %d lane %d: the others differ\n", active, l); break; }
     }
   }
-  printf("dpp check: %d bad\n", bad);
+  printf("dpp check: %d bad (the forms the kernels use); the folded form: %d lanes wrong of %d\n", bad, badFolded, 8 + 40 + 64 + 16);
   return bad != 0;
 }
