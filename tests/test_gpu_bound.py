@@ -70,6 +70,14 @@ def test_long_read_batches_equal_oracle_with_the_filter_and_the_counters_add_up(
         if indel == 0.05:   # reads that do not align: most pieces are proved unalignable before their chain runs, most of the reference's search nodes are never put
             assert what["oracle_observer"]["pieces_rejected"] > 0.5 * what["oracle_observer"]["pieces_examined"] > 0, what
             assert ref_side["nodes_in_rejected_searches"] + ref_side["nodes_in_rejected_pieces"] > 0.75 * ref_side["nodes"], what
+        # the forms the eight-lane passes were measured against: two lanes per read (every lane computes every cell), and eight lanes that only repeat the pair's work
+        for knob in ("XM_GROUP_LANES", "XM_GROUP_SWEEP"):
+            monkeypatch.setenv(knob, "0")
+            alt = db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, api.AlignmentParameters())
+            monkeypatch.delenv(knob)
+            assert streams_equal(want, alt), (knob, first_difference(want, alt, b.nq))
+            ok, what_alt = filter_counters(alt.counters, alt.extra, want.counters)
+            assert ok, (knob, what_alt)
         monkeypatch.setenv("XM_BOUND_FILTER", "0")   # the same batch without the filter: same streams, the reference's node count
         off = db.align_arrays(b.mate_count, b.mate_offset, b.mate_length, b.codes, b.expected_inner, b.deviation, api.AlignmentParameters())
         assert streams_equal(want, off), first_difference(want, off, b.nq)
