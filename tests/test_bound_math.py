@@ -107,3 +107,67 @@ def test_prefix_minimum_form_equals_the_sequential_recurrence():
         for k, (h, ee) in b.items():
             if h <= thr:
                 assert k in a and a[k] == (h, ee), (trial, k, b[k], a.get(k))
+
+
+# ---------------------------------------------------------------- the matcher's section tables (xm_extend.h, matcherIndexSectionEight; HashBlock_Matcher.java:40-77)
+M_NO_MATCHES, M_MULTIPLE = -1, -2
+
+
+def index_section_sequential(text, start, end, block_length):
+    """The reference's loop on a text without ambiguous bases: an entry holds the position of a code that occurs once, M_MULTIPLE for one that occurs more often."""
+    digit = {1: 0, 2: 1, 4: 2, 8: 3}
+    table = {}
+    for i in range(start, end):
+        code = 0
+        for b in range(block_length):
+            code = code * 4 + digit[int(text[i + b])]
+        table[code] = (i - start) if table.get(code, M_NO_MATCHES) == M_NO_MATCHES else M_MULTIPLE
+    return table
+
+
+def index_section_eight_lanes(text, start, end, block_length, G=8):
+    """The device's order: lane g takes the g-th eighth of the section with a rolling code, a round handles one position per lane - entries read before any of the round's writes,
+    codes that meet in the round marked by comparing across the lanes, then the writes."""
+    digit = {1: 0, 2: 1, 4: 2, 8: 3}
+    mask = (1 << (2 * block_length)) - 1
+    table = {}
+    count = max(end - start, 0)
+    chunk = (count + G - 1) // G
+    pos = [start + g * chunk for g in range(G)]
+    stop = [min(p + chunk, end) for p in pos]
+    code = [0] * G
+    for g in range(G):
+        if pos[g] < stop[g]:
+            for b in range(block_length - 1):
+                code[g] = code[g] * 4 + digit[int(text[pos[g] + b])]
+    for r in range(chunk):
+        enc = []
+        for g in range(G):
+            if pos[g] < stop[g]:
+                code[g] = ((code[g] * 4) & mask) + digit[int(text[pos[g] + block_length - 1])]
+                enc.append(code[g])
+            else:
+                enc.append(-1 - g)
+        cur = [table.get(c, M_NO_MATCHES) if c >= 0 else 0 for c in enc]
+        new = []
+        for g in range(G):
+            dup = any(enc[j] == enc[g] for j in range(G) if j != g)
+            new.append(M_MULTIPLE if (dup or cur[g] != M_NO_MATCHES) else pos[g] - start)
+        for g in range(G):
+            if enc[g] >= 0:
+                table[enc[g]] = new[g]
+                pos[g] += 1
+    return table
+
+
+def test_section_table_does_not_depend_on_the_order_of_the_positions():
+    rng = np.random.default_rng(0x5EC7)
+    for trial in range(400):
+        block_length = int(rng.integers(3, 8))
+        n = int(rng.integers(0, 300))
+        # few distinct bases now and then: many repeated codes, also inside one round
+        alphabet = [1, 2, 4, 8] if rng.random() < 0.7 else [1, 2]
+        text = rng.choice(alphabet, n + block_length + 4).astype(np.uint8)
+        start = int(rng.integers(0, 3))
+        end = start + n
+        assert index_section_sequential(text, start, end, block_length) == index_section_eight_lanes(text, start, end, block_length), trial
